@@ -1,0 +1,110 @@
+/* moby_hip.h -- C ABI of libmoby_hip.so, the MI355X (gfx950) many-worlds
+ * contact-dynamics core that stands in for Moby's LCP / impact-handling hot
+ * path.  Plain pointers and sizes only; no C++ or torch types cross this line.
+ *
+ * The reference has no plugin boundary around this path; each
+ * entry point below names the C++ seam of /root/reference it replaces.
+ * INTEGRATION.md shows the reference-side adapter (a Moby::LCP-shaped C++
+ * class, moby_amd/cpp/MobyHipLCP.h) that a maintainer links instead of
+ * src/LCP.cpp.
+ *
+ * Conventions
+ *   - all matrices are column-major doubles (Ravelin::MatrixNd::data()/
+ *     leading_dim()), all vectors contiguous doubles;
+ *   - functions return MH_OK (0) or a negative MH_ERR_* code and never throw;
+ *     mh_last_error() returns a thread-local message for the last failure;
+ *   - `_dev` entry points take DEVICE pointers and enqueue on `stream`
+ *     (a hipStream_t, NULL = default stream) without synchronising;
+ *     the unsuffixed ones take HOST pointers, copy, run and synchronise;
+ *   - per-problem outputs: status[b] = 1 where the reference solver would
+ *     return true, 0 where it would return false (it never throws,
+ *     include/Moby/LCP.h:21-27);
+ *   - every world carries its own libc rand() stream (32 uint32 words,
+ *     mh_rand_seed(state, 1) == a fresh process of the reference).
+ */
+#ifndef MOBY_HIP_H
+#define MOBY_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_OK 0
+#define MH_ERR_INVALID_ARG   (-1)
+#define MH_ERR_UNSUPPORTED_N (-2)  /* n outside the range the kernels cover */
+#define MH_ERR_HIP           (-3)  /* a HIP runtime call failed */
+#define MH_ERR_NO_DEVICE     (-4)
+
+#define MH_RAND_WORDS 32
+#define MH_LCP_MAX_N_WAVE 64       /* one-wavefront-per-world solver limit */
+
+/* solver selector: include/Moby/LCP.h:21-27 */
+#define MH_LCP_FAST       0  /* LCP::lcp_fast              src/LCP.cpp:41   */
+#define MH_LCP_FAST_REG   1  /* LCP::lcp_fast_regularized  src/LCP.cpp:212  */
+#define MH_LCP_LEMKE      2  /* LCP::lcp_lemke (dense)     src/LCP.cpp:545  */
+#define MH_LCP_LEMKE_REG  3  /* LCP::lcp_lemke_regularized src/LCP.cpp:353  */
+
+/* trace encoding (optional pivot trace, one int32 stream per problem)
+ *   lcp_fast : +(i+1) variable i moved basic->nonbasic, -(i+1) the reverse
+ *   lcp_lemke: (entering+1), (leaving+1) per pivot
+ *   0x40000000|k : start of attempt k of a regularised wrapper (0 = lambda 0) */
+#define MH_TRACE_ATTEMPT 0x40000000
+
+typedef struct mh_lcp_opts {
+  int      min_exp;   /* regularised wrappers: first exponent (default -20)   */
+  unsigned step_exp;  /* exponent step (lcp_fast_regularized default 4)       */
+  int      max_exp;   /* exclusive upper exponent                             */
+  double   piv_tol;   /* <= 0: solver default (LCP.cpp:761)                   */
+  double   zero_tol;  /* <= 0: solver default (LCP.cpp:58,228,570)            */
+} mh_lcp_opts;
+
+/* library / device ------------------------------------------------------- */
+int         mh_version(void);
+const char* mh_last_error(void);
+int         mh_device_count(void);
+
+/* glibc srand(seed) state for one world (host helper, no GPU needed) */
+void        mh_rand_seed(uint32_t* state32, uint32_t seed);
+/* next rand() of that stream (host helper; used by adapters and tests) */
+int         mh_rand_next(uint32_t* state32);
+
+/* B independent dense LCPs  w = M z + q, w,z >= 0, w'z = 0  of equal size n.
+ * Replaces Moby::LCP::{lcp_fast, lcp_fast_regularized, lcp_lemke,
+ * lcp_lemke_regularized} (include/Moby/LCP.h:21-27; callers
+ * src/ImpactConstraintHandlerQP.cpp:219,224, src/ConstraintStabilization.cpp:954-955,
+ * src/ImpactConstraintHandler.cpp:1239-1281).
+ *
+ *   M       B matrices, problem b at M + b*strideM, leading dimension ld >= n
+ *   q       B*n
+ *   z       B*n, in/out: warm start in (only read where z_size_in[b] == n),
+ *           solution out
+ *   z_size_in   B ints or NULL (= all n): z.size() on entry.  lcp_fast
+ *           warm-starts iff it equals n (LCP.cpp:65); lcp_lemke draws n rand()
+ *           values iff it differs from n (LCP.cpp:564-567,611-621)
+ *   z_size_out  B ints or NULL: z.size() on return (2n after some Lemke
+ *           failures, LCP.cpp:840-903)
+ *   rng     B*32 words in/out (mh_rand_seed)
+ *   status  B ints; pivots B unsigned (LCP::pivots) or NULL
+ *   trace   B*trace_cap int32 or NULL; trace_len B ints or NULL
+ */
+int mh_lcp_solve_batch_dev(void* stream, int kind, int B, int n,
+                           const double* M, int ld, long strideM,
+                           const double* q, double* z,
+                           const int* z_size_in, int* z_size_out,
+                           uint32_t* rng, int* status, unsigned* pivots,
+                           int32_t* trace, int trace_cap, int* trace_len,
+                           const mh_lcp_opts* opts);
+
+int mh_lcp_solve_batch(int kind, int B, int n,
+                       const double* M, int ld, long strideM,
+                       const double* q, double* z,
+                       const int* z_size_in, int* z_size_out,
+                       uint32_t* rng, int* status, unsigned* pivots,
+                       int32_t* trace, int trace_cap, int* trace_len,
+                       const mh_lcp_opts* opts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,72 @@
+"""ctypes binding of libmoby_hip.so (the C ABI of include/moby_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call
+fails this module raises.  (The CPU oracle under oracle/ is test
+infrastructure and is never imported from here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmoby_hip.so")
+
+MH_OK = 0
+MH_ERR_INVALID_ARG = -1
+MH_ERR_UNSUPPORTED_N = -2
+MH_ERR_HIP = -3
+MH_ERR_NO_DEVICE = -4
+
+MH_LCP_FAST, MH_LCP_FAST_REG, MH_LCP_LEMKE, MH_LCP_LEMKE_REG = 0, 1, 2, 3
+MH_RAND_WORDS = 32
+MH_LCP_MAX_N_WAVE = 64
+MH_TRACE_ATTEMPT = 0x40000000
+
+
+class MobyHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmoby_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class mh_lcp_opts(ctypes.Structure):
+    _fields_ = [("min_exp", ctypes.c_int), ("step_exp", ctypes.c_uint), ("max_exp", ctypes.c_int),
+                ("piv_tol", ctypes.c_double), ("zero_tol", ctypes.c_double)]
+
+
+# every symbol include/moby_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _l, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_double
+_LCP_TAIL = [_i, _i, _vp, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, ctypes.POINTER(mh_lcp_opts)]
+SYMBOLS = {
+    "mh_version": (_i, []),
+    "mh_last_error": (ctypes.c_char_p, []),
+    "mh_device_count": (_i, []),
+    "mh_rand_seed": (None, [_vp, ctypes.c_uint32]),
+    "mh_rand_next": (_i, [_vp]),
+    "mh_lcp_solve_batch_dev": (_i, [_vp, _i] + _LCP_TAIL),
+    "mh_lcp_solve_batch": (_i, [_i] + _LCP_TAIL),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmoby_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "moby_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != MH_OK:
+        raise MobyHipError(rc, load().mh_last_error().decode("utf-8", "replace"))

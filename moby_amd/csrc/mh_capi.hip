@@ -1,0 +1,233 @@
+// libmoby_hip.so: kernels + the C ABI declared in include/moby_hip.h.
+// gfx950 only.  Build: see __graft_entry__.build() / moby_amd/csrc/Makefile.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <cstdarg>
+#include <vector>
+#include "../../include/moby_hip.h"
+#include "mh_lcp_wave.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+  va_list ap; va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define MH_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  return fail(MH_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+mh::Pow10Table make_pow10()
+{
+  mh::Pow10Table t;
+  for (int i = 0; i < 64; i++) t.v[i] = std::pow(10.0, (double)(i - 32)); // LCP.cpp:285
+  return t;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// One wavefront (= one 64-thread workgroup) per LCP.  M is streamed once from
+// HBM into LDS (the only HBM read of size n^2), the LU scratch sits beside it.
+// LDS per workgroup: (2 n^2 + n) * 8 bytes (n = 42: 28.6 KB -> 5 worlds per CU).
+__global__ __launch_bounds__(64)
+void mh_k_lcp_wave(int B, int n, const double* __restrict__ Mg, int ld, long strideM,
+                   const double* __restrict__ qg, double* __restrict__ zg,
+                   const int* __restrict__ zsz_in, int* __restrict__ zsz_out,
+                   uint32_t* __restrict__ rngg, int* __restrict__ status, unsigned* __restrict__ pivots_out,
+                   int32_t* __restrict__ trace, int trace_cap, int* __restrict__ trace_len,
+                   mh::LcpParams P, mh::Pow10Table p10)
+{
+  extern __shared__ double lds[];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int lane = mh::lane_id();
+  double* Ms = lds;
+  double* A = Ms + n * n;
+  double* art = A + n * n;
+  const double* Mb = Mg + (size_t)b * strideM;
+  // stream M into LDS, tracking the off-diagonal max |m| for norm_inf
+  double offmax = 0.0;
+  const int nn = n * n;
+  if (ld == n) {
+    for (int e = lane; e < nn; e += 64) {
+      const double v = Mb[e];
+      Ms[e] = v;
+      const int c = e / n, r = e - c * n;
+      if (r != c) { const double a = fabs(v); offmax = (a > offmax) ? a : offmax; }
+    }
+  } else {
+    for (int e = lane; e < nn; e += 64) {
+      const int c = e / n, r = e - c * n;
+      const double v = Mb[r + (size_t)ld * c];
+      Ms[e] = v;
+      if (r != c) { const double a = fabs(v); offmax = (a > offmax) ? a : offmax; }
+    }
+  }
+  offmax = mh::wave_max(offmax);
+  mh::wave_sync();
+  const bool valid = lane < n;
+  const double dii = valid ? Ms[lane + n * lane] : 0.0;
+  const double qi = valid ? qg[(size_t)b * n + lane] : 0.0;
+  int zsize = zsz_in ? mh::uni(zsz_in[b]) : n;
+  double zi = (valid && zsize == n) ? zg[(size_t)b * n + lane] : 0.0;
+  mh::WaveRand rng; rng.load(rngg + (size_t)b * MH_RAND_WORDS);
+  mh::Trace tr; tr.buf = trace ? trace + (size_t)b * trace_cap : nullptr; tr.cap = trace_cap; tr.len = 0;
+  unsigned piv = 0;
+  const bool ok = mh::lcp_solve_wave(P, p10, n, Ms, A, art, offmax, dii, qi, zi, zsize, rng, piv, tr);
+  if (valid) zg[(size_t)b * n + lane] = zi;
+  rng.store(rngg + (size_t)b * MH_RAND_WORDS);
+  if (lane == 0) {
+    status[b] = ok ? 1 : 0;
+    if (pivots_out) pivots_out[b] = piv;
+    if (zsz_out) zsz_out[b] = zsize;
+    if (trace_len) trace_len[b] = tr.len;
+  }
+}
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int mh_version(void) { return 100; }
+const char* mh_last_error(void) { return g_err; }
+
+int mh_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void mh_rand_seed(uint32_t* st, uint32_t seed)
+{
+  // glibc srandom_r, TYPE_3: r[i] = 16807*r[i-1] mod (2^31-1), then 310 draws
+  // are discarded.  Ring layout: word i of the sequence lives in slot i % 31.
+  int32_t r[31];
+  if (seed == 0) seed = 1;
+  r[0] = (int32_t)seed;
+  for (int i = 1; i < 31; i++) {
+    int64_t hi = r[i-1] / 127773, lo = r[i-1] % 127773;
+    int64_t w = 16807 * lo - 2836 * hi;
+    if (w < 0) w += 2147483647;
+    r[i] = (int32_t)w;
+  }
+  for (int i = 0; i < 31; i++) st[i] = (uint32_t)r[i];
+  uint32_t idx = 3; // words 31..33 repeat 0..2; word 34 lands in slot 3
+  for (int i = 34; i < 344; i++) {
+    st[idx] = st[idx] + st[(idx + 28) % 31];
+    idx = (idx + 1) % 31;
+  }
+  st[31] = idx;
+}
+
+int mh_rand_next(uint32_t* st)
+{
+  uint32_t idx = st[31];
+  uint32_t v = st[idx] + st[(idx + 28) % 31];
+  st[idx] = v;
+  st[31] = (idx + 1) % 31;
+  return (int)(v >> 1);
+}
+
+static int lcp_params(int kind, const mh_lcp_opts* o, mh::LcpParams& P)
+{
+  if (kind < MH_LCP_FAST || kind > MH_LCP_LEMKE_REG) return fail(MH_ERR_INVALID_ARG, "unknown LCP kind %d", kind);
+  P.kind = kind;
+  // defaults of include/Moby/LCP.h:21,26
+  P.min_exp = -20; P.step_exp = (kind == MH_LCP_FAST_REG) ? 4u : 1u; P.max_exp = (kind == MH_LCP_FAST_REG) ? 20 : 1;
+  P.piv_tol = -1.0; P.zero_tol = -1.0;
+  if (o) { P.min_exp = o->min_exp; P.step_exp = o->step_exp; P.max_exp = o->max_exp; P.piv_tol = o->piv_tol; P.zero_tol = o->zero_tol; }
+  if ((kind == MH_LCP_FAST_REG || kind == MH_LCP_LEMKE_REG)) {
+    if (P.step_exp == 0) return fail(MH_ERR_INVALID_ARG, "step_exp must be > 0");
+    if (P.min_exp < -32 || P.max_exp > 32) return fail(MH_ERR_INVALID_ARG, "regularisation exponents must lie in [-32, 32]");
+  }
+  return MH_OK;
+}
+
+int mh_lcp_solve_batch_dev(void* stream, int kind, int B, int n,
+                           const double* M, int ld, long strideM,
+                           const double* q, double* z,
+                           const int* z_size_in, int* z_size_out,
+                           uint32_t* rng, int* status, unsigned* pivots,
+                           int32_t* trace, int trace_cap, int* trace_len,
+                           const mh_lcp_opts* opts)
+{
+  mh::LcpParams P;
+  int rc = lcp_params(kind, opts, P);
+  if (rc != MH_OK) return rc;
+  if (B < 0 || n < 0) return fail(MH_ERR_INVALID_ARG, "negative batch (%d) or size (%d)", B, n);
+  if (B == 0) return MH_OK;
+  if (n == 0) return fail(MH_ERR_INVALID_ARG, "n == 0: the reference returns an empty z without work; handle on the host");
+  if (!M || !q || !z || !rng || !status) return fail(MH_ERR_INVALID_ARG, "null M/q/z/rng/status");
+  if (ld < n) return fail(MH_ERR_INVALID_ARG, "ld (%d) < n (%d)", ld, n);
+  if (strideM < (long)ld * (n - 1) + n) return fail(MH_ERR_INVALID_ARG, "strideM (%ld) smaller than one matrix", strideM);
+  if (n > MH_LCP_MAX_N_WAVE)
+    return fail(MH_ERR_UNSUPPORTED_N, "n = %d > %d: large-island solver not built yet", n, MH_LCP_MAX_N_WAVE);
+  if (trace && trace_cap <= 0) return fail(MH_ERR_INVALID_ARG, "trace given with trace_cap <= 0");
+  static const mh::Pow10Table p10 = make_pow10();
+  const size_t lds = (size_t)(2 * n * n + n) * sizeof(double);
+  hipLaunchKernelGGL(mh_k_lcp_wave, dim3(B), dim3(64), lds, (hipStream_t)stream,
+                     B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
+                     trace, trace_cap, trace_len, P, p10);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+int mh_lcp_solve_batch(int kind, int B, int n,
+                       const double* M, int ld, long strideM,
+                       const double* q, double* z,
+                       const int* z_size_in, int* z_size_out,
+                       uint32_t* rng, int* status, unsigned* pivots,
+                       int32_t* trace, int trace_cap, int* trace_len,
+                       const mh_lcp_opts* opts)
+{
+  if (B <= 0) return (B == 0) ? MH_OK : fail(MH_ERR_INVALID_ARG, "negative batch");
+  if (mh_device_count() <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
+  if (!M || !q || !z || !rng || !status) return fail(MH_ERR_INVALID_ARG, "null M/q/z/rng/status");
+  if (n <= 0 || ld < n) return fail(MH_ERR_INVALID_ARG, "bad n/ld");
+  double *dM = nullptr, *dq = nullptr, *dz = nullptr; int *dzi = nullptr, *dzo = nullptr, *dst = nullptr, *dtl = nullptr;
+  uint32_t* drng = nullptr; unsigned* dpiv = nullptr; int32_t* dtr = nullptr;
+  const size_t szM = ((size_t)(B - 1) * strideM + (size_t)ld * (n - 1) + n) * sizeof(double);
+  const size_t szv = (size_t)B * n * sizeof(double);
+  int rc = MH_OK;
+  auto cleanup = [&]() {
+    void* ps[] = {dM, dq, dz, dzi, dzo, dst, dtl, drng, dpiv, dtr};
+    for (void* p : ps) if (p) (void)hipFree(p);
+  };
+#define MH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); \
+  return fail(MH_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+  MH_TRY(hipMalloc(&dM, szM)); MH_TRY(hipMalloc(&dq, szv)); MH_TRY(hipMalloc(&dz, szv));
+  MH_TRY(hipMalloc(&drng, (size_t)B * MH_RAND_WORDS * 4)); MH_TRY(hipMalloc(&dst, (size_t)B * 4));
+  MH_TRY(hipMemcpy(dM, M, szM, hipMemcpyHostToDevice));
+  MH_TRY(hipMemcpy(dq, q, szv, hipMemcpyHostToDevice));
+  MH_TRY(hipMemcpy(dz, z, szv, hipMemcpyHostToDevice));
+  MH_TRY(hipMemcpy(drng, rng, (size_t)B * MH_RAND_WORDS * 4, hipMemcpyHostToDevice));
+  if (z_size_in) { MH_TRY(hipMalloc(&dzi, (size_t)B * 4)); MH_TRY(hipMemcpy(dzi, z_size_in, (size_t)B * 4, hipMemcpyHostToDevice)); }
+  if (z_size_out) MH_TRY(hipMalloc(&dzo, (size_t)B * 4));
+  if (pivots) MH_TRY(hipMalloc(&dpiv, (size_t)B * 4));
+  if (trace) { MH_TRY(hipMalloc(&dtr, (size_t)B * trace_cap * 4)); MH_TRY(hipMemset(dtr, 0, (size_t)B * trace_cap * 4)); }
+  if (trace_len) MH_TRY(hipMalloc(&dtl, (size_t)B * 4));
+  rc = mh_lcp_solve_batch_dev(nullptr, kind, B, n, dM, ld, strideM, dq, dz, dzi, dzo, drng, dst, dpiv,
+                              dtr, trace_cap, dtl, opts);
+  if (rc != MH_OK) { cleanup(); return rc; }
+  MH_TRY(hipDeviceSynchronize());
+  MH_TRY(hipMemcpy(z, dz, szv, hipMemcpyDeviceToHost));
+  MH_TRY(hipMemcpy(rng, drng, (size_t)B * MH_RAND_WORDS * 4, hipMemcpyDeviceToHost));
+  MH_TRY(hipMemcpy(status, dst, (size_t)B * 4, hipMemcpyDeviceToHost));
+  if (z_size_out) MH_TRY(hipMemcpy(z_size_out, dzo, (size_t)B * 4, hipMemcpyDeviceToHost));
+  if (pivots) MH_TRY(hipMemcpy(pivots, dpiv, (size_t)B * 4, hipMemcpyDeviceToHost));
+  if (trace) MH_TRY(hipMemcpy(trace, dtr, (size_t)B * trace_cap * 4, hipMemcpyDeviceToHost));
+  if (trace_len) MH_TRY(hipMemcpy(trace_len, dtl, (size_t)B * 4, hipMemcpyDeviceToHost));
+  cleanup();
+#undef MH_TRY
+  return MH_OK;
+}
+
+} // extern "C"

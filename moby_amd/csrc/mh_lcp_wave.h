@@ -1,0 +1,352 @@
+// Dense LCP solvers, one wavefront per problem, n <= 64 (lane i <-> variable i).
+//
+// Replaces (same algorithms, same floating-point operation order as the CPU
+// oracle in oracle/lcp.hpp, which restates the reference line by line):
+//   LCP::lcp_fast               /root/reference/src/LCP.cpp:41-196
+//   LCP::rand_min               src/LCP.cpp:199-209
+//   LCP::lcp_fast_regularized   src/LCP.cpp:212-350
+//   LCP::lcp_lemke_regularized  src/LCP.cpp:353-487
+//   LCP::lcp_lemke (dense)      src/LCP.cpp:545-1003
+//   LinAlgd::solve_fast (dgesv) call sites src/LCP.cpp:120,838
+//
+// MI355X mapping (not a translation of the reference's data structures):
+//   * the sorted index vectors _bas/_nonbas become ONE 64-bit ballot mask in
+//     SGPRs; "position in the list" is a popcount prefix, "r-th element" a
+//     scalar bit scan -- no list maintenance, no insertion sort;
+//   * M (n x n, col-major) and the LU scratch live in LDS; the right-hand
+//     side, q, z, w and Lemke's x/d vectors live one element per lane in
+//     VGPRs; pivot rows/values are broadcast with v_readlane, reductions
+//     (argmin with first-index ties, idamax) are xor-shuffle butterflies;
+//   * the per-world libc rand() ring is spread over lanes 0..30.
+// Build with -ffp-contract=off: parity with the oracle is bit-exact.
+#pragma once
+#include "mh_wave.h"
+#include "../../include/moby_hip.h"
+
+namespace mh {
+
+struct Trace {
+  int32_t* buf; int cap; int len;
+  MH_DEV void push(int32_t v) { if (buf && len < cap && lane_id() == 0) buf[len] = v; len++; }
+};
+
+#define MH_DBL_EPS 2.220446049250313e-16
+#define MH_NEAR_ZERO 1.4901161193847656e-08 /* sqrt(eps), Constants.h:21 */
+#define MH_SFMIN 2.2250738585072014e-308
+
+// M(r,c) of the caller's (possibly regularised) copy _MM = M + lam*I
+MH_DEV double mat_at(const double* M, int n, int r, int c, double lam) {
+  double m = M[r + n * c];
+  return (r == c) ? m + lam : m;
+}
+
+// dgesv for one rhs: A (k x k, col-major, ld=k) in LDS, lane r owns row r and
+// rhs element b.  Returns LAPACK info (uniform); on info != 0 b is garbage.
+// dgetf2 order: idamax -> row swap (all columns) -> scale by reciprocal ->
+// rank-1 update; then dlaswp / unit-lower / upper triangular solves.
+MH_DEV int lu_solve_wave(int k, double* A, double& b)
+{
+  const int lane = lane_id();
+  for (int j = 0; j < k; j++) {
+    const bool mine = (lane >= j) && (lane < k);
+    double a = mine ? fabs(A[lane + k * j]) : -1.0;
+    double amax; int jp;
+    argmax_first(a, mine, amax, jp);
+    if (!(amax != 0.0)) return j + 1;         // exact zero pivot column: singular
+    if (jp != j) {
+      if (lane < k) { double t0 = A[j + k * lane], t1 = A[jp + k * lane]; A[j + k * lane] = t1; A[jp + k * lane] = t0; }
+      double bj = read_lane(b, j), bjp = read_lane(b, jp);
+      if (lane == j) b = bjp; else if (lane == jp) b = bj;
+      wave_sync();
+    }
+    if (j < k - 1) {
+      const double piv = A[j + k * j];        // LDS broadcast
+      if (lane > j && lane < k) {
+        double l = A[lane + k * j];
+        if (fabs(piv) >= MH_SFMIN) { const double r = 1.0 / piv; l = l * r; } else l = l / piv;
+        A[lane + k * j] = l;
+        for (int c = j + 1; c < k; c++)
+          A[lane + k * c] = A[lane + k * c] - l * A[j + k * c];
+      }
+      wave_sync();
+    }
+  }
+  // unit lower
+  for (int kk = 0; kk < k; kk++) {
+    const double bk = read_lane(b, kk);
+    if (lane > kk && lane < k) b = b - bk * A[lane + k * kk];
+  }
+  // upper
+  for (int kk = k - 1; kk >= 0; kk--) {
+    if (lane == kk) b = b / A[kk + k * kk];
+    const double bk = read_lane(b, kk);
+    if (lane < kk) b = b - bk * A[lane + k * kk];
+  }
+  return 0;
+}
+
+// LCP.cpp:199-209: v is defined on the lanes of `mask` (list order = lane
+// order).  Consumes exactly one rand().  Returns the chosen lane.
+MH_DEV int rand_min_wave(double v, uint64_t mask, double tol, WaveRand& rng, double& val)
+{
+  const int lane = lane_id();
+  const bool in = (mask >> lane) & 1ull;
+  double vmin; int imin;
+  argmin_first(v, in, vmin, imin);
+  const uint64_t qm = ballot(in && lane != imin && v < vmin + tol);
+  const int cnt = 1 + popc(qm);
+  const int r = rng.next() % cnt;
+  const int chosen = (r == 0) ? imin : nth_set_bit(qm, r - 1);
+  val = read_lane(v, chosen);
+  return chosen;
+}
+
+// norm_inf of M + lam*I given the off-diagonal max and this lane's diagonal
+MH_DEV double norm_reg(double offmax, double dii, bool valid, double lam) {
+  double d = valid ? fabs(dii + lam) : 0.0;
+  double m = wave_max(d);
+  return (m > offmax) ? m : offmax;
+}
+
+// LCP.cpp:41-196.  qi/zi: this lane's q[i], z[i].  zsize (uniform): z.size()
+// on entry -- == n selects the warm start (LCP.cpp:65); left unchanged when the
+// solver fails before writing z (LCP.cpp:125,195), set to n on success.
+MH_DEV bool lcp_fast_wave(int n, const double* M, double lam, double* A,
+                          double qi, double& zi, int& zsize, double zero_tol,
+                          double nrm_lam, WaveRand& rng, unsigned& pivots, Trace& tr)
+{
+  const int lane = lane_id();
+  const bool valid = lane < n;
+  const uint64_t vmask = lanes_below(n);
+  if (zero_tol < 0.0) zero_tol = (double)n * nrm_lam * MH_DBL_EPS;
+  uint64_t nbmask;
+  if (zsize == n) {
+    nbmask = ballot(valid && !(fabs(zi) < zero_tol));
+  } else {
+    double qmin; int minw;
+    argmin_first(qi, valid, qmin, minw);
+    if (qmin > -zero_tol) { zi = 0.0; zsize = n; pivots = 0; return true; }
+    nbmask = bit(minw);
+  }
+  const unsigned MAX_PIV = 2u * (unsigned)n;
+  for (pivots = 0; pivots < MAX_PIV; pivots++) {
+    const int k = popc(nbmask);
+    const bool is_nb = (nbmask >> lane) & 1ull;
+    const bool is_b = valid && !is_nb;
+    const int pos = popc(nbmask & lanes_below(lane));
+    // gather _Msub (rows by position) and the rhs -q[nonbas]
+    double b = 0.0;
+    if (k > 0) {
+      wave_sync();
+      uint64_t m = nbmask;
+      for (int c = 0; c < k; c++) {
+        const int j = ctz(m); m &= m - 1;
+        if (is_nb) A[pos + k * c] = mat_at(M, n, lane, j, lam);
+      }
+      // route -q[i] from the variable's lane to its row lane (nonbasic
+      // variables to rows 0..k-1, everything else to the unused lanes above)
+      b = push_to(-qi, is_nb ? pos : k + popc(~nbmask & lanes_below(lane)));
+      wave_sync();
+      if (lu_solve_wave(k, A, b) != 0) return false;
+    }
+    // w = Mmix * z + qbas on the basic lanes (dgemv column order)
+    double w = 0.0;
+    {
+      uint64_t m = nbmask;
+      for (int c = 0; c < k; c++) {
+        const int j = ctz(m); m &= m - 1;
+        const double t = read_lane(b, c);
+        if (is_b) w = w + t * mat_at(M, n, lane, j, lam);
+      }
+      w = w + qi;
+    }
+    // z value of this variable (position -> variable routing)
+    const double zv = __shfl(b, pos);
+    const uint64_t bmask = vmask & ~nbmask;
+    double wsel = 0.0; int minw = -1;
+    if (bmask != 0ull) minw = rand_min_wave(w, bmask, zero_tol, rng, wsel);
+    if (minw < 0 || wsel > -zero_tol) {
+      double zsel = 0.0; int minz = -1;
+      if (k > 0) minz = rand_min_wave(zv, nbmask, zero_tol, rng, zsel);
+      if (minz >= 0 && zsel < -zero_tol) {
+        nbmask &= ~bit(minz);
+        tr.push(-(int32_t)(minz + 1));
+      } else {
+        zi = is_nb ? zv : 0.0;
+        zsize = n;
+        return true;
+      }
+    } else {
+      const uint64_t nb_new = nbmask | bit(minw);
+      tr.push((int32_t)(minw + 1));
+      double zsel = 0.0; int minzv = -1;
+      if (k > 0) minzv = rand_min_wave(zv, nbmask, zero_tol, rng, zsel);
+      nbmask = nb_new;
+      if (minzv >= 0 && zsel < -zero_tol) {
+        // LCP.cpp:176-187: the POSITION found in the old _z indexes the NEW,
+        // re-sorted _nonbas
+        const int posz = popc((nb_new & ~bit(minw)) & lanes_below(minzv));
+        const int idx2 = nth_set_bit(nb_new, posz);
+        nbmask &= ~bit(idx2);
+        tr.push(-(int32_t)(idx2 + 1));
+      }
+    }
+  }
+  return false;
+}
+
+// solution check shared by the regularised wrappers
+// (LCP.cpp:240-249 strict=false; :303-312 strict=true, against M + lam*I)
+MH_DEV bool verify_wave(int n, const double* M, double lam, double qi, double zi, double ZERO_TOL, bool strict)
+{
+  const int lane = lane_id();
+  const bool valid = lane < n;
+  const double INF = __longlong_as_double(0x7ff0000000000000ll);
+  const double zmin = wave_min(valid ? zi : INF);
+  if (strict ? !(zmin > -ZERO_TOL) : !(zmin >= -ZERO_TOL)) return false;
+  double w = 0.0;
+  uint64_t nz = ballot(valid && zi != 0.0);
+  while (nz) {
+    const int c = ctz(nz); nz &= nz - 1;
+    const double t = read_lane(zi, c);
+    if (valid) w = w + t * mat_at(M, n, lane, c, lam);
+  }
+  w = w + qi;
+  const double wmin = wave_min(valid ? w : INF);
+  if (strict ? !(wmin > -ZERO_TOL) : !(wmin >= -ZERO_TOL)) return false;
+  const double zw = zi * w;
+  const double mn = wave_min(valid ? zw : INF);
+  const double mx = wave_max(valid ? zw : -INF);
+  if (strict ? !(mn > -ZERO_TOL) : !(mn >= -ZERO_TOL)) return false;
+  return mx < ZERO_TOL;
+}
+
+// LCP.cpp:545-1003.  Lane p owns basis position p (and matrix row p): bv =
+// _bas[p], x = _x[p].  Bl is never stored: column p of Bl is -e_(bv-n) for a w
+// variable, M(:,bv) for a z variable, `art` for the artificial variable t.
+// zsize: z.size() on entry (!= n draws n rand() values, LCP.cpp:611-621) and on
+// exit (2n after a singular-basis/ray-termination failure, LCP.cpp:840-903).
+MH_DEV bool lcp_lemke_wave(int n, const double* M, double lam, double* A, double* art,
+                           double qi, double& zi, int& zsize, double piv_tol, double zero_tol,
+                           double nrm_lam, WaveRand& rng, unsigned& pivots, Trace& tr)
+{
+  const int lane = lane_id();
+  const bool valid = lane < n;
+  const double INF = __longlong_as_double(0x7ff0000000000000ll);
+  const unsigned MAXITER = (50u * (unsigned)n < 1000u) ? 50u * (unsigned)n : 1000u;
+  pivots = 0;
+  zi = 0.0;                                   // z.set_zero() (:564)
+  const int z0size = zsize;
+  if (zero_tol <= 0.0) zero_tol = MH_DBL_EPS * nrm_lam * (double)n;
+  const double qmin = wave_min(valid ? qi : INF);
+  if (qmin > -zero_tol) { zsize = n; return true; }
+  zsize = 2 * n;                              // z.set_zero(2n) (:596)
+  const int t = 2 * n;
+  if (z0size != n) for (int i = 0; i < n; i++) (void)rng.next();   // _restart_z0 (:618-620)
+  int bv = n + lane;                          // all w variables basic, B = -I
+  double x = valid ? qi : 0.0;
+  if (ballot(valid && x < 0.0) == 0ull) { zsize = n; return true; }  // (:737)
+  const double PIV_TOL = (piv_tol > 0.0) ? piv_tol : MH_DBL_EPS * (double)n * ((nrm_lam > 1.0) ? nrm_lam : 1.0);
+  double xmin; int lvindex;
+  argmin_first(x, valid, xmin, lvindex);
+  const double tval = -xmin;
+  int leaving = n + lvindex;
+  int entering = t;
+  double u = (valid && x < 0.0) ? 1.0 : 0.0;
+  wave_sync();
+  if (valid) art[lane] = u;                   // Be = -(Bl*u) with Bl = -I
+  u = u * tval;
+  x = x + u;
+  if (lane == lvindex) { x = tval; bv = t; }
+  wave_sync();
+  for (pivots = 0; pivots < MAXITER; pivots++) {
+    if (leaving == t) {
+      // z[_bas[p]] = x[p] (:804-806): route x from position lanes to variable lanes
+      wave_sync();
+      if (valid) A[lane] = 0.0;
+      wave_sync();
+      if (valid && bv < n) A[bv] = x;
+      wave_sync();
+      zi = valid ? A[lane] : 0.0;
+      zsize = n;
+      return true;
+    }
+    double be;
+    if (leaving < n) { entering = n + leaving; be = (lane == leaving) ? -1.0 : 0.0; }
+    else { entering = leaving - n; be = valid ? mat_at(M, n, lane, entering, lam) : 0.0; }
+    // gather Al = Bl from the basis description
+    wave_sync();
+    for (int p = 0; p < n; p++) {
+      const int id = read_lane(bv, p);
+      double a;
+      if (id == t) a = valid ? art[lane] : 0.0;
+      else if (id >= n) a = (lane == id - n) ? -1.0 : 0.0;
+      else a = valid ? mat_at(M, n, lane, id, lam) : 0.0;
+      if (valid) A[lane + n * p] = a;
+    }
+    wave_sync();
+    double d = be;
+    if (lu_solve_wave(n, A, d) != 0) return false;            // singular basis (:840-850), size stays 2n
+    const uint64_t jm = ballot(valid && d > PIV_TOL);
+    if (jm == 0ull) return false;                              // ray termination (:892-903)
+    const bool inj = (jm >> lane) & 1ull;
+    const double theta = wave_min(inj ? (x + zero_tol) / d : INF);
+    const uint64_t keep = ballot(inj && (x / d <= theta));
+    if (keep == 0ull) { zsize = n; return false; }            // (:946-958)
+    const uint64_t tm = ballot(valid && bv == t);
+    lvindex = (keep & tm) ? ctz(tm) : ctz(keep);
+    leaving = read_lane(bv, lvindex);
+    const double ratio = read_lane(x, lvindex) / read_lane(d, lvindex);
+    d = d * ratio;
+    x = x - d;
+    if (lane == lvindex) { x = ratio; bv = entering; }
+    tr.push((int32_t)entering + 1); tr.push((int32_t)leaving + 1);
+  }
+  zsize = n;
+  return false;
+}
+
+// kind selectors: MH_LCP_* of include/moby_hip.h
+
+struct LcpParams { int kind; int min_exp; unsigned step_exp; int max_exp; double piv_tol; double zero_tol; };
+
+// 10^rf exactly as std::pow(10.0, rf) rounds it for the exponents the
+// handlers use (-20..1); table produced by the host's libm at load time.
+struct Pow10Table { double v[64]; }; // index rf + 32
+
+// Dispatch over the four public solvers.  offmax/dii: off-diagonal max |M| and
+// this lane's diagonal entry (for norm_inf of M + lam*I).
+MH_DEV bool lcp_solve_wave(const LcpParams& P, const Pow10Table& p10, int n, const double* M, double* A, double* art,
+                           double offmax, double dii, double qi, double& zi, int& zsize,
+                           WaveRand& rng, unsigned& pivots, Trace& tr)
+{
+  const bool valid = lane_id() < n;
+  const double nrm0 = norm_reg(offmax, dii, valid, 0.0);
+  if (P.kind == MH_LCP_FAST)
+    return lcp_fast_wave(n, M, 0.0, A, qi, zi, zsize, P.zero_tol, nrm0, rng, pivots, tr);
+  if (P.kind == MH_LCP_LEMKE)
+    return lcp_lemke_wave(n, M, 0.0, A, art, qi, zi, zsize, P.piv_tol, P.zero_tol, nrm0, rng, pivots, tr);
+  const bool fast = (P.kind == MH_LCP_FAST_REG);
+  // plain norm_inf(M) -- the unregularised matrix -- sets ZERO_TOL (LCP.cpp:228,369)
+  const double ZERO_TOL = (P.zero_tol > 0.0) ? P.zero_tol : (double)n * nrm0 * MH_NEAR_ZERO;
+  unsigned total = 0;
+  tr.push(0x40000000);
+  bool ok = fast ? lcp_fast_wave(n, M, 0.0, A, qi, zi, zsize, P.zero_tol, nrm0, rng, pivots, tr)
+                 : lcp_lemke_wave(n, M, 0.0, A, art, qi, zi, zsize, P.piv_tol, P.zero_tol, nrm0, rng, pivots, tr);
+  if (ok && verify_wave(n, M, 0.0, qi, zi, ZERO_TOL, false)) return true;
+  total += pivots;
+  int attempt = 1;
+  for (int rf = P.min_exp; rf < P.max_exp; rf += (int)P.step_exp, attempt++) {
+    const double lam = p10.v[rf + 32];
+    const double nrm = norm_reg(offmax, dii, valid, lam);
+    tr.push(0x40000000 | attempt);
+    ok = fast ? lcp_fast_wave(n, M, lam, A, qi, zi, zsize, P.zero_tol, nrm, rng, pivots, tr)
+              : lcp_lemke_wave(n, M, lam, A, art, qi, zi, zsize, P.piv_tol, P.zero_tol, nrm, rng, pivots, tr);
+    total += pivots;
+    if (ok && verify_wave(n, M, lam, qi, zi, ZERO_TOL, true)) { pivots = total; return true; }
+  }
+  pivots = total;
+  return false;
+}
+
+} // namespace mh

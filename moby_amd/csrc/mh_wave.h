@@ -1,0 +1,122 @@
+// Wavefront-level building blocks for the many-worlds kernels (gfx950, wave64).
+// One wavefront owns one world; lane i owns variable/row i.  Everything that
+// steers control flow is made wave-uniform (SGPR) with readfirstlane so the
+// pivoting loops compile to scalar branches.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MH_WAVE 64
+#define MH_DEV __device__ __forceinline__
+
+namespace mh {
+
+MH_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+MH_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+MH_DEV unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+MH_DEV double uni(double v) {
+  long long b = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+  int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+MH_DEV uint64_t uni(uint64_t v) {
+  unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffull));
+  unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// value held by lane `src` (src must be wave-uniform)
+MH_DEV double read_lane(double v, int src) {
+  long long b = __double_as_longlong(v);
+  int s = __builtin_amdgcn_readfirstlane(src);
+  int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), s);
+  int hi = __builtin_amdgcn_readlane((int)(b >> 32), s);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+MH_DEV int read_lane(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+MH_DEV unsigned read_lane(unsigned v, int src) { return (unsigned)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src)); }
+
+MH_DEV uint64_t ballot(bool p) { return __ballot(p); }
+MH_DEV uint64_t lanes_below(int lane) { return (lane >= 64) ? ~0ull : ((1ull << lane) - 1ull); }
+MH_DEV uint64_t bit(int i) { return 1ull << i; }
+MH_DEV int popc(uint64_t m) { return __popcll(m); }
+MH_DEV int ctz(uint64_t m) { return __ffsll((long long)m) - 1; }
+// index of the r-th (0-based) set bit of m; m must have > r bits (uniform inputs)
+MH_DEV int nth_set_bit(uint64_t m, int r) {
+  for (int i = 0; i < r; i++) m &= m - 1;
+  return ctz(m);
+}
+
+// first-index argmin over the lanes with valid==true; returns uniform (value, lane).
+// Ties resolve to the lowest lane, as std::min_element does.
+MH_DEV void argmin_first(double v, bool valid, double& vmin, int& imin) {
+  int idx = valid ? lane_id() : 0x7fffffff;
+  if (!valid) v = __longlong_as_double(0x7ff0000000000000ll); // +inf
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    double ov = __shfl_xor(v, off);
+    int oi = __shfl_xor(idx, off);
+    if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+  vmin = uni(v); imin = uni(idx);
+}
+// first-index argmax (idamax over |a| supplied by the caller)
+MH_DEV void argmax_first(double v, bool valid, double& vmax, int& imax) {
+  int idx = valid ? lane_id() : 0x7fffffff;
+  if (!valid) v = -1.0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    double ov = __shfl_xor(v, off);
+    int oi = __shfl_xor(idx, off);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+  vmax = uni(v); imax = uni(idx);
+}
+MH_DEV double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { double ov = __shfl_xor(v, off); v = (ov > v) ? ov : v; }
+  return uni(v);
+}
+MH_DEV double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { double ov = __shfl_xor(v, off); v = (ov < v) ? ov : v; }
+  return uni(v);
+}
+
+// forward permute: every lane sends v to lane dest (dest must be a permutation
+// of 0..63 across the wave)
+MH_DEV double push_to(double v, int dest) {
+  long long b = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_ds_permute(dest << 2, (int)(b & 0xffffffffll));
+  int hi = __builtin_amdgcn_ds_permute(dest << 2, (int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// LDS visibility point between lanes of the SAME wavefront.  Kernels here
+// run one wave per workgroup (__launch_bounds__(64)), for which the backend
+// drops the s_barrier and keeps the LDS waitcnt.
+MH_DEV void wave_sync() { __syncthreads(); }
+
+// ---------------------------------------------------------------------------
+// glibc rand() (TYPE_3) with the 31-word ring spread over lanes 0..30: lane s
+// holds ring slot s; `idx` (uniform) is the slot the next output overwrites.
+// Same layout as oracle/glibc_rand.h so states can be exchanged verbatim.
+// Reference consumers: src/LCP.cpp:208,620,641,688.
+struct WaveRand {
+  unsigned r;    // per-lane ring word (lanes 0..30)
+  int idx;       // uniform
+  MH_DEV void load(const uint32_t* st) { int l = lane_id(); r = (l < 31) ? st[l] : 0u; idx = uni((int)st[31]); }
+  MH_DEV void store(uint32_t* st) const { int l = lane_id(); if (l < 31) st[l] = r; if (l == 31) st[31] = (unsigned)idx; }
+  MH_DEV int next() {
+    int i3 = idx + 28; if (i3 >= 31) i3 -= 31;
+    unsigned a = read_lane(r, idx), b = read_lane(r, i3);
+    unsigned v = a + b;
+    if (lane_id() == idx) r = v;
+    idx = (idx + 1 == 31) ? 0 : idx + 1;
+    return (int)(v >> 1);
+  }
+};
+
+} // namespace mh

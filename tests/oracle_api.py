@@ -1,0 +1,72 @@
+"""ctypes wrapper of oracle/liboracle.so -- TEST INFRASTRUCTURE (tests/, smoke, cpu_baseline only)."""
+import ctypes
+import numpy as np
+
+FAST, FAST_REG, LEMKE, LEMKE_REG = 0, 1, 2, 3
+DEFAULT_EXPS = {FAST: (-20, 1, 1), FAST_REG: (-20, 4, 20), LEMKE: (-20, 1, 1), LEMKE_REG: (-20, 1, 1)}
+
+
+class Oracle:
+    def __init__(self, path):
+        self.lib = ctypes.CDLL(path)
+        self.lib.oracle_lcp_solve.restype = ctypes.c_int
+        self.lib.oracle_lcp_solve_batch.restype = ctypes.c_double
+        self.lib.oracle_rand_next.restype = ctypes.c_int
+        self.lib.oracle_lu_solve.restype = ctypes.c_int
+
+    def rand_state(self, seed=1):
+        st = np.zeros(32, dtype=np.uint32)
+        self.lib.oracle_srand_state(st.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint32(seed))
+        return st
+
+    def rand_next(self, st):
+        return self.lib.oracle_rand_next(st.ctypes.data_as(ctypes.c_void_p))
+
+    def lu_solve(self, A, b):
+        n = len(b)
+        Af = np.asfortranarray(np.array(A, dtype=np.float64))
+        x = np.array(b, dtype=np.float64)
+        info = self.lib.oracle_lu_solve(n, Af.ctypes.data_as(ctypes.c_void_p), n, x.ctypes.data_as(ctypes.c_void_p))
+        return info, x
+
+    def lcp(self, kind, M, q, z=None, z_size=None, rng=None, exps=None, piv_tol=-1.0, zero_tol=-1.0, trace_cap=4096):
+        """One problem.  M is row-major numpy (M[r, c]).  Returns dict(ok, z, z_size, pivots, trace, rng)."""
+        n = len(q)
+        Mf = np.asfortranarray(np.array(M, dtype=np.float64))
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        zz = np.zeros(2 * n + 2)
+        if z is not None:
+            zz[:n] = z
+        zs = ctypes.c_int(n if z_size is None else int(z_size))
+        if rng is None:
+            rng = self.rand_state(1)
+        rng = np.array(rng, dtype=np.uint32)
+        e = exps if exps is not None else DEFAULT_EXPS[kind]
+        piv = ctypes.c_uint(0)
+        tr = np.zeros(trace_cap, dtype=np.int32)
+        tl = ctypes.c_int(0)
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        ok = self.lib.oracle_lcp_solve(kind, n, P(Mf), n, P(q), P(zz), ctypes.byref(zs),
+                                       int(e[0]), ctypes.c_uint(int(e[1])), int(e[2]),
+                                       ctypes.c_double(piv_tol), ctypes.c_double(zero_tol),
+                                       P(rng), ctypes.byref(piv), P(tr), trace_cap, ctypes.byref(tl))
+        return dict(ok=bool(ok), z=zz[:n].copy(), z_size=zs.value, pivots=piv.value,
+                    trace=tr[:min(tl.value, trace_cap)].copy(), trace_len=tl.value, rng=rng)
+
+    def lcp_batch(self, kind, M, q, z, z_size=None, rng=None, exps=None, piv_tol=-1.0, zero_tol=-1.0):
+        """B problems sequentially (CPU baseline).  Returns (seconds, status, pivots, z, rng)."""
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        B, n = q.shape
+        Mcm = np.ascontiguousarray(np.transpose(M, (0, 2, 1)))
+        zz = np.zeros((B, 2 * n)); zz[:, :n] = z
+        if rng is None:
+            rng = np.tile(self.rand_state(1), (B, 1))
+        rng = np.ascontiguousarray(rng, dtype=np.uint32)
+        zs = np.full(B, n, dtype=np.int32) if z_size is None else np.ascontiguousarray(z_size, dtype=np.int32)
+        st = np.zeros(B, dtype=np.int32); piv = np.zeros(B, dtype=np.uint32)
+        e = exps if exps is not None else DEFAULT_EXPS[kind]
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        secs = self.lib.oracle_lcp_solve_batch(kind, B, n, P(Mcm), n, ctypes.c_long(n * n), P(q), P(zz), P(zs),
+                                               int(e[0]), ctypes.c_uint(int(e[1])), int(e[2]),
+                                               ctypes.c_double(piv_tol), ctypes.c_double(zero_tol), P(rng), P(st), P(piv))
+        return secs, st, piv, zz[:, :n].copy(), rng, zs

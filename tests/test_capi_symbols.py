@@ -1,0 +1,72 @@
+"""The C-ABI library loads and exports every symbol include/moby_hip.h
+declares; argument validation and host helpers work without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "moby_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from moby_amd import _lib
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert "mh_lcp_solve_batch_dev" in declared and "mh_rand_seed" in declared
+    for name in declared:
+        assert hasattr(lib, name), "libmoby_hip.so does not export %s" % name
+    assert set(declared) == set(_lib.SYMBOLS), "ctypes table out of sync with moby_hip.h"
+    assert lib.mh_version() >= 100
+
+
+def test_rand_seed_matches_libc():
+    from moby_amd import _lib
+    lib = _lib.load()
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (1, 7):
+        st = np.zeros(32, dtype=np.uint32)
+        lib.mh_rand_seed(st.ctypes.data, seed)
+        libc.srand(seed)
+        assert [libc.rand() for _ in range(1000)] == [lib.mh_rand_next(st.ctypes.data) for _ in range(1000)]
+
+
+def test_rand_state_layout_equals_oracle(oracle):
+    from moby_amd import _lib
+    lib = _lib.load()
+    st = np.zeros(32, dtype=np.uint32)
+    lib.mh_rand_seed(st.ctypes.data, 1)
+    np.testing.assert_array_equal(st, oracle.rand_state(1))
+
+
+def test_argument_validation_without_gpu():
+    from moby_amd import _lib
+    lib = _lib.load()
+    buf = np.zeros(64)
+    rc = lib.mh_lcp_solve_batch_dev(None, 99, 1, 2, buf.ctypes.data, 2, 4, buf.ctypes.data, buf.ctypes.data,
+                                    None, None, buf.ctypes.data, buf.ctypes.data, None, None, 0, None, None)
+    assert rc == _lib.MH_ERR_INVALID_ARG and b"kind" in lib.mh_last_error()
+    rc = lib.mh_lcp_solve_batch_dev(None, 0, 1, 65, buf.ctypes.data, 65, 65 * 65, buf.ctypes.data, buf.ctypes.data,
+                                    None, None, buf.ctypes.data, buf.ctypes.data, None, None, 0, None, None)
+    assert rc == _lib.MH_ERR_UNSUPPORTED_N
+    rc = lib.mh_lcp_solve_batch_dev(None, 0, 1, 4, buf.ctypes.data, 2, 16, buf.ctypes.data, buf.ctypes.data,
+                                    None, None, buf.ctypes.data, buf.ctypes.data, None, None, 0, None, None)
+    assert rc == _lib.MH_ERR_INVALID_ARG
+
+
+def test_product_never_imports_oracle():
+    """The product package must not reference oracle/ (no CPU fallback)."""
+    pkg = os.path.join(ROOT, "moby_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".hpp", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "liboracle" not in txt and "oracle_api" not in txt, f
+                assert not re.search(r'#include\s+"[^"]*oracle', txt), f

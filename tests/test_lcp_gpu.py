@@ -1,0 +1,122 @@
+"""GPU parity: the HIP LCP solvers (through the C ABI) against the CPU oracle,
+bit-exact on status / pivots / pivot trace / rand() state / z."""
+import numpy as np
+import pytest
+
+from moby_amd import synth
+from moby_amd.lcp import LCP
+from tests.oracle_api import FAST, FAST_REG, LEMKE, LEMKE_REG, DEFAULT_EXPS
+
+pytestmark = pytest.mark.gpu
+
+TRACE_CAP = 2048
+
+
+def run_gpu(kind, M, q, z0=None, z_size=None, exps=None, seed=1):
+    B, n = q.shape
+    lcp = LCP(B, seed=seed)
+    z = np.zeros((B, n)) if z0 is None else np.array(z0, dtype=np.float64)
+    e = exps if exps is not None else DEFAULT_EXPS[kind]
+    if kind == FAST:
+        ok = lcp.lcp_fast(M, q, z, z_size=z_size, trace_cap=TRACE_CAP)
+    elif kind == FAST_REG:
+        ok = lcp.lcp_fast_regularized(M, q, z, *e, z_size=z_size, trace_cap=TRACE_CAP)
+    elif kind == LEMKE:
+        ok = lcp.lcp_lemke(M, q, z, z_size=z_size, trace_cap=TRACE_CAP)
+    else:
+        ok = lcp.lcp_lemke_regularized(M, q, z, *e, z_size=z_size, trace_cap=TRACE_CAP)
+    return ok, z, lcp
+
+
+def assert_parity(oracle, kind, M, q, z0=None, z_size=None, exps=None, seed=1):
+    B, n = q.shape
+    ok, z, lcp = run_gpu(kind, M, q, z0, z_size, exps, seed)
+    for b in range(B):
+        zs = n if z_size is None else int(z_size[b])
+        r = oracle.lcp(kind, M[b], q[b], z=None if z0 is None else z0[b], z_size=zs,
+                       rng=oracle.rand_state(seed), exps=exps, trace_cap=TRACE_CAP)
+        tag = "kind %d n %d problem %d" % (kind, n, b)
+        assert bool(ok[b]) == r["ok"], tag
+        assert int(lcp.pivots[b]) == r["pivots"], tag
+        assert int(lcp.trace_len[b]) == r["trace_len"], tag
+        L = min(r["trace_len"], TRACE_CAP)
+        np.testing.assert_array_equal(lcp.trace[b, :L], r["trace"][:L], err_msg=tag)
+        np.testing.assert_array_equal(lcp.rng[b], r["rng"], err_msg=tag)
+        assert int(lcp.z_size[b]) == r["z_size"], tag
+        if r["ok"]:
+            np.testing.assert_array_equal(z[b], r["z"], err_msg=tag)   # bit-exact (-0 == 0)
+    return ok
+
+
+@pytest.mark.parametrize("kind", [FAST, FAST_REG, LEMKE, LEMKE_REG])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 17, 42, 64])
+def test_random_pd_cold(oracle, kind, n):
+    M, q = synth.random_lcp(6, n, "pd", seed=100 + n)
+    assert_parity(oracle, kind, M, q, z_size=np.zeros(6, dtype=np.int32))
+
+
+@pytest.mark.parametrize("kind", [FAST, FAST_REG, LEMKE, LEMKE_REG])
+@pytest.mark.parametrize("fam", ["psd", "copos"])
+@pytest.mark.parametrize("n", [4, 10, 42])
+def test_degenerate_families(oracle, kind, fam, n):
+    M, q = synth.random_lcp(6, n, fam, seed=7 * n)
+    assert_parity(oracle, kind, M, q, z_size=np.zeros(6, dtype=np.int32))
+
+
+@pytest.mark.parametrize("kind", [FAST, FAST_REG])
+def test_warm_start(oracle, kind):
+    n = 24
+    M, q = synth.random_lcp(8, n, "pd", seed=11)
+    ok, z, _ = run_gpu(LEMKE, M, q)
+    assert ok.all()
+    # perturb q slightly and warm start from the previous solution
+    q2 = q + 1e-3 * np.random.default_rng(1).standard_normal(q.shape)
+    assert_parity(oracle, kind, M, q2, z0=z)
+
+
+def test_sphere_stack_bundle(oracle):
+    """The config-2 impact LCPs (n = 42): the handler's first call
+    lcp_fast_regularized(-20,4,-8) (ICH-QP:219), then the Lemke ladder on the
+    failures (ICH-QP:221-225) with the rand() stream carried over."""
+    B = 64
+    M, q = synth.sphere_stack_impact_lcp(B)
+    ok = assert_parity(oracle, FAST_REG, M, q, z0=np.zeros((B, 42)), exps=(-20, 4, -8))
+    assert ok[0]
+    assert_parity(oracle, LEMKE_REG, M, q, z0=np.zeros((B, 42)))
+
+
+def test_kats_on_gpu(oracle):
+    g, dt = 9.81, 1e-3
+    M = np.array([[[1.0, -1, 0], [-1, 2, -1], [0, -1, 2]]])
+    q = np.array([[-g * dt, 0.0, 0.0]])
+    for kind in (FAST, FAST_REG, LEMKE, LEMKE_REG):
+        ok, z, _ = run_gpu(kind, M, q, z_size=np.zeros(1, dtype=np.int32))
+        assert ok[0]
+        np.testing.assert_allclose(z[0], g * dt * np.array([3.0, 2.0, 1.0]), rtol=1e-13)
+    # singular first pivot -> ladder (see tests/test_oracle_lcp.py)
+    M = np.array([[[0.0, 0.0], [0.0, 1.0]]]); q = np.array([[-1.0, -1.0]])
+    assert_parity(oracle, FAST, M, q, z_size=np.zeros(1, dtype=np.int32))
+    assert_parity(oracle, FAST_REG, M, q, z_size=np.zeros(1, dtype=np.int32), exps=(-20, 4, 20))
+
+
+def test_lemke_rand_consumption(oracle):
+    M, q = synth.random_lcp(4, 6, "pd", seed=9)
+    assert_parity(oracle, LEMKE, M, q, z_size=np.array([6, 0, 12, 6], dtype=np.int32))
+
+
+def test_full_batch_properties():
+    """4096 worlds (BASELINE config 2 size): size-independent properties --
+    complementarity of every accepted solution and batch-order independence."""
+    B = 4096
+    M64, q64 = synth.sphere_stack_impact_lcp(64)
+    reps = B // 64
+    M = np.tile(M64, (reps, 1, 1)); q = np.tile(q64, (reps, 1))
+    ok, z, lcp = run_gpu(FAST_REG, M, q, z0=np.zeros((B, 42)), exps=(-20, 4, -8))
+    # identical problems with identical rand() streams give identical answers
+    for r in range(1, reps):
+        np.testing.assert_array_equal(ok[:64], ok[r * 64:(r + 1) * 64])
+        np.testing.assert_array_equal(z[:64], z[r * 64:(r + 1) * 64])
+    w = np.einsum("bij,bj->bi", M, z) + q
+    good = ok.astype(bool)
+    assert good.sum() > 0
+    assert z[good].min() > -1e-9 and w[good].min() > -1e-7 and np.abs(z[good] * w[good]).max() < 1e-7
