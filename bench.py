@@ -70,7 +70,7 @@ def main():
     # synthetic batch: 64 distinct perturbed worlds (world 0 = the reference
     # scene), tiled to B; shard r of an N-GPU job takes worlds offset by r*64
     base = 64
-    Mh, qh = synth.sphere_stack_impact_lcp(base, first_world=0 if rank == 0 else rank * base)
+    Mh, qh = synth.sphere_stack_impact_lcp(base, first_world=0 if rank == 0 else rank * base, hard=False)
     reps = (B + base - 1) // base
     Mcm = np.ascontiguousarray(np.transpose(np.tile(Mh, (reps, 1, 1))[:B], (0, 2, 1)))
     qb = np.tile(qh, (reps, 1))[:B].copy()

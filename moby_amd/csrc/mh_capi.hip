@@ -53,25 +53,37 @@ void mh_k_lcp_wave(int B, int n, const double* __restrict__ Mg, int ld, long str
   double* A = Ms + n * n;
   double* art = A + n * n;
   const double* Mb = Mg + (size_t)b * strideM;
-  // stream M into LDS, tracking the off-diagonal max |m| for norm_inf
-  double offmax = 0.0;
+  // stream M into LDS (the one HBM read of n^2 doubles), 8 x 16 B loads in
+  // flight per lane, tracking norm_inf(M) = max |m| on the way
+  double nrm0 = 0.0;
   const int nn = n * n;
-  if (ld == n) {
-    for (int e = lane; e < nn; e += 64) {
-      const double v = Mb[e];
-      Ms[e] = v;
-      const int c = e / n, r = e - c * n;
-      if (r != c) { const double a = fabs(v); offmax = (a > offmax) ? a : offmax; }
+  if (ld == n && ((((size_t)Mb) & 15) == 0) && (nn & 1) == 0) {
+    const double2* src = reinterpret_cast<const double2*>(Mb);
+    double2* dst = reinterpret_cast<double2*>(Ms);
+    const int n2 = nn >> 1;
+    for (int e0 = 0; e0 < n2; e0 += 8 * 64) {
+      double2 v[8];
+#pragma unroll
+      for (int t = 0; t < 8; t++) { const int e = e0 + t * 64 + lane; v[t] = (e < n2) ? src[e] : make_double2(0.0, 0.0); }
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const int e = e0 + t * 64 + lane;
+        if (e < n2) dst[e] = v[t];
+        const double a0 = fabs(v[t].x), a1 = fabs(v[t].y);
+        nrm0 = (a0 > nrm0) ? a0 : nrm0; nrm0 = (a1 > nrm0) ? a1 : nrm0;
+      }
     }
   } else {
-    for (int e = lane; e < nn; e += 64) {
-      const int c = e / n, r = e - c * n;
-      const double v = Mb[r + (size_t)ld * c];
-      Ms[e] = v;
-      if (r != c) { const double a = fabs(v); offmax = (a > offmax) ? a : offmax; }
+    for (int c = 0; c < n; c++) {
+      if (lane < n) {
+        const double v = Mb[lane + (size_t)ld * c];
+        Ms[lane + n * c] = v;
+        const double a = fabs(v);
+        nrm0 = (a > nrm0) ? a : nrm0;
+      }
     }
   }
-  offmax = mh::wave_max(offmax);
+  nrm0 = mh::wave_max(nrm0);
   mh::wave_sync();
   const bool valid = lane < n;
   const double dii = valid ? Ms[lane + n * lane] : 0.0;
@@ -81,7 +93,7 @@ void mh_k_lcp_wave(int B, int n, const double* __restrict__ Mg, int ld, long str
   mh::WaveRand rng; rng.load(rngg + (size_t)b * MH_RAND_WORDS);
   mh::Trace tr; tr.buf = trace ? trace + (size_t)b * trace_cap : nullptr; tr.cap = trace_cap; tr.len = 0;
   unsigned piv = 0;
-  const bool ok = mh::lcp_solve_wave(P, p10, n, Ms, A, art, offmax, dii, qi, zi, zsize, rng, piv, tr);
+  const bool ok = mh::lcp_solve_wave(P, p10, n, Ms, A, art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
   if (valid) zg[(size_t)b * n + lane] = zi;
   rng.store(rngg + (size_t)b * MH_RAND_WORDS);
   if (lane == 0) {

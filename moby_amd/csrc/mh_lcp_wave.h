@@ -65,8 +65,19 @@ MH_DEV int lu_solve_wave(int k, double* A, double& b)
         double l = A[lane + k * j];
         if (fabs(piv) >= MH_SFMIN) { const double r = 1.0 / piv; l = l * r; } else l = l / piv;
         A[lane + k * j] = l;
-        for (int c = j + 1; c < k; c++)
-          A[lane + k * c] = A[lane + k * c] - l * A[j + k * c];
+        // rank-1 update, 8 columns per trip: all LDS reads of a trip are
+        // issued before its writes so their latencies overlap
+        for (int c0 = j + 1; c0 < k; c0 += 8) {
+          double a[8], u[8];
+#pragma unroll
+          for (int t = 0; t < 8; t++) {
+            const int c = (c0 + t < k) ? c0 + t : k - 1;
+            a[t] = A[lane + k * c]; u[t] = A[j + k * c];
+          }
+#pragma unroll
+          for (int t = 0; t < 8; t++)
+            if (c0 + t < k) A[lane + k * (c0 + t)] = a[t] - l * u[t];
+        }
       }
       wave_sync();
     }
@@ -314,14 +325,26 @@ struct LcpParams { int kind; int min_exp; unsigned step_exp; int max_exp; double
 // handlers use (-20..1); table produced by the host's libm at load time.
 struct Pow10Table { double v[64]; }; // index rf + 32
 
-// Dispatch over the four public solvers.  offmax/dii: off-diagonal max |M| and
-// this lane's diagonal entry (for norm_inf of M + lam*I).
+// Dispatch over the four public solvers.  nrm0 = norm_inf(M) (max |m|), dii =
+// this lane's diagonal entry (for norm_inf of M + lam*I on the ladder).
+// max |M(r,c)|, r != c, from the LDS copy (only the regularisation ladder needs it)
+MH_DEV double offdiag_max(int n, const double* M)
+{
+  const int lane = lane_id();
+  double m = 0.0;
+  if (lane < n)
+    for (int c = 0; c < n; c++) {
+      const double a = fabs(M[lane + n * c]);
+      if (c != lane && a > m) m = a;
+    }
+  return wave_max(m);
+}
+
 MH_DEV bool lcp_solve_wave(const LcpParams& P, const Pow10Table& p10, int n, const double* M, double* A, double* art,
-                           double offmax, double dii, double qi, double& zi, int& zsize,
+                           double nrm0, double dii, double qi, double& zi, int& zsize,
                            WaveRand& rng, unsigned& pivots, Trace& tr)
 {
   const bool valid = lane_id() < n;
-  const double nrm0 = norm_reg(offmax, dii, valid, 0.0);
   if (P.kind == MH_LCP_FAST)
     return lcp_fast_wave(n, M, 0.0, A, qi, zi, zsize, P.zero_tol, nrm0, rng, pivots, tr);
   if (P.kind == MH_LCP_LEMKE)
@@ -336,6 +359,7 @@ MH_DEV bool lcp_solve_wave(const LcpParams& P, const Pow10Table& p10, int n, con
   if (ok && verify_wave(n, M, 0.0, qi, zi, ZERO_TOL, false)) return true;
   total += pivots;
   int attempt = 1;
+  const double offmax = offdiag_max(n, M);
   for (int rf = P.min_exp; rf < P.max_exp; rf += (int)P.step_exp, attempt++) {
     const double lam = p10.v[rf + 32];
     const double nrm = norm_reg(offmax, dii, valid, lam);

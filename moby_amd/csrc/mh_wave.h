@@ -49,40 +49,47 @@ MH_DEV int nth_set_bit(uint64_t m, int r) {
   return ctz(m);
 }
 
+// ---- DPP wave reductions (VALU-latency, no LDS crossbar) -------------------
+// Classic gfx9 pattern: xor-1 / xor-2 inside a quad, half-mirror (8), mirror
+// (16), then row_bcast15 / row_bcast31 to fold the four rows; lane 63 ends up
+// with the reduction over all 64 lanes.
+template <int CTRL, int ROW_MASK>
+MH_DEV double dpp_move(double v) {
+  long long b = __double_as_longlong(v);
+  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+#define MH_DPP_REDUCE(v, PICK)                                            \
+  { double o_;                                                            \
+    o_ = dpp_move<0xB1, 0xf>(v);  v = PICK(o_, v);  /* quad_perm [1,0,3,2] */ \
+    o_ = dpp_move<0x4E, 0xf>(v);  v = PICK(o_, v);  /* quad_perm [2,3,0,1] */ \
+    o_ = dpp_move<0x141, 0xf>(v); v = PICK(o_, v);  /* row_half_mirror    */ \
+    o_ = dpp_move<0x140, 0xf>(v); v = PICK(o_, v);  /* row_mirror         */ \
+    o_ = dpp_move<0x142, 0xa>(v); v = PICK(o_, v);  /* row_bcast15        */ \
+    o_ = dpp_move<0x143, 0xc>(v); v = PICK(o_, v);  /* row_bcast31        */ }
+#define MH_PICK_MIN(o, v) (((o) < (v)) ? (o) : (v))
+#define MH_PICK_MAX(o, v) (((o) > (v)) ? (o) : (v))
+
+MH_DEV double wave_max(double v) { MH_DPP_REDUCE(v, MH_PICK_MAX); return read_lane(v, 63); }
+MH_DEV double wave_min(double v) { MH_DPP_REDUCE(v, MH_PICK_MIN); return read_lane(v, 63); }
+
 // first-index argmin over the lanes with valid==true; returns uniform (value, lane).
-// Ties resolve to the lowest lane, as std::min_element does.
+// Ties resolve to the lowest lane, as std::min_element does: reduce the value,
+// then ballot the lanes that hold it.
 MH_DEV void argmin_first(double v, bool valid, double& vmin, int& imin) {
-  int idx = valid ? lane_id() : 0x7fffffff;
   if (!valid) v = __longlong_as_double(0x7ff0000000000000ll); // +inf
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    double ov = __shfl_xor(v, off);
-    int oi = __shfl_xor(idx, off);
-    if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-  }
-  vmin = uni(v); imin = uni(idx);
+  vmin = wave_min(v);
+  const uint64_t m = ballot(valid && v == vmin);
+  imin = m ? ctz(m) : 0x7fffffff;
 }
-// first-index argmax (idamax over |a| supplied by the caller)
+// first-index argmax (idamax over |a| supplied by the caller, a >= 0)
 MH_DEV void argmax_first(double v, bool valid, double& vmax, int& imax) {
-  int idx = valid ? lane_id() : 0x7fffffff;
   if (!valid) v = -1.0;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    double ov = __shfl_xor(v, off);
-    int oi = __shfl_xor(idx, off);
-    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-  }
-  vmax = uni(v); imax = uni(idx);
-}
-MH_DEV double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) { double ov = __shfl_xor(v, off); v = (ov > v) ? ov : v; }
-  return uni(v);
-}
-MH_DEV double wave_min(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) { double ov = __shfl_xor(v, off); v = (ov < v) ? ov : v; }
-  return uni(v);
+  vmax = wave_max(v);
+  const uint64_t m = ballot(valid && v == vmax);
+  imax = m ? ctz(m) : 0x7fffffff;
 }
 
 // forward permute: every lane sends v to lane dest (dest must be a permutation

@@ -100,14 +100,18 @@ def impact_lcp_from_contacts(bodies, contacts, nk=16, mu=0.0, mu_visc=0.0):
     return MM, qq
 
 
-def sphere_stack_world(world, dt=1e-3, g=9.81):
+def sphere_stack_world(world, dt=1e-3, g=9.81, hard=True):
     """State of world `world` just before its first impact solve: world 0 is the
-    reference scene; others get x,y offsets U(-1e-3,1e-3) per sphere and
-    initial v_z U(-0.1,0)."""
+    reference scene; others get x,y offsets U(-1e-3,1e-3) and initial v_z
+    U(-0.1,0) per sphere.  hard=True offsets every sphere
+    independently (tilted sphere-sphere normals: degenerate LCPs on which
+    lcp_fast cycles -- the parity set); hard=False shifts the whole stack (the
+    scene the simulator produces -- the bench set)."""
     u = world_uniforms(world, 9) if world > 0 else np.full(9, 0.5)
     bodies = []
     for k in range(3):
-        off = (u[3 * k:3 * k + 2] - 0.5) * 2e-3 if world > 0 else np.zeros(2)
+        kk = k if hard else 0
+        off = (u[3 * kk:3 * kk + 2] - 0.5) * 2e-3 if world > 0 else np.zeros(2)
         vz0 = -0.1 * u[3 * k + 2] if world > 0 else 0.0
         bodies.append(dict(x=np.array([off[0], off[1], 1.0 + 2.0 * k]),
                            v=np.array([0, 0, vz0 - g * dt, 0, 0, 0.0]), m=1.0, J=[0.4, 0.4, 0.4]))
@@ -119,11 +123,11 @@ def sphere_stack_world(world, dt=1e-3, g=9.81):
     return bodies, contacts
 
 
-def sphere_stack_impact_lcp(B, first_world=0):
+def sphere_stack_impact_lcp(B, first_world=0, hard=True):
     """(M (B,42,42) row-major, q (B,42)) for worlds first_world..first_world+B-1."""
     Ms = np.zeros((B, 42, 42)); qs = np.zeros((B, 42))
     for w in range(B):
-        bodies, contacts = sphere_stack_world(first_world + w)
+        bodies, contacts = sphere_stack_world(first_world + w, hard=hard)
         Ms[w], qs[w] = impact_lcp_from_contacts(bodies, contacts, nk=16, mu=0.0)
     return Ms, qs
 
