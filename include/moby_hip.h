@@ -104,6 +104,91 @@ int mh_lcp_solve_batch(int kind, int B, int n,
                        int32_t* trace, int trace_cap, int* trace_len,
                        const mh_lcp_opts* opts);
 
+
+/* ------------------------------------------------------------------------
+ * Many-worlds stepping: B independent instances of one scene topology.
+ * Replaces, per world, TimeSteppingSimulator::step (src/TimeSteppingSimulator.cpp:
+ * 52-222), ConstraintSimulator::{broad_phase, calc_pairwise_distances,
+ * find_unilateral_constraints, calc_impacting_unilateral_constraint_forces}
+ * (src/ConstraintSimulator.cpp:298-537), ImpactConstraintHandler::
+ * process_constraints (src/ImpactConstraintHandler.cpp:75) with the Drumwright-
+ * Shell QP->LCP model (src/ImpactConstraintHandlerQP.cpp:94-497) and
+ * ConstraintStabilization::stabilize (src/ConstraintStabilization.cpp:167).
+ *
+ * Scene scope of this build: up to MH_MAX_BODIES free rigid bodies with sphere
+ * geometry plus one static plane (the closed-form pairs of CCD.inl:804-847,
+ * 1164-1207), gravity, per-pair ContactParameters.  Body ids are 0..nb-1 in
+ * the order the reference sorts them (by id string); the ground plane, when
+ * present, has id nb.  Pair p enumerates (i<j) lexicographically.
+ */
+#define MH_MAX_BODIES 8
+#define MH_MAX_PAIRS  36            /* C(MH_MAX_BODIES + 1, 2) */
+#define MH_BODY_STATE 13            /* x(3) quat xyzw(4) v(3) omega(3), world axes, at the COM */
+#define MH_GEOM_SPHERE 0
+
+typedef struct mh_scene {
+  int    nb;                               /* enabled rigid bodies */
+  int    has_ground;                       /* static Plane primitive present */
+  int    geom_type[MH_MAX_BODIES];         /* MH_GEOM_* */
+  double geom_dim[MH_MAX_BODIES][3];       /* sphere: radius,-,- */
+  double mass[MH_MAX_BODIES];
+  double inertia[MH_MAX_BODIES][3];        /* body-frame principal inertia (SpherePrimitive.cpp:138-155) */
+  double plane_R[9];                       /* row-major rotation of the plane frame; its +Y is the normal (PlanePrimitive) */
+  double plane_o[3];
+  double gravity[3];                       /* GravityForce accel (GravityForce.cpp:33-69) */
+  int    pair_enabled[MH_MAX_PAIRS];       /* 0 = <DisabledPair> */
+  double cp_epsilon[MH_MAX_PAIRS];         /* ContactParameters.cpp:98-135 */
+  double cp_mu_coulomb[MH_MAX_PAIRS];
+  double cp_mu_viscous[MH_MAX_PAIRS];
+  double cp_compliance[MH_MAX_PAIRS];
+  int    cp_nk[MH_MAX_PAIRS];              /* friction-cone-edges (>= 4) */
+  double min_step_size;                    /* TimeSteppingSimulator.cpp:48  (sqrt eps) */
+  double contact_dist_thresh;              /* ConstraintSimulator.cpp:56    (1e-6)     */
+  double cstab_eps;                        /* ConstraintStabilization.cpp:59 (sqrt eps) */
+  unsigned cstab_max_iterations;           /* ConstraintStabilization.cpp:56 (UINT_MAX) */
+} mh_scene;
+
+/* status bits of mh_world_aux.status */
+#define MH_WORLD_OK            0
+#define MH_WORLD_LCP_FAILED    1   /* LCPSolverException (ImpactConstraintHandlerQP.cpp:225) */
+#define MH_WORLD_IMPACT_TOL    2   /* ImpactToleranceException (warned only, ConstraintSimulator.cpp:342) */
+#define MH_WORLD_UNSUPPORTED   4   /* island larger than the wave solver covers / unsupported model */
+#define MH_WORLD_STAB_FAILED   8   /* update_q gave up (ConstraintStabilization.cpp:230-234) */
+#define MH_WORLD_STALLED       16   /* > 100000 zero-length mini-steps in one step (the reference would not return) */
+
+/* persistent per-world solver state (what the reference keeps in the
+ * simulator / handler / libc between steps) + counters */
+typedef struct mh_world_aux {
+  uint32_t rng[MH_RAND_WORDS];     /* libc rand() stream                                   */
+  double   time;                   /* Simulator::current_time                              */
+  double   zlast[MH_LCP_MAX_N_WAVE];  /* ImpactConstraintHandler::_zlast (ICH-QP:158-162,233) */
+  double   zbuf[MH_LCP_MAX_N_WAVE];   /* storage of ImpactConstraintHandler::_z            */
+  int      zlast_size;
+  int      zbuf_size;              /* _z.size()                                            */
+  int      zbuf_cap;               /* entries of zbuf ever written (Ravelin keeps them)    */
+  int      status;                 /* MH_WORLD_* bits, sticky                              */
+  unsigned long long steps;        /* step() calls                                         */
+  unsigned long long mini_steps;   /* do_mini_step calls                                   */
+  unsigned long long lcp_solves;   /* impact + stabilisation LCPs solved                   */
+  unsigned long long lcp_rows;     /* sum of their dimensions (BASELINE metric "rows")     */
+  unsigned long long lcp_pivots;
+  unsigned long long stab_iters;
+} mh_world_aux;
+
+void mh_scene_defaults(mh_scene* s);   /* zero + the reference's default tolerances */
+void mh_world_aux_init(mh_world_aux* a, uint32_t seed);
+
+/* Advance B worlds by nsteps steps of size dt, all inside one launch.
+ *   state   B * nb * MH_BODY_STATE doubles, in/out
+ *   aux     B structs, in/out
+ *   traj    optional B * nsteps * nb * 7 doubles: generalized coordinates (x, quat xyzw)
+ *           AFTER each step (the rows programs/regress.cpp:82-93 prints), or NULL
+ */
+int mh_world_step_batch_dev(void* stream, const mh_scene* scene_host, int B, double dt, int nsteps,
+                            double* state, mh_world_aux* aux, double* traj);
+int mh_world_step_batch(const mh_scene* scene, int B, double dt, int nsteps,
+                        double* state, mh_world_aux* aux, double* traj);
+
 #ifdef __cplusplus
 }
 #endif

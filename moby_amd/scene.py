@@ -1,0 +1,180 @@
+"""Host-side scene description for the many-worlds stepper.
+
+ctypes mirrors of ``mh_scene`` / ``mh_world_aux`` (include/moby_hip.h) and
+builders for the reference scenes the BASELINE configs name:
+
+* ``sphere_stack_scene``   /root/reference/example/stacks/sphere-stack.xml
+* ``bouncing_ball_scene``  /root/reference/example/bouncing-ball/bouncing-ball.xml
+
+Body order = the order programs/regress.cpp:82-93 prints them (sorted by id);
+the static ground is the last id.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+MH_MAX_BODIES = 8
+MH_MAX_PAIRS = 36
+MH_BODY_STATE = 13
+MH_RAND_WORDS = 32
+MH_LCP_MAX_N_WAVE = 64
+NEAR_ZERO = math.sqrt(np.finfo(np.float64).eps)   # include/Moby/Constants.h:21
+
+MH_WORLD_OK, MH_WORLD_LCP_FAILED, MH_WORLD_IMPACT_TOL, MH_WORLD_UNSUPPORTED, MH_WORLD_STAB_FAILED, MH_WORLD_STALLED = 0, 1, 2, 4, 8, 16
+
+
+class mh_scene(ctypes.Structure):
+    _fields_ = [
+        ("nb", ctypes.c_int), ("has_ground", ctypes.c_int),
+        ("geom_type", ctypes.c_int * MH_MAX_BODIES),
+        ("geom_dim", (ctypes.c_double * 3) * MH_MAX_BODIES),
+        ("mass", ctypes.c_double * MH_MAX_BODIES),
+        ("inertia", (ctypes.c_double * 3) * MH_MAX_BODIES),
+        ("plane_R", ctypes.c_double * 9), ("plane_o", ctypes.c_double * 3),
+        ("gravity", ctypes.c_double * 3),
+        ("pair_enabled", ctypes.c_int * MH_MAX_PAIRS),
+        ("cp_epsilon", ctypes.c_double * MH_MAX_PAIRS),
+        ("cp_mu_coulomb", ctypes.c_double * MH_MAX_PAIRS),
+        ("cp_mu_viscous", ctypes.c_double * MH_MAX_PAIRS),
+        ("cp_compliance", ctypes.c_double * MH_MAX_PAIRS),
+        ("cp_nk", ctypes.c_int * MH_MAX_PAIRS),
+        ("min_step_size", ctypes.c_double), ("contact_dist_thresh", ctypes.c_double),
+        ("cstab_eps", ctypes.c_double), ("cstab_max_iterations", ctypes.c_uint),
+    ]
+
+
+class mh_world_aux(ctypes.Structure):
+    _fields_ = [
+        ("rng", ctypes.c_uint32 * MH_RAND_WORDS), ("time", ctypes.c_double),
+        ("zlast", ctypes.c_double * MH_LCP_MAX_N_WAVE), ("zbuf", ctypes.c_double * MH_LCP_MAX_N_WAVE),
+        ("zlast_size", ctypes.c_int), ("zbuf_size", ctypes.c_int), ("zbuf_cap", ctypes.c_int), ("status", ctypes.c_int),
+        ("steps", ctypes.c_ulonglong), ("mini_steps", ctypes.c_ulonglong), ("lcp_solves", ctypes.c_ulonglong),
+        ("lcp_rows", ctypes.c_ulonglong), ("lcp_pivots", ctypes.c_ulonglong), ("stab_iters", ctypes.c_ulonglong),
+    ]
+
+
+AUX_DTYPE = np.dtype([
+    ("rng", np.uint32, MH_RAND_WORDS), ("time", np.float64),
+    ("zlast", np.float64, MH_LCP_MAX_N_WAVE), ("zbuf", np.float64, MH_LCP_MAX_N_WAVE),
+    ("zlast_size", np.int32), ("zbuf_size", np.int32), ("zbuf_cap", np.int32), ("status", np.int32),
+    ("steps", np.uint64), ("mini_steps", np.uint64), ("lcp_solves", np.uint64),
+    ("lcp_rows", np.uint64), ("lcp_pivots", np.uint64), ("stab_iters", np.uint64)], align=True)
+assert AUX_DTYPE.itemsize == ctypes.sizeof(mh_world_aux), (AUX_DTYPE.itemsize, ctypes.sizeof(mh_world_aux))
+
+
+def rpy_to_R(roll, pitch, yaw):
+    """Rotation matrix of an XML ``rpy`` attribute: Rz(yaw) Ry(pitch) Rx(roll)."""
+    cr, sr, cp, sp, cy, sy = math.cos(roll), math.sin(roll), math.cos(pitch), math.sin(pitch), math.cos(yaw), math.sin(yaw)
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                     [-sp, cp * sr, cp * cr]])
+
+
+def pair_index(i, j, ntot):
+    return i * ntot - (i * (i + 1)) // 2 + (j - i - 1)
+
+
+def _defaults(sc):
+    sc.min_step_size = NEAR_ZERO          # TimeSteppingSimulator.cpp:48
+    sc.contact_dist_thresh = 1e-6         # ConstraintSimulator.cpp:56
+    sc.cstab_eps = NEAR_ZERO              # ConstraintStabilization.cpp:59
+    sc.cstab_max_iterations = 0xFFFFFFFF  # ConstraintStabilization.cpp:56
+    for p in range(MH_MAX_PAIRS):
+        sc.pair_enabled[p] = 1
+        sc.cp_nk[p] = 4                   # ContactParameters.cpp:26
+
+
+def make_scene(radii, masses, gravity, ground_rpy=None, ground_o=(0.0, 0.0, 0.0), params=None, inertias=None):
+    """Spheres 0..nb-1 (+ optional plane with id nb).  params: {(i, j): dict(epsilon, mu_coulomb,
+    mu_viscous, compliance, nk)} with i < j."""
+    sc = mh_scene()
+    _defaults(sc)
+    nb = len(radii)
+    sc.nb = nb
+    sc.has_ground = 1 if ground_rpy is not None else 0
+    for b in range(nb):
+        sc.geom_type[b] = 0
+        sc.geom_dim[b][0] = radii[b]
+        sc.mass[b] = masses[b]
+        diag = (radii[b] * radii[b] * masses[b] * 2.0 / 5.0) if inertias is None else inertias[b]   # SpherePrimitive.cpp:149
+        for k in range(3):
+            sc.inertia[b][k] = diag
+    R = rpy_to_R(*ground_rpy) if ground_rpy is not None else np.eye(3)
+    for k in range(9):
+        sc.plane_R[k] = R.flat[k]
+    for k in range(3):
+        sc.plane_o[k] = ground_o[k]
+        sc.gravity[k] = gravity[k]
+    ntot = nb + sc.has_ground
+    for (i, j), d in (params or {}).items():
+        p = pair_index(i, j, ntot)
+        sc.cp_epsilon[p] = d.get("epsilon", 0.0)
+        sc.cp_mu_coulomb[p] = d.get("mu_coulomb", 0.0)
+        sc.cp_mu_viscous[p] = d.get("mu_viscous", 0.0)
+        sc.cp_compliance[p] = d.get("compliance", 0.0)
+        sc.cp_nk[p] = max(4, d.get("nk", 4))
+    return sc
+
+
+def sphere_stack_scene(cstab_max_iterations=10):
+    """example/stacks/sphere-stack.xml:11-51.
+
+    ``constraint-stabilization-max-iterations`` is not set in the XML (default
+    UINT_MAX, ConstraintStabilization.cpp:56), but with the arithmetic restated
+    in oracle/world.hpp the stabilisation loop enters an exact 2-cycle at step 3
+    of this scene (tests/test_oracle_world.py::test_stabilisation_cycle), so the
+    batch configs run it with a finite cap ("stabilisation cap")."""
+    cp = dict(epsilon=0.0, mu_coulomb=0.0, mu_viscous=0.0, nk=16)
+    sc = _sphere_stack_scene(cp)
+    sc.cstab_max_iterations = cstab_max_iterations
+    return sc
+
+
+def _sphere_stack_scene(cp):
+    return make_scene([1.0, 1.0, 1.0], [1.0, 1.0, 1.0], (0.0, 0.0, -9.81),
+                      ground_rpy=(1.5707963267949, 0.0, 0.0),
+                      params={(0, 3): cp, (0, 1): cp, (1, 2): cp})
+
+
+def sphere_stack_state(B=1, perturb=True):
+    """Initial states (B, 3*13): world 0 is the reference scene; world w > 0 shifts
+    the stack by U(-1e-3,1e-3) in x,y and gives each sphere v_z U(-0.1,0)."""
+    from .synth import world_uniforms
+    st = np.zeros((B, 3, MH_BODY_STATE))
+    for w in range(B):
+        u = world_uniforms(w, 5) if (perturb and w > 0) else None
+        for k in range(3):
+            st[w, k, 0:3] = (0.0, 0.0, 1.0 + 2.0 * k)
+            st[w, k, 6] = 1.0
+            if u is not None:
+                st[w, k, 0] += (u[0] - 0.5) * 2e-3
+                st[w, k, 1] += (u[1] - 0.5) * 2e-3
+                st[w, k, 9] = -0.1 * u[2 + k]
+    return st.reshape(B, 3 * MH_BODY_STATE)
+
+
+def bouncing_ball_scene():
+    """example/bouncing-ball/bouncing-ball.xml:11-37 (density 1 => m = 4 pi / 3)."""
+    r = 1.0
+    m = 1.0 * (math.pi * r * r * r * 4.0 / 3.0)     # SpherePrimitive.cpp:144-146
+    return make_scene([r], [m], (0.0, -9.81, 0.0), ground_rpy=(0.0, 0.0, 0.0),
+                      params={(0, 1): dict(epsilon=1.0, mu_coulomb=0.0, mu_viscous=0.0, nk=4)})
+
+
+def bouncing_ball_state(B=1):
+    st = np.zeros((B, 1, MH_BODY_STATE))
+    st[:, 0, 0:3] = (0.0, 1.5, 0.0)
+    st[:, 0, 6] = 1.0
+    st[:, 0, 10:13] = (0.0, 10.0, 0.0)
+    return st.reshape(B, MH_BODY_STATE)
+
+
+def new_aux(B, seed=1):
+    """B fresh mh_world_aux records (numpy structured array), rand() at srand(seed)."""
+    from . import _lib
+    aux = np.zeros(B, dtype=AUX_DTYPE)
+    st = np.zeros(MH_RAND_WORDS, dtype=np.uint32)
+    _lib.load().mh_rand_seed(st.ctypes.data, seed)
+    aux["rng"][:] = st
+    return aux

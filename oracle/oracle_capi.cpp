@@ -87,3 +87,65 @@ double oracle_lcp_solve_batch(int kind, int B, int n, const double* M, int ld, l
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------
+// world stepper (oracle/world.hpp)
+#include "world.hpp"
+
+extern "C" {
+
+void oracle_world_aux_init(mh_world_aux* a, uint32_t seed)
+{
+  std::memset(a, 0, sizeof(*a));
+  oracle_srand_state(a->rng, seed);
+}
+
+// Steps ONE world nsteps times; traj (nsteps x nb x 7) and trace optional.
+// Returns elapsed seconds.
+double oracle_world_step(const mh_scene* sc, double dt, int nsteps, double* state, mh_world_aux* aux,
+                         double* traj, int32_t* trace, int trace_cap, int* trace_len)
+{
+  timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+  World w(sc, state, aux);
+  w.trace = trace; w.trace_cap = trace_cap;
+  for (int s = 0; s < nsteps; s++) {
+    w.step(dt);
+    if (traj) for (int b = 0; b < sc->nb; b++) for (int k = 0; k < 7; k++) traj[((size_t)s * sc->nb + b) * 7 + k] = state[13*b + k];
+  }
+  if (trace_len) *trace_len = w.trace_len;
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}
+
+// B worlds sequentially on one thread (CPU baseline); returns elapsed seconds
+double oracle_world_step_batch(const mh_scene* sc, int B, double dt, int nsteps, double* state, mh_world_aux* aux)
+{
+  timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int b = 0; b < B; b++) {
+    World w(sc, state + (size_t)b * sc->nb * 13, aux + b);
+    for (int s = 0; s < nsteps; s++) w.step(dt);
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}
+
+// the impact LCP (_MM column-major n x n, _qq) the handler would assemble for the
+// current state's contacts (first active island), for cross-checks; returns n
+int oracle_world_impact_lcp(const mh_scene* sc, double* state, mh_world_aux* aux, double* MM, double* qq, int cap)
+{
+  World w(sc, state, aux);
+  std::vector<int> pairs; w.broad_phase(0.0, pairs);
+  std::vector<PairDist> pd; w.calc_pairwise_distances(pairs, pd);
+  std::vector<Contact> cs;
+  for (const PairDist& d : pd) if (d.dist < sc->contact_dist_thresh) w.find_contacts(d.pair, sc->contact_dist_thresh, cs);
+  std::vector<World::Island> isl; w.find_islands(cs, isl);
+  if (isl.empty()) return 0;
+  World::ProblemData p; w.compute_problem_data(cs, isl[0], p, false);
+  std::vector<double> M, q; int n; w.build_impact_lcp(p, M, q, n);
+  if (n > cap) return -n;
+  std::memcpy(MM, M.data(), sizeof(double) * (size_t)n * n);
+  std::memcpy(qq, q.data(), sizeof(double) * n);
+  return n;
+}
+
+} // extern "C"

@@ -1,0 +1,843 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU restatement of one Moby world: TimeSteppingSimulator::step and
+// everything it drives, for scenes of free rigid SPHERES plus one static
+// PLANE (BASELINE configs 1 and 2).  Each function cites the reference code it
+// follows (/root/reference/...).  Arithmetic that lives in Ravelin (poses,
+// spatial transforms, rigid-body dynamics, quaternion maps, dense products) is
+// NOT in the tree: it is restated here from first principles with
+// an explicit operation order, which is the order the HIP kernels reproduce
+// bit for bit.  Those parts are "parity unpinned" against a reference binary
+// and pinned only through regress/sphere-stack.dat (6 digits) and physics
+// property tests.
+//
+// Canonical orders (the reference's are heap-address dependent):
+//   bodies by id 0..nb-1, ground = nb; pairs (i<j) lexicographic; geometry of
+//   the lower id is "A" of a pair; islands start from the lowest body id.
+//
+// Reference quirks reproduced on purpose:
+//   * swept bounding volumes and calc_max_dist use the velocity of the body
+//     point at the GLOBAL ORIGIN (Pose3d::transform(GLOBAL, v) of a spatial
+//     velocity: BoundingSphere.cpp:88, CCD.cpp:597);
+//   * positions are integrated with the OLD velocity (TSS:156-164);
+//   * lcp_fast warm-starts from whatever is in _z when sizes differ
+//     (ICH-QP:158-162 + LCP.cpp:65);
+//   * stabilisation measures progress on the SIMULATOR's pair list but builds
+//     its LCP from its own broad phase with dt = 0 (CStab:97,364);
+//   * restitution re-applies z on top of the compression impulse (ICH:578-602).
+#ifndef ORACLE_WORLD_HPP
+#define ORACLE_WORLD_HPP
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cfloat>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "../include/moby_hip.h"
+#include "lcp.hpp"
+
+namespace oracle {
+
+struct V3 { double x, y, z; };
+static inline V3 v3(double x, double y, double z) { V3 r = {x, y, z}; return r; }
+static inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+static inline V3 operator*(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+static inline V3 operator/(V3 a, double s) { return v3(a.x / s, a.y / s, a.z / s); }
+static inline double dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
+static inline double comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+static const double NEAR_ZERO = 1.4901161193847656e-08;  // Constants.h:21
+static const double INF = DBL_MAX;
+
+struct Contact {            // UnilateralConstraint (eContact)
+  int g1, g2;               // contact_geom1 / contact_geom2 body ids (nb = ground)
+  int pair;                 // pair index (contact parameters)
+  V3 p, n, s, t;            // contact_point, normal (from g2 toward g1), tangents
+  double dist;              // signed_violation
+  double mu, muv, eps, compliance; int nk;
+};
+
+struct PairDist { int pair, a, b; double dist; V3 pa, pb; };  // PairwiseDistInfo (global points)
+
+class World {
+ public:
+  const mh_scene* sc;
+  double* st;               // nb * 13
+  mh_world_aux* aux;
+  int32_t* trace = nullptr; int trace_cap = 0; int trace_len = 0;  // concatenated LCP traces (tests)
+
+  World(const mh_scene* scene, double* state, mh_world_aux* a) : sc(scene), st(state), aux(a) {}
+
+  // ---- state access -------------------------------------------------------
+  V3 X(int b) const { return v3(st[13*b], st[13*b+1], st[13*b+2]); }
+  V3 Vl(int b) const { return v3(st[13*b+7], st[13*b+8], st[13*b+9]); }
+  V3 Wa(int b) const { return v3(st[13*b+10], st[13*b+11], st[13*b+12]); }
+  void setX(int b, V3 v) { st[13*b] = v.x; st[13*b+1] = v.y; st[13*b+2] = v.z; }
+  void setV(int b, V3 v) { st[13*b+7] = v.x; st[13*b+8] = v.y; st[13*b+9] = v.z; }
+  void setW(int b, V3 v) { st[13*b+10] = v.x; st[13*b+11] = v.y; st[13*b+12] = v.z; }
+  bool enabled(int b) const { return b < sc->nb; }
+  int nbodies_all() const { return sc->nb + (sc->has_ground ? 1 : 0); }
+  static int pair_index(int i, int j, int ntot) { // i<j, lexicographic
+    return i * ntot - (i * (i + 1)) / 2 + (j - i - 1);
+  }
+  // rotation matrix of body b from its quaternion (x,y,z,w)
+  void rot(int b, double R[9]) const {
+    const double x = st[13*b+3], y = st[13*b+4], z = st[13*b+5], w = st[13*b+6];
+    R[0] = 1.0 - 2.0 * (y*y + z*z); R[1] = 2.0 * (x*y - z*w);       R[2] = 2.0 * (x*z + y*w);
+    R[3] = 2.0 * (x*y + z*w);       R[4] = 1.0 - 2.0 * (x*x + z*z); R[5] = 2.0 * (y*z - x*w);
+    R[6] = 2.0 * (x*z - y*w);       R[7] = 2.0 * (y*z + x*w);       R[8] = 1.0 - 2.0 * (x*x + y*y);
+  }
+  // velocity of the body point at world point p (spatial velocity transformed to a frame at p)
+  V3 point_vel(int b, V3 p) const {
+    if (!enabled(b)) return v3(0, 0, 0);
+    return Vl(b) + cross(Wa(b), p - X(b));
+  }
+  V3 plane_n() const { return v3(sc->plane_R[1], sc->plane_R[4], sc->plane_R[7]); }
+  V3 to_plane(V3 p) const { // R^T (p - o)
+    const double* R = sc->plane_R; V3 d = p - v3(sc->plane_o[0], sc->plane_o[1], sc->plane_o[2]);
+    return v3((R[0]*d.x + R[3]*d.y) + R[6]*d.z, (R[1]*d.x + R[4]*d.y) + R[7]*d.z, (R[2]*d.x + R[5]*d.y) + R[8]*d.z);
+  }
+  V3 from_plane(V3 p) const { // o + R p
+    const double* R = sc->plane_R;
+    return v3(sc->plane_o[0] + ((R[0]*p.x + R[1]*p.y) + R[2]*p.z),
+              sc->plane_o[1] + ((R[3]*p.x + R[4]*p.y) + R[5]*p.z),
+              sc->plane_o[2] + ((R[6]*p.x + R[7]*p.y) + R[8]*p.z));
+  }
+
+  // ---- collision detection --------------------------------------------------
+  // CCD::broad_phase (CCD.cpp:702-876) with SSL bounds (SSL.cpp:550-579) of the
+  // swept bounding sphere (BoundingSphere.cpp:71-95); the plane has an infinite
+  // DummyBV (DummyBV.h:53-56).
+  void broad_phase(double dt, std::vector<int>& pairs) const {
+    const int ntot = nbodies_all();
+    double lo[MH_MAX_BODIES + 1][3], hi[MH_MAX_BODIES + 1][3];
+    for (int b = 0; b < ntot; b++) {
+      if (!enabled(b)) { for (int k = 0; k < 3; k++) { lo[b][k] = -INF; hi[b][k] = INF; } continue; }
+      const V3 c = X(b);
+      const V3 vdt = Vl(b) * dt, wdt = Wa(b) * dt;
+      const V3 lin = vdt + cross(c, wdt);            // linear part of (v dt) expressed at the global origin
+      const V3 p2 = c + lin;
+      const double r = sc->geom_dim[b][0];
+      for (int k = 0; k < 3; k++) {
+        const double a = comp(c, k), e = comp(p2, k);
+        lo[b][k] = ((a < e) ? a : e) - r;
+        hi[b][k] = ((a > e) ? a : e) + r;
+      }
+    }
+    pairs.clear();
+    for (int i = 0; i < ntot; i++)
+      for (int j = i + 1; j < ntot; j++) {
+        const int p = pair_index(i, j, ntot);
+        bool ov = true;
+        for (int k = 0; k < 3; k++) if (!(lo[i][k] <= hi[j][k] && lo[j][k] <= hi[i][k])) ov = false;
+        if (!ov) continue;                          // needs overlap on all three axes (CCD.cpp:857)
+        if (!sc->pair_enabled[p]) continue;
+        if (!enabled(i) && !enabled(j)) continue;
+        pairs.push_back(p);
+      }
+  }
+  void pair_bodies(int p, int& a, int& b) const {
+    const int ntot = nbodies_all();
+    for (int i = 0; i < ntot; i++) for (int j = i + 1; j < ntot; j++) if (pair_index(i, j, ntot) == p) { a = i; b = j; return; }
+    a = b = -1;
+  }
+  // CollisionGeometry::calc_signed_dist (CollisionGeometry.cpp:236-250) ->
+  // SpherePrimitive.cpp:104-136 / PlanePrimitive.cpp:385-411
+  PairDist signed_dist(int p) const {
+    PairDist d; d.pair = p; pair_bodies(p, d.a, d.b);
+    if (enabled(d.a) && enabled(d.b)) {
+      const V3 ca = X(d.a), cb = X(d.b);
+      const double ra = sc->geom_dim[d.a][0], rb = sc->geom_dim[d.b][0];
+      const V3 ab = cb - ca;
+      const double len = norm(ab);
+      d.dist = len - ra - rb;
+      const V3 u = ab / len;
+      const double sa = (d.dist > 0.0) ? ra : ra + d.dist, sb = (d.dist > 0.0) ? rb : rb + d.dist;
+      d.pa = ca + u * sa;
+      d.pb = cb - u * sb;
+    } else {
+      const int s = enabled(d.a) ? d.a : d.b;       // the sphere
+      const V3 cp = to_plane(X(s));
+      const double r = sc->geom_dim[s][0];
+      const double low = cp.y + (-1.0 * r);
+      d.dist = low;
+      const V3 on_plane = from_plane(v3(cp.x, 0.0, cp.z));
+      const V3 on_sphere = from_plane(v3(cp.x, low, cp.z));
+      if (s == d.a) { d.pa = on_sphere; d.pb = on_plane; } else { d.pa = on_plane; d.pb = on_sphere; }
+    }
+    return d;
+  }
+  void calc_pairwise_distances(const std::vector<int>& pairs, std::vector<PairDist>& out) const {
+    out.clear();
+    for (int p : pairs) out.push_back(signed_dist(p));
+  }
+  // Vector3d::determine_orthonormal_basis (Ravelin; pinned choice: cross with the
+  // axis of the smallest |component|)
+  static void orthonormal_basis(V3 n, V3& s, V3& t) {
+    const double ax = std::fabs(n.x), ay = std::fabs(n.y), az = std::fabs(n.z);
+    V3 e;
+    if (ax <= ay && ax <= az) e = v3(1, 0, 0); else if (ay <= az) e = v3(0, 1, 0); else e = v3(0, 0, 1);
+    s = cross(n, e); s = s / norm(s);
+    t = cross(n, s);
+  }
+  void fill_params(Contact& c) const {             // ConstraintSimulator::preprocess_constraint (CSim:390-416)
+    c.mu = sc->cp_mu_coulomb[c.pair]; c.muv = sc->cp_mu_viscous[c.pair];
+    c.eps = sc->cp_epsilon[c.pair]; c.compliance = sc->cp_compliance[c.pair]; c.nk = sc->cp_nk[c.pair];
+  }
+  // CCD::find_contacts (CCD.inl:3-83) -> sphere/sphere (CCD.inl:1164-1207),
+  // sphere/plane (CCD.inl:804-847); create_contact (CollisionDetection.cpp:57-95)
+  void find_contacts(int p, double TOL, std::vector<Contact>& out) const {
+    int a, b; pair_bodies(p, a, b);
+    Contact c; c.pair = p;
+    if (enabled(a) && enabled(b)) {
+      const V3 cA = X(a), cB = X(b);
+      const double rA = sc->geom_dim[a][0], rB = sc->geom_dim[b][0];
+      const V3 d = cA - cB;
+      const double len = norm(d);
+      const double dist = len - rA - rB;
+      if (dist > TOL) return;
+      const V3 n = d / len;
+      const V3 closest_A = cA - n * rA, closest_B = cB + n * rB;
+      c.p = (closest_A + closest_B) * 0.5;
+      c.n = n; c.g1 = a; c.g2 = b; c.dist = dist;
+    } else {
+      const int s = enabled(a) ? a : b, pl = enabled(a) ? b : a;
+      const V3 cp = to_plane(X(s));
+      const double r = sc->geom_dim[s][0];
+      const double dist = cp.y - r;
+      if (dist > TOL) return;
+      c.p = from_plane(v3(cp.x, 0.5 * (cp.y - r), cp.z));
+      c.n = plane_n(); c.g1 = s; c.g2 = pl; c.dist = dist;
+    }
+    orthonormal_basis(c.n, c.s, c.t);
+    fill_params(c);
+    out.push_back(c);
+  }
+  // UnilateralConstraint::calc_contact_vel / calc_constraint_vel (UC:695-747,1357-1384)
+  double contact_vel(const Contact& c, V3 dir) const {
+    return dot(dir, point_vel(c.g1, c.p) - point_vel(c.g2, c.p));
+  }
+  // CCD::calc_max_dist (CCD.cpp:585-609): velocity at the global origin
+  double calc_max_dist(int b, V3 n, double rmax) const {
+    if (!enabled(b)) return 0.0;
+    const V3 xd0 = Vl(b) + cross(X(b), Wa(b));
+    const V3 w0 = Wa(b);
+    return dot(n, xd0) + norm(cross(w0, n)) * rmax;
+  }
+  // CCD::calc_next_CA_Euler_step_generic (CCD.cpp:238-405) for sphere pairs
+  double next_CA_generic(const PairDist& d) const {
+    std::vector<Contact> cs; find_contacts(d.pair, NEAR_ZERO, cs);
+    if (cs.empty()) return INF;
+    for (const Contact& c : cs) if (contact_vel(c, c.n) < -NEAR_ZERO) return 0.0;
+    return INF;
+  }
+  // CCD::calc_CA_Euler_step_generic (CCD.cpp:169-235)
+  double CA_generic(const PairDist& d) const {
+    if (d.dist <= 0.0) return next_CA_generic(d);
+    const V3 d0 = d.pa - d.pb;
+    const V3 n0 = d0 / norm(d0);
+    const double tA = calc_max_dist(d.a, -n0, enabled(d.a) ? sc->geom_dim[d.a][0] : 0.0);
+    const double tB = calc_max_dist(d.b, n0, enabled(d.b) ? sc->geom_dim[d.b][0] : 0.0);
+    double total = tA + tB;
+    if (total < 0.0) total = 0.0;
+    const double cand = d.dist / total;
+    return (cand < INF) ? cand : INF;               // std::min(maxt, dist/total)
+  }
+  // CCD::calc_CA_Euler_step_sphere (CCD.cpp:138-166)
+  double CA_step(const PairDist& d) const {
+    if (d.dist > NEAR_ZERO) return CA_generic(d);
+    std::vector<Contact> cs; find_contacts(d.pair, NEAR_ZERO, cs);
+    if (cs.size() == 1 && std::fabs(contact_vel(cs[0], cs[0].n)) < NEAR_ZERO * 10) return INF;
+    return CA_generic(d);
+  }
+
+  // ---- rigid body dynamics (Ravelin::RigidBodyd, restated) -----------------
+  // world-frame inertia R J R^T and its SPD inverse (inverse_SPD, ICH:1607)
+  void inertia_world(int b, double Jw[9]) const {
+    double R[9]; rot(b, R);
+    const double* J = sc->inertia[b];
+    double T[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[3*i+j] = R[3*i+j] * J[j];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+      Jw[3*i+j] = (T[3*i] * R[3*j] + T[3*i+1] * R[3*j+1]) + T[3*i+2] * R[3*j+2];
+    // enforce exact symmetry (upper := lower), as a symmetric-storage inertia has
+    Jw[1] = Jw[3]; Jw[2] = Jw[6]; Jw[5] = Jw[7];
+  }
+  // X block of body b: blockdiag(inv(m I3), inv(Jw)), both via Cholesky (inverse_spd)
+  void inv_inertia(int b, double& im, double Ji[9]) const {
+    double Mm[1] = { sc->mass[b] };
+    inverse_spd(1, Mm, 1); im = Mm[0];
+    double Jw[9]; inertia_world(b, Jw);
+    double A[9]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i + 3*j] = Jw[3*i+j];
+    inverse_spd(3, A, 3);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ji[3*i+j] = A[i + 3*j];
+  }
+  // DynamicBodyd::calc_fwd_dyn for a free body with gravity (Sim:552; GravityForce.cpp:33-69):
+  // xdd = (g m) / m ; wd = Jw^-1 (0 - w x (Jw w))
+  void fwd_dyn(int b, V3& xdd, V3& wd) const {
+    const double m = sc->mass[b];
+    const V3 f = v3(sc->gravity[0] * m, sc->gravity[1] * m, sc->gravity[2] * m);
+    xdd = f / m;
+    double Jw[9]; inertia_world(b, Jw);
+    const V3 w = Wa(b);
+    const V3 Jww = v3((Jw[0]*w.x + Jw[1]*w.y) + Jw[2]*w.z, (Jw[3]*w.x + Jw[4]*w.y) + Jw[5]*w.z, (Jw[6]*w.x + Jw[7]*w.y) + Jw[8]*w.z);
+    const V3 tau = -cross(w, Jww);
+    double im, Ji[9]; inv_inertia(b, im, Ji);
+    wd = v3((Ji[0]*tau.x + Ji[1]*tau.y) + Ji[2]*tau.z, (Ji[3]*tau.x + Ji[4]*tau.y) + Ji[5]*tau.z, (Ji[6]*tau.x + Ji[7]*tau.y) + Ji[8]*tau.z);
+  }
+  // generalized velocity in eEuler form: [xd ; qd], qd = 1/2 (0,w) (x) q
+  void euler_vel(int b, double qd[7]) const {
+    const V3 v = Vl(b), w = Wa(b);
+    const double x = st[13*b+3], y = st[13*b+4], z = st[13*b+5], ww = st[13*b+6];
+    qd[0] = v.x; qd[1] = v.y; qd[2] = v.z;
+    qd[3] = 0.5 * ((ww * w.x + z * w.y) - y * w.z);
+    qd[4] = 0.5 * ((ww * w.y + x * w.z) - z * w.x);
+    qd[5] = 0.5 * ((ww * w.z + y * w.x) - x * w.y);
+    qd[6] = 0.5 * (((-x * w.x) - y * w.y) - z * w.z);
+  }
+  void get_coords(int b, double q[7]) const { for (int i = 0; i < 7; i++) q[i] = st[13*b+i]; }
+  // set_generalized_coordinates_euler: stores x and the NORMALISED quaternion
+  void set_coords(int b, const double q[7]) {
+    for (int i = 0; i < 3; i++) st[13*b+i] = q[i];
+    const double nrm = std::sqrt(((q[3]*q[3] + q[4]*q[4]) + q[5]*q[5]) + q[6]*q[6]);
+    for (int i = 3; i < 7; i++) st[13*b+i] = q[i] / nrm;
+  }
+
+  // ---- impact handling ------------------------------------------------------
+  struct Island { std::vector<int> contacts; std::vector<int> bodies; };
+
+  // UnilateralConstraint::determine_connected_constraints (UC:940-1194), contacts only
+  void find_islands(const std::vector<Contact>& cs, std::vector<Island>& out) const {
+    out.clear();
+    const int nb = sc->nb;
+    std::vector<char> node(nb, 0), done(cs.size(), 0);
+    std::vector<std::vector<int> > adj(nb);           // multimap in insertion order
+    for (size_t i = 0; i < cs.size(); i++) {
+      const int a = cs[i].g1, b = cs[i].g2;
+      if (enabled(a)) node[a] = 1;
+      if (enabled(b)) node[b] = 1;
+      if (enabled(a) && enabled(b)) { adj[a].push_back(b); adj[b].push_back(a); }
+    }
+    for (int start = 0; start < nb; start++) {
+      if (!node[start]) continue;
+      Island isl;
+      std::vector<int> queue; queue.push_back(start);
+      std::vector<char> processed(nb, 0);
+      for (size_t qi = 0; qi < queue.size(); qi++) {
+        const int nd = queue[qi];
+        node[nd] = 0;
+        isl.bodies.push_back(nd);                     // NB: may hold duplicates, as the reference's list does
+        processed[nd] = 1;
+        for (int nbr : adj[nd]) if (!processed[nbr]) queue.push_back(nbr);
+        for (size_t i = 0; i < cs.size(); i++)
+          if (!done[i] && (cs[i].g1 == nd || cs[i].g2 == nd)) { isl.contacts.push_back((int)i); done[i] = 1; }
+      }
+      if (!isl.contacts.empty()) out.push_back(isl);
+    }
+  }
+
+  // problem data of one island: rows [d, r x d] per body (ICH:1847-1895),
+  // X = blockdiag(M_i^-1) (ICH:1590-1695 without bilateral rows), the C X C' blocks
+  // (ICH:2125-2149 via SparseJacobian::mult, SparseJacobian.cpp:46-82) and C v.
+  struct ProblemData {
+    int nc, ngc;
+    std::vector<int> bodies;                 // sorted unique super bodies
+    std::vector<const Contact*> c;
+    std::vector<double> J[3];                // Cn, Cs, Ct dense rows: nc x ngc (row-major)
+    std::vector<double> XJ[3];               // X * C^T : ngc x nc (col-major, column = contact)
+    std::vector<double> G[3][3];             // C_a X C_b^T nc x nc row-major (a<=b used)
+    std::vector<double> Cv[3];
+    std::vector<double> cn, cs, ct;
+    std::vector<double> X;                   // ngc x ngc dense (block diagonal)
+  };
+
+  int gc_of(const ProblemData& pd, int body) const {
+    for (size_t i = 0; i < pd.bodies.size(); i++) if (pd.bodies[i] == body) return 6 * (int)i;
+    return -1;
+  }
+
+  void compute_problem_data(const std::vector<Contact>& all, const Island& isl, ProblemData& pd, bool normals_only) const {
+    pd.bodies = isl.bodies;
+    std::sort(pd.bodies.begin(), pd.bodies.end());
+    pd.bodies.erase(std::unique(pd.bodies.begin(), pd.bodies.end()), pd.bodies.end());
+    pd.c.clear();
+    for (int ci : isl.contacts) pd.c.push_back(&all[ci]);
+    const int nc = pd.nc = (int)pd.c.size();
+    const int ngc = pd.ngc = 6 * (int)pd.bodies.size();
+    // X
+    pd.X.assign((size_t)ngc * ngc, 0.0);
+    for (size_t bi = 0; bi < pd.bodies.size(); bi++) {
+      double im, Ji[9]; inv_inertia(pd.bodies[bi], im, Ji);
+      const int o = 6 * (int)bi;
+      for (int k = 0; k < 3; k++) pd.X[(o + k) * ngc + (o + k)] = im;
+      for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) pd.X[(o + 3 + r) * ngc + (o + 3 + cc)] = Ji[3*r+cc];
+    }
+    const int ndir = normals_only ? 1 : 3;
+    // stacked generalized velocity
+    std::vector<double> v(ngc, 0.0);
+    for (size_t bi = 0; bi < pd.bodies.size(); bi++) {
+      const V3 vl = Vl(pd.bodies[bi]), wa = Wa(pd.bodies[bi]);
+      double* o = &v[6 * bi]; o[0] = vl.x; o[1] = vl.y; o[2] = vl.z; o[3] = wa.x; o[4] = wa.y; o[5] = wa.z;
+    }
+    // block lists per row: (gc offset, 6 values) for body g1 then body g2
+    struct Blk { int off; double w[6]; };
+    std::vector<std::vector<Blk> > blocks[3];
+    for (int d = 0; d < ndir; d++) {
+      blocks[d].assign(nc, std::vector<Blk>());
+      pd.J[d].assign((size_t)nc * ngc, 0.0);
+      for (int i = 0; i < nc; i++) {
+        const Contact& c = *pd.c[i];
+        const V3 dir = (d == 0) ? c.n : (d == 1 ? c.s : c.t);
+        const int bodies2[2] = { c.g1, c.g2 };
+        for (int k = 0; k < 2; k++) {
+          const int b = bodies2[k];
+          if (!enabled(b)) continue;
+          const V3 dd = (k == 0) ? dir : -dir;
+          const V3 r = c.p - X(b);
+          const V3 rxd = cross(r, dd);
+          Blk blk; blk.off = gc_of(pd, b);
+          blk.w[0] = dd.x; blk.w[1] = dd.y; blk.w[2] = dd.z; blk.w[3] = rxd.x; blk.w[4] = rxd.y; blk.w[5] = rxd.z;
+          blocks[d][i].push_back(blk);
+          for (int q = 0; q < 6; q++) pd.J[d][(size_t)i * ngc + blk.off + q] = blk.w[q];
+        }
+      }
+    }
+    // X_C*T = (C X)^T : result(i,col) = sum_blocks [ sum_k block[k] * X[off+k][col] ]
+    for (int d = 0; d < ndir; d++) {
+      pd.XJ[d].assign((size_t)ngc * nc, 0.0);
+      for (int i = 0; i < nc; i++)
+        for (int col = 0; col < ngc; col++) {
+          double res = 0.0;
+          for (const Blk& blk : blocks[d][i]) {
+            double tmp = 0.0;
+            for (int k = 0; k < 6; k++) tmp = tmp + blk.w[k] * pd.X[(blk.off + k) * ngc + col];
+            res = res + tmp;
+          }
+          pd.XJ[d][(size_t)col + (size_t)ngc * i] = res;
+        }
+    }
+    // C_a X C_b^T (i,j) = sum_blocks of row i [ sum_k block[k] * X_CbT[off+k][j] ]
+    for (int a = 0; a < ndir; a++) for (int b = a; b < ndir; b++) {
+      pd.G[a][b].assign((size_t)nc * nc, 0.0);
+      for (int i = 0; i < nc; i++) for (int j = 0; j < nc; j++) {
+        double res = 0.0;
+        for (const Blk& blk : blocks[a][i]) {
+          double tmp = 0.0;
+          for (int k = 0; k < 6; k++) tmp = tmp + blk.w[k] * pd.XJ[b][(size_t)(blk.off + k) + (size_t)ngc * j];
+          res = res + tmp;
+        }
+        pd.G[a][b][(size_t)i * nc + j] = res;
+      }
+    }
+    // C v
+    for (int d = 0; d < ndir; d++) {
+      pd.Cv[d].assign(nc, 0.0);
+      for (int i = 0; i < nc; i++) {
+        double res = 0.0;
+        for (const Blk& blk : blocks[d][i]) {
+          double tmp = 0.0;
+          for (int k = 0; k < 6; k++) tmp = tmp + blk.w[k] * v[blk.off + k];
+          res = res + tmp;
+        }
+        pd.Cv[d][i] = res;
+      }
+    }
+    pd.cn.assign(nc, 0.0); pd.cs.assign(nc, 0.0); pd.ct.assign(nc, 0.0);
+  }
+
+  // element (r,c) of block a,b with a<=b stored; transposes give the rest (setup_QP :392-401)
+  static double Gab(const ProblemData& pd, int a, int b, int i, int j) {
+    return (a <= b) ? pd.G[a][b][(size_t)i * pd.nc + j] : pd.G[b][a][(size_t)j * pd.nc + i];
+  }
+
+  // ImpactConstraintHandler::solve_qp_work + setup_QP (ICH-QP:94-263, 271-497), no limits.
+  // z layout of the LCP: [cn cs ct ncs nct | Cn v+>=0 rows | friction polygon rows]
+  void build_impact_lcp(const ProblemData& pd, std::vector<double>& MM, std::vector<double>& qq, int& n) const {
+    const int nc = pd.nc;
+    const int nvars = 5 * nc;
+    int nk_total = 0;
+    for (int i = 0; i < nc; i++) nk_total += pd.c[i]->nk / 2;
+    const int nineq = nc + nk_total;
+    n = nvars + nineq;
+    MM.assign((size_t)n * n, 0.0); qq.assign(n, 0.0);   // column-major
+    auto at = [&](int r, int c) -> double& { return MM[(size_t)r + (size_t)n * c]; };
+    // H: 5x5 blocks over [n, s, t, -s, -t]
+    const int dirs[5] = { 0, 1, 2, 1, 2 }; const double sgn[5] = { 1, 1, 1, -1, -1 };
+    for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++)
+      for (int i = 0; i < nc; i++) for (int j = 0; j < nc; j++) {
+        double g = Gab(pd, dirs[a], dirs[b], i, j);
+        if (sgn[a] * sgn[b] < 0) g = -g;
+        at(a * nc + i, b * nc + j) = g;
+      }
+    for (int i = 0; i < nc; i++) at(i, i) = at(i, i) + pd.c[i]->compliance;     // ICH-QP:438-440
+    // c
+    for (int i = 0; i < nc; i++) {
+      qq[i] = pd.Cv[0][i]; qq[nc + i] = pd.Cv[1][i]; qq[2*nc + i] = pd.Cv[2][i];
+      qq[3*nc + i] = -pd.Cv[1][i]; qq[4*nc + i] = -pd.Cv[2][i];
+    }
+    // M rows: Cn v+ >= 0 (copy of H's first block row, with compliance), then friction polygons
+    for (int i = 0; i < nc; i++) for (int c = 0; c < nvars; c++) at(nvars + i, c) = at(i, c);
+    for (int i = 0; i < nc; i++) qq[nvars + i] = pd.Cv[0][i];
+    int row = nvars + nc;
+    for (int i = 0; i < nc; i++) {
+      const double vel = std::sqrt(pd.Cv[1][i] * pd.Cv[1][i] + pd.Cv[2][i] * pd.Cv[2][i]);
+      const int kh = pd.c[i]->nk / 2;
+      for (int j = 0; j < kh; j++) {
+        const double theta = (double)j / (kh - 1) * M_PI_2;
+        const double ct = std::cos(theta), st_ = std::sin(theta);
+        at(row, i) = pd.c[i]->mu;
+        at(row, nc + i) = -ct; at(row, 3*nc + i) = -ct;
+        at(row, 2*nc + i) = -st_; at(row, 4*nc + i) = -st_;
+        qq[row] = pd.c[i]->muv * vel;
+        row++;
+      }
+    }
+    // upper right = -M^T
+    for (int r = nvars; r < n; r++) for (int c = 0; c < nvars; c++) at(c, r) = -at(r, c);
+  }
+
+  void lcp_account(int n, unsigned pivots) { aux->lcp_solves++; aux->lcp_rows += (unsigned long long)n; aux->lcp_pivots += pivots; }
+
+  // solve_qp_work's solver chain (ICH-QP:157-233) on the persistent _z / _zlast
+  bool solve_impact_lcp(const std::vector<double>& MM, const std::vector<double>& qq, int n, std::vector<double>& zout) {
+    Vec z; z.d.assign(aux->zbuf, aux->zbuf + aux->zbuf_cap); z.len = (unsigned)aux->zbuf_size;
+    z.resize((unsigned)n);                                   // ICH-QP:158
+    if ((int)z.size() == aux->zlast_size) for (int i = 0; i < n; i++) z[i] = aux->zlast[i];
+    oracle_rand_t rs; std::memcpy(&rs, aux->rng, sizeof(rs));
+    LCP lcp; lcp.rng = &rs;
+    Trace tr; tr.buf = trace ? trace + trace_len : nullptr; tr.cap = trace ? trace_cap - trace_len : 0; if (tr.cap < 0) tr.cap = 0;
+    lcp.trace = &tr;
+    unsigned piv = 0;
+    bool ok = lcp.lcp_fast_regularized(n, MM.data(), n, qq.data(), z, -20, 4, -8);
+    piv += lcp.pivots;
+    if (!ok) {
+      z.set_zero();                                          // ICH-QP:222
+      ok = lcp.lcp_lemke_regularized(n, MM.data(), n, qq.data(), z);
+      piv += lcp.pivots;
+    }
+    trace_len += tr.len;
+    std::memcpy(aux->rng, &rs, sizeof(rs));
+    lcp_account(n, piv);
+    if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; return false; }   // LCPSolverException
+    // _zlast = z (ICH-QP:233)
+    aux->zlast_size = n;
+    for (int i = 0; i < n; i++) aux->zlast[i] = z[i];
+    zout.assign(z.d.begin(), z.d.begin() + n);
+    // persist _z's storage: entries [0,n) are rewritten, entries beyond keep what
+    // they held (Ravelin keeps a vector's storage when it shrinks).  Growth of
+    // the buffer inside lcp_lemke (z.set_zero(2n)) is not modelled: only reads
+    // of [0,n) ever happen (documented deviation).
+    for (int i = 0; i < n; i++) aux->zbuf[i] = z[i];
+    if (aux->zbuf_cap < n) aux->zbuf_cap = n;
+    aux->zbuf_size = n;
+    return true;
+  }
+
+  // update_from_stacked (ICH:298-410): dv = X_CnT cn + X_CsT cs + X_CtT ct; v += dv
+  void apply_impulses(const ProblemData& pd) {
+    const int ngc = pd.ngc, nc = pd.nc;
+    std::vector<double> dv(ngc, 0.0), tmp(ngc);
+    const std::vector<double>* imp[3] = { &pd.cn, &pd.cs, &pd.ct };
+    for (int d = 0; d < 3; d++) {
+      if (pd.XJ[d].empty()) continue;
+      std::fill(tmp.begin(), tmp.end(), 0.0);
+      for (int j = 0; j < nc; j++) { const double t = (*imp[d])[j]; for (int r = 0; r < ngc; r++) tmp[r] = tmp[r] + t * pd.XJ[d][(size_t)r + (size_t)ngc * j]; }
+      if (d == 0) dv = tmp; else for (int r = 0; r < ngc; r++) dv[r] = dv[r] + tmp[r];
+    }
+    for (size_t bi = 0; bi < pd.bodies.size(); bi++) {
+      const int b = pd.bodies[bi]; const double* o = &dv[6 * bi];
+      setV(b, Vl(b) + v3(o[0], o[1], o[2]));
+      setW(b, Wa(b) + v3(o[3], o[4], o[5]));
+    }
+  }
+  // update_constraint_velocities_from_impulses (ICH:427-464)
+  void update_constraint_vels(ProblemData& pd) const {
+    const int nc = pd.nc;
+    auto addmul = [&](std::vector<double>& y, int a, int b, const std::vector<double>& x, bool) {
+      // y += G_ab * x (dgemv: tmp = 0; for j: tmp += x_j * col_j; y += tmp); G_ab(i,j) via Gab handles transposes
+      std::vector<double> t(nc, 0.0);
+      for (int j = 0; j < nc; j++) { const double xj = x[j]; for (int i = 0; i < nc; i++) t[i] = t[i] + xj * Gab(pd, a, b, i, j); }
+      for (int i = 0; i < nc; i++) y[i] = y[i] + t[i];
+    };
+    addmul(pd.Cv[0], 0, 0, pd.cn, false); addmul(pd.Cv[0], 0, 1, pd.cs, false); addmul(pd.Cv[0], 0, 2, pd.ct, false);
+    addmul(pd.Cv[1], 1, 0, pd.cn, true);  addmul(pd.Cv[1], 1, 1, pd.cs, false); addmul(pd.Cv[1], 1, 2, pd.ct, false);
+    addmul(pd.Cv[2], 2, 0, pd.cn, true);  addmul(pd.Cv[2], 2, 1, pd.cs, true);  addmul(pd.Cv[2], 2, 2, pd.ct, false);
+  }
+  static void from_stacked_qp(ProblemData& pd, const std::vector<double>& zepd) {   // UCPD:218-228
+    const int nc = pd.nc;
+    for (int i = 0; i < nc; i++) {
+      pd.cn[i] = zepd[i];
+      double s = zepd[nc + i];   s = s - zepd[3*nc + i]; pd.cs[i] = s;
+      double t = zepd[2*nc + i]; t = t - zepd[4*nc + i]; pd.ct[i] = t;
+    }
+  }
+
+  // apply_model_to_connected_constraints (ICH:530-626), Drumwright-Shell path
+  void apply_model(const std::vector<Contact>& all, const Island& isl) {
+    ProblemData pd; compute_problem_data(all, isl, pd, false);
+    const int nc = pd.nc;
+    std::vector<double> MM, qq, z; int n;
+    auto solve_and_store = [&]() -> bool {
+      build_impact_lcp(pd, MM, qq, n);
+      if (n > MH_LCP_MAX_N_WAVE) { aux->status |= MH_WORLD_UNSUPPORTED; return false; }
+      if (!solve_impact_lcp(MM, qq, n, z)) return false;
+      // repack z in the epd layout (ICH-QP:236-250): here identical to the first 5 nc entries
+      for (int i = 0; i < 5 * nc; i++) aux->zbuf[i] = z[i];
+      aux->zbuf_size = 5 * nc;
+      if (aux->zbuf_cap < 5 * nc) aux->zbuf_cap = 5 * nc;
+      return true;
+    };
+    if (!solve_and_store()) return;
+    std::vector<double> zepd(aux->zbuf, aux->zbuf + 5 * nc);
+    from_stacked_qp(pd, zepd); apply_impulses(pd);                  // ICH:569
+    update_constraint_vels(pd);                                      // ICH:572
+    double minv = *std::min_element(pd.Cv[0].begin(), pd.Cv[0].end());   // ICH:575
+    // apply_restitution(_epd, _z) (ICH:470-491): scales z[cn] only
+    bool changed = false;
+    for (int i = 0; i < nc; i++) { zepd[i] = zepd[i] * pd.c[i]->eps; if (!changed && zepd[i] > NEAR_ZERO) changed = true; }
+    for (int i = 0; i < nc; i++) aux->zbuf[i] = zepd[i];
+    if (changed) {
+      from_stacked_qp(pd, zepd); apply_impulses(pd);                // ICH:581
+      update_constraint_vels(pd);
+      const double minv_plus = *std::min_element(pd.Cv[0].begin(), pd.Cv[0].end());
+      if (minv_plus < 0.0 && minv_plus < minv - NEAR_ZERO) {        // ICH:591
+        // second solve reuses the problem data with the updated C*v vectors
+        if (!solve_and_store()) return;
+        std::vector<double> z2(aux->zbuf, aux->zbuf + 5 * nc);
+        from_stacked_qp(pd, z2); apply_impulses(pd);                // ICH:600
+      }
+    }
+  }
+
+  // calc_impacting_unilateral_constraint_forces (CSim:298-355) + apply_model (ICH:96-168)
+  void handle_impacts(const std::vector<Contact>& cs) {
+    if (cs.empty()) return;
+    bool none = true;
+    for (const Contact& c : cs) if (contact_vel(c, c.n) < -NEAR_ZERO) { none = false; break; }
+    if (none) return;
+    std::vector<Island> islands; find_islands(cs, islands);
+    // remove_inactive_groups (UC:1197-1225)
+    std::vector<Island> active;
+    for (const Island& isl : islands) {
+      bool act = false;
+      for (int ci : isl.contacts) if (contact_vel(cs[ci], cs[ci].n) < -NEAR_ZERO) { act = true; break; }
+      if (act) active.push_back(isl);
+    }
+    for (const Island& isl : active) {
+      bool all_inf = true;
+      for (int ci : isl.contacts) if (cs[ci].mu < 1e2) all_inf = false;
+      if (all_inf) { aux->status |= MH_WORLD_UNSUPPORTED; continue; }   // no-slip model (ICH:1009-1417): not built yet
+      apply_model(cs, isl);
+    }
+    for (const Island& isl : active)
+      for (int ci : isl.contacts) if (contact_vel(cs[ci], cs[ci].n) < -NEAR_ZERO) { aux->status |= MH_WORLD_IMPACT_TOL; }
+  }
+
+  // ---- time stepping ------------------------------------------------------------
+  std::vector<int> pairs_to_check;            // ConstraintSimulator::_pairs_to_check
+  std::vector<PairDist> pairwise;             // _pairwise_distances
+
+  // TimeSteppingSimulator::calc_next_CA_Euler_step (TSS:272-331)
+  double next_CA_step() const {
+    double t = INF;
+    for (const PairDist& d : pairwise) { const double e = CA_step(d); t = (e < t) ? e : t; }
+    return t;
+  }
+
+  // TimeSteppingSimulator::do_mini_step (TSS:114-222)
+  double do_mini_step(double dt) {
+    const int nb = sc->nb;
+    double qsave[MH_MAX_BODIES][7];
+    for (int b = 0; b < nb; b++) get_coords(b, qsave[b]);
+    double h = 0.0;
+    while (h < dt) {
+      broad_phase(dt - h, pairs_to_check);
+      calc_pairwise_distances(pairs_to_check, pairwise);
+      const double CA = next_CA_step();
+      if (CA <= 0.0) break;
+      double tc = (sc->min_step_size > CA) ? sc->min_step_size : CA;
+      tc = ((dt - h) < tc) ? (dt - h) : tc;
+      for (int b = 0; b < nb; b++) {
+        set_coords(b, qsave[b]);
+        double qd[7]; euler_vel(b, qd);
+        double q[7];
+        for (int i = 0; i < 7; i++) { q[i] = qd[i] * (h + tc); q[i] = q[i] + qsave[b][i]; }
+        set_coords(b, q);
+      }
+      h += tc;
+    }
+    // forward dynamics + velocity integration by h (TSS:173-192)
+    for (int b = 0; b < nb; b++) {
+      V3 xdd, wd; fwd_dyn(b, xdd, wd);
+      setV(b, Vl(b) + xdd * h);
+      setW(b, Wa(b) + wd * h);
+    }
+    calc_pairwise_distances(pairs_to_check, pairwise);             // TSS:206
+    std::vector<Contact> cs;                                       // find_unilateral_constraints (CSim:488-537)
+    for (const PairDist& d : pairwise) if (d.dist < sc->contact_dist_thresh) find_contacts(d.pair, sc->contact_dist_thresh, cs);
+    handle_impacts(cs);                                            // TSS:212
+    aux->time += h;
+    aux->mini_steps++;
+    return h;
+  }
+
+  // ---- constraint stabilisation (ConstraintStabilization.cpp) ------------------------
+  double eval_unilateral(std::vector<double>& uC) {                 // CStab:88-131
+    double vio = INF;
+    uC.clear();
+    calc_pairwise_distances(pairs_to_check, pairwise);
+    for (const PairDist& d : pairwise) { uC.push_back(d.dist); vio = (d.dist < vio) ? d.dist : vio; }
+    return vio;
+  }
+  void get_q(std::vector<double>& q) const { q.resize(7 * sc->nb); for (int b = 0; b < sc->nb; b++) get_coords(b, &q[7*b]); }
+  void set_q(const std::vector<double>& q) { for (int b = 0; b < sc->nb; b++) set_coords(b, &q[7*b]); }
+  double eval_at(double t, unsigned i, const std::vector<double>& dq, const std::vector<double>& q) {   // CStab:1281-1298
+    std::vector<double> qs(q.size()), uC;
+    for (size_t k = 0; k < q.size(); k++) { qs[k] = dq[k] * t; qs[k] = qs[k] + q[k]; }
+    set_q(qs);
+    eval_unilateral(uC);
+    return uC[i];
+  }
+  static double sign2(double x, double y) { return (y > 0.0) ? std::fabs(x) : -std::fabs(x); }
+  double ridders(double x1, double x2, double fl, double fh, unsigned idx, const std::vector<double>& dq, const std::vector<double>& q) {  // CStab:1322-1379
+    const double TOL = 1e-4;
+    double ans = INF, fm, fnew, s, xh, xl, xm, xnew;
+    if ((fl > 0.0 && fh < 0.0) || (fl < 0.0 && fh > 0.0)) {
+      xl = x1; xh = x2;
+      for (unsigned j = 0; j < 25; j++) {
+        xm = 0.5 * (xl + xh);
+        fm = eval_at(xm, idx, dq, q);
+        s = std::sqrt(fm * fm - fl * fh);
+        if (s == 0.0) return ans;
+        xnew = xm + (xm - xl) * ((fl >= fh ? 1.0 : -1.0) * fm / s);
+        ans = xnew;
+        fnew = eval_at(ans, idx, dq, q);
+        if (std::fabs(fnew) < TOL && fnew >= 0.0) return xnew;
+        if (sign2(fm, fnew) != fm) { xl = xm; fl = fm; xh = ans; fh = fnew; }
+        else if (sign2(fl, fnew) != fl) { xh = ans; fh = fnew; }
+        else if (sign2(fh, fnew) != fh) { xl = ans; fl = fnew; }
+      }
+    } else {
+      if (fl == 0.0) return x1;
+      if (fh == 0.0) return x2;
+    }
+    return 0.0;
+  }
+  // update_q (CStab:1056-1216), unilateral part
+  bool update_q(const std::vector<double>& dq, std::vector<double>& q) {
+    std::vector<double> uC, uC_old, qstar(q.size());
+    eval_unilateral(uC_old);
+    for (size_t k = 0; k < q.size(); k++) { qstar[k] = dq[k]; qstar[k] = qstar[k] + q[k]; }
+    set_q(qstar);
+    eval_unilateral(uC);
+    std::vector<char> br(uC.size(), 0);
+    for (size_t i = 0; i < uC.size(); i++)
+      br[i] = ((uC_old[i] < 0.0 && uC[i] > 0.0) || (uC_old[i] > 0.0 && uC[i] < 0.0)) ? 1 : 0;
+    double t = 1.0;
+    for (size_t i = 0; i < br.size(); i++) {
+      if (!br[i]) continue;
+      const double root = ridders(0, t, uC_old[i], uC[i], (unsigned)i, dq, q);
+      if (root > 0.0 && root < 1.0) t = (root < t) ? root : t;
+    }
+    for (size_t k = 0; k < q.size(); k++) { qstar[k] = dq[k] * t; qstar[k] = qstar[k] + q[k]; }
+    set_q(qstar);
+    eval_unilateral(uC);
+    const double BETA = 0.6;
+    while (true) {
+      bool stop = true;
+      for (size_t i = 0; i < br.size(); i++) if (!br[i] && uC[i] < 0.0 && uC_old[i] > uC[i]) { stop = false; break; }
+      if (stop) break;                                              // no bilateral constraints: cvio 0 < bilateral_eps
+      t *= BETA;
+      if (t < NEAR_ZERO) return false;
+      for (size_t k = 0; k < q.size(); k++) { qstar[k] = dq[k] * t; qstar[k] = qstar[k] + q[k]; }
+      set_q(qstar);
+      eval_unilateral(uC);
+    }
+    q = qstar;
+    return true;
+  }
+  // ConstraintStabilization::stabilize (CStab:167-254)
+  void stabilize() {
+    if (sc->cstab_max_iterations == 0) return;
+    const int nb = sc->nb;
+    double vsave[MH_MAX_BODIES][6];
+    for (int b = 0; b < nb; b++) for (int k = 0; k < 6; k++) vsave[b][k] = st[13*b + 7 + k];
+    std::vector<double> q; get_q(q);
+    std::vector<double> uC;
+    double max_uvio = eval_unilateral(uC);
+    unsigned iterations = 0;
+    while (max_uvio < sc->cstab_eps) {
+      if (iterations == sc->cstab_max_iterations) break;
+      for (int b = 0; b < nb; b++) for (int k = 0; k < 6; k++) st[13*b + 7 + k] = 0.0;
+      // compute_problem_data (CStab:347-492): own broad phase with dt = 0, one contact per pair
+      std::vector<int> cpairs; broad_phase(0.0, cpairs);
+      std::vector<Contact> cs;
+      for (int p : cpairs) {
+        const PairDist d = signed_dist(p);
+        if (d.dist >= NEAR_ZERO) {                                 // separated: synthetic contact (CStab:316-331)
+          Contact c; c.pair = p; c.g1 = d.a; c.g2 = d.b; c.p = d.pa;
+          const V3 nn = d.pb - d.pa;
+          c.n = nn / norm(nn);
+          c.dist = d.dist;
+          orthonormal_basis(c.n, c.s, c.t); fill_params(c);
+          cs.push_back(c);
+        } else find_contacts(p, NEAR_ZERO, cs);                    // CStab:337
+      }
+      std::vector<Island> islands; find_islands(cs, islands);
+      std::vector<double> dq(q.size(), 0.0);
+      for (const Island& isl : islands) {
+        ProblemData pd; compute_problem_data(cs, isl, pd, true);
+        const int nc = pd.nc;
+        for (int i = 0; i < nc; i++) pd.Cv[0][i] = pd.c[i]->dist - std::fabs(sc->cstab_eps) - NEAR_ZERO;   // CStab:431
+        // determine_dq (CStab:932-970): MM = Cn X Cn', cold lcp_fast then Lemke ladder
+        if (nc > MH_LCP_MAX_N_WAVE) { aux->status |= MH_WORLD_UNSUPPORTED; continue; }
+        std::vector<double> MM((size_t)nc * nc);
+        for (int i = 0; i < nc; i++) for (int j = 0; j < nc; j++) MM[(size_t)i + (size_t)nc * j] = pd.G[0][0][(size_t)i * nc + j];
+        Vec z;                                                       // fresh local: size 0 -> cold start
+        oracle_rand_t rs; std::memcpy(&rs, aux->rng, sizeof(rs));
+        LCP lcp; lcp.rng = &rs;
+        Trace tr; tr.buf = trace ? trace + trace_len : nullptr; tr.cap = trace ? std::max(0, trace_cap - trace_len) : 0;
+        lcp.trace = &tr;
+        unsigned piv = 0;
+        bool ok = lcp.lcp_fast(nc, MM.data(), nc, pd.Cv[0].data(), z, -1.0);
+        piv += lcp.pivots;
+        if (!ok) { ok = lcp.lcp_lemke_regularized(nc, MM.data(), nc, pd.Cv[0].data(), z); piv += lcp.pivots; }
+        trace_len += tr.len;
+        std::memcpy(aux->rng, &rs, sizeof(rs));
+        lcp_account(nc, piv);
+        // update_from_stacked(pd, z): cn = z (whatever z holds, even after a failed solve)
+        for (int i = 0; i < nc; i++) pd.cn[i] = (i < (int)z.size()) ? z[i] : 0.0;
+        pd.XJ[1].clear(); pd.XJ[2].clear();
+        apply_impulses(pd);
+        for (int b : pd.bodies) { double qd[7]; euler_vel(b, qd); for (int k = 0; k < 7; k++) dq[7*b + k] = qd[k]; }
+      }
+      if (!update_q(dq, q)) { aux->status |= MH_WORLD_STAB_FAILED; break; }
+      max_uvio = eval_unilateral(uC);
+      iterations++;
+      aux->stab_iters++;
+    }
+    for (int b = 0; b < nb; b++) for (int k = 0; k < 6; k++) st[13*b + 7 + k] = vsave[b][k];
+  }
+
+  // TimeSteppingSimulator::step (TSS:52-111)
+  void step(double dt) {
+    broad_phase(dt, pairs_to_check);
+    calc_pairwise_distances(pairs_to_check, pairwise);
+    double h = 0.0;
+    unsigned guard = 0;
+    while (h < dt) {
+      h += do_mini_step(dt - h);
+      if (++guard > 100000u) { aux->status |= MH_WORLD_STALLED; break; }   // the reference would spin forever
+    }
+    stabilize();
+    aux->steps++;
+  }
+};
+
+} // namespace oracle
+#endif

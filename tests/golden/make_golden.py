@@ -1,0 +1,31 @@
+"""Generates the committed golden fixtures from the reference's own regression
+data (run in the build container, where /root/reference exists):
+
+  sphere_stack_dat.npz  rows of /root/reference/regress/sphere-stack.dat
+                        (t + 3 x [x y z qx qy qz qw], printed with 6 significant
+                        digits by programs/regress.cpp:82-93): the first 30 rows,
+                        then every 25th, and the last row; plus the CPU-seconds
+                        footer (regress.cpp:274-277).
+
+Only DATA is stored (inputs / expected outputs), never reference source.
+"""
+import os
+import numpy as np
+
+REF = "/root/reference/regress"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    lines = open(os.path.join(REF, "sphere-stack.dat")).read().split("\n")
+    rows = [l for l in lines if len(l.split()) == 22]
+    footer = [l for l in lines if len(l.split()) == 1 and l.strip()]
+    data = np.array([[float(x) for x in r.split()] for r in rows])
+    keep = sorted(set(list(range(30)) + list(range(0, len(data), 25)) + [len(data) - 1]))
+    np.savez_compressed(os.path.join(HERE, "sphere_stack_dat.npz"), row_index=np.array(keep), rows=data[keep],
+                        n_rows=len(data), cpu_seconds=float(footer[-1]) if footer else np.nan)
+    print("sphere-stack.dat: %d rows -> %d kept" % (len(data), len(keep)))
+
+
+if __name__ == "__main__":
+    main()

@@ -70,3 +70,45 @@ class Oracle:
                                                int(e[0]), ctypes.c_uint(int(e[1])), int(e[2]),
                                                ctypes.c_double(piv_tol), ctypes.c_double(zero_tol), P(rng), P(st), P(piv))
         return secs, st, piv, zz[:, :n].copy(), rng, zs
+
+
+# ---- world stepper ------------------------------------------------------------
+def _world_protos(lib):
+    lib.oracle_world_step.restype = ctypes.c_double
+    lib.oracle_world_step_batch.restype = ctypes.c_double
+    lib.oracle_world_impact_lcp.restype = ctypes.c_int
+
+
+def oracle_world_step(self, scene, state, aux, dt, nsteps, want_traj=True, trace_cap=0):
+    """Steps ONE world (state: (nb*13,), aux: 1-element structured array) in place.
+    Returns dict(traj (nsteps, nb, 7) or None, trace, seconds)."""
+    _world_protos(self.lib)
+    nb = scene.nb
+    traj = np.zeros((nsteps, nb, 7)) if want_traj else None
+    tr = np.zeros(max(trace_cap, 1), dtype=np.int32); tl = ctypes.c_int(0)
+    P = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    secs = self.lib.oracle_world_step(ctypes.byref(scene), ctypes.c_double(dt), int(nsteps), P(state), P(aux), P(traj),
+                                      P(tr) if trace_cap else None, int(trace_cap), ctypes.byref(tl))
+    return dict(traj=traj, trace=tr[:min(tl.value, trace_cap)].copy(), trace_len=tl.value, seconds=secs)
+
+
+def oracle_world_step_batch(self, scene, state, aux, dt, nsteps):
+    _world_protos(self.lib)
+    B = state.shape[0]
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    return self.lib.oracle_world_step_batch(ctypes.byref(scene), int(B), ctypes.c_double(dt), int(nsteps), P(state), P(aux))
+
+
+def oracle_world_impact_lcp(self, scene, state, aux, cap=64):
+    _world_protos(self.lib)
+    MM = np.zeros(cap * cap); qq = np.zeros(cap)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    n = self.lib.oracle_world_impact_lcp(ctypes.byref(scene), P(state), P(aux), P(MM), P(qq), int(cap))
+    if n <= 0:
+        return n, None, None
+    return n, MM[:n * n].reshape(n, n).T.copy(), qq[:n].copy()   # row-major M[r, c]
+
+
+Oracle.world_step = oracle_world_step
+Oracle.world_step_batch = oracle_world_step_batch
+Oracle.world_impact_lcp = oracle_world_impact_lcp
