@@ -146,6 +146,8 @@ typedef struct mh_scene {
   double contact_dist_thresh;              /* ConstraintSimulator.cpp:56    (1e-6)     */
   double cstab_eps;                        /* ConstraintStabilization.cpp:59 (sqrt eps) */
   unsigned cstab_max_iterations;           /* ConstraintStabilization.cpp:56 (UINT_MAX) */
+  int    lcp_n_max;                        /* largest LCP the wave solver must hold in LDS (0 = 64); worlds
+                                              that exceed it get MH_WORLD_UNSUPPORTED */
 } mh_scene;
 
 /* status bits of mh_world_aux.status */

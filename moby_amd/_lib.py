@@ -44,6 +44,10 @@ SYMBOLS = {
     "mh_rand_next": (_i, [_vp]),
     "mh_lcp_solve_batch_dev": (_i, [_vp, _i] + _LCP_TAIL),
     "mh_lcp_solve_batch": (_i, [_i] + _LCP_TAIL),
+    "mh_scene_defaults": (None, [_vp]),
+    "mh_world_aux_init": (None, [_vp, ctypes.c_uint32]),
+    "mh_world_step_batch_dev": (_i, [_vp, _vp, _i, _d, _i, _vp, _vp, _vp]),
+    "mh_world_step_batch": (_i, [_vp, _i, _d, _i, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -243,3 +243,152 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 }
 
 } // extern "C"
+
+// ===========================================================================
+// many-worlds stepping
+#include <mutex>
+#include "mh_world_wave.h"
+
+__global__ __launch_bounds__(64)
+void mh_k_world_step(mh_scene sc, int B, double dt, int nsteps, double* __restrict__ state,
+                     mh_world_aux* __restrict__ aux, double* __restrict__ traj, int nmax)
+{
+  extern __shared__ double lds[];
+  const int w = blockIdx.x;
+  if (w >= B) return;
+  mh::WorldWave W(sc);
+  W.L.carve(lds, nmax);
+  const int lane = mh::lane_id();
+  W.lane = lane; W.nb = sc.nb; W.ntot = sc.nb + (sc.has_ground ? 1 : 0); W.npt = W.ntot * (W.ntot - 1) / 2; W.nmax = nmax;
+  const int nst = MH_BODY_STATE * sc.nb;
+  double* stg = state + (size_t)w * nst;
+  for (int e = lane; e < nst; e += 64) W.L.st[e] = stg[e];
+  mh_world_aux* a = aux + w;
+  W.rng.load(a->rng);
+  W.zlast_l = a->zlast[lane]; W.zbuf_l = a->zbuf[lane];
+  W.zlast_size = mh::uni(a->zlast_size); W.zbuf_size = mh::uni(a->zbuf_size); W.zbuf_cap = mh::uni(a->zbuf_cap);
+  W.status = mh::uni(a->status);
+  W.time = mh::uni(a->time);
+  W.n_steps = a->steps; W.n_mini = a->mini_steps; W.n_lcp = a->lcp_solves; W.n_rows = a->lcp_rows; W.n_piv = a->lcp_pivots; W.n_stab = a->stab_iters;
+  W.npairs = 0; W.nc = 0;
+  mh::wave_sync();
+  for (int s = 0; s < nsteps; s++) {
+    W.step(dt);
+    if (traj) {
+      mh::wave_sync();
+      for (int e = lane; e < 7 * sc.nb; e += 64) { const int b = e / 7, k = e - 7 * b; traj[(((size_t)w * nsteps + s) * sc.nb + b) * 7 + k] = W.L.st[13 * b + k]; }
+    }
+  }
+  mh::wave_sync();
+  for (int e = lane; e < nst; e += 64) stg[e] = W.L.st[e];
+  W.rng.store(a->rng);
+  a->zlast[lane] = W.zlast_l; a->zbuf[lane] = W.zbuf_l;
+  if (lane == 0) {
+    a->zlast_size = W.zlast_size; a->zbuf_size = W.zbuf_size; a->zbuf_cap = W.zbuf_cap; a->status = W.status; a->time = W.time;
+    a->steps = W.n_steps; a->mini_steps = W.n_mini; a->lcp_solves = W.n_lcp; a->lcp_rows = W.n_rows; a->lcp_pivots = W.n_piv; a->stab_iters = W.n_stab;
+  }
+}
+
+namespace {
+std::once_flag g_tables_once;
+hipError_t g_tables_err = hipSuccess;
+void init_tables()
+{
+  static mh::FricTable ft;
+  for (int kh = 0; kh < 33; kh++)
+    for (int j = 0; j < 32; j++) {
+      double c = 0.0, s = 0.0;
+      if (kh >= 2 && j < kh) { const double theta = (double)j / (kh - 1) * M_PI_2; c = std::cos(theta); s = std::sin(theta); }  // ICH-QP:466-468
+      ft.c[kh][j] = c; ft.s[kh][j] = s;
+    }
+  g_tables_err = hipMemcpyToSymbol(HIP_SYMBOL(mh::c_fric), &ft, sizeof(ft));
+  if (g_tables_err != hipSuccess) return;
+  const mh::Pow10Table p10 = make_pow10();
+  g_tables_err = hipMemcpyToSymbol(HIP_SYMBOL(mh::c_pow10), &p10, sizeof(p10));
+}
+int check_scene(const mh_scene* sc)
+{
+  if (!sc) return fail(MH_ERR_INVALID_ARG, "null scene");
+  if (sc->nb < 1 || sc->nb > MH_MAX_BODIES) return fail(MH_ERR_INVALID_ARG, "nb = %d outside [1, %d]", sc->nb, MH_MAX_BODIES);
+  const int ntot = sc->nb + (sc->has_ground ? 1 : 0);
+  for (int b = 0; b < sc->nb; b++) {
+    if (sc->geom_type[b] != MH_GEOM_SPHERE) return fail(MH_ERR_INVALID_ARG, "body %d: only sphere geometry is built", b);
+    if (!(sc->geom_dim[b][0] > 0.0) || !(sc->mass[b] > 0.0)) return fail(MH_ERR_INVALID_ARG, "body %d: radius and mass must be > 0", b);
+    for (int k = 0; k < 3; k++) if (!(sc->inertia[b][k] > 0.0)) return fail(MH_ERR_INVALID_ARG, "body %d: inertia must be > 0", b);
+  }
+  for (int p = 0; p < ntot * (ntot - 1) / 2; p++)
+    if (sc->cp_nk[p] < 4 || sc->cp_nk[p] > 64) return fail(MH_ERR_INVALID_ARG, "pair %d: friction-cone-edges %d outside [4, 64]", p, sc->cp_nk[p]);
+  if (sc->lcp_n_max < 0 || sc->lcp_n_max > MH_LCP_MAX_N_WAVE) return fail(MH_ERR_INVALID_ARG, "lcp_n_max outside [0, %d]", MH_LCP_MAX_N_WAVE);
+  return MH_OK;
+}
+} // namespace
+
+extern "C" {
+
+void mh_scene_defaults(mh_scene* s)
+{
+  std::memset(s, 0, sizeof(*s));
+  s->min_step_size = std::sqrt(2.220446049250313e-16);       // TimeSteppingSimulator.cpp:48
+  s->contact_dist_thresh = 1e-6;                             // ConstraintSimulator.cpp:56
+  s->cstab_eps = std::sqrt(2.220446049250313e-16);           // ConstraintStabilization.cpp:59
+  s->cstab_max_iterations = 0xFFFFFFFFu;                     // ConstraintStabilization.cpp:56
+  s->plane_R[0] = s->plane_R[4] = s->plane_R[8] = 1.0;
+  for (int p = 0; p < MH_MAX_PAIRS; p++) { s->pair_enabled[p] = 1; s->cp_nk[p] = 4; }   // ContactParameters.cpp:26
+}
+
+void mh_world_aux_init(mh_world_aux* a, uint32_t seed)
+{
+  std::memset(a, 0, sizeof(*a));
+  mh_rand_seed(a->rng, seed);
+}
+
+int mh_world_step_batch_dev(void* stream, const mh_scene* scene, int B, double dt, int nsteps,
+                            double* state, mh_world_aux* aux, double* traj)
+{
+  int rc = check_scene(scene);
+  if (rc != MH_OK) return rc;
+  if (B < 0 || nsteps < 0) return fail(MH_ERR_INVALID_ARG, "negative batch or step count");
+  if (B == 0 || nsteps == 0) return MH_OK;
+  if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
+  if (!state || !aux) return fail(MH_ERR_INVALID_ARG, "null state/aux");
+  std::call_once(g_tables_once, init_tables);
+  if (g_tables_err != hipSuccess) return fail(MH_ERR_HIP, "constant table upload failed: %s", hipGetErrorString(g_tables_err));
+  const int nmax = scene->lcp_n_max ? scene->lcp_n_max : MH_LCP_MAX_N_WAVE;
+  const size_t lds = mh::WorldLds::doubles(nmax) * sizeof(double) + mh::WorldLds::ints() * sizeof(int);
+  if (lds > 160 * 1024) return fail(MH_ERR_UNSUPPORTED_N, "world kernel needs %zu B of LDS (> 160 KiB)", lds);
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] { (void)hipFuncSetAttribute((const void*)mh_k_world_step, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+  hipLaunchKernelGGL(mh_k_world_step, dim3(B), dim3(64), lds, (hipStream_t)stream, *scene, B, dt, nsteps, state, aux, traj, nmax);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+int mh_world_step_batch(const mh_scene* scene, int B, double dt, int nsteps,
+                        double* state, mh_world_aux* aux, double* traj)
+{
+  int rc = check_scene(scene);
+  if (rc != MH_OK) return rc;
+  if (B <= 0 || nsteps <= 0) return (B == 0 || nsteps == 0) ? MH_OK : fail(MH_ERR_INVALID_ARG, "negative batch or step count");
+  if (mh_device_count() <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
+  double *dst = nullptr, *dtraj = nullptr; mh_world_aux* daux = nullptr;
+  const size_t sz_st = (size_t)B * scene->nb * MH_BODY_STATE * sizeof(double);
+  const size_t sz_tr = (size_t)B * nsteps * scene->nb * 7 * sizeof(double);
+  auto cleanup = [&]() { if (dst) (void)hipFree(dst); if (dtraj) (void)hipFree(dtraj); if (daux) (void)hipFree(daux); };
+#define MH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); \
+  return fail(MH_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+  MH_TRY(hipMalloc(&dst, sz_st)); MH_TRY(hipMalloc(&daux, (size_t)B * sizeof(mh_world_aux)));
+  if (traj) MH_TRY(hipMalloc(&dtraj, sz_tr));
+  MH_TRY(hipMemcpy(dst, state, sz_st, hipMemcpyHostToDevice));
+  MH_TRY(hipMemcpy(daux, aux, (size_t)B * sizeof(mh_world_aux), hipMemcpyHostToDevice));
+  rc = mh_world_step_batch_dev(nullptr, scene, B, dt, nsteps, dst, daux, dtraj);
+  if (rc != MH_OK) { cleanup(); return rc; }
+  MH_TRY(hipDeviceSynchronize());
+  MH_TRY(hipMemcpy(state, dst, sz_st, hipMemcpyDeviceToHost));
+  MH_TRY(hipMemcpy(aux, daux, (size_t)B * sizeof(mh_world_aux), hipMemcpyDeviceToHost));
+  if (traj) MH_TRY(hipMemcpy(traj, dtraj, sz_tr, hipMemcpyDeviceToHost));
+  cleanup();
+#undef MH_TRY
+  return MH_OK;
+}
+
+} // extern "C"

@@ -40,7 +40,7 @@ class mh_scene(ctypes.Structure):
         ("cp_compliance", ctypes.c_double * MH_MAX_PAIRS),
         ("cp_nk", ctypes.c_int * MH_MAX_PAIRS),
         ("min_step_size", ctypes.c_double), ("contact_dist_thresh", ctypes.c_double),
-        ("cstab_eps", ctypes.c_double), ("cstab_max_iterations", ctypes.c_uint),
+        ("cstab_eps", ctypes.c_double), ("cstab_max_iterations", ctypes.c_uint), ("lcp_n_max", ctypes.c_int),
     ]
 
 
@@ -128,6 +128,7 @@ def sphere_stack_scene(cstab_max_iterations=10):
     cp = dict(epsilon=0.0, mu_coulomb=0.0, mu_viscous=0.0, nk=16)
     sc = _sphere_stack_scene(cp)
     sc.cstab_max_iterations = cstab_max_iterations
+    sc.lcp_n_max = 42          # 3 contacts x (6 + NK/2) rows
     return sc
 
 
@@ -158,8 +159,10 @@ def bouncing_ball_scene():
     """example/bouncing-ball/bouncing-ball.xml:11-37 (density 1 => m = 4 pi / 3)."""
     r = 1.0
     m = 1.0 * (math.pi * r * r * r * 4.0 / 3.0)     # SpherePrimitive.cpp:144-146
-    return make_scene([r], [m], (0.0, -9.81, 0.0), ground_rpy=(0.0, 0.0, 0.0),
-                      params={(0, 1): dict(epsilon=1.0, mu_coulomb=0.0, mu_viscous=0.0, nk=4)})
+    sc = make_scene([r], [m], (0.0, -9.81, 0.0), ground_rpy=(0.0, 0.0, 0.0),
+                    params={(0, 1): dict(epsilon=1.0, mu_coulomb=0.0, mu_viscous=0.0, nk=4)})
+    sc.lcp_n_max = 8
+    return sc
 
 
 def bouncing_ball_state(B=1):
