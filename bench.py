@@ -4,20 +4,20 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Workload (config.workload): BASELINE.json configs[1], sphere-stack x4096 --
-4096 independent instances of example/stacks/sphere-stack.xml per GPU.  One
-"step" = one pass of the hot path over the whole batch:
+Workload (config.workload): BASELINE.json configs[1] -- sphere-stack x4096:
+4096 independent instances of /root/reference/example/stacks/sphere-stack.xml
+per GPU, dt = 1e-3 (world 0 of rank 0 is the reference scene, the others are
+perturbed as SURVEY 8d.2 says).  One "step" = TimeSteppingSimulator::step(dt)
+on every world of the batch: broad phase, conservative-advancement mini-steps,
+forward dynamics, contact generation, the impact QP->LCP (n = 42 / 14) with
+lcp_fast_regularized and the Lemke ladder, restitution, constraint
+stabilisation.  The K timed steps run inside ONE persistent launch (state never
+leaves the GPU between steps); inputs are resident in HBM before the clock starts.
 
-  round-1 state of the build: the impact LCP of every world (n = 42,
-  ImpactConstraintHandlerQP.cpp:219 lcp_fast_regularized(-20,4,-8) with the
-  Lemke ladder ICH-QP:224 on the worlds where it fails), M/q resident in HBM.
-
-Prints ONE JSON line on rank 0 (contract in the task statement) with
-`roofline` for the dominant kernel and `cpu_baseline` (the oracle timed on
-the host cores, rank 0, N = 1 only).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel) and
+`cpu_baseline` (the CPU oracle on the host cores; rank 0, N = 1 only).
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -28,9 +28,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-N_LCP = 42
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 WORLDS_PER_GPU = 4096
+DT = 1e-3
 
 
 def main():
@@ -50,7 +50,7 @@ def main():
     if world_size != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world_size))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
@@ -62,82 +62,56 @@ def main():
         ge.build()
     if world_size > 1:
         dist.barrier()
-    from moby_amd import _lib, synth
-    from moby_amd.lcp import LCPDevice
-    lib = _lib.load()
+    from moby_amd import scene as S
+    from moby_amd.world import WorldBatchDevice
 
-    B, n = args.worlds, N_LCP
-    # synthetic batch: 64 distinct perturbed worlds (world 0 = the reference
-    # scene), tiled to B; shard r of an N-GPU job takes worlds offset by r*64
-    base = 64
-    Mh, qh = synth.sphere_stack_impact_lcp(base, first_world=0 if rank == 0 else rank * base, hard=False)
-    reps = (B + base - 1) // base
-    Mcm = np.ascontiguousarray(np.transpose(np.tile(Mh, (reps, 1, 1))[:B], (0, 2, 1)))
-    qb = np.tile(qh, (reps, 1))[:B].copy()
-    M = torch.from_numpy(Mcm).to(dev)
-    q = torch.from_numpy(qb).to(dev)
-    z0 = torch.zeros(B, n, dtype=torch.float64, device=dev)
-    z = torch.zeros_like(z0)
-    solver = LCPDevice(B, dev)
-    rng0 = solver.rng.clone()
-    opts_fast = _lib.mh_lcp_opts(-20, 4, -8, -1.0, -1.0)
-    status_fast = torch.zeros(B, dtype=torch.int32, device=dev)
+    B = args.worlds
+    sc = S.sphere_stack_scene()
+    # shard r of an N-GPU job simulates worlds r*B .. r*B+B-1 (no data-path collective)
+    st0 = S.sphere_stack_state_range(rank * B, B)
+    wb = WorldBatchDevice(sc, st0)
+    stream = torch.cuda.current_stream(dev).cuda_stream   # HIP events below are recorded on this stream
 
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    kern_ms = []
-
-    def step(timed_kernel=False):
-        # handler state at the first impact of every world: z = 0 of size n,
-        # every world's rand() stream at srand(1)
-        z.copy_(z0)
-        solver.rng.copy_(rng0)
-        if timed_kernel:
-            ev0.record()
-        solver.solve(_lib.MH_LCP_FAST_REG, M, q, z, opts_fast)
-        if timed_kernel:
-            ev1.record()
-        status_fast.copy_(solver.status)
-        # ICH-QP:221-225: z.set_zero(); lcp_lemke_regularized on the failures.
-        # The batch entry solves all worlds; failures are selected afterwards.
-        return None
-
-    for _ in range(args.warmup):
-        step()
+    # warmup: W untimed steps (one launch)
+    if args.warmup > 0:
+        wb.step(DT, args.warmup, stream)
     torch.cuda.synchronize()
+    _, aux0 = wb.download()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     if world_size > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    evs = []
-    for _ in range(args.steps):
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        z.copy_(z0)
-        solver.rng.copy_(rng0)
-        e0.record()
-        solver.solve(_lib.MH_LCP_FAST_REG, M, q, z, opts_fast)
-        e1.record()
-        evs.append((e0, e1))
+    ev0.record()
+    wb.step(DT, args.steps, stream)  # EXACTLY K steps of every world, one persistent launch
+    ev1.record()
     torch.cuda.synchronize()
     if world_size > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    kern_s = ev0.elapsed_time(ev1) * 1e-3
+    _, aux1 = wb.download()
+    d = lambda f: int(aux1[f].astype(np.int64).sum() - aux0[f].astype(np.int64).sum())
+    tot = np.array([d("lcp_rows"), d("lcp_solves"), d("lcp_pivots"), d("mini_steps"), d("stab_iters"), d("lcp_alg_bytes"),
+                    int((aux1["status"] & ~S.MH_WORLD_IMPACT_TOL != 0).sum())], dtype=np.float64)
     if world_size > 1:
+        # the per-interval reduction of SURVEY 8e: one small all-reduce over xGMI
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = [a.elapsed_time(b) for a, b in evs]
-    kern_avg_s = float(np.mean(kern_ms)) * 1e-3
-    n_ok = int(solver.status.sum().item())
+        c = torch.from_numpy(tot).to(dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        tot = c.cpu().numpy()
+    rows, solves, pivots, minis, stabs, alg_bytes_all, bad = [float(x) for x in tot]
 
-    rows_per_step = B * n * world_size
-    value = rows_per_step * args.steps / elapsed
-    ms_per_step = elapsed / args.steps * 1e3
-    # algorithmic bytes of one launch: M + q in, z out  (8(n^2+2n) per LCP)
-    alg_bytes = 8.0 * (n * n + 2 * n) * B
-    achieved = alg_bytes / kern_avg_s / 1e9
-
+    world_steps = B * world_size * args.steps
+    value = rows / elapsed
+    # roofline of the dominant (only) kernel, per launch, this rank: algorithmic bytes by the
+    # LCP-entry model of SURVEY 8(d): 8 (n^2 + 2n) per LCP solved, summed over the launch
+    alg_bytes = float(d("lcp_alg_bytes"))
+    achieved = alg_bytes / kern_s / 1e9
+    fused_bytes = float(B) * (2 * sc.nb * S.MH_BODY_STATE * 8 + 2 * S.AUX_DTYPE.itemsize)
     out = {
         "metric": "lcp_rows_per_sec",
         "value": value,
@@ -145,35 +119,39 @@ def main():
         "n_gpus": world_size,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
+        "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "sphere-stack x%d per GPU: impact LCP n=42, lcp_fast_regularized(-20,4,-8)" % B,
-                   "worlds_per_gpu": B, "lcp_n": n, "parallelism": "worlds sharded x%d, no collective" % world_size},
-        "world_steps_per_sec": B * world_size * args.steps / elapsed,
-        "solved_by_fast_ladder": n_ok,
+        "config": {"workload": "sphere-stack x%d per GPU (example/stacks/sphere-stack.xml, dt=1e-3): full TimeSteppingSimulator::step per world" % B,
+                   "worlds_per_gpu": B, "dt": DT, "parallelism": "worlds sharded x%d, no data-path collective" % world_size},
+        "world_steps_per_sec": world_steps / elapsed,
+        "batch_steps_per_sec": args.steps / elapsed,
+        "lcp_solves": solves, "lcp_rows": rows, "lcp_pivots": pivots, "mini_steps": minis, "stab_iters": stabs,
+        "worlds_with_errors": bad,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "mh_k_lcp_wave", "kernel_avg_us": kern_avg_s * 1e6,
-                     "algorithmic_bytes_per_launch": alg_bytes},
+                     "kernel": "mh_k_world_step", "kernel_avg_us": kern_s * 1e6, "launches": 1,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "model": "LCP-entry bytes 8(n^2+2n) per solved LCP (SURVEY 8d); the fused kernel itself only moves %d B of state per launch" % int(fused_bytes)},
     }
 
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
-        from tests.oracle_api import Oracle, FAST_REG
+        from tests.oracle_api import Oracle
         oracle = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
-        sample = min(B, 1024)
-        Ms = np.tile(Mh, ((sample + base - 1) // base, 1, 1))[:sample]
-        qs = np.tile(qh, ((sample + base - 1) // base, 1))[:sample]
-        reps_cpu, secs = 0, 0.0
-        while secs < 10.0 and reps_cpu < 50:
-            s, st, piv, zz, _, _ = oracle.lcp_batch(FAST_REG, Ms, qs, np.zeros((sample, n)), exps=(-20, 4, -8))
-            secs += s; reps_cpu += 1
-        out["cpu_baseline"] = {"value": sample * n * reps_cpu / secs, "unit": "LCP rows/s", "cores": 1, "kind": "port",
-                               "sample": "%d of the same sphere-stack impact LCPs x %d passes, oracle lcp_fast_regularized, 1 thread (host has %d cores)"
-                                         % (sample, reps_cpu, os.cpu_count())}
+        nw, ns = min(B, 256), min(args.steps + args.warmup, 200)
+        secs, crow, cstep, passes = 0.0, 0, 0, 0
+        while secs < 10.0 and passes < 40:
+            st = S.sphere_stack_state_range(0, nw)
+            aux = S.new_aux(nw)
+            secs += oracle.world_step_batch(sc, st, aux, DT, ns)
+            crow += int(aux["lcp_rows"].sum()); cstep += nw * ns; passes += 1
+        out["cpu_baseline"] = {"value": crow / secs, "unit": "LCP rows/s", "cores": 1, "kind": "port",
+                               "world_steps_per_sec": cstep / secs,
+                               "sample": "%d worlds x %d steps of the same batch x %d passes, CPU oracle (oracle/world.hpp), 1 thread; host has %d cores"
+                                         % (nw, ns, passes, os.cpu_count())}
     if rank == 0:
         print(json.dumps(out))
     if world_size > 1:

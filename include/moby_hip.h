@@ -175,19 +175,40 @@ typedef struct mh_world_aux {
   unsigned long long lcp_rows;     /* sum of their dimensions (BASELINE metric "rows")     */
   unsigned long long lcp_pivots;
   unsigned long long stab_iters;
+  unsigned long long lcp_alg_bytes;/* sum of 8 (n^2 + 2n): bytes the same solves move through the LCP entry */
 } mh_world_aux;
 
 void mh_scene_defaults(mh_scene* s);   /* zero + the reference's default tolerances */
 void mh_world_aux_init(mh_world_aux* a, uint32_t seed);
 
-/* Advance B worlds by nsteps steps of size dt, all inside one launch.
- *   state   B * nb * MH_BODY_STATE doubles, in/out
- *   aux     B structs, in/out
- *   traj    optional B * nsteps * nb * 7 doubles: generalized coordinates (x, quat xyzw)
- *           AFTER each step (the rows programs/regress.cpp:82-93 prints), or NULL
+/* A batch of B worlds resident on the GPU (device copies of the scene, the
+ * body states and the per-world solver state).  This is what a batched
+ * TimeSteppingSimulator subclass holds instead of B simulator objects.
+ *   create    allocates device memory, uploads the scene, initialises every
+ *             world's aux record (rand() stream at srand(1))
+ *   upload    state: B * nb * MH_BODY_STATE doubles (host); aux: B records or NULL
+ *   step      enqueues ONE launch that advances every world by nsteps steps of dt
+ *             (TimeSteppingSimulator::step called nsteps times) on `stream`
+ *             (hipStream_t, NULL = default); does not synchronise.
+ *             traj_dev: optional DEVICE buffer B * nsteps * nb * 7 doubles receiving
+ *             the generalized coordinates (x, quat xyzw) after each step -- the rows
+ *             programs/regress.cpp:82-93 prints -- or NULL
+ *   download  synchronises the device and copies state / aux back (either may be NULL)
+ *   device_ptrs  raw device pointers for zero-copy interop (e.g. torch tensors)
  */
-int mh_world_step_batch_dev(void* stream, const mh_scene* scene_host, int B, double dt, int nsteps,
-                            double* state, mh_world_aux* aux, double* traj);
+typedef struct mh_world_batch mh_world_batch;
+int mh_world_batch_create(const mh_scene* scene, int B, mh_world_batch** out);
+int mh_world_batch_destroy(mh_world_batch* wb);
+int mh_world_batch_upload(mh_world_batch* wb, const double* state, const mh_world_aux* aux);
+int mh_world_batch_step(mh_world_batch* wb, void* stream, double dt, int nsteps, double* traj_dev);
+int mh_world_batch_download(mh_world_batch* wb, double* state, mh_world_aux* aux);
+int mh_world_batch_device_ptrs(mh_world_batch* wb, double** state_dev, mh_world_aux** aux_dev);
+/* diagnostic build of the same launch with in-kernel s_memtime stamps: mean cycles per world spent in
+ * each phase (order: broad phase + CA, position integration, forward dynamics, contact generation,
+ * islands, problem data, LCP matrix build, LCP solve, impulse application, stabilisation) */
+int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* phase_cycles, int nphase);
+
+/* Host convenience: create + upload + step + download (+ trajectory) + destroy. */
 int mh_world_step_batch(const mh_scene* scene, int B, double dt, int nsteps,
                         double* state, mh_world_aux* aux, double* traj);
 

@@ -46,7 +46,13 @@ SYMBOLS = {
     "mh_lcp_solve_batch": (_i, [_i] + _LCP_TAIL),
     "mh_scene_defaults": (None, [_vp]),
     "mh_world_aux_init": (None, [_vp, ctypes.c_uint32]),
-    "mh_world_step_batch_dev": (_i, [_vp, _vp, _i, _d, _i, _vp, _vp, _vp]),
+    "mh_world_batch_create": (_i, [_vp, _i, ctypes.POINTER(_vp)]),
+    "mh_world_batch_destroy": (_i, [_vp]),
+    "mh_world_batch_upload": (_i, [_vp, _vp, _vp]),
+    "mh_world_batch_step": (_i, [_vp, _vp, _d, _i, _vp]),
+    "mh_world_batch_download": (_i, [_vp, _vp, _vp]),
+    "mh_world_batch_profile": (_i, [_vp, _d, _i, _vp, _i]),
+    "mh_world_batch_device_ptrs": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "mh_world_step_batch": (_i, [_vp, _i, _d, _i, _vp, _vp, _vp]),
 }
 

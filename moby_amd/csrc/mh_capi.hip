@@ -93,7 +93,8 @@ void mh_k_lcp_wave(int B, int n, const double* __restrict__ Mg, int ld, long str
   mh::WaveRand rng; rng.load(rngg + (size_t)b * MH_RAND_WORDS);
   mh::Trace tr; tr.buf = trace ? trace + (size_t)b * trace_cap : nullptr; tr.cap = trace_cap; tr.len = 0;
   unsigned piv = 0;
-  const bool ok = mh::lcp_solve_wave(P, p10, n, Ms, A, art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
+  mh::DenseLds Md; Md.M = Ms; Md.n = n;
+  const bool ok = mh::lcp_solve_wave(P, p10, n, Md, A, art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
   if (valid) zg[(size_t)b * n + lane] = zi;
   rng.store(rngg + (size_t)b * MH_RAND_WORDS);
   if (lane == 0) {
@@ -250,12 +251,13 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 #include "mh_world_wave.h"
 
 __global__ __launch_bounds__(64)
-void mh_k_world_step(mh_scene sc, int B, double dt, int nsteps, double* __restrict__ state,
-                     mh_world_aux* __restrict__ aux, double* __restrict__ traj, int nmax)
+void mh_k_world_step(const mh_scene* __restrict__ scp, int B, double dt, int nsteps, double* __restrict__ state,
+                     mh_world_aux* __restrict__ aux, double* __restrict__ traj, int nmax, unsigned long long* __restrict__ prof)
 {
   extern __shared__ double lds[];
   const int w = blockIdx.x;
   if (w >= B) return;
+  const mh_scene& sc = *scp;
   mh::WorldWave W(sc);
   W.L.carve(lds, nmax);
   const int lane = mh::lane_id();
@@ -269,8 +271,10 @@ void mh_k_world_step(mh_scene sc, int B, double dt, int nsteps, double* __restri
   W.zlast_size = mh::uni(a->zlast_size); W.zbuf_size = mh::uni(a->zbuf_size); W.zbuf_cap = mh::uni(a->zbuf_cap);
   W.status = mh::uni(a->status);
   W.time = mh::uni(a->time);
-  W.n_steps = a->steps; W.n_mini = a->mini_steps; W.n_lcp = a->lcp_solves; W.n_rows = a->lcp_rows; W.n_piv = a->lcp_pivots; W.n_stab = a->stab_iters;
+  W.n_steps = a->steps; W.n_mini = a->mini_steps; W.n_lcp = a->lcp_solves; W.n_rows = a->lcp_rows; W.n_piv = a->lcp_pivots; W.n_stab = a->stab_iters; W.n_bytes = a->lcp_alg_bytes;
   W.npairs = 0; W.nc = 0;
+  W.prof = prof ? prof + (size_t)w * mh::PH_COUNT : nullptr;
+  for (int i = 0; i < mh::PH_COUNT; i++) W.pacc[i] = 0ull;
   mh::wave_sync();
   for (int s = 0; s < nsteps; s++) {
     W.step(dt);
@@ -285,7 +289,8 @@ void mh_k_world_step(mh_scene sc, int B, double dt, int nsteps, double* __restri
   a->zlast[lane] = W.zlast_l; a->zbuf[lane] = W.zbuf_l;
   if (lane == 0) {
     a->zlast_size = W.zlast_size; a->zbuf_size = W.zbuf_size; a->zbuf_cap = W.zbuf_cap; a->status = W.status; a->time = W.time;
-    a->steps = W.n_steps; a->mini_steps = W.n_mini; a->lcp_solves = W.n_lcp; a->lcp_rows = W.n_rows; a->lcp_pivots = W.n_piv; a->stab_iters = W.n_stab;
+    a->steps = W.n_steps; a->mini_steps = W.n_mini; a->lcp_solves = W.n_lcp; a->lcp_rows = W.n_rows; a->lcp_pivots = W.n_piv; a->stab_iters = W.n_stab; a->lcp_alg_bytes = W.n_bytes;
+    if (W.prof) for (int i = 0; i < mh::PH_COUNT; i++) W.prof[i] = W.pacc[i];
   }
 }
 
@@ -342,53 +347,139 @@ void mh_world_aux_init(mh_world_aux* a, uint32_t seed)
   mh_rand_seed(a->rng, seed);
 }
 
-int mh_world_step_batch_dev(void* stream, const mh_scene* scene, int B, double dt, int nsteps,
-                            double* state, mh_world_aux* aux, double* traj)
+struct mh_world_batch {
+  mh_scene scene;
+  int B;
+  int nmax;
+  size_t lds;
+  mh_scene* d_scene;
+  double* d_state;
+  mh_world_aux* d_aux;
+};
+
+int mh_world_batch_create(const mh_scene* scene, int B, mh_world_batch** out)
 {
+  if (!out) return fail(MH_ERR_INVALID_ARG, "null out");
+  *out = nullptr;
   int rc = check_scene(scene);
   if (rc != MH_OK) return rc;
-  if (B < 0 || nsteps < 0) return fail(MH_ERR_INVALID_ARG, "negative batch or step count");
-  if (B == 0 || nsteps == 0) return MH_OK;
-  if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
-  if (!state || !aux) return fail(MH_ERR_INVALID_ARG, "null state/aux");
+  if (B <= 0) return fail(MH_ERR_INVALID_ARG, "batch must be > 0");
+  if (mh_device_count() <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
   std::call_once(g_tables_once, init_tables);
   if (g_tables_err != hipSuccess) return fail(MH_ERR_HIP, "constant table upload failed: %s", hipGetErrorString(g_tables_err));
-  const int nmax = scene->lcp_n_max ? scene->lcp_n_max : MH_LCP_MAX_N_WAVE;
-  const size_t lds = mh::WorldLds::doubles(nmax) * sizeof(double) + mh::WorldLds::ints() * sizeof(int);
-  if (lds > 160 * 1024) return fail(MH_ERR_UNSUPPORTED_N, "world kernel needs %zu B of LDS (> 160 KiB)", lds);
+  mh_world_batch* wb = new mh_world_batch();
+  wb->scene = *scene; wb->B = B;
+  wb->nmax = scene->lcp_n_max ? scene->lcp_n_max : MH_LCP_MAX_N_WAVE;
+  wb->lds = mh::WorldLds::doubles(wb->nmax) * sizeof(double) + mh::WorldLds::ints() * sizeof(int);
+  wb->d_scene = nullptr; wb->d_state = nullptr; wb->d_aux = nullptr;
+  if (wb->lds > 160 * 1024) { delete wb; return fail(MH_ERR_UNSUPPORTED_N, "world kernel needs more than 160 KiB of LDS"); }
   static std::once_flag attr_once;
   std::call_once(attr_once, [] { (void)hipFuncSetAttribute((const void*)mh_k_world_step, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-  hipLaunchKernelGGL(mh_k_world_step, dim3(B), dim3(64), lds, (hipStream_t)stream, *scene, B, dt, nsteps, state, aux, traj, nmax);
+  hipError_t e = hipMalloc(&wb->d_scene, sizeof(mh_scene));
+  if (e == hipSuccess) e = hipMalloc(&wb->d_state, (size_t)B * scene->nb * MH_BODY_STATE * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&wb->d_aux, (size_t)B * sizeof(mh_world_aux));
+  if (e == hipSuccess) e = hipMemcpy(wb->d_scene, scene, sizeof(mh_scene), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(wb->d_state, 0, (size_t)B * scene->nb * MH_BODY_STATE * sizeof(double));
+  if (e == hipSuccess) {
+    std::vector<mh_world_aux> a((size_t)B);
+    mh_world_aux_init(&a[0], 1);
+    for (int b = 1; b < B; b++) a[b] = a[0];
+    e = hipMemcpy(wb->d_aux, a.data(), (size_t)B * sizeof(mh_world_aux), hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) { mh_world_batch_destroy(wb); return fail(MH_ERR_HIP, "device allocation/upload failed: %s", hipGetErrorString(e)); }
+  *out = wb;
+  return MH_OK;
+}
+
+int mh_world_batch_destroy(mh_world_batch* wb)
+{
+  if (!wb) return MH_OK;
+  if (wb->d_scene) (void)hipFree(wb->d_scene);
+  if (wb->d_state) (void)hipFree(wb->d_state);
+  if (wb->d_aux) (void)hipFree(wb->d_aux);
+  delete wb;
+  return MH_OK;
+}
+
+int mh_world_batch_upload(mh_world_batch* wb, const double* state, const mh_world_aux* aux)
+{
+  if (!wb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  if (state) MH_HIP(hipMemcpy(wb->d_state, state, (size_t)wb->B * wb->scene.nb * MH_BODY_STATE * sizeof(double), hipMemcpyHostToDevice));
+  if (aux) MH_HIP(hipMemcpy(wb->d_aux, aux, (size_t)wb->B * sizeof(mh_world_aux), hipMemcpyHostToDevice));
+  return MH_OK;
+}
+
+int mh_world_batch_step(mh_world_batch* wb, void* stream, double dt, int nsteps, double* traj_dev)
+{
+  if (!wb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  if (nsteps < 0) return fail(MH_ERR_INVALID_ARG, "negative step count");
+  if (nsteps == 0) return MH_OK;
+  if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
+  hipLaunchKernelGGL(mh_k_world_step, dim3(wb->B), dim3(64), wb->lds, (hipStream_t)stream,
+                     wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, traj_dev, wb->nmax, (unsigned long long*)nullptr);
   MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+// diagnostic: one launch with per-phase cycle accumulators (mh::PH_*), averaged over worlds on the host
+int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* phase_cycles, int nphase)
+{
+  if (!wb || !phase_cycles) return fail(MH_ERR_INVALID_ARG, "null argument");
+  unsigned long long* dprof = nullptr;
+  const size_t sz = (size_t)wb->B * mh::PH_COUNT * sizeof(unsigned long long);
+  MH_HIP(hipMalloc(&dprof, sz));
+  MH_HIP(hipMemset(dprof, 0, sz));
+  hipLaunchKernelGGL(mh_k_world_step, dim3(wb->B), dim3(64), wb->lds, (hipStream_t)nullptr,
+                     wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, dprof);
+  hipError_t e = hipDeviceSynchronize();
+  std::vector<unsigned long long> h((size_t)wb->B * mh::PH_COUNT);
+  if (e == hipSuccess) e = hipMemcpy(h.data(), dprof, sz, hipMemcpyDeviceToHost);
+  (void)hipFree(dprof);
+  if (e != hipSuccess) return fail(MH_ERR_HIP, "profile launch failed: %s", hipGetErrorString(e));
+  for (int p = 0; p < nphase; p++) {
+    double acc = 0.0;
+    if (p < mh::PH_COUNT) for (int b = 0; b < wb->B; b++) acc += (double)h[(size_t)b * mh::PH_COUNT + p];
+    phase_cycles[p] = acc / wb->B;
+  }
+  return MH_OK;
+}
+
+int mh_world_batch_download(mh_world_batch* wb, double* state, mh_world_aux* aux)
+{
+  if (!wb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_HIP(hipDeviceSynchronize());
+  if (state) MH_HIP(hipMemcpy(state, wb->d_state, (size_t)wb->B * wb->scene.nb * MH_BODY_STATE * sizeof(double), hipMemcpyDeviceToHost));
+  if (aux) MH_HIP(hipMemcpy(aux, wb->d_aux, (size_t)wb->B * sizeof(mh_world_aux), hipMemcpyDeviceToHost));
+  return MH_OK;
+}
+
+int mh_world_batch_device_ptrs(mh_world_batch* wb, double** state_dev, mh_world_aux** aux_dev)
+{
+  if (!wb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  if (state_dev) *state_dev = wb->d_state;
+  if (aux_dev) *aux_dev = wb->d_aux;
   return MH_OK;
 }
 
 int mh_world_step_batch(const mh_scene* scene, int B, double dt, int nsteps,
                         double* state, mh_world_aux* aux, double* traj)
 {
-  int rc = check_scene(scene);
+  if (B == 0 || nsteps == 0) return MH_OK;
+  if (B < 0 || nsteps < 0) return fail(MH_ERR_INVALID_ARG, "negative batch or step count");
+  if (!state || !aux) return fail(MH_ERR_INVALID_ARG, "null state/aux");
+  mh_world_batch* wb = nullptr;
+  int rc = mh_world_batch_create(scene, B, &wb);
   if (rc != MH_OK) return rc;
-  if (B <= 0 || nsteps <= 0) return (B == 0 || nsteps == 0) ? MH_OK : fail(MH_ERR_INVALID_ARG, "negative batch or step count");
-  if (mh_device_count() <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
-  double *dst = nullptr, *dtraj = nullptr; mh_world_aux* daux = nullptr;
-  const size_t sz_st = (size_t)B * scene->nb * MH_BODY_STATE * sizeof(double);
+  double* dtraj = nullptr;
   const size_t sz_tr = (size_t)B * nsteps * scene->nb * 7 * sizeof(double);
-  auto cleanup = [&]() { if (dst) (void)hipFree(dst); if (dtraj) (void)hipFree(dtraj); if (daux) (void)hipFree(daux); };
-#define MH_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); \
-  return fail(MH_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
-  MH_TRY(hipMalloc(&dst, sz_st)); MH_TRY(hipMalloc(&daux, (size_t)B * sizeof(mh_world_aux)));
-  if (traj) MH_TRY(hipMalloc(&dtraj, sz_tr));
-  MH_TRY(hipMemcpy(dst, state, sz_st, hipMemcpyHostToDevice));
-  MH_TRY(hipMemcpy(daux, aux, (size_t)B * sizeof(mh_world_aux), hipMemcpyHostToDevice));
-  rc = mh_world_step_batch_dev(nullptr, scene, B, dt, nsteps, dst, daux, dtraj);
-  if (rc != MH_OK) { cleanup(); return rc; }
-  MH_TRY(hipDeviceSynchronize());
-  MH_TRY(hipMemcpy(state, dst, sz_st, hipMemcpyDeviceToHost));
-  MH_TRY(hipMemcpy(aux, daux, (size_t)B * sizeof(mh_world_aux), hipMemcpyDeviceToHost));
-  if (traj) MH_TRY(hipMemcpy(traj, dtraj, sz_tr, hipMemcpyDeviceToHost));
-  cleanup();
-#undef MH_TRY
-  return MH_OK;
+  rc = mh_world_batch_upload(wb, state, aux);
+  if (rc == MH_OK && traj && hipMalloc(&dtraj, sz_tr) != hipSuccess) rc = fail(MH_ERR_HIP, "trajectory allocation failed");
+  if (rc == MH_OK) rc = mh_world_batch_step(wb, nullptr, dt, nsteps, dtraj);
+  if (rc == MH_OK) rc = mh_world_batch_download(wb, state, aux);
+  if (rc == MH_OK && traj && hipMemcpy(traj, dtraj, sz_tr, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MH_ERR_HIP, "trajectory download failed");
+  if (dtraj) (void)hipFree(dtraj);
+  mh_world_batch_destroy(wb);
+  return rc;
 }
 
 } // extern "C"

@@ -34,10 +34,35 @@ struct Trace {
 #define MH_NEAR_ZERO 1.4901161193847656e-08 /* sqrt(eps), Constants.h:21 */
 #define MH_SFMIN 2.2250738585072014e-308
 
-// M(r,c) of the caller's (possibly regularised) copy _MM = M + lam*I
-MH_DEV double mat_at(const double* M, int n, int r, int c, double lam) {
-  double m = M[r + n * c];
-  return (r == c) ? m + lam : m;
+// Matrix accessors.  The solvers only ever read M(lane, c) for a wave-uniform
+// column c (plus the lane's own diagonal entry), so a matrix is anything that
+// provides
+//   at_row(c)      M(lane, c), c uniform
+//   diag()         M(lane, lane)
+//   offdiag_max()  max |M(r,c)|, r != c  (uniform; regularisation ladder only)
+// DenseLds is an explicit column-major n x n array in LDS (the C-ABI LCP entry);
+// the world kernels plug in implicit matrices that are never materialised.
+struct DenseLds {
+  const double* M; int n;
+  MH_DEV double at_row(int c) const { const int l = lane_id(); return (l < n) ? M[l + n * c] : 0.0; }
+  MH_DEV double diag() const { const int l = lane_id(); return (l < n) ? M[l + n * l] : 0.0; }
+  MH_DEV double offdiag_max() const {
+    const int lane = lane_id();
+    double m = 0.0;
+    if (lane < n)
+      for (int c = 0; c < n; c++) {
+        const double a = fabs(M[lane + n * c]);
+        if (c != lane && a > m) m = a;
+      }
+    return wave_max(m);
+  }
+};
+
+// M(lane,c) of the caller's (possibly regularised) copy _MM = M + lam*I
+template <class MatT>
+MH_DEV double mat_at(const MatT& M, int c, double lam) {
+  const double m = M.at_row(c);
+  return (lane_id() == c) ? m + lam : m;
 }
 
 // dgesv for one rhs: A (k x k, col-major, ld=k) in LDS, lane r owns row r and
@@ -122,7 +147,8 @@ MH_DEV double norm_reg(double offmax, double dii, bool valid, double lam) {
 // LCP.cpp:41-196.  qi/zi: this lane's q[i], z[i].  zsize (uniform): z.size()
 // on entry -- == n selects the warm start (LCP.cpp:65); left unchanged when the
 // solver fails before writing z (LCP.cpp:125,195), set to n on success.
-MH_DEV bool lcp_fast_wave(int n, const double* M, double lam, double* A,
+template <class MatT>
+MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, double* A,
                           double qi, double& zi, int& zsize, double zero_tol,
                           double nrm_lam, WaveRand& rng, unsigned& pivots, Trace& tr)
 {
@@ -152,7 +178,7 @@ MH_DEV bool lcp_fast_wave(int n, const double* M, double lam, double* A,
       uint64_t m = nbmask;
       for (int c = 0; c < k; c++) {
         const int j = ctz(m); m &= m - 1;
-        if (is_nb) A[pos + k * c] = mat_at(M, n, lane, j, lam);
+        if (is_nb) A[pos + k * c] = mat_at(M, j, lam);
       }
       // route -q[i] from the variable's lane to its row lane (nonbasic
       // variables to rows 0..k-1, everything else to the unused lanes above)
@@ -167,7 +193,7 @@ MH_DEV bool lcp_fast_wave(int n, const double* M, double lam, double* A,
       for (int c = 0; c < k; c++) {
         const int j = ctz(m); m &= m - 1;
         const double t = read_lane(b, c);
-        if (is_b) w = w + t * mat_at(M, n, lane, j, lam);
+        if (is_b) w = w + t * mat_at(M, j, lam);
       }
       w = w + qi;
     }
@@ -208,7 +234,8 @@ MH_DEV bool lcp_fast_wave(int n, const double* M, double lam, double* A,
 
 // solution check shared by the regularised wrappers
 // (LCP.cpp:240-249 strict=false; :303-312 strict=true, against M + lam*I)
-MH_DEV bool verify_wave(int n, const double* M, double lam, double qi, double zi, double ZERO_TOL, bool strict)
+template <class MatT>
+MH_DEV bool verify_wave(int n, const MatT& M, double lam, double qi, double zi, double ZERO_TOL, bool strict)
 {
   const int lane = lane_id();
   const bool valid = lane < n;
@@ -220,7 +247,7 @@ MH_DEV bool verify_wave(int n, const double* M, double lam, double qi, double zi
   while (nz) {
     const int c = ctz(nz); nz &= nz - 1;
     const double t = read_lane(zi, c);
-    if (valid) w = w + t * mat_at(M, n, lane, c, lam);
+    if (valid) w = w + t * mat_at(M, c, lam);
   }
   w = w + qi;
   const double wmin = wave_min(valid ? w : INF);
@@ -237,7 +264,8 @@ MH_DEV bool verify_wave(int n, const double* M, double lam, double qi, double zi
 // variable, M(:,bv) for a z variable, `art` for the artificial variable t.
 // zsize: z.size() on entry (!= n draws n rand() values, LCP.cpp:611-621) and on
 // exit (2n after a singular-basis/ray-termination failure, LCP.cpp:840-903).
-MH_DEV bool lcp_lemke_wave(int n, const double* M, double lam, double* A, double* art,
+template <class MatT>
+MH_DEV bool lcp_lemke_wave(int n, const MatT& M, double lam, double* A, double* art,
                            double qi, double& zi, int& zsize, double piv_tol, double zero_tol,
                            double nrm_lam, WaveRand& rng, unsigned& pivots, Trace& tr)
 {
@@ -284,7 +312,7 @@ MH_DEV bool lcp_lemke_wave(int n, const double* M, double lam, double* A, double
     }
     double be;
     if (leaving < n) { entering = n + leaving; be = (lane == leaving) ? -1.0 : 0.0; }
-    else { entering = leaving - n; be = valid ? mat_at(M, n, lane, entering, lam) : 0.0; }
+    else { entering = leaving - n; be = valid ? mat_at(M, entering, lam) : 0.0; }
     // gather Al = Bl from the basis description
     wave_sync();
     for (int p = 0; p < n; p++) {
@@ -292,7 +320,7 @@ MH_DEV bool lcp_lemke_wave(int n, const double* M, double lam, double* A, double
       double a;
       if (id == t) a = valid ? art[lane] : 0.0;
       else if (id >= n) a = (lane == id - n) ? -1.0 : 0.0;
-      else a = valid ? mat_at(M, n, lane, id, lam) : 0.0;
+      else a = valid ? mat_at(M, id, lam) : 0.0;
       if (valid) A[lane + n * p] = a;
     }
     wave_sync();
@@ -327,20 +355,8 @@ struct Pow10Table { double v[64]; }; // index rf + 32
 
 // Dispatch over the four public solvers.  nrm0 = norm_inf(M) (max |m|), dii =
 // this lane's diagonal entry (for norm_inf of M + lam*I on the ladder).
-// max |M(r,c)|, r != c, from the LDS copy (only the regularisation ladder needs it)
-MH_DEV double offdiag_max(int n, const double* M)
-{
-  const int lane = lane_id();
-  double m = 0.0;
-  if (lane < n)
-    for (int c = 0; c < n; c++) {
-      const double a = fabs(M[lane + n * c]);
-      if (c != lane && a > m) m = a;
-    }
-  return wave_max(m);
-}
-
-MH_DEV bool lcp_solve_wave(const LcpParams& P, const Pow10Table& p10, int n, const double* M, double* A, double* art,
+template <class MatT>
+MH_DEV bool lcp_solve_wave(const LcpParams& P, const Pow10Table& p10, int n, const MatT& M, double* A, double* art,
                            double nrm0, double dii, double qi, double& zi, int& zsize,
                            WaveRand& rng, unsigned& pivots, Trace& tr)
 {
@@ -359,7 +375,7 @@ MH_DEV bool lcp_solve_wave(const LcpParams& P, const Pow10Table& p10, int n, con
   if (ok && verify_wave(n, M, 0.0, qi, zi, ZERO_TOL, false)) return true;
   total += pivots;
   int attempt = 1;
-  const double offmax = offdiag_max(n, M);
+  const double offmax = M.offdiag_max();
   for (int rf = P.min_exp; rf < P.max_exp; rf += (int)P.step_exp, attempt++) {
     const double lam = p10.v[rf + 32];
     const double nrm = norm_reg(offmax, dii, valid, lam);

@@ -58,12 +58,12 @@ __constant__ Pow10Table c_pow10;
 struct WorldLds {
   double *st, *qsave, *vsave, *qv, *dqv, *xinv;
   double *cpt, *cnr, *cs1, *cs2, *cdist, *cmu, *cmuv, *ceps, *ccomp;
-  double *J, *XJ, *G, *Cv, *imp, *zsol, *qq, *M, *A, *art;
+  double *J, *XJ, *G, *Cv, *imp, *zsol, *qq, *A, *art;
   int *pairs, *cg1, *cg2, *cpair, *cnk, *rowoff, *islc, *islb, *koff, *scr;
   __host__ __device__ static size_t doubles(int nmax) {
     return 13 * MH_MAX_BODIES + 7 * MH_MAX_BODIES + 6 * MH_MAX_BODIES + 7 * MH_MAX_BODIES + 7 * MH_MAX_BODIES + 10 * MH_MAX_BODIES
          + MHW_MAX_CONTACTS * (3 * 4 + 5)
-         + MHW_MAX_ROWS * 12 * 2 + MHW_MAX_GROWS * MHW_MAX_GROWS + MHW_MAX_ROWS * 2 + 64 + 64 + (size_t)2 * nmax * nmax + nmax;
+         + MHW_MAX_ROWS * 12 * 2 + MHW_MAX_GROWS * MHW_MAX_GROWS + MHW_MAX_ROWS * 2 + 64 + 64 + (size_t)nmax * nmax + nmax;
   }
   __host__ __device__ static size_t ints() { return MH_MAX_PAIRS + MHW_MAX_CONTACTS * 4 + MHW_MAX_ROWS * 2 + MHW_MAX_CONTACTS + MH_MAX_BODIES * 4 + MHW_MAX_CONTACTS + 1 + 64; }
   MH_DEV void carve(double* base, int nmax) {
@@ -74,15 +74,128 @@ struct WorldLds {
     cdist = p; p += MHW_MAX_CONTACTS; cmu = p; p += MHW_MAX_CONTACTS; cmuv = p; p += MHW_MAX_CONTACTS; ceps = p; p += MHW_MAX_CONTACTS; ccomp = p; p += MHW_MAX_CONTACTS;
     J = p; p += MHW_MAX_ROWS * 12; XJ = p; p += MHW_MAX_ROWS * 12; G = p; p += MHW_MAX_GROWS * MHW_MAX_GROWS;
     Cv = p; p += MHW_MAX_ROWS; imp = p; p += MHW_MAX_ROWS; zsol = p; p += 64; qq = p; p += 64;
-    M = p; p += (size_t)nmax * nmax; A = p; p += (size_t)nmax * nmax; art = p; p += nmax;
+    A = p; p += (size_t)nmax * nmax; art = p; p += nmax;
     int* q = reinterpret_cast<int*>(p);
     pairs = q; q += MH_MAX_PAIRS; cg1 = q; q += MHW_MAX_CONTACTS; cg2 = q; q += MHW_MAX_CONTACTS; cpair = q; q += MHW_MAX_CONTACTS; cnk = q; q += MHW_MAX_CONTACTS;
     rowoff = q; q += MHW_MAX_ROWS * 2; islc = q; q += MHW_MAX_CONTACTS; islb = q; q += MH_MAX_BODIES * 4; koff = q; q += MHW_MAX_CONTACTS + 1; scr = q; q += 64;
   }
 };
 
+// ---- implicit LCP matrices -------------------------------------------------------
+// _MM of solve_qp_work (ICH-QP:129-148 + setup_QP :271-497), never materialised:
+//   [ H  -N' ]   H = [n s t -s -t] blocks of C X C' (+ compliance), N = [Cn rows of H ; friction polygons]
+//   [ N   0  ]
+// Every entry is one value of G = [Cn;Cs;Ct] X [Cn;Cs;Ct]' (upper blocks stored, lower
+// ones read transposed exactly as setup_QP does), mu_i, or -cos/-sin of a polygon edge.
+// Lane r caches the description of ITS row; the column is wave-uniform.
+struct ImpactMat {
+  const double* G; int nic, R, nvars, n;
+  const int* koff; const int* islc; const double* cmu; const double* ccomp; const int* cnk;
+  // this lane's row
+  int rkind;      // 0 variable row (block ra, contact ri), 1 Cn v+ >= 0 row, 2 friction polygon row, 3 none
+  int ra, ri, rj;
+  double rmu, rcos, rsin, rcomp;
+  MH_DEV static int dir_of(int a) { return (a == 0) ? 0 : ((a == 1 || a == 3) ? 1 : 2); }
+  MH_DEV double Gab(int a, int b, int i, int j) const {
+    return (a <= b) ? G[(a * nic + i) * R + (b * nic + j)] : G[(b * nic + j) * R + (a * nic + i)];
+  }
+  MH_DEV void init(const double* G_, int nic_, int n_, const int* koff_, const int* islc_, const double* cmu_, const double* ccomp_, const int* cnk_) {
+    G = G_; nic = nic_; R = 3 * nic_; nvars = 5 * nic_; n = n_; koff = koff_; islc = islc_; cmu = cmu_; ccomp = ccomp_; cnk = cnk_;
+    const int r = lane_id();
+    rkind = 3; ra = 0; ri = 0; rj = 0; rmu = 0.0; rcos = 0.0; rsin = 0.0; rcomp = 0.0;
+    if (r < nvars) { rkind = 0; ra = r / nic; ri = r - ra * nic; rcomp = ccomp[islc[ri]]; }
+    else if (r < nvars + nic) { rkind = 1; ri = r - nvars; rcomp = ccomp[islc[ri]]; }
+    else if (r < n) {
+      rkind = 2;
+      const int rr = r - nvars - nic;
+      int i = 0; while (rr >= koff[i + 1]) i++;
+      ri = i; rj = rr - koff[i];
+      const int ci = islc[i]; const int kh = cnk[ci] / 2;
+      rmu = cmu[ci]; rcos = c_fric.c[kh][rj]; rsin = c_fric.s[kh][rj];
+    }
+  }
+  // H(row (a,i), col (b,j)) incl. sign and compliance
+  MH_DEV double H(int a, int i, int b, int j, double comp) const {
+    double g = Gab(dir_of(a), dir_of(b), i, j);
+    if ((a >= 3) != (b >= 3)) g = -g;
+    if (a == 0 && b == 0 && i == j) g = g + comp;
+    return g;
+  }
+  MH_DEV double at_row(int c) const {
+    if (c < nvars) {
+      const int b = c / nic, j = c - b * nic;
+      if (rkind == 0) return H(ra, ri, b, j, rcomp);
+      if (rkind == 1) return H(0, ri, b, j, rcomp);
+      if (rkind == 2) {
+        if (j != ri) return 0.0;
+        return (b == 0) ? rmu : ((b == 1 || b == 3) ? -rcos : -rsin);
+      }
+      return 0.0;
+    }
+    // constraint column cc: -(M(c, r)) for variable rows, 0 otherwise
+    if (rkind != 0) return 0.0;
+    const int cc = c - nvars;
+    if (cc < nic) {   // M(c, r) = H(cc, (ra,ri)) with the compliance of contact cc on (0,cc)
+      double g = Gab(0, dir_of(ra), cc, ri);
+      if (ra >= 3) g = -g;
+      if (ra == 0 && ri == cc) g = g + rcomp;
+      return -g;
+    }
+    int i = 0; const int rr = cc - nic; while (rr >= koff[i + 1]) i++;
+    if (i != ri) return -0.0;
+    const int jj = rr - koff[i]; const int ci = islc[i]; const int kh = cnk[ci] / 2;
+    const double v = (ra == 0) ? cmu[ci] : ((ra == 1 || ra == 3) ? -c_fric.c[kh][jj] : -c_fric.s[kh][jj]);
+    return -v;
+  }
+  MH_DEV double diag() const { return (rkind == 0) ? H(ra, ri, ra, ri, rcomp) : 0.0; }
+  // norm_inf(M) = max |entry|: H entries, mu, and the polygon edges (cos 0 = sin pi/2 = 1)
+  MH_DEV double norm_all() const {
+    const int lane = lane_id();
+    double m = 0.0;
+    for (int e = lane; e < R * R; e += 64) {
+      const int r = e / R, c = e - r * R;
+      if (c < r && (c / nic) != (r / nic)) continue;       // lower direction blocks are never read
+      double g = G[e];
+      if (r == c && r < nic) g = g + ccomp[islc[r]];
+      const double a = fabs(g); m = (a > m) ? a : m;
+    }
+    if (lane < nic) { const double a = fabs(cmu[islc[lane]]); m = (a > m) ? a : m; }
+    m = wave_max(m);
+    return (m > 1.0) ? m : 1.0;
+  }
+  MH_DEV double offdiag_max() const {
+    // off-diagonal entries include every polygon edge (|.| = 1 at the ends), every mu, every
+    // off-diagonal H entry and the H DIAGONAL values again through the Cn v+ rows / -N' columns
+    return norm_all();
+  }
+};
+
+// stabilisation LCP (CStab:932-947): MM = Cn X Cn' (nc x nc), read straight from G
+struct StabMat {
+  const double* G; int n;
+  MH_DEV double at_row(int c) const { const int l = lane_id(); return (l < n) ? G[l * n + c] : 0.0; }
+  MH_DEV double diag() const { const int l = lane_id(); return (l < n) ? G[l * n + l] : 0.0; }
+  MH_DEV double offdiag_max() const {
+    const int lane = lane_id(); double m = 0.0;
+    if (lane < n) for (int c = 0; c < n; c++) { const double a = fabs(G[lane * n + c]); if (c != lane && a > m) m = a; }
+    return wave_max(m);
+  }
+  MH_DEV double norm_all() const {
+    const int lane = lane_id(); double m = 0.0;
+    if (lane < n) for (int c = 0; c < n; c++) { const double a = fabs(G[lane * n + c]); m = (a > m) ? a : m; }
+    return wave_max(m);
+  }
+};
+
+// phase ids of the optional in-kernel profile (diagnostic launches only)
+enum { PH_BROAD_CA = 0, PH_INTEGRATE, PH_FWDDYN, PH_CONTACTS, PH_ISLANDS, PH_PDATA, PH_MBUILD, PH_LCP, PH_APPLY, PH_STAB, PH_COUNT };
+
 struct WorldWave {
   const mh_scene& sc;
+  unsigned long long* prof = nullptr;   // PH_COUNT accumulators (cycles) or null
+  unsigned long long pacc[PH_COUNT];
+  MH_DEV unsigned long long tick() const { return prof ? __builtin_amdgcn_s_memtime() : 0ull; }
+  MH_DEV void tock(int ph, unsigned long long t0) { if (prof) pacc[ph] += __builtin_amdgcn_s_memtime() - t0; }
   WorldLds L;
   int lane, nb, ntot, npt;       // npt: number of (i<j) pairs of the scene
   int nmax;
@@ -92,7 +205,7 @@ struct WorldWave {
   int zlast_size, zbuf_size, zbuf_cap;
   int status;
   double time;
-  unsigned long long n_steps, n_mini, n_lcp, n_rows, n_piv, n_stab;
+  unsigned long long n_steps, n_mini, n_lcp, n_rows, n_piv, n_stab, n_bytes;
   int npairs;                    // ConstraintSimulator::_pairs_to_check (L.pairs)
   int nc;                        // current constraint list size (L.c*)
 
@@ -469,51 +582,7 @@ struct WorldWave {
   MH_DEV double Gab(int R, int nic, int a, int b, int i, int j) const {
     return (a <= b) ? L.G[(a * nic + i) * R + (b * nic + j)] : L.G[(b * nic + j) * R + (a * nic + i)];
   }
-  // element (r,c) of _MM (ICH-QP:129-148 + setup_QP), nvars = 5 nic
-  MH_DEV double impact_mat(int nic, int r, int c) const {
-    const int R = 3 * nic, nvars = 5 * nic;
-    const int dirs[5] = { 0, 1, 2, 1, 2 };
-    if (r >= nvars && c >= nvars) return 0.0;
-    bool neg = false;
-    if (c >= nvars) { const int t = r; r = c; c = t; neg = true; }     // upper right = -(lower left)^T
-    double val;
-    int rr = r;
-    bool done = false;
-    if (r >= nvars) {
-      rr = r - nvars;
-      if (rr >= nic) {   // friction polygon row
-        int i = 0; while (rr - nic >= L.koff[i + 1]) i++;
-        const int j = rr - nic - L.koff[i];
-        const int ci = L.islc[i];
-        const int kh = L.cnk[ci] / 2;
-        if (c == i) val = L.cmu[ci];
-        else if (c == nic + i || c == 3 * nic + i) val = -c_fric.c[kh][j];
-        else if (c == 2 * nic + i || c == 4 * nic + i) val = -c_fric.s[kh][j];
-        else val = 0.0;
-        done = true;
-      }
-    }
-    if (!done) {       // H(rr, c)
-      const int a = rr / nic, i = rr - a * nic, b = c / nic, j = c - b * nic;
-      double g = Gab(R, nic, dirs[a], dirs[b], i, j);
-      if ((a >= 3) != (b >= 3)) g = -g;
-      if (rr == c && rr < nic) g = g + L.ccomp[L.islc[rr]];
-      val = g;
-    }
-    return neg ? -val : val;
-  }
-
-  MH_DEV void account(int n, unsigned piv) { n_lcp++; n_rows += (unsigned long long)n; n_piv += piv; }
-
-  // dense M (n x n col-major in L.M) -> norm_inf and this lane's diagonal
-  MH_DEV void dense_norms(int n, double& nrm0, double& dii) const {
-    double m = 0.0; dii = 0.0;
-    if (lane < n) {
-      for (int c = 0; c < n; c++) { const double a = fabs(L.M[lane + n * c]); m = (a > m) ? a : m; }
-      dii = L.M[lane + n * lane];
-    }
-    nrm0 = wave_max(m);
-  }
+  MH_DEV void account(int n, unsigned piv) { n_lcp++; n_rows += (unsigned long long)n; n_piv += piv; n_bytes += 8ull * ((unsigned long long)n * n + 2ull * n); }
 
   // solve_qp_work's chain on the persistent _z/_zlast (ICH-QP:157-233); on success the
   // solution is left in L.zsol[0..n) and in zlast/zbuf
@@ -525,12 +594,13 @@ struct WorldWave {
     nk_total = L.koff[nic];
     const int nvars = 5 * nic, n = nvars + nic + nk_total;
     if (n > nmax || n > MH_LCP_MAX_N_WAVE) { status |= MH_WORLD_UNSUPPORTED; return false; }
-    // materialise _MM and _qq
-    for (int e = lane; e < n * n; e += 64) { const int c = e / n, r = e - c * n; L.M[e] = impact_mat(nic, r, c); }
+    // _MM stays implicit (ImpactMat); _qq per lane
+    unsigned long long tm = tick();
+    ImpactMat Mi; Mi.init(L.G, nic, n, L.koff, L.islc, L.cmu, L.ccomp, L.cnk);
     double qi = 0.0;
     if (lane < n) {
       const int r = lane;
-      if (r < nvars) { const int a = r / nic, i = r - a * nic; const int dirs[5] = { 0, 1, 2, 1, 2 }; const double v = L.Cv[dirs[a] * nic + i]; qi = (a >= 3) ? -v : v; }
+      if (r < nvars) { const int a = r / nic, i = r - a * nic; const double v = L.Cv[ImpactMat::dir_of(a) * nic + i]; qi = (a >= 3) ? -v : v; }
       else if (r < nvars + nic) qi = L.Cv[r - nvars];
       else {
         int i = 0; const int rr = r - nvars - nic; while (rr >= L.koff[i + 1]) i++;
@@ -539,8 +609,10 @@ struct WorldWave {
         qi = L.cmuv[L.islc[i]] * vel;
       }
     }
-    wave_sync();
-    double nrm0, dii; dense_norms(n, nrm0, dii);
+    const double nrm0 = Mi.norm_all();
+    const double dii = Mi.diag();
+    tock(PH_MBUILD, tm);
+    tm = tick();
     // z.resize(n); warm start from _zlast when sizes match (ICH-QP:158-162)
     double zi;
     if (n > zbuf_cap) zi = 0.0; else zi = zbuf_l;
@@ -550,15 +622,16 @@ struct WorldWave {
     Trace tr; tr.buf = nullptr; tr.cap = 0; tr.len = 0;
     unsigned piv = 0, ptot = 0;
     LcpParams P; P.kind = MH_LCP_FAST_REG; P.min_exp = -20; P.step_exp = 4; P.max_exp = -8; P.piv_tol = -1.0; P.zero_tol = -1.0;
-    bool ok = lcp_solve_wave(P, c_pow10, n, L.M, L.A, L.art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
+    bool ok = lcp_solve_wave(P, c_pow10, n, Mi, L.A, L.art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
     ptot += piv;
     if (!ok) {
       zi = 0.0;                                             // z.set_zero() keeps the size (ICH-QP:222)
       P.kind = MH_LCP_LEMKE_REG; P.min_exp = -20; P.step_exp = 1; P.max_exp = 1;
-      ok = lcp_solve_wave(P, c_pow10, n, L.M, L.A, L.art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
+      ok = lcp_solve_wave(P, c_pow10, n, Mi, L.A, L.art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
       ptot += piv;
     }
     account(n, ptot);
+    tock(PH_LCP, tm);
     if (!ok) { status |= MH_WORLD_LCP_FAILED; return false; }
     zlast_size = n; if (lane < n) zlast_l = zi;
     if (lane < n) zbuf_l = zi;
@@ -625,8 +698,11 @@ struct WorldWave {
 
   // apply_model_to_connected_constraints (ICH:530-626)
   MH_DEV void apply_model(int nic, int nib) {
+    unsigned long long t0 = tick();
     compute_problem_data(nic, nib, 3);
+    tock(PH_PDATA, t0);
     if (!solve_impact_lcp(nic)) return;
+    t0 = tick();
     // repack: the epd layout equals the first 5 nic entries; _z shrinks to N_VARS (ICH-QP:244)
     zbuf_size = 5 * nic;
     impulses_from_z(nic); apply_impulses(nic, nib, 3);
@@ -650,6 +726,7 @@ struct WorldWave {
         impulses_from_z(nic); apply_impulses(nic, nib, 3);
       }
     }
+    tock(PH_APPLY, t0);
   }
 
   // calc_impacting_unilateral_constraint_forces + apply_model (CSim:298-355, ICH:96-168)
@@ -662,7 +739,11 @@ struct WorldWave {
     // decisions because islands share no enabled body
     uint32_t active_contacts = 0;
     int nic, nib;
-    while (next_island(nic, nib)) {
+    while (true) {
+      const unsigned long long ti = tick();
+      const bool more = next_island(nic, nib);
+      tock(PH_ISLANDS, ti);
+      if (!more) break;
       const uint64_t act = ballot(lane < nic && contact_vn(L.islc[lane < nic ? lane : 0]) < -MH_NEAR_ZERO);
       if (act == 0ull) continue;                                    // remove_inactive_groups
       const bool all_inf = ballot(lane < nic && L.cmu[L.islc[lane < nic ? lane : 0]] < 1e2) == 0ull;
@@ -700,9 +781,12 @@ struct WorldWave {
     wave_sync();
     double h = 0.0;
     while (h < dt) {
+      unsigned long long t0 = tick();
       npairs = broad_phase(dt - h, L.pairs);
       const double CA = next_CA_step();
+      tock(PH_BROAD_CA, t0);
       if (CA <= 0.0) break;
+      t0 = tick();
       double tc = (sc.min_step_size > CA) ? sc.min_step_size : CA;
       tc = ((dt - h) < tc) ? (dt - h) : tc;
       wave_sync();
@@ -716,8 +800,10 @@ struct WorldWave {
       }
       wave_sync();
       h += tc;
+      tock(PH_INTEGRATE, t0);
     }
     // forward dynamics + velocity integration (TSS:173-192; GravityForce.cpp:33-69)
+    unsigned long long t1 = tick();
     if (lane < nb) {
       const int b = lane;
       const double m = sc.mass[b];
@@ -734,7 +820,10 @@ struct WorldWave {
       L.st[13*b+10] = wn.x; L.st[13*b+11] = wn.y; L.st[13*b+12] = wn.z;
     }
     wave_sync();
+    tock(PH_FWDDYN, t1);
+    t1 = tick();
     find_unilateral_constraints();
+    tock(PH_CONTACTS, t1);
     handle_impacts();
     time += h;
     n_mini++;
@@ -852,18 +941,18 @@ struct WorldWave {
         const int n_ = nic;
         if (n_ > nmax) { status |= MH_WORLD_UNSUPPORTED; continue; }
         // determine_dq (CStab:932-970): MM = Cn X Cn', qq = dist - |eps| - NEAR_ZERO
-        for (int e = lane; e < n_ * n_; e += 64) { const int c = e / n_, r = e - c * n_; L.M[e] = L.G[r * n_ + c]; }
+        StabMat Ms; Ms.G = L.G; Ms.n = n_;
         double qi = 0.0;
         if (lane < n_) qi = L.cdist[L.islc[lane]] - fabs(sc.cstab_eps) - MH_NEAR_ZERO;
         wave_sync();
-        double nrm0, dii; dense_norms(n_, nrm0, dii);
+        const double nrm0 = Ms.norm_all(), dii = Ms.diag();
         double zi = 0.0; int zsize = 0;                            // fresh local z: cold start
         Trace tr; tr.buf = nullptr; tr.cap = 0; tr.len = 0;
         unsigned piv = 0, ptot = 0;
         LcpParams P; P.kind = MH_LCP_FAST; P.min_exp = -20; P.step_exp = 1; P.max_exp = 1; P.piv_tol = -1.0; P.zero_tol = -1.0;
-        bool ok = lcp_solve_wave(P, c_pow10, n_, L.M, L.A, L.art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
+        bool ok = lcp_solve_wave(P, c_pow10, n_, Ms, L.A, L.art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
         ptot += piv;
-        if (!ok) { P.kind = MH_LCP_LEMKE_REG; ok = lcp_solve_wave(P, c_pow10, n_, L.M, L.A, L.art, nrm0, dii, qi, zi, zsize, rng, piv, tr); ptot += piv; }
+        if (!ok) { P.kind = MH_LCP_LEMKE_REG; ok = lcp_solve_wave(P, c_pow10, n_, Ms, L.A, L.art, nrm0, dii, qi, zi, zsize, rng, piv, tr); ptot += piv; }
         account(n_, ptot);
         // update_from_stacked(pd, z): cn = z[0..nc) (zeros where z is shorter)
         wave_sync();
@@ -892,7 +981,9 @@ struct WorldWave {
       h += do_mini_step(dt - h);
       if (++guard > 100000u) { status |= MH_WORLD_STALLED; break; }
     }
+    const unsigned long long ts = tick();
     stabilize();
+    tock(PH_STAB, ts);
     n_steps++;
   }
 };

@@ -51,6 +51,7 @@ class mh_world_aux(ctypes.Structure):
         ("zlast_size", ctypes.c_int), ("zbuf_size", ctypes.c_int), ("zbuf_cap", ctypes.c_int), ("status", ctypes.c_int),
         ("steps", ctypes.c_ulonglong), ("mini_steps", ctypes.c_ulonglong), ("lcp_solves", ctypes.c_ulonglong),
         ("lcp_rows", ctypes.c_ulonglong), ("lcp_pivots", ctypes.c_ulonglong), ("stab_iters", ctypes.c_ulonglong),
+        ("lcp_alg_bytes", ctypes.c_ulonglong),
     ]
 
 
@@ -59,7 +60,8 @@ AUX_DTYPE = np.dtype([
     ("zlast", np.float64, MH_LCP_MAX_N_WAVE), ("zbuf", np.float64, MH_LCP_MAX_N_WAVE),
     ("zlast_size", np.int32), ("zbuf_size", np.int32), ("zbuf_cap", np.int32), ("status", np.int32),
     ("steps", np.uint64), ("mini_steps", np.uint64), ("lcp_solves", np.uint64),
-    ("lcp_rows", np.uint64), ("lcp_pivots", np.uint64), ("stab_iters", np.uint64)], align=True)
+    ("lcp_rows", np.uint64), ("lcp_pivots", np.uint64), ("stab_iters", np.uint64),
+    ("lcp_alg_bytes", np.uint64)], align=True)
 assert AUX_DTYPE.itemsize == ctypes.sizeof(mh_world_aux), (AUX_DTYPE.itemsize, ctypes.sizeof(mh_world_aux))
 
 
@@ -152,6 +154,23 @@ def sphere_stack_state(B=1, perturb=True):
                 st[w, k, 0] += (u[0] - 0.5) * 2e-3
                 st[w, k, 1] += (u[1] - 0.5) * 2e-3
                 st[w, k, 9] = -0.1 * u[2 + k]
+    return st.reshape(B, 3 * MH_BODY_STATE)
+
+
+def sphere_stack_state_range(first_world, B):
+    """Worlds first_world .. first_world+B-1 of the infinite perturbed family."""
+    from .synth import world_uniforms
+    st = np.zeros((B, 3, MH_BODY_STATE))
+    for i in range(B):
+        w = first_world + i
+        u = world_uniforms(w, 5) if w > 0 else None
+        for k in range(3):
+            st[i, k, 0:3] = (0.0, 0.0, 1.0 + 2.0 * k)
+            st[i, k, 6] = 1.0
+            if u is not None:
+                st[i, k, 0] += (u[0] - 0.5) * 2e-3
+                st[i, k, 1] += (u[1] - 0.5) * 2e-3
+                st[i, k, 9] = -0.1 * u[2 + k]
     return st.reshape(B, 3 * MH_BODY_STATE)
 
 

@@ -39,25 +39,35 @@ class WorldBatch:
 
 
 class WorldBatchDevice:
-    """Same, with state/aux resident in HBM (torch tensors); asynchronous on torch's current stream."""
+    """Same, with state/aux resident in HBM behind an ``mh_world_batch`` handle;
+    ``step`` is asynchronous on the given (torch) stream."""
 
-    def __init__(self, scene, state, device="cuda", seed=1):
-        import torch
-        self.torch = torch
-        self.scene = scene
-        self.device = torch.device(device)
-        self.B = state.shape[0]
-        self.state = torch.from_numpy(np.ascontiguousarray(state, dtype=np.float64)).to(self.device)
-        aux = S.new_aux(self.B, seed)
-        self.aux = torch.from_numpy(aux.view(np.uint8).reshape(self.B, -1).copy()).to(self.device)
-
-    def step(self, dt, nsteps=1, traj=None):
+    def __init__(self, scene, state, seed=1):
         lib = _lib.load()
-        stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        rc = lib.mh_world_step_batch_dev(stream, ctypes.addressof(self.scene), self.B, float(dt), int(nsteps),
-                                         self.state.data_ptr(), self.aux.data_ptr(),
-                                         None if traj is None else traj.data_ptr())
-        _lib.check(rc)
+        self.scene = scene
+        self.B = state.shape[0]
+        self.handle = ctypes.c_void_p()
+        _lib.check(lib.mh_world_batch_create(ctypes.addressof(scene), self.B, ctypes.byref(self.handle)))
+        st = np.ascontiguousarray(state, dtype=np.float64)
+        aux = S.new_aux(self.B, seed)
+        _lib.check(lib.mh_world_batch_upload(self.handle, st.ctypes.data, aux.ctypes.data))
 
-    def aux_host(self):
-        return self.aux.cpu().numpy().view(S.AUX_DTYPE).reshape(self.B)
+    def step(self, dt, nsteps=1, stream=None, traj_ptr=None):
+        _lib.check(_lib.load().mh_world_batch_step(self.handle, stream, float(dt), int(nsteps), traj_ptr))
+
+    def download(self):
+        st = np.zeros((self.B, self.scene.nb * S.MH_BODY_STATE))
+        aux = np.zeros(self.B, dtype=S.AUX_DTYPE)
+        _lib.check(_lib.load().mh_world_batch_download(self.handle, st.ctypes.data, aux.ctypes.data))
+        return st, aux
+
+    def close(self):
+        if self.handle:
+            _lib.load().mh_world_batch_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -501,7 +501,7 @@ class World {
     for (int r = nvars; r < n; r++) for (int c = 0; c < nvars; c++) at(c, r) = -at(r, c);
   }
 
-  void lcp_account(int n, unsigned pivots) { aux->lcp_solves++; aux->lcp_rows += (unsigned long long)n; aux->lcp_pivots += pivots; }
+  void lcp_account(int n, unsigned pivots) { aux->lcp_solves++; aux->lcp_rows += (unsigned long long)n; aux->lcp_pivots += pivots; aux->lcp_alg_bytes += 8ull * ((unsigned long long)n * n + 2ull * n); }
 
   // solve_qp_work's solver chain (ICH-QP:157-233) on the persistent _z / _zlast
   bool solve_impact_lcp(const std::vector<double>& MM, const std::vector<double>& qq, int n, std::vector<double>& zout) {

@@ -1,0 +1,25 @@
+"""In-kernel phase profile of the world-step kernel (diagnostic launch with s_memtime stamps)."""
+import ctypes, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from moby_amd import _lib, scene as S
+from moby_amd.world import WorldBatchDevice
+import torch
+
+NAMES = ["broad+CA", "integrate", "fwd dyn", "contacts", "islands", "problem data", "M build", "LCP solve", "apply/update", "stabilise"]
+if __name__ == "__main__":
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    lib = _lib.load()
+    sc = S.sphere_stack_scene()
+    wb = WorldBatchDevice(sc, S.sphere_stack_state_range(0, B))
+    wb.step(1e-3, 20); torch.cuda.synchronize()
+    t0 = time.perf_counter(); wb.step(1e-3, nsteps); torch.cuda.synchronize(); t = time.perf_counter() - t0
+    print("plain launch: %.3f ms for %d steps x %d worlds -> %.1f us per batch step, %.3g world-steps/s" % (t * 1e3, nsteps, B, t / nsteps * 1e6, B * nsteps / t))
+    ph = np.zeros(len(NAMES))
+    _lib.check(lib.mh_world_batch_profile(wb.handle, 1e-3, nsteps, ph.ctypes.data, len(NAMES)))
+    tot = ph.sum()
+    for n, c in zip(NAMES, ph):
+        print("  %-14s %10.0f cycles/world-step  %5.1f %%" % (n, c / nsteps, 100 * c / tot))
+    print("  total stamped  %10.0f cycles/world-step" % (tot / nsteps))
