@@ -44,6 +44,7 @@ SYMBOLS = {
     "mh_rand_next": (_i, [_vp]),
     "mh_lcp_solve_batch_dev": (_i, [_vp, _i] + _LCP_TAIL),
     "mh_lcp_solve_batch": (_i, [_i] + _LCP_TAIL),
+    "mh_debug_set": (_i, [_i, _i]),
     "mh_scene_defaults": (None, [_vp]),
     "mh_world_aux_init": (None, [_vp, ctypes.c_uint32]),
     "mh_world_batch_create": (_i, [_vp, _i, ctypes.POINTER(_vp)]),

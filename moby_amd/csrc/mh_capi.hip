@@ -94,7 +94,8 @@ void mh_k_lcp_wave(int B, int n, const double* __restrict__ Mg, int ld, long str
   mh::Trace tr; tr.buf = trace ? trace + (size_t)b * trace_cap : nullptr; tr.cap = trace_cap; tr.len = 0;
   unsigned piv = 0;
   mh::DenseLds Md; Md.M = Ms; Md.n = n;
-  const bool ok = mh::lcp_solve_wave(P, p10, n, Md, A, art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
+  mh::LuScratch S; S.small = A; S.ka = n; S.big = A;
+  const bool ok = mh::lcp_solve_wave(P, p10, n, Md, S, art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
   if (valid) zg[(size_t)b * n + lane] = zi;
   rng.store(rngg + (size_t)b * MH_RAND_WORDS);
   if (lane == 0) {
@@ -250,16 +251,17 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 #include <mutex>
 #include "mh_world_wave.h"
 
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64, 2)
 void mh_k_world_step(const mh_scene* __restrict__ scp, int B, double dt, int nsteps, double* __restrict__ state,
-                     mh_world_aux* __restrict__ aux, double* __restrict__ traj, int nmax, unsigned long long* __restrict__ prof)
+                     mh_world_aux* __restrict__ aux, double* __restrict__ traj, int nmax, double* __restrict__ lu_ws, int ka,
+                     unsigned long long* __restrict__ prof)
 {
-  extern __shared__ double lds[];
   const int w = blockIdx.x;
   if (w >= B) return;
   const mh_scene& sc = *scp;
   mh::WorldWave W(sc);
-  W.L.carve(lds, nmax);
+  W.L.carve();
+  W.lu_ws = lu_ws + (size_t)w * nmax * nmax; W.ka = ka;
   const int lane = mh::lane_id();
   W.lane = lane; W.nb = sc.nb; W.ntot = sc.nb + (sc.has_ground ? 1 : 0); W.npt = W.ntot * (W.ntot - 1) / 2; W.nmax = nmax;
   const int nst = MH_BODY_STATE * sc.nb;
@@ -295,6 +297,7 @@ void mh_k_world_step(const mh_scene* __restrict__ scp, int B, double dt, int nst
 }
 
 namespace {
+int g_debug_ka = MHW_KA;   // LDS LU block edge; mh_debug_set(1, 0) forces the HBM workspace path
 std::once_flag g_tables_once;
 hipError_t g_tables_err = hipSuccess;
 void init_tables()
@@ -330,6 +333,12 @@ int check_scene(const mh_scene* sc)
 
 extern "C" {
 
+int mh_debug_set(int key, int value)
+{
+  if (key == 1) { if (value < 0 || value > MHW_KA) return fail(MH_ERR_INVALID_ARG, "LU block edge outside [0, %d]", MHW_KA); g_debug_ka = value; return MH_OK; }
+  return fail(MH_ERR_INVALID_ARG, "unknown debug key %d", key);
+}
+
 void mh_scene_defaults(mh_scene* s)
 {
   std::memset(s, 0, sizeof(*s));
@@ -351,8 +360,8 @@ struct mh_world_batch {
   mh_scene scene;
   int B;
   int nmax;
-  size_t lds;
   mh_scene* d_scene;
+  double* d_lu_ws;
   double* d_state;
   mh_world_aux* d_aux;
 };
@@ -370,12 +379,9 @@ int mh_world_batch_create(const mh_scene* scene, int B, mh_world_batch** out)
   mh_world_batch* wb = new mh_world_batch();
   wb->scene = *scene; wb->B = B;
   wb->nmax = scene->lcp_n_max ? scene->lcp_n_max : MH_LCP_MAX_N_WAVE;
-  wb->lds = mh::WorldLds::doubles(wb->nmax) * sizeof(double) + mh::WorldLds::ints() * sizeof(int);
-  wb->d_scene = nullptr; wb->d_state = nullptr; wb->d_aux = nullptr;
-  if (wb->lds > 160 * 1024) { delete wb; return fail(MH_ERR_UNSUPPORTED_N, "world kernel needs more than 160 KiB of LDS"); }
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [] { (void)hipFuncSetAttribute((const void*)mh_k_world_step, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+  wb->d_scene = nullptr; wb->d_state = nullptr; wb->d_aux = nullptr; wb->d_lu_ws = nullptr;
   hipError_t e = hipMalloc(&wb->d_scene, sizeof(mh_scene));
+  if (e == hipSuccess) e = hipMalloc(&wb->d_lu_ws, (size_t)B * wb->nmax * wb->nmax * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&wb->d_state, (size_t)B * scene->nb * MH_BODY_STATE * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&wb->d_aux, (size_t)B * sizeof(mh_world_aux));
   if (e == hipSuccess) e = hipMemcpy(wb->d_scene, scene, sizeof(mh_scene), hipMemcpyHostToDevice);
@@ -397,6 +403,7 @@ int mh_world_batch_destroy(mh_world_batch* wb)
   if (wb->d_scene) (void)hipFree(wb->d_scene);
   if (wb->d_state) (void)hipFree(wb->d_state);
   if (wb->d_aux) (void)hipFree(wb->d_aux);
+  if (wb->d_lu_ws) (void)hipFree(wb->d_lu_ws);
   delete wb;
   return MH_OK;
 }
@@ -415,8 +422,9 @@ int mh_world_batch_step(mh_world_batch* wb, void* stream, double dt, int nsteps,
   if (nsteps < 0) return fail(MH_ERR_INVALID_ARG, "negative step count");
   if (nsteps == 0) return MH_OK;
   if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
-  hipLaunchKernelGGL(mh_k_world_step, dim3(wb->B), dim3(64), wb->lds, (hipStream_t)stream,
-                     wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, traj_dev, wb->nmax, (unsigned long long*)nullptr);
+  hipLaunchKernelGGL(mh_k_world_step, dim3(wb->B), dim3(64), 0, (hipStream_t)stream,
+                     wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, traj_dev, wb->nmax, wb->d_lu_ws, g_debug_ka,
+                     (unsigned long long*)nullptr);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
@@ -429,8 +437,8 @@ int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* ph
   const size_t sz = (size_t)wb->B * mh::PH_COUNT * sizeof(unsigned long long);
   MH_HIP(hipMalloc(&dprof, sz));
   MH_HIP(hipMemset(dprof, 0, sz));
-  hipLaunchKernelGGL(mh_k_world_step, dim3(wb->B), dim3(64), wb->lds, (hipStream_t)nullptr,
-                     wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, dprof);
+  hipLaunchKernelGGL(mh_k_world_step, dim3(wb->B), dim3(64), 0, (hipStream_t)nullptr,
+                     wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, wb->d_lu_ws, g_debug_ka, dprof);
   hipError_t e = hipDeviceSynchronize();
   std::vector<unsigned long long> h((size_t)wb->B * mh::PH_COUNT);
   if (e == hipSuccess) e = hipMemcpy(h.data(), dprof, sz, hipMemcpyDeviceToHost);

@@ -69,7 +69,22 @@ MH_DEV double mat_at(const MatT& M, int c, double lam) {
 // rhs element b.  Returns LAPACK info (uniform); on info != 0 b is garbage.
 // dgetf2 order: idamax -> row swap (all columns) -> scale by reciprocal ->
 // rank-1 update; then dlaswp / unit-lower / upper triangular solves.
+struct LuOut { int info; double b; };
+MH_DEV int lu_solve_body(int k, double* A, double& b);
+// One out-of-line copy shared by every caller (the world kernel is instruction-cache
+// bound when this is inlined at each of its ~16 call sites).  `A` may point to LDS or
+// to the HBM workspace (flat addressing).
+__device__ __noinline__ LuOut lu_solve_call(int k, double* A, double b)
+{
+  LuOut o; o.info = lu_solve_body(k, A, b); o.b = b; return o;
+}
 MH_DEV int lu_solve_wave(int k, double* A, double& b)
+{
+  const LuOut o = lu_solve_call(k, A, b);
+  b = o.b;
+  return o.info;
+}
+MH_DEV int lu_solve_body(int k, double* A, double& b)
 {
   const int lane = lane_id();
   for (int j = 0; j < k; j++) {
@@ -147,8 +162,30 @@ MH_DEV double norm_reg(double offmax, double dii, bool valid, double lam) {
 // LCP.cpp:41-196.  qi/zi: this lane's q[i], z[i].  zsize (uniform): z.size()
 // on entry -- == n selects the warm start (LCP.cpp:65); left unchanged when the
 // solver fails before writing z (LCP.cpp:125,195), set to n on success.
+// LU scratch: `small` holds up to ka x ka doubles (LDS in the world kernel), `big`
+// n x n (LDS in the LCP-entry kernel, an HBM workspace in the world kernel).
+struct LuScratch { double* small; int ka; double* big; };
+
 template <class MatT>
-MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, double* A,
+MH_DEV int gather_and_solve(const MatT& M, double lam, uint64_t nbmask, int k, bool is_nb, int pos, double qi, double* A, double& b)
+{
+  const int lane = lane_id();
+  wave_sync();
+  uint64_t m = nbmask;
+  for (int c = 0; c < k; c++) {
+    const int j = ctz(m); m &= m - 1;
+    const double v = mat_at(M, j, lam);
+    if (is_nb) A[pos + k * c] = v;
+  }
+  // route -q[i] from the variable's lane to its row lane (nonbasic
+  // variables to rows 0..k-1, everything else to the unused lanes above)
+  b = push_to(-qi, is_nb ? pos : k + popc(~nbmask & lanes_below(lane)));
+  wave_sync();
+  return lu_solve_wave(k, A, b);
+}
+
+template <class MatT>
+MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, LuScratch S,
                           double qi, double& zi, int& zsize, double zero_tol,
                           double nrm_lam, WaveRand& rng, unsigned& pivots, Trace& tr)
 {
@@ -174,17 +211,8 @@ MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, double* A,
     // gather _Msub (rows by position) and the rhs -q[nonbas]
     double b = 0.0;
     if (k > 0) {
-      wave_sync();
-      uint64_t m = nbmask;
-      for (int c = 0; c < k; c++) {
-        const int j = ctz(m); m &= m - 1;
-        if (is_nb) A[pos + k * c] = mat_at(M, j, lam);
-      }
-      // route -q[i] from the variable's lane to its row lane (nonbasic
-      // variables to rows 0..k-1, everything else to the unused lanes above)
-      b = push_to(-qi, is_nb ? pos : k + popc(~nbmask & lanes_below(lane)));
-      wave_sync();
-      if (lu_solve_wave(k, A, b) != 0) return false;
+      double* Ause = (k <= S.ka) ? S.small : S.big;
+      if (gather_and_solve(M, lam, nbmask, k, is_nb, pos, qi, Ause, b) != 0) return false;
     }
     // w = Mmix * z + qbas on the basic lanes (dgemv column order)
     double w = 0.0;
@@ -265,7 +293,25 @@ MH_DEV bool verify_wave(int n, const MatT& M, double lam, double qi, double zi, 
 // zsize: z.size() on entry (!= n draws n rand() values, LCP.cpp:611-621) and on
 // exit (2n after a singular-basis/ray-termination failure, LCP.cpp:840-903).
 template <class MatT>
-MH_DEV bool lcp_lemke_wave(int n, const MatT& M, double lam, double* A, double* art,
+MH_DEV int lemke_gather_and_solve(int n, const MatT& M, double lam, int bv, int t, const double* art, double* A, double& d)
+{
+  const int lane = lane_id();
+  const bool valid = lane < n;
+  wave_sync();
+  for (int p = 0; p < n; p++) {
+    const int id = read_lane(bv, p);
+    double a;
+    if (id == t) a = valid ? art[lane] : 0.0;
+    else if (id >= n) a = (lane == id - n) ? -1.0 : 0.0;
+    else a = mat_at(M, id, lam);
+    if (valid) A[lane + n * p] = a;
+  }
+  wave_sync();
+  return lu_solve_wave(n, A, d);
+}
+
+template <class MatT>
+MH_DEV bool lcp_lemke_wave(int n, const MatT& M, double lam, LuScratch S, double* art,
                            double qi, double& zi, int& zsize, double piv_tol, double zero_tol,
                            double nrm_lam, WaveRand& rng, unsigned& pivots, Trace& tr)
 {
@@ -301,31 +347,25 @@ MH_DEV bool lcp_lemke_wave(int n, const MatT& M, double lam, double* A, double* 
   for (pivots = 0; pivots < MAXITER; pivots++) {
     if (leaving == t) {
       // z[_bas[p]] = x[p] (:804-806): route x from position lanes to variable lanes
+      // (art is dead once t has left the basis: reuse it as the routing buffer)
       wave_sync();
-      if (valid) A[lane] = 0.0;
+      if (valid) art[lane] = 0.0;
       wave_sync();
-      if (valid && bv < n) A[bv] = x;
+      if (valid && bv < n) art[bv] = x;
       wave_sync();
-      zi = valid ? A[lane] : 0.0;
+      zi = valid ? art[lane] : 0.0;
       zsize = n;
       return true;
     }
     double be;
     if (leaving < n) { entering = n + leaving; be = (lane == leaving) ? -1.0 : 0.0; }
     else { entering = leaving - n; be = valid ? mat_at(M, entering, lam) : 0.0; }
-    // gather Al = Bl from the basis description
-    wave_sync();
-    for (int p = 0; p < n; p++) {
-      const int id = read_lane(bv, p);
-      double a;
-      if (id == t) a = valid ? art[lane] : 0.0;
-      else if (id >= n) a = (lane == id - n) ? -1.0 : 0.0;
-      else a = valid ? mat_at(M, id, lam) : 0.0;
-      if (valid) A[lane + n * p] = a;
-    }
-    wave_sync();
+    // gather Al = Bl from the basis description and solve Al d = Be
     double d = be;
-    if (lu_solve_wave(n, A, d) != 0) return false;            // singular basis (:840-850), size stays 2n
+    {
+      double* Ause = (n <= S.ka) ? S.small : S.big;
+      if (lemke_gather_and_solve(n, M, lam, bv, t, art, Ause, d) != 0) return false;   // singular basis (:840-850), size stays 2n
+    }
     const uint64_t jm = ballot(valid && d > PIV_TOL);
     if (jm == 0ull) return false;                              // ray termination (:892-903)
     const bool inj = (jm >> lane) & 1ull;
@@ -356,34 +396,36 @@ struct Pow10Table { double v[64]; }; // index rf + 32
 // Dispatch over the four public solvers.  nrm0 = norm_inf(M) (max |m|), dii =
 // this lane's diagonal entry (for norm_inf of M + lam*I on the ladder).
 template <class MatT>
-MH_DEV bool lcp_solve_wave(const LcpParams& P, const Pow10Table& p10, int n, const MatT& M, double* A, double* art,
+MH_DEV bool lcp_solve_wave(const LcpParams& P, const Pow10Table& p10, int n, const MatT& M, LuScratch A, double* art,
                            double nrm0, double dii, double qi, double& zi, int& zsize,
                            WaveRand& rng, unsigned& pivots, Trace& tr)
 {
   const bool valid = lane_id() < n;
-  if (P.kind == MH_LCP_FAST)
-    return lcp_fast_wave(n, M, 0.0, A, qi, zi, zsize, P.zero_tol, nrm0, rng, pivots, tr);
-  if (P.kind == MH_LCP_LEMKE)
-    return lcp_lemke_wave(n, M, 0.0, A, art, qi, zi, zsize, P.piv_tol, P.zero_tol, nrm0, rng, pivots, tr);
-  const bool fast = (P.kind == MH_LCP_FAST_REG);
+  const bool reg = (P.kind == MH_LCP_FAST_REG) || (P.kind == MH_LCP_LEMKE_REG);
+  const bool fast = (P.kind == MH_LCP_FAST) || (P.kind == MH_LCP_FAST_REG);
   // plain norm_inf(M) -- the unregularised matrix -- sets ZERO_TOL (LCP.cpp:228,369)
   const double ZERO_TOL = (P.zero_tol > 0.0) ? P.zero_tol : (double)n * nrm0 * MH_NEAR_ZERO;
   unsigned total = 0;
-  tr.push(0x40000000);
-  bool ok = fast ? lcp_fast_wave(n, M, 0.0, A, qi, zi, zsize, P.zero_tol, nrm0, rng, pivots, tr)
-                 : lcp_lemke_wave(n, M, 0.0, A, art, qi, zi, zsize, P.piv_tol, P.zero_tol, nrm0, rng, pivots, tr);
-  if (ok && verify_wave(n, M, 0.0, qi, zi, ZERO_TOL, false)) return true;
-  total += pivots;
-  int attempt = 1;
-  const double offmax = M.offdiag_max();
-  for (int rf = P.min_exp; rf < P.max_exp; rf += (int)P.step_exp, attempt++) {
-    const double lam = p10.v[rf + 32];
-    const double nrm = norm_reg(offmax, dii, valid, lam);
-    tr.push(0x40000000 | attempt);
-    ok = fast ? lcp_fast_wave(n, M, lam, A, qi, zi, zsize, P.zero_tol, nrm, rng, pivots, tr)
-              : lcp_lemke_wave(n, M, lam, A, art, qi, zi, zsize, P.piv_tol, P.zero_tol, nrm, rng, pivots, tr);
-    total += pivots;
-    if (ok && verify_wave(n, M, lam, qi, zi, ZERO_TOL, true)) { pivots = total; return true; }
+  double offmax = 0.0;
+  // attempt 0 is the unregularised solve (verified against M with >=, LCP.cpp:236-256),
+  // attempts 1.. walk the ladder (verified against M + lambda I with >, :281-340); one
+  // loop so that each solver is instantiated once
+  int rf = P.min_exp;
+  for (int attempt = 0; ; attempt++) {
+    double lam = 0.0, nrm = nrm0;
+    if (attempt > 0) {
+      if (!reg || !(rf < P.max_exp)) break;
+      if (attempt == 1) offmax = M.offdiag_max();
+      lam = p10.v[rf + 32];
+      nrm = norm_reg(offmax, dii, valid, lam);
+    }
+    if (reg) tr.push(0x40000000 | attempt);
+    const bool ok = fast ? lcp_fast_wave(n, M, lam, A, qi, zi, zsize, P.zero_tol, nrm, rng, pivots, tr)
+                         : lcp_lemke_wave(n, M, lam, A, art, qi, zi, zsize, P.piv_tol, P.zero_tol, nrm, rng, pivots, tr);
+    if (!reg) return ok;                                      // plain lcp_fast / lcp_lemke
+    const bool good = ok && verify_wave(n, M, lam, qi, zi, ZERO_TOL, attempt > 0);
+    if (attempt == 0) { if (good) return true; total += pivots; }
+    else { total += pivots; if (good) { pivots = total; return true; } rf += (int)P.step_exp; }
   }
   pivots = total;
   return false;

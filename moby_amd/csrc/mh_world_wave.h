@@ -54,44 +54,52 @@ struct FricTable { double c[33][32]; double s[33][32]; };
 __constant__ FricTable c_fric;
 __constant__ Pow10Table c_pow10;
 
-// LDS carve-up (doubles first, then ints)
+// LDS carve-up: every array sits at a compile-time offset of two static __shared__
+// arrays, so no register holds an LDS pointer.  The LU scratch in LDS is MHW_KA x MHW_KA
+// (the usual nonbasic set of a warm-started contact LCP is 1..6 wide); larger systems
+// and Lemke's n x n basis use the per-world HBM workspace.
+#define MHW_KA 8
+#define MHW_LDS_DOUBLES (13 * MH_MAX_BODIES + 7 * MH_MAX_BODIES + 6 * MH_MAX_BODIES + 7 * MH_MAX_BODIES + 7 * MH_MAX_BODIES + 10 * MH_MAX_BODIES \
+                         + MHW_MAX_CONTACTS * (3 * 4 + 5) + MHW_MAX_ROWS * 12 * 2 + MHW_MAX_GROWS * MHW_MAX_GROWS + MHW_MAX_ROWS * 2 + 64 + 64 \
+                         + MHW_KA * MHW_KA + 64)
+#define MHW_LDS_INTS (MH_MAX_PAIRS + MHW_MAX_CONTACTS * 4 + MHW_MAX_ROWS * 2 + MHW_MAX_CONTACTS + MH_MAX_BODIES * 4 + MHW_MAX_CONTACTS + 1 + 64)
+// the one LDS image of a world (file scope so that out-of-line device functions see it)
+__shared__ double g_lds_d[MHW_LDS_DOUBLES];
+__shared__ int g_lds_i[MHW_LDS_INTS];
+
 struct WorldLds {
   double *st, *qsave, *vsave, *qv, *dqv, *xinv;
   double *cpt, *cnr, *cs1, *cs2, *cdist, *cmu, *cmuv, *ceps, *ccomp;
   double *J, *XJ, *G, *Cv, *imp, *zsol, *qq, *A, *art;
   int *pairs, *cg1, *cg2, *cpair, *cnk, *rowoff, *islc, *islb, *koff, *scr;
-  __host__ __device__ static size_t doubles(int nmax) {
-    return 13 * MH_MAX_BODIES + 7 * MH_MAX_BODIES + 6 * MH_MAX_BODIES + 7 * MH_MAX_BODIES + 7 * MH_MAX_BODIES + 10 * MH_MAX_BODIES
-         + MHW_MAX_CONTACTS * (3 * 4 + 5)
-         + MHW_MAX_ROWS * 12 * 2 + MHW_MAX_GROWS * MHW_MAX_GROWS + MHW_MAX_ROWS * 2 + 64 + 64 + (size_t)nmax * nmax + nmax;
-  }
-  __host__ __device__ static size_t ints() { return MH_MAX_PAIRS + MHW_MAX_CONTACTS * 4 + MHW_MAX_ROWS * 2 + MHW_MAX_CONTACTS + MH_MAX_BODIES * 4 + MHW_MAX_CONTACTS + 1 + 64; }
-  MH_DEV void carve(double* base, int nmax) {
-    double* p = base;
+  MH_DEV void carve() {
+    double* p = g_lds_d; int* ibase = g_lds_i;
     st = p; p += 13 * MH_MAX_BODIES; qsave = p; p += 7 * MH_MAX_BODIES; vsave = p; p += 6 * MH_MAX_BODIES;
     qv = p; p += 7 * MH_MAX_BODIES; dqv = p; p += 7 * MH_MAX_BODIES; xinv = p; p += 10 * MH_MAX_BODIES;
     cpt = p; p += 3 * MHW_MAX_CONTACTS; cnr = p; p += 3 * MHW_MAX_CONTACTS; cs1 = p; p += 3 * MHW_MAX_CONTACTS; cs2 = p; p += 3 * MHW_MAX_CONTACTS;
     cdist = p; p += MHW_MAX_CONTACTS; cmu = p; p += MHW_MAX_CONTACTS; cmuv = p; p += MHW_MAX_CONTACTS; ceps = p; p += MHW_MAX_CONTACTS; ccomp = p; p += MHW_MAX_CONTACTS;
     J = p; p += MHW_MAX_ROWS * 12; XJ = p; p += MHW_MAX_ROWS * 12; G = p; p += MHW_MAX_GROWS * MHW_MAX_GROWS;
     Cv = p; p += MHW_MAX_ROWS; imp = p; p += MHW_MAX_ROWS; zsol = p; p += 64; qq = p; p += 64;
-    A = p; p += (size_t)nmax * nmax; art = p; p += nmax;
-    int* q = reinterpret_cast<int*>(p);
+    A = p; p += MHW_KA * MHW_KA; art = p; p += 64;
+    int* q = ibase;
     pairs = q; q += MH_MAX_PAIRS; cg1 = q; q += MHW_MAX_CONTACTS; cg2 = q; q += MHW_MAX_CONTACTS; cpair = q; q += MHW_MAX_CONTACTS; cnk = q; q += MHW_MAX_CONTACTS;
     rowoff = q; q += MHW_MAX_ROWS * 2; islc = q; q += MHW_MAX_CONTACTS; islb = q; q += MH_MAX_BODIES * 4; koff = q; q += MHW_MAX_CONTACTS + 1; scr = q; q += 64;
   }
 };
 
 // ---- implicit LCP matrices -------------------------------------------------------
-// _MM of solve_qp_work (ICH-QP:129-148 + setup_QP :271-497), never materialised:
+// mode 0: _MM of solve_qp_work (ICH-QP:129-148 + setup_QP :271-497), never materialised:
 //   [ H  -N' ]   H = [n s t -s -t] blocks of C X C' (+ compliance), N = [Cn rows of H ; friction polygons]
 //   [ N   0  ]
 // Every entry is one value of G = [Cn;Cs;Ct] X [Cn;Cs;Ct]' (upper blocks stored, lower
 // ones read transposed exactly as setup_QP does), mu_i, or -cos/-sin of a polygon edge.
-// Lane r caches the description of ITS row; the column is wave-uniform.
-struct ImpactMat {
+// mode 1: the stabilisation matrix Cn X Cn' (CStab:932-947), read straight from G.
+// Lane r caches the description of ITS row; the column is wave-uniform.  One type for
+// both so the solvers are instantiated once.
+struct WorldMat {
+  int mode;
   const double* G; int nic, R, nvars, n;
   const int* koff; const int* islc; const double* cmu; const double* ccomp; const int* cnk;
-  // this lane's row
   int rkind;      // 0 variable row (block ra, contact ri), 1 Cn v+ >= 0 row, 2 friction polygon row, 3 none
   int ra, ri, rj;
   double rmu, rcos, rsin, rcomp;
@@ -99,10 +107,12 @@ struct ImpactMat {
   MH_DEV double Gab(int a, int b, int i, int j) const {
     return (a <= b) ? G[(a * nic + i) * R + (b * nic + j)] : G[(b * nic + j) * R + (a * nic + i)];
   }
-  MH_DEV void init(const double* G_, int nic_, int n_, const int* koff_, const int* islc_, const double* cmu_, const double* ccomp_, const int* cnk_) {
-    G = G_; nic = nic_; R = 3 * nic_; nvars = 5 * nic_; n = n_; koff = koff_; islc = islc_; cmu = cmu_; ccomp = ccomp_; cnk = cnk_;
+  MH_DEV void init(int mode_, const WorldLds& L, int nic_, int n_) {
+    mode = mode_; G = L.G; nic = nic_; n = n_; koff = L.koff; islc = L.islc; cmu = L.cmu; ccomp = L.ccomp; cnk = L.cnk;
+    R = (mode == 0) ? 3 * nic_ : nic_; nvars = 5 * nic_;
     const int r = lane_id();
     rkind = 3; ra = 0; ri = 0; rj = 0; rmu = 0.0; rcos = 0.0; rsin = 0.0; rcomp = 0.0;
+    if (mode != 0) return;
     if (r < nvars) { rkind = 0; ra = r / nic; ri = r - ra * nic; rcomp = ccomp[islc[ri]]; }
     else if (r < nvars + nic) { rkind = 1; ri = r - nvars; rcomp = ccomp[islc[ri]]; }
     else if (r < n) {
@@ -114,7 +124,6 @@ struct ImpactMat {
       rmu = cmu[ci]; rcos = c_fric.c[kh][rj]; rsin = c_fric.s[kh][rj];
     }
   }
-  // H(row (a,i), col (b,j)) incl. sign and compliance
   MH_DEV double H(int a, int i, int b, int j, double comp) const {
     double g = Gab(dir_of(a), dir_of(b), i, j);
     if ((a >= 3) != (b >= 3)) g = -g;
@@ -122,6 +131,7 @@ struct ImpactMat {
     return g;
   }
   MH_DEV double at_row(int c) const {
+    if (mode != 0) { const int l = lane_id(); return (l < n) ? G[l * n + c] : 0.0; }
     if (c < nvars) {
       const int b = c / nic, j = c - b * nic;
       if (rkind == 0) return H(ra, ri, b, j, rcomp);
@@ -132,10 +142,9 @@ struct ImpactMat {
       }
       return 0.0;
     }
-    // constraint column cc: -(M(c, r)) for variable rows, 0 otherwise
     if (rkind != 0) return 0.0;
     const int cc = c - nvars;
-    if (cc < nic) {   // M(c, r) = H(cc, (ra,ri)) with the compliance of contact cc on (0,cc)
+    if (cc < nic) {
       double g = Gab(0, dir_of(ra), cc, ri);
       if (ra >= 3) g = -g;
       if (ra == 0 && ri == cc) g = g + rcomp;
@@ -147,11 +156,18 @@ struct ImpactMat {
     const double v = (ra == 0) ? cmu[ci] : ((ra == 1 || ra == 3) ? -c_fric.c[kh][jj] : -c_fric.s[kh][jj]);
     return -v;
   }
-  MH_DEV double diag() const { return (rkind == 0) ? H(ra, ri, ra, ri, rcomp) : 0.0; }
-  // norm_inf(M) = max |entry|: H entries, mu, and the polygon edges (cos 0 = sin pi/2 = 1)
+  MH_DEV double diag() const {
+    if (mode != 0) { const int l = lane_id(); return (l < n) ? G[l * n + l] : 0.0; }
+    return (rkind == 0) ? H(ra, ri, ra, ri, rcomp) : 0.0;
+  }
+  // norm_inf(M) = max |entry|.  mode 0: H entries, mu, and the polygon edges (cos 0 = sin pi/2 = 1)
   MH_DEV double norm_all() const {
     const int lane = lane_id();
     double m = 0.0;
+    if (mode != 0) {
+      if (lane < n) for (int c = 0; c < n; c++) { const double a = fabs(G[lane * n + c]); m = (a > m) ? a : m; }
+      return wave_max(m);
+    }
     for (int e = lane; e < R * R; e += 64) {
       const int r = e / R, c = e - r * R;
       if (c < r && (c / nic) != (r / nic)) continue;       // lower direction blocks are never read
@@ -164,28 +180,52 @@ struct ImpactMat {
     return (m > 1.0) ? m : 1.0;
   }
   MH_DEV double offdiag_max() const {
-    // off-diagonal entries include every polygon edge (|.| = 1 at the ends), every mu, every
-    // off-diagonal H entry and the H DIAGONAL values again through the Cn v+ rows / -N' columns
+    if (mode != 0) {
+      const int lane = lane_id(); double m = 0.0;
+      if (lane < n) for (int c = 0; c < n; c++) { const double a = fabs(G[lane * n + c]); if (c != lane && a > m) m = a; }
+      return wave_max(m);
+    }
+    // mode 0: the off-diagonal part contains every polygon edge, every mu, every off-diagonal
+    // H entry and the H DIAGONAL values again through the Cn v+ rows / -N' columns
     return norm_all();
   }
 };
 
-// stabilisation LCP (CStab:932-947): MM = Cn X Cn' (nc x nc), read straight from G
-struct StabMat {
-  const double* G; int n;
-  MH_DEV double at_row(int c) const { const int l = lane_id(); return (l < n) ? G[l * n + c] : 0.0; }
-  MH_DEV double diag() const { const int l = lane_id(); return (l < n) ? G[l * n + l] : 0.0; }
-  MH_DEV double offdiag_max() const {
-    const int lane = lane_id(); double m = 0.0;
-    if (lane < n) for (int c = 0; c < n; c++) { const double a = fabs(G[lane * n + c]); if (c != lane && a > m) m = a; }
-    return wave_max(m);
+// The solver chains of the two handlers as ONE out-of-line function (a single copy of
+// lcp_fast / lcp_lemke / verify / ladder in the code object):
+//   mode 0  ICH-QP:219-225  lcp_fast_regularized(-20,4,-8); on failure z.set_zero(), lcp_lemke_regularized
+//   mode 1  CStab:954-955   lcp_fast; on failure lcp_lemke_regularized
+struct ChainOut { int ok; double zi; int zsize; unsigned rng_r; int rng_idx; unsigned piv; };
+__device__ __noinline__ ChainOut world_lcp_chain(int mode, int nic, int n, double qi, double zi, int zsize,
+                                                 unsigned rng_r, int rng_idx, double* lu_ws, int ka)
+{
+  mode = uni(mode); nic = uni(nic); n = uni(n); zsize = uni(zsize); rng_idx = uni(rng_idx); ka = uni(ka);
+  lu_ws = reinterpret_cast<double*>(uni((uint64_t)reinterpret_cast<uintptr_t>(lu_ws)));
+  WorldLds L; L.carve();
+  WorldMat M; M.init(mode, L, nic, n);
+  const double nrm0 = M.norm_all(), dii = M.diag();
+  WaveRand rng; rng.r = rng_r; rng.idx = rng_idx;
+  LuScratch S; S.small = L.A; S.ka = ka; S.big = lu_ws;
+  Trace tr; tr.buf = nullptr; tr.cap = 0; tr.len = 0;
+  unsigned ptot = 0;
+  bool ok = false;
+  for (int stage = 0; stage < 2; stage++) {
+    LcpParams P; P.piv_tol = -1.0; P.zero_tol = -1.0; P.min_exp = -20;
+    if (stage == 0) {
+      if (mode == 0) { P.kind = MH_LCP_FAST_REG; P.step_exp = 4; P.max_exp = -8; }
+      else { P.kind = MH_LCP_FAST; P.step_exp = 1; P.max_exp = 1; }
+    } else {
+      if (mode == 0) zi = 0.0;                              // z.set_zero() keeps the size (ICH-QP:222)
+      P.kind = MH_LCP_LEMKE_REG; P.step_exp = 1; P.max_exp = 1;
+    }
+    unsigned piv = 0;
+    ok = lcp_solve_wave(P, c_pow10, n, M, S, L.art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
+    ptot += piv;
+    if (ok) break;
   }
-  MH_DEV double norm_all() const {
-    const int lane = lane_id(); double m = 0.0;
-    if (lane < n) for (int c = 0; c < n; c++) { const double a = fabs(G[lane * n + c]); m = (a > m) ? a : m; }
-    return wave_max(m);
-  }
-};
+  ChainOut o; o.ok = ok ? 1 : 0; o.zi = zi; o.zsize = zsize; o.rng_r = rng.r; o.rng_idx = rng.idx; o.piv = ptot;
+  return o;
+}
 
 // phase ids of the optional in-kernel profile (diagnostic launches only)
 enum { PH_BROAD_CA = 0, PH_INTEGRATE, PH_FWDDYN, PH_CONTACTS, PH_ISLANDS, PH_PDATA, PH_MBUILD, PH_LCP, PH_APPLY, PH_STAB, PH_COUNT };
@@ -199,6 +239,8 @@ struct WorldWave {
   WorldLds L;
   int lane, nb, ntot, npt;       // npt: number of (i<j) pairs of the scene
   int nmax;
+  double* lu_ws;                 // this world's HBM LU workspace (nmax x nmax doubles)
+  int ka;                        // LDS LU block edge (MHW_KA; 0 forces the workspace: test hook)
   // persistent solver state
   WaveRand rng;
   double zlast_l, zbuf_l;        // lane i holds _zlast[i] / storage of _z [i]
@@ -594,13 +636,12 @@ struct WorldWave {
     nk_total = L.koff[nic];
     const int nvars = 5 * nic, n = nvars + nic + nk_total;
     if (n > nmax || n > MH_LCP_MAX_N_WAVE) { status |= MH_WORLD_UNSUPPORTED; return false; }
-    // _MM stays implicit (ImpactMat); _qq per lane
+    // _MM stays implicit (WorldMat mode 0); _qq per lane
     unsigned long long tm = tick();
-    ImpactMat Mi; Mi.init(L.G, nic, n, L.koff, L.islc, L.cmu, L.ccomp, L.cnk);
     double qi = 0.0;
     if (lane < n) {
       const int r = lane;
-      if (r < nvars) { const int a = r / nic, i = r - a * nic; const double v = L.Cv[ImpactMat::dir_of(a) * nic + i]; qi = (a >= 3) ? -v : v; }
+      if (r < nvars) { const int a = r / nic, i = r - a * nic; const double v = L.Cv[WorldMat::dir_of(a) * nic + i]; qi = (a >= 3) ? -v : v; }
       else if (r < nvars + nic) qi = L.Cv[r - nvars];
       else {
         int i = 0; const int rr = r - nvars - nic; while (rr >= L.koff[i + 1]) i++;
@@ -609,8 +650,6 @@ struct WorldWave {
         qi = L.cmuv[L.islc[i]] * vel;
       }
     }
-    const double nrm0 = Mi.norm_all();
-    const double dii = Mi.diag();
     tock(PH_MBUILD, tm);
     tm = tick();
     // z.resize(n); warm start from _zlast when sizes match (ICH-QP:158-162)
@@ -618,18 +657,11 @@ struct WorldWave {
     if (n > zbuf_cap) zi = 0.0; else zi = zbuf_l;
     if (lane >= n) zi = 0.0;
     if (n == zlast_size) zi = (lane < n) ? zlast_l : 0.0;
-    int zsize = n;
-    Trace tr; tr.buf = nullptr; tr.cap = 0; tr.len = 0;
-    unsigned piv = 0, ptot = 0;
-    LcpParams P; P.kind = MH_LCP_FAST_REG; P.min_exp = -20; P.step_exp = 4; P.max_exp = -8; P.piv_tol = -1.0; P.zero_tol = -1.0;
-    bool ok = lcp_solve_wave(P, c_pow10, n, Mi, L.A, L.art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
-    ptot += piv;
-    if (!ok) {
-      zi = 0.0;                                             // z.set_zero() keeps the size (ICH-QP:222)
-      P.kind = MH_LCP_LEMKE_REG; P.min_exp = -20; P.step_exp = 1; P.max_exp = 1;
-      ok = lcp_solve_wave(P, c_pow10, n, Mi, L.A, L.art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
-      ptot += piv;
-    }
+    const ChainOut co = world_lcp_chain(0, nic, n, qi, zi, n, rng.r, rng.idx, lu_ws, ka);
+    rng.r = co.rng_r; rng.idx = uni(co.rng_idx);
+    zi = co.zi;
+    const bool ok = uni(co.ok) != 0;
+    const unsigned ptot = uni(co.piv);
     account(n, ptot);
     tock(PH_LCP, tm);
     if (!ok) { status |= MH_WORLD_LCP_FAILED; return false; }
@@ -941,18 +973,13 @@ struct WorldWave {
         const int n_ = nic;
         if (n_ > nmax) { status |= MH_WORLD_UNSUPPORTED; continue; }
         // determine_dq (CStab:932-970): MM = Cn X Cn', qq = dist - |eps| - NEAR_ZERO
-        StabMat Ms; Ms.G = L.G; Ms.n = n_;
         double qi = 0.0;
         if (lane < n_) qi = L.cdist[L.islc[lane]] - fabs(sc.cstab_eps) - MH_NEAR_ZERO;
         wave_sync();
-        const double nrm0 = Ms.norm_all(), dii = Ms.diag();
-        double zi = 0.0; int zsize = 0;                            // fresh local z: cold start
-        Trace tr; tr.buf = nullptr; tr.cap = 0; tr.len = 0;
-        unsigned piv = 0, ptot = 0;
-        LcpParams P; P.kind = MH_LCP_FAST; P.min_exp = -20; P.step_exp = 1; P.max_exp = 1; P.piv_tol = -1.0; P.zero_tol = -1.0;
-        bool ok = lcp_solve_wave(P, c_pow10, n_, Ms, L.A, L.art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
-        ptot += piv;
-        if (!ok) { P.kind = MH_LCP_LEMKE_REG; ok = lcp_solve_wave(P, c_pow10, n_, Ms, L.A, L.art, nrm0, dii, qi, zi, zsize, rng, piv, tr); ptot += piv; }
+        const ChainOut co = world_lcp_chain(1, nic, n_, qi, 0.0, 0, rng.r, rng.idx, lu_ws, ka);   // fresh local z: cold start
+        rng.r = co.rng_r; rng.idx = uni(co.rng_idx);
+        const double zi = co.zi; const int zsize = uni(co.zsize);
+        const unsigned ptot = uni(co.piv);
         account(n_, ptot);
         // update_from_stacked(pd, z): cn = z[0..nc) (zeros where z is shorter)
         wave_sync();

@@ -99,3 +99,20 @@ def test_full_batch_4096_properties():
     for r in range(1, 64):
         np.testing.assert_array_equal(s[:64], s[r * 64:(r + 1) * 64])
     assert wb.aux["lcp_rows"].sum() > 0
+
+
+def test_hbm_lu_workspace_path_is_bit_identical(oracle):
+    """k > MHW_KA nonbasic sets and Lemke bases factorise in the per-world HBM
+    workspace instead of LDS; force that path for every LU and compare."""
+    from moby_amd import _lib
+    lib = _lib.load()
+    sc = S.sphere_stack_scene()
+    st0 = S.sphere_stack_state(12)
+    a = WorldBatch(sc, st0.copy()); a.step(1e-3, 40)
+    try:
+        _lib.check(lib.mh_debug_set(1, 0))
+        b = WorldBatch(sc, st0.copy()); b.step(1e-3, 40)
+    finally:
+        _lib.check(lib.mh_debug_set(1, 8))
+    np.testing.assert_array_equal(a.state, b.state)
+    np.testing.assert_array_equal(a.aux, b.aux)
