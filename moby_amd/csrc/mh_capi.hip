@@ -90,6 +90,8 @@ void mh_k_lcp_wave(int B, int n, const double* __restrict__ Mg, int ld, long str
   const double qi = valid ? qg[(size_t)b * n + lane] : 0.0;
   int zsize = zsz_in ? mh::uni(zsz_in[b]) : n;
   double zi = (valid && zsize == n) ? zg[(size_t)b * n + lane] : 0.0;
+  if (lane == 0) mh::g_lcp_prof_on = 0;
+  mh::wave_sync();
   mh::WaveRand rng; rng.load(rngg + (size_t)b * MH_RAND_WORDS);
   mh::Trace tr; tr.buf = trace ? trace + (size_t)b * trace_cap : nullptr; tr.cap = trace_cap; tr.len = 0;
   unsigned piv = 0;
@@ -249,55 +251,35 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 // ===========================================================================
 // many-worlds stepping
 #include <mutex>
-#include "mh_world_wave.h"
-
-__global__ __launch_bounds__(64, 2)
-void mh_k_world_step(const mh_scene* __restrict__ scp, int B, double dt, int nsteps, double* __restrict__ state,
-                     mh_world_aux* __restrict__ aux, double* __restrict__ traj, int nmax, double* __restrict__ lu_ws, int ka,
-                     unsigned long long* __restrict__ prof)
-{
-  const int w = blockIdx.x;
-  if (w >= B) return;
-  const mh_scene& sc = *scp;
-  mh::WorldWave W(sc);
-  W.L.carve();
-  W.lu_ws = lu_ws + (size_t)w * nmax * nmax; W.ka = ka;
-  const int lane = mh::lane_id();
-  W.lane = lane; W.nb = sc.nb; W.ntot = sc.nb + (sc.has_ground ? 1 : 0); W.npt = W.ntot * (W.ntot - 1) / 2; W.nmax = nmax;
-  const int nst = MH_BODY_STATE * sc.nb;
-  double* stg = state + (size_t)w * nst;
-  for (int e = lane; e < nst; e += 64) W.L.st[e] = stg[e];
-  mh_world_aux* a = aux + w;
-  W.rng.load(a->rng);
-  W.zlast_l = a->zlast[lane]; W.zbuf_l = a->zbuf[lane];
-  W.zlast_size = mh::uni(a->zlast_size); W.zbuf_size = mh::uni(a->zbuf_size); W.zbuf_cap = mh::uni(a->zbuf_cap);
-  W.status = mh::uni(a->status);
-  W.time = mh::uni(a->time);
-  W.n_steps = a->steps; W.n_mini = a->mini_steps; W.n_lcp = a->lcp_solves; W.n_rows = a->lcp_rows; W.n_piv = a->lcp_pivots; W.n_stab = a->stab_iters; W.n_bytes = a->lcp_alg_bytes;
-  W.npairs = 0; W.nc = 0;
-  W.prof = prof ? prof + (size_t)w * mh::PH_COUNT : nullptr;
-  for (int i = 0; i < mh::PH_COUNT; i++) W.pacc[i] = 0ull;
-  mh::wave_sync();
-  for (int s = 0; s < nsteps; s++) {
-    W.step(dt);
-    if (traj) {
-      mh::wave_sync();
-      for (int e = lane; e < 7 * sc.nb; e += 64) { const int b = e / 7, k = e - 7 * b; traj[(((size_t)w * nsteps + s) * sc.nb + b) * 7 + k] = W.L.st[13 * b + k]; }
-    }
-  }
-  mh::wave_sync();
-  for (int e = lane; e < nst; e += 64) stg[e] = W.L.st[e];
-  W.rng.store(a->rng);
-  a->zlast[lane] = W.zlast_l; a->zbuf[lane] = W.zbuf_l;
-  if (lane == 0) {
-    a->zlast_size = W.zlast_size; a->zbuf_size = W.zbuf_size; a->zbuf_cap = W.zbuf_cap; a->status = W.status; a->time = W.time;
-    a->steps = W.n_steps; a->mini_steps = W.n_mini; a->lcp_solves = W.n_lcp; a->lcp_rows = W.n_rows; a->lcp_pivots = W.n_piv; a->stab_iters = W.n_stab; a->lcp_alg_bytes = W.n_bytes;
-    if (W.prof) for (int i = 0; i < mh::PH_COUNT; i++) W.prof[i] = W.pacc[i];
-  }
-}
+// two size variants of the world kernel (LDS image and occupancy differ):
+//   small  <= 4 bodies, <= 6 pairs, <= 6 contacts, <= 12 Jacobian rows  (~8.5 KB LDS)
+//   large  <= 8 bodies, <= 36 pairs, <= 12 contacts, <= 24 rows         (~17 KB LDS)
+#define MHW_NS small
+#define MHW_NB 4
+#define MHW_MAX_PAIRS 6
+#define MHW_MAX_CONTACTS 6
+#define MHW_MAX_ROWS 12
+#define MHW_MAX_GROWS 12
+#define MHW_WAVES_PER_SIMD 3
+#include "mh_world_wave.inc"
+#undef MHW_NS
+#undef MHW_NB
+#undef MHW_MAX_PAIRS
+#undef MHW_MAX_CONTACTS
+#undef MHW_MAX_ROWS
+#undef MHW_MAX_GROWS
+#undef MHW_WAVES_PER_SIMD
+#define MHW_NS large
+#define MHW_NB MH_MAX_BODIES
+#define MHW_MAX_PAIRS MH_MAX_PAIRS
+#define MHW_MAX_CONTACTS 12
+#define MHW_MAX_ROWS 24
+#define MHW_MAX_GROWS 24
+#define MHW_WAVES_PER_SIMD 2
+#include "mh_world_wave.inc"
 
 namespace {
-int g_debug_ka = MHW_KA;   // LDS LU block edge; mh_debug_set(1, 0) forces the HBM workspace path
+int g_debug_ka = MHW_KA;      // LDS LU block edge; mh_debug_set(1, 0) forces the HBM workspace path
 std::once_flag g_tables_once;
 hipError_t g_tables_err = hipSuccess;
 void init_tables()
@@ -360,6 +342,7 @@ struct mh_world_batch {
   mh_scene scene;
   int B;
   int nmax;
+  int small;
   mh_scene* d_scene;
   double* d_lu_ws;
   double* d_state;
@@ -379,6 +362,12 @@ int mh_world_batch_create(const mh_scene* scene, int B, mh_world_batch** out)
   mh_world_batch* wb = new mh_world_batch();
   wb->scene = *scene; wb->B = B;
   wb->nmax = scene->lcp_n_max ? scene->lcp_n_max : MH_LCP_MAX_N_WAVE;
+  {
+    const int ntot = scene->nb + (scene->has_ground ? 1 : 0), npairs = ntot * (ntot - 1) / 2;
+    int khmin = 32; for (int p = 0; p < npairs; p++) khmin = std::min(khmin, scene->cp_nk[p] / 2);
+    const int maxnc = std::min(npairs, MH_LCP_MAX_N_WAVE / (6 + khmin));
+    wb->small = (scene->nb <= 4 && npairs <= 6 && 3 * maxnc <= 12) ? 1 : 0;
+  }
   wb->d_scene = nullptr; wb->d_state = nullptr; wb->d_aux = nullptr; wb->d_lu_ws = nullptr;
   hipError_t e = hipMalloc(&wb->d_scene, sizeof(mh_scene));
   if (e == hipSuccess) e = hipMalloc(&wb->d_lu_ws, (size_t)B * wb->nmax * wb->nmax * sizeof(double));
@@ -422,9 +411,14 @@ int mh_world_batch_step(mh_world_batch* wb, void* stream, double dt, int nsteps,
   if (nsteps < 0) return fail(MH_ERR_INVALID_ARG, "negative step count");
   if (nsteps == 0) return MH_OK;
   if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
-  hipLaunchKernelGGL(mh_k_world_step, dim3(wb->B), dim3(64), 0, (hipStream_t)stream,
-                     wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, traj_dev, wb->nmax, wb->d_lu_ws, g_debug_ka,
-                     (unsigned long long*)nullptr);
+  if (wb->small)
+    hipLaunchKernelGGL(mh::small::mh_k_world_step, dim3(wb->B), dim3(64), 0, (hipStream_t)stream,
+                       wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, traj_dev, wb->nmax, wb->d_lu_ws, g_debug_ka,
+                       (unsigned long long*)nullptr);
+  else
+    hipLaunchKernelGGL(mh::large::mh_k_world_step, dim3(wb->B), dim3(64), 0, (hipStream_t)stream,
+                       wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, traj_dev, wb->nmax, wb->d_lu_ws, g_debug_ka,
+                       (unsigned long long*)nullptr);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
@@ -434,19 +428,23 @@ int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* ph
 {
   if (!wb || !phase_cycles) return fail(MH_ERR_INVALID_ARG, "null argument");
   unsigned long long* dprof = nullptr;
-  const size_t sz = (size_t)wb->B * mh::PH_COUNT * sizeof(unsigned long long);
+  const size_t sz = (size_t)wb->B * mh::large::PH_COUNT * sizeof(unsigned long long);
   MH_HIP(hipMalloc(&dprof, sz));
   MH_HIP(hipMemset(dprof, 0, sz));
-  hipLaunchKernelGGL(mh_k_world_step, dim3(wb->B), dim3(64), 0, (hipStream_t)nullptr,
-                     wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, wb->d_lu_ws, g_debug_ka, dprof);
+  if (wb->small)
+    hipLaunchKernelGGL(mh::small::mh_k_world_step, dim3(wb->B), dim3(64), 0, (hipStream_t)nullptr,
+                       wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, wb->d_lu_ws, g_debug_ka, dprof);
+  else
+    hipLaunchKernelGGL(mh::large::mh_k_world_step, dim3(wb->B), dim3(64), 0, (hipStream_t)nullptr,
+                       wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, wb->d_lu_ws, g_debug_ka, dprof);
   hipError_t e = hipDeviceSynchronize();
-  std::vector<unsigned long long> h((size_t)wb->B * mh::PH_COUNT);
+  std::vector<unsigned long long> h((size_t)wb->B * mh::large::PH_COUNT);
   if (e == hipSuccess) e = hipMemcpy(h.data(), dprof, sz, hipMemcpyDeviceToHost);
   (void)hipFree(dprof);
   if (e != hipSuccess) return fail(MH_ERR_HIP, "profile launch failed: %s", hipGetErrorString(e));
   for (int p = 0; p < nphase; p++) {
     double acc = 0.0;
-    if (p < mh::PH_COUNT) for (int b = 0; b < wb->B; b++) acc += (double)h[(size_t)b * mh::PH_COUNT + p];
+    if (p < mh::large::PH_COUNT) for (int b = 0; b < wb->B; b++) acc += (double)h[(size_t)b * mh::large::PH_COUNT + p];
     phase_cycles[p] = acc / wb->B;
   }
   return MH_OK;

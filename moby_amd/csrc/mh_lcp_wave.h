@@ -25,6 +25,13 @@
 
 namespace mh {
 
+// optional in-solver cycle accumulators (diagnostic launches of the world kernel only)
+enum { LP_SETUP = 0, LP_GATHER, LP_LU, LP_GEMV, LP_RANDMIN, LP_VERIFY, LP_LEMKE, LP_COUNT };
+__shared__ unsigned long long g_lcp_prof[LP_COUNT];
+__shared__ int g_lcp_prof_on;
+MH_DEV unsigned long long lp_tick() { return g_lcp_prof_on ? __builtin_amdgcn_s_memtime() : 0ull; }
+MH_DEV void lp_tock(int ph, unsigned long long t0) { if (g_lcp_prof_on) { const unsigned long long d = __builtin_amdgcn_s_memtime() - t0; if (lane_id() == 0) g_lcp_prof[ph] += d; } }
+
 struct Trace {
   int32_t* buf; int cap; int len;
   MH_DEV void push(int32_t v) { if (buf && len < cap && lane_id() == 0) buf[len] = v; len++; }
@@ -171,6 +178,7 @@ MH_DEV int gather_and_solve(const MatT& M, double lam, uint64_t nbmask, int k, b
 {
   const int lane = lane_id();
   wave_sync();
+  unsigned long long t0 = lp_tick();
   uint64_t m = nbmask;
   for (int c = 0; c < k; c++) {
     const int j = ctz(m); m &= m - 1;
@@ -181,7 +189,11 @@ MH_DEV int gather_and_solve(const MatT& M, double lam, uint64_t nbmask, int k, b
   // variables to rows 0..k-1, everything else to the unused lanes above)
   b = push_to(-qi, is_nb ? pos : k + popc(~nbmask & lanes_below(lane)));
   wave_sync();
-  return lu_solve_wave(k, A, b);
+  lp_tock(LP_GATHER, t0);
+  t0 = lp_tick();
+  const int info = lu_solve_wave(k, A, b);
+  lp_tock(LP_LU, t0);
+  return info;
 }
 
 template <class MatT>
@@ -215,6 +227,7 @@ MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, LuScratch S,
       if (gather_and_solve(M, lam, nbmask, k, is_nb, pos, qi, Ause, b) != 0) return false;
     }
     // w = Mmix * z + qbas on the basic lanes (dgemv column order)
+    unsigned long long tg = lp_tick();
     double w = 0.0;
     {
       uint64_t m = nbmask;
@@ -227,12 +240,15 @@ MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, LuScratch S,
     }
     // z value of this variable (position -> variable routing)
     const double zv = __shfl(b, pos);
+    lp_tock(LP_GEMV, tg);
+    tg = lp_tick();
     const uint64_t bmask = vmask & ~nbmask;
     double wsel = 0.0; int minw = -1;
     if (bmask != 0ull) minw = rand_min_wave(w, bmask, zero_tol, rng, wsel);
     if (minw < 0 || wsel > -zero_tol) {
       double zsel = 0.0; int minz = -1;
       if (k > 0) minz = rand_min_wave(zv, nbmask, zero_tol, rng, zsel);
+      lp_tock(LP_RANDMIN, tg);
       if (minz >= 0 && zsel < -zero_tol) {
         nbmask &= ~bit(minz);
         tr.push(-(int32_t)(minz + 1));
@@ -246,6 +262,7 @@ MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, LuScratch S,
       tr.push((int32_t)(minw + 1));
       double zsel = 0.0; int minzv = -1;
       if (k > 0) minzv = rand_min_wave(zv, nbmask, zero_tol, rng, zsel);
+      lp_tock(LP_RANDMIN, tg);
       nbmask = nb_new;
       if (minzv >= 0 && zsel < -zero_tol) {
         // LCP.cpp:176-187: the POSITION found in the old _z indexes the NEW,
@@ -420,10 +437,14 @@ MH_DEV bool lcp_solve_wave(const LcpParams& P, const Pow10Table& p10, int n, con
       nrm = norm_reg(offmax, dii, valid, lam);
     }
     if (reg) tr.push(0x40000000 | attempt);
+    unsigned long long tl = lp_tick();
     const bool ok = fast ? lcp_fast_wave(n, M, lam, A, qi, zi, zsize, P.zero_tol, nrm, rng, pivots, tr)
                          : lcp_lemke_wave(n, M, lam, A, art, qi, zi, zsize, P.piv_tol, P.zero_tol, nrm, rng, pivots, tr);
+    if (!fast) lp_tock(LP_LEMKE, tl);
     if (!reg) return ok;                                      // plain lcp_fast / lcp_lemke
+    tl = lp_tick();
     const bool good = ok && verify_wave(n, M, lam, qi, zi, ZERO_TOL, attempt > 0);
+    lp_tock(LP_VERIFY, tl);
     if (attempt == 0) { if (good) return true; total += pivots; }
     else { total += pivots; if (good) { pivots = total; return true; } rf += (int)P.step_exp; }
   }
