@@ -209,6 +209,7 @@ int mh_world_batch_device_ptrs(mh_world_batch* wb, double** state_dev, mh_world_
 /* diagnostic build of the same launch with in-kernel s_memtime stamps: mean cycles per world spent in
  * each phase (order: broad phase + CA, position integration, forward dynamics, contact generation,
  * islands, problem data, LCP matrix build, LCP solve, impulse application, stabilisation) */
+int mh_world_batch_occupancy(mh_world_batch* wb);   /* diagnostic: resident workgroups per CU (runtime query) */
 int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* phase_cycles, int nphase);
 
 /* Host convenience: create + upload + step + download (+ trajectory) + destroy. */

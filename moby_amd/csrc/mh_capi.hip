@@ -260,7 +260,7 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 #define MHW_MAX_CONTACTS 6
 #define MHW_MAX_ROWS 12
 #define MHW_MAX_GROWS 12
-#define MHW_WAVES_PER_SIMD 3
+#define MHW_WAVES_PER_SIMD 4
 #include "mh_world_wave.inc"
 #undef MHW_NS
 #undef MHW_NB
@@ -349,6 +349,18 @@ struct mh_world_batch {
   mh_world_aux* d_aux;
 };
 
+// diagnostic: blocks per CU the runtime's occupancy query reports for the kernel this batch uses
+int mh_world_batch_occupancy(mh_world_batch* wb);
+int mh_world_batch_occupancy(mh_world_batch* wb)
+{
+  if (!wb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  int n = 0;
+  hipError_t e = wb->small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mh::small::mh_k_world_step, 64, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mh::large::mh_k_world_step, 64, 0);
+  if (e != hipSuccess) return fail(MH_ERR_HIP, "occupancy query failed: %s", hipGetErrorString(e));
+  return n;
+}
+
 int mh_world_batch_create(const mh_scene* scene, int B, mh_world_batch** out)
 {
   if (!out) return fail(MH_ERR_INVALID_ARG, "null out");
@@ -363,10 +375,11 @@ int mh_world_batch_create(const mh_scene* scene, int B, mh_world_batch** out)
   wb->scene = *scene; wb->B = B;
   wb->nmax = scene->lcp_n_max ? scene->lcp_n_max : MH_LCP_MAX_N_WAVE;
   {
+    // small variant: <= 4 bodies, <= 6 pairs, islands of <= 4 contacts (12 Jacobian rows); the
+    // caller opts in by bounding the LCP size (lcp_n_max <= 56 = 4 contacts x (6 + 16/2) rows).
+    // A world that outgrows the variant's limits at run time gets MH_WORLD_UNSUPPORTED.
     const int ntot = scene->nb + (scene->has_ground ? 1 : 0), npairs = ntot * (ntot - 1) / 2;
-    int khmin = 32; for (int p = 0; p < npairs; p++) khmin = std::min(khmin, scene->cp_nk[p] / 2);
-    const int maxnc = std::min(npairs, MH_LCP_MAX_N_WAVE / (6 + khmin));
-    wb->small = (scene->nb <= 4 && npairs <= 6 && 3 * maxnc <= 12) ? 1 : 0;
+    wb->small = (scene->nb <= 4 && npairs <= 6 && scene->lcp_n_max > 0 && scene->lcp_n_max <= 56) ? 1 : 0;
   }
   wb->d_scene = nullptr; wb->d_state = nullptr; wb->d_aux = nullptr; wb->d_lu_ws = nullptr;
   hipError_t e = hipMalloc(&wb->d_scene, sizeof(mh_scene));

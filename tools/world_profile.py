@@ -15,6 +15,7 @@ if __name__ == "__main__":
     lib = _lib.load()
     sc = S.sphere_stack_scene()
     wb = WorldBatchDevice(sc, S.sphere_stack_state_range(0, B))
+    print("runtime occupancy query: %d workgroups per CU" % lib.mh_world_batch_occupancy(wb.handle))
     wb.step(1e-3, 20); torch.cuda.synchronize()
     t0 = time.perf_counter(); wb.step(1e-3, nsteps); torch.cuda.synchronize(); t = time.perf_counter() - t0
     print("plain launch: %.3f ms for %d steps x %d worlds -> %.1f us per batch step, %.3g world-steps/s" % (t * 1e3, nsteps, B, t / nsteps * 1e6, B * nsteps / t))
