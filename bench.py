@@ -63,12 +63,14 @@ def main():
     if world_size > 1:
         dist.barrier()
     from moby_amd import scene as S
+    from moby_amd import dist as mdist
     from moby_amd.world import WorldBatchDevice
 
     B = args.worlds
     sc = S.sphere_stack_scene()
     # shard r of an N-GPU job simulates worlds r*B .. r*B+B-1 (no data-path collective)
-    st0 = S.sphere_stack_state_range(rank * B, B)
+    first, count = mdist.shard_range(rank, B)
+    st0 = S.sphere_stack_state_range(first, count)
     wb = WorldBatchDevice(sc, st0)
     stream = torch.cuda.current_stream(dev).cuda_stream   # HIP events below are recorded on this stream
 
@@ -93,16 +95,9 @@ def main():
     kern_s = ev0.elapsed_time(ev1) * 1e-3
     _, aux1 = wb.download()
     d = lambda f: int(aux1[f].astype(np.int64).sum() - aux0[f].astype(np.int64).sum())
-    tot = np.array([d("lcp_rows"), d("lcp_solves"), d("lcp_pivots"), d("mini_steps"), d("stab_iters"), d("lcp_alg_bytes"),
-                    int((aux1["status"] & ~S.MH_WORLD_IMPACT_TOL != 0).sum())], dtype=np.float64)
-    if world_size > 1:
-        # the per-interval reduction of SURVEY 8e: one small all-reduce over xGMI
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.from_numpy(tot).to(dev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        tot = c.cpu().numpy()
+    tot = mdist.counter_vector(aux0, aux1, (aux1["status"] & ~S.MH_WORLD_IMPACT_TOL) != 0)
+    # the per-interval reduction of SURVEY 8e: one MAX + one SUM all-reduce (RCCL over xGMI)
+    elapsed, tot = mdist.reduce_interval(elapsed, tot, dist if world_size > 1 else None, dev)
     rows, solves, pivots, minis, stabs, alg_bytes_all, bad = [float(x) for x in tot]
 
     world_steps = B * world_size * args.steps

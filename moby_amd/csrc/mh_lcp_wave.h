@@ -76,22 +76,10 @@ MH_DEV double mat_at(const MatT& M, int c, double lam) {
 // rhs element b.  Returns LAPACK info (uniform); on info != 0 b is garbage.
 // dgetf2 order: idamax -> row swap (all columns) -> scale by reciprocal ->
 // rank-1 update; then dlaswp / unit-lower / upper triangular solves.
-struct LuOut { int info; double b; };
-MH_DEV int lu_solve_body(int k, double* A, double& b);
-// One out-of-line copy shared by every caller (the world kernel is instruction-cache
-// bound when this is inlined at each of its ~16 call sites).  `A` may point to LDS or
-// to the HBM workspace (flat addressing).
-__device__ __noinline__ LuOut lu_solve_call(int k, double* A, double b)
-{
-  LuOut o; o.info = lu_solve_body(k, A, b); o.b = b; return o;
-}
+// `A` may point to LDS or to the HBM workspace (flat addressing).  Inlined at its two call
+// sites (lcp_fast / lcp_lemke gathers): as an out-of-line function its callee-saved VGPR
+// spills made the world kernel write ~50 GB of scratch per 200-step launch.
 MH_DEV int lu_solve_wave(int k, double* A, double& b)
-{
-  const LuOut o = lu_solve_call(k, A, b);
-  b = o.b;
-  return o.info;
-}
-MH_DEV int lu_solve_body(int k, double* A, double& b)
 {
   const int lane = lane_id();
   for (int j = 0; j < k; j++) {

@@ -70,3 +70,18 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in txt and "oracle_api" not in txt, f
                 assert not re.search(r'#include\s+"[^"]*oracle', txt), f
+
+
+def test_cpp_adapter_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """The reference-side C++ adapter builds against include/moby_hip.h with plain
+    g++; with no device the call reports an error instead of falling back."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU test")
+    cpp = os.path.join(ROOT, "moby_amd", "cpp")
+    exe = str(tmp_path / "example_lcp")
+    subprocess.check_call(["g++", "-std=c++11", os.path.join(cpp, "example_lcp.cpp"), "-L" + os.path.join(ROOT, "moby_amd"),
+                           "-lmoby_hip", "-Wl,-rpath," + os.path.join(ROOT, "moby_amd"), "-o", exe])
+    p = subprocess.run([exe], capture_output=True, timeout=120)
+    assert p.returncode == 2 and b"no HIP device" in p.stdout

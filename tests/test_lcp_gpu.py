@@ -120,3 +120,18 @@ def test_full_batch_properties():
     good = ok.astype(bool)
     assert good.sum() > 0
     assert z[good].min() > -1e-9 and w[good].min() > -1e-7 and np.abs(z[good] * w[good]).max() < 1e-7
+
+
+def test_cpp_adapter_example():
+    """The Moby::LCP-shaped C++ adapter (moby_amd/cpp/MobyHipLCP.h) links against
+    the C ABI and reproduces the KAT."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = os.path.join(root, "moby_amd", "cpp")
+    exe = os.path.join(cpp, "example_lcp")
+    subprocess.check_call(["g++", "-std=c++11", os.path.join(cpp, "example_lcp.cpp"), "-L" + os.path.join(root, "moby_amd"),
+                           "-lmoby_hip", "-Wl,-rpath," + os.path.join(root, "moby_amd"), "-o", exe])
+    out = subprocess.check_output([exe]).decode()
+    vals = [float(x) for x in out.splitlines()[0].split("z=")[1].split()]
+    np.testing.assert_allclose(vals, 9.81e-3 * np.array([3.0, 2.0, 1.0]), rtol=1e-13)
+    assert "lemke ok=1" in out
