@@ -138,7 +138,13 @@ MH_DEV int rand_min_wave(double v, uint64_t mask, double tol, WaveRand& rng, dou
   const int lane = lane_id();
   const bool in = (mask >> lane) & 1ull;
   double vmin; int imin;
-  argmin_first(v, in, vmin, imin);
+  if (popc(mask) <= 4) {
+    // few candidates (the nonbasic z's): scan them in list order, first minimum wins
+    uint64_t m = mask;
+    imin = ctz(m); m &= m - 1;
+    vmin = read_lane(v, imin);
+    while (m) { const int i = ctz(m); m &= m - 1; const double x = read_lane(v, i); if (x < vmin) { vmin = x; imin = i; } }
+  } else argmin_first(v, in, vmin, imin);
   const uint64_t qm = ballot(in && lane != imin && v < vmin + tol);
   const int cnt = 1 + popc(qm);
   const int r = rng.next() % cnt;
@@ -161,14 +167,95 @@ MH_DEV double norm_reg(double offmax, double dii, bool valid, double lam) {
 // n x n (LDS in the LCP-entry kernel, an HBM workspace in the world kernel).
 struct LuScratch { double* small; int ka; double* big; };
 
+// dgesv for K = 2..4 with the whole system held redundantly in every lane's registers: no LDS
+// round trips, no cross-lane reductions, pivot decisions are wave-uniform scalar branches.  Same
+// operation order as lu_solve_wave (dgetf2 + dgetrs), so the result is bit-identical.
+template <int K>
+MH_DEV int lu_small(const double* A, double& b)
+{
+  double a[K][K], x[K];
+#pragma unroll
+  for (int c = 0; c < K; c++)
+#pragma unroll
+    for (int r = 0; r < K; r++) a[r][c] = A[r + K * c];       // LDS broadcast reads
+#pragma unroll
+  for (int r = 0; r < K; r++) x[r] = read_lane(b, r);
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    int jp = j; double amax = fabs(a[j][j]);
+#pragma unroll
+    for (int i = j + 1; i < K; i++) { const double v = fabs(a[i][j]); if (v > amax) { amax = v; jp = i; } }
+    jp = uni(jp);
+    if (ballot(!(amax != 0.0)) != 0ull) return j + 1;
+#pragma unroll
+    for (int i = j + 1; i < K; i++)
+      if (jp == i) {
+#pragma unroll
+        for (int c = 0; c < K; c++) { const double t = a[j][c]; a[j][c] = a[i][c]; a[i][c] = t; }
+        const double t = x[j]; x[j] = x[i]; x[i] = t;
+      }
+    if (j < K - 1) {
+      const double piv = a[j][j];
+      const bool big = fabs(piv) >= MH_SFMIN;
+      const double r = 1.0 / piv;
+#pragma unroll
+      for (int i = j + 1; i < K; i++) {
+        const double l = big ? a[i][j] * r : a[i][j] / piv;
+        a[i][j] = l;
+#pragma unroll
+        for (int c = j + 1; c < K; c++) a[i][c] = a[i][c] - l * a[j][c];
+      }
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < K; kk++)
+#pragma unroll
+    for (int i = kk + 1; i < K; i++) x[i] = x[i] - x[kk] * a[i][kk];
+#pragma unroll
+  for (int kk = K - 1; kk >= 0; kk--) {
+    x[kk] = x[kk] / a[kk][kk];
+#pragma unroll
+    for (int i = 0; i < kk; i++) x[i] = x[i] - x[kk] * a[i][kk];
+  }
+  const int lane = lane_id();
+  double out = 0.0;
+#pragma unroll
+  for (int r = 0; r < K; r++) out = (lane == r) ? x[r] : out;
+  b = out;
+  return 0;
+}
+
+#define MH_COLCACHE 8
 template <class MatT>
-MH_DEV int gather_and_solve(const MatT& M, double lam, uint64_t nbmask, int k, bool is_nb, int pos, double qi, double* A, double& b)
+MH_DEV int gather_and_solve(const MatT& M, double lam, uint64_t nbmask, int k, bool is_nb, int pos, double qi, double* A, double& b,
+                            double (&colv)[MH_COLCACHE])
 {
   const int lane = lane_id();
-  wave_sync();
   unsigned long long t0 = lp_tick();
+  if (k == 1) {
+    // 1 x 1 system: dgetf2 finds the only pivot, dgetrs divides once (same arithmetic as the general path)
+    const int j = ctz(nbmask);
+    const double v = mat_at(M, j, lam);
+    colv[0] = v;
+    const double a00 = read_lane(v, j);
+    const double rhs = read_lane(-qi, j);
+    lp_tock(LP_GATHER, t0);
+    if (!(fabs(a00) != 0.0)) return 1;
+    b = (lane == 0) ? rhs / a00 : 0.0;
+    return 0;
+  }
+  wave_sync();
   uint64_t m = nbmask;
-  for (int c = 0; c < k; c++) {
+#pragma unroll
+  for (int c = 0; c < MH_COLCACHE; c++) {
+    if (c < k) {
+      const int j = ctz(m); m &= m - 1;
+      const double v = mat_at(M, j, lam);
+      colv[c] = v;
+      if (is_nb) A[pos + k * c] = v;
+    }
+  }
+  for (int c = MH_COLCACHE; c < k; c++) {
     const int j = ctz(m); m &= m - 1;
     const double v = mat_at(M, j, lam);
     if (is_nb) A[pos + k * c] = v;
@@ -179,7 +266,11 @@ MH_DEV int gather_and_solve(const MatT& M, double lam, uint64_t nbmask, int k, b
   wave_sync();
   lp_tock(LP_GATHER, t0);
   t0 = lp_tick();
-  const int info = lu_solve_wave(k, A, b);
+  int info;
+  if (k == 2) info = lu_small<2>(A, b);
+  else if (k == 3) info = lu_small<3>(A, b);
+  else if (k == 4) info = lu_small<4>(A, b);
+  else info = lu_solve_wave(k, A, b);
   lp_tock(LP_LU, t0);
   return info;
 }
@@ -208,21 +299,32 @@ MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, LuScratch S,
     const bool is_nb = (nbmask >> lane) & 1ull;
     const bool is_b = valid && !is_nb;
     const int pos = popc(nbmask & lanes_below(lane));
-    // gather _Msub (rows by position) and the rhs -q[nonbas]
+    // gather _Msub (rows by position) and the rhs -q[nonbas]; the columns M(:, nonbas[c]) are
+    // kept in registers for the product below
     double b = 0.0;
+    double colv[MH_COLCACHE];
     if (k > 0) {
       double* Ause = (k <= S.ka) ? S.small : S.big;
-      if (gather_and_solve(M, lam, nbmask, k, is_nb, pos, qi, Ause, b) != 0) return false;
+      if (gather_and_solve(M, lam, nbmask, k, is_nb, pos, qi, Ause, b, colv) != 0) return false;
     }
     // w = Mmix * z + qbas on the basic lanes (dgemv column order)
     unsigned long long tg = lp_tick();
     double w = 0.0;
     {
       uint64_t m = nbmask;
-      for (int c = 0; c < k; c++) {
+#pragma unroll
+      for (int c = 0; c < MH_COLCACHE; c++) {
+        if (c < k) {
+          m &= m - 1;
+          const double t = read_lane(b, c);
+          if (is_b) w = w + t * colv[c];
+        }
+      }
+      for (int c = MH_COLCACHE; c < k; c++) {
         const int j = ctz(m); m &= m - 1;
         const double t = read_lane(b, c);
-        if (is_b) w = w + t * mat_at(M, j, lam);
+        const double v = mat_at(M, j, lam);
+        if (is_b) w = w + t * v;
       }
       w = w + qi;
     }
@@ -270,33 +372,27 @@ MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, LuScratch S,
 template <class MatT>
 MH_DEV bool verify_wave(int n, const MatT& M, double lam, double qi, double zi, double ZERO_TOL, bool strict)
 {
+  // "min_element(v) >= -T" holds iff no element violates it: one ballot per test instead
+  // of a wave reduction (LCP.cpp:240-249 with >=, :303-312 with >)
   const int lane = lane_id();
   const bool valid = lane < n;
-  const double INF = __longlong_as_double(0x7ff0000000000000ll);
-  const double zmin = wave_min(valid ? zi : INF);
-  if (strict ? !(zmin > -ZERO_TOL) : !(zmin >= -ZERO_TOL)) return false;
+  const double nT = -ZERO_TOL;
+  if (ballot(valid && !(strict ? (zi > nT) : (zi >= nT))) != 0ull) return false;
   double w = 0.0;
   uint64_t nz = ballot(valid && zi != 0.0);
   while (nz) {
     const int c = ctz(nz); nz &= nz - 1;
     const double t = read_lane(zi, c);
-    if (valid) w = w + t * mat_at(M, c, lam);
+    const double m = mat_at(M, c, lam);
+    if (valid) w = w + t * m;
   }
   w = w + qi;
-  const double wmin = wave_min(valid ? w : INF);
-  if (strict ? !(wmin > -ZERO_TOL) : !(wmin >= -ZERO_TOL)) return false;
+  if (ballot(valid && !(strict ? (w > nT) : (w >= nT))) != 0ull) return false;
   const double zw = zi * w;
-  const double mn = wave_min(valid ? zw : INF);
-  const double mx = wave_max(valid ? zw : -INF);
-  if (strict ? !(mn > -ZERO_TOL) : !(mn >= -ZERO_TOL)) return false;
-  return mx < ZERO_TOL;
+  if (ballot(valid && !(strict ? (zw > nT) : (zw >= nT))) != 0ull) return false;
+  return ballot(valid && !(zw < ZERO_TOL)) == 0ull;
 }
 
-// LCP.cpp:545-1003.  Lane p owns basis position p (and matrix row p): bv =
-// _bas[p], x = _x[p].  Bl is never stored: column p of Bl is -e_(bv-n) for a w
-// variable, M(:,bv) for a z variable, `art` for the artificial variable t.
-// zsize: z.size() on entry (!= n draws n rand() values, LCP.cpp:611-621) and on
-// exit (2n after a singular-basis/ray-termination failure, LCP.cpp:840-903).
 template <class MatT>
 MH_DEV int lemke_gather_and_solve(int n, const MatT& M, double lam, int bv, int t, const double* art, double* A, double& d)
 {
