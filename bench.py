@@ -33,6 +33,19 @@ WORLDS_PER_GPU = 4096
 DT = 1e-3
 
 
+def pmc_traffic(B, steps):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/pmc_traffic.json, written from profiles/r01_*_pmc.csv); None when the
+    configuration differs from the profiled one (counters cannot be read in-process)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except OSError:
+        return None
+    if t.get("worlds") != B or t.get("steps") != steps:
+        return None
+    return (t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,7 +140,7 @@ def main():
         "lcp_solves": solves, "lcp_rows": rows, "lcp_pivots": pivots, "mini_steps": minis, "stab_iters": stabs,
         "worlds_with_errors": bad,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(B, args.steps),
                      "kernel": "mh_k_world_step", "kernel_avg_us": kern_s * 1e6, "launches": 1,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "model": "LCP-entry bytes 8(n^2+2n) per solved LCP (SURVEY 8d); the fused kernel itself only moves %d B of state per launch" % int(fused_bytes)},
