@@ -125,12 +125,17 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 #define MH_MAX_PAIRS  36            /* C(MH_MAX_BODIES + 1, 2) */
 #define MH_BODY_STATE 13            /* x(3) quat xyzw(4) v(3) omega(3), world axes, at the COM */
 #define MH_GEOM_SPHERE 0
+#define MH_GEOM_SPOKES 1            /* rimless wheel: N point "spoke tips" at radius R in the body's x-z plane
+                                       (example/rimless-wheel/coldet-plugin.cpp:104-137, params.h:4-6); it is
+                                       only ever tested against the ground plane, and always (plugin :53-74) */
+#define MH_MAX_SPOKES 8
+#define MH_NOSLIP_MAX 16            /* largest no-slip LCP (contacts of one island) whose warm start is kept */
 
 typedef struct mh_scene {
   int    nb;                               /* enabled rigid bodies */
   int    has_ground;                       /* static Plane primitive present */
   int    geom_type[MH_MAX_BODIES];         /* MH_GEOM_* */
-  double geom_dim[MH_MAX_BODIES][3];       /* sphere: radius,-,- */
+  double geom_dim[MH_MAX_BODIES][3];       /* sphere: radius,-,- ; spokes: R, number of spokes, - */
   double mass[MH_MAX_BODIES];
   double inertia[MH_MAX_BODIES][3];        /* body-frame principal inertia (SpherePrimitive.cpp:138-155) */
   double plane_R[9];                       /* row-major rotation of the plane frame; its +Y is the normal (PlanePrimitive) */
@@ -169,6 +174,9 @@ typedef struct mh_world_aux {
   int      zbuf_size;              /* _z.size()                                            */
   int      zbuf_cap;               /* entries of zbuf ever written (Ravelin keeps them)    */
   int      status;                 /* MH_WORLD_* bits, sticky                              */
+  double   vns[MH_NOSLIP_MAX];     /* ImpactConstraintHandler::_v, the no-slip LCP's z (ICH:1239) */
+  int      vns_size;               /* _v.size()                                            */
+  int      pad0;
   unsigned long long steps;        /* step() calls                                         */
   unsigned long long mini_steps;   /* do_mini_step calls                                   */
   unsigned long long lcp_solves;   /* impact + stabilisation LCPs solved                   */

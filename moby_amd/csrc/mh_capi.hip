@@ -251,10 +251,12 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 // ===========================================================================
 // many-worlds stepping
 #include <mutex>
-// two size variants of the world kernel (LDS image and occupancy differ):
-//   small  <= 4 bodies, <= 6 pairs, <= 6 contacts, <= 12 Jacobian rows  (~8.5 KB LDS)
-//   large  <= 8 bodies, <= 36 pairs, <= 12 contacts, <= 24 rows         (~17 KB LDS)
+// three variants of the world kernel (LDS image, occupancy and feature set differ):
+//   small  <= 4 bodies, <= 6 pairs, <= 6 contacts, <= 12 Jacobian rows, spheres + Drumwright-Shell model only
+//   wheel  <= 2 bodies, <= 3 pairs, <= 4 contacts, + spokes geometry and the no-slip model (rimless wheel)
+//   large  <= 8 bodies, <= 36 pairs, <= 12 contacts, <= 24 rows, every feature
 #define MHW_NS small
+#define MHW_NOSLIP 0
 #define MHW_NB 4
 #define MHW_MAX_PAIRS 6
 #define MHW_MAX_CONTACTS 6
@@ -269,7 +271,26 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 #undef MHW_MAX_ROWS
 #undef MHW_MAX_GROWS
 #undef MHW_WAVES_PER_SIMD
+#undef MHW_NOSLIP
+#define MHW_NS wheel
+#define MHW_NOSLIP 1
+#define MHW_NB 2
+#define MHW_MAX_PAIRS 3
+#define MHW_MAX_CONTACTS 4
+#define MHW_MAX_ROWS 12
+#define MHW_MAX_GROWS 12
+#define MHW_WAVES_PER_SIMD 2
+#include "mh_world_wave.inc"
+#undef MHW_NS
+#undef MHW_NB
+#undef MHW_MAX_PAIRS
+#undef MHW_MAX_CONTACTS
+#undef MHW_MAX_ROWS
+#undef MHW_MAX_GROWS
+#undef MHW_WAVES_PER_SIMD
+#undef MHW_NOSLIP
 #define MHW_NS large
+#define MHW_NOSLIP 1
 #define MHW_NB MH_MAX_BODIES
 #define MHW_MAX_PAIRS MH_MAX_PAIRS
 #define MHW_MAX_CONTACTS 12
@@ -301,8 +322,18 @@ int check_scene(const mh_scene* sc)
   if (!sc) return fail(MH_ERR_INVALID_ARG, "null scene");
   if (sc->nb < 1 || sc->nb > MH_MAX_BODIES) return fail(MH_ERR_INVALID_ARG, "nb = %d outside [1, %d]", sc->nb, MH_MAX_BODIES);
   const int ntot = sc->nb + (sc->has_ground ? 1 : 0);
+  int spokes_body = -1;
   for (int b = 0; b < sc->nb; b++) {
-    if (sc->geom_type[b] != MH_GEOM_SPHERE) return fail(MH_ERR_INVALID_ARG, "body %d: only sphere geometry is built", b);
+    if (sc->geom_type[b] != MH_GEOM_SPHERE && sc->geom_type[b] != MH_GEOM_SPOKES)
+      return fail(MH_ERR_INVALID_ARG, "body %d: geometry type %d is not built (sphere, spokes)", b, sc->geom_type[b]);
+    if (sc->geom_type[b] == MH_GEOM_SPOKES) {
+      const double N = sc->geom_dim[b][1];
+      if (!sc->has_ground) return fail(MH_ERR_INVALID_ARG, "body %d: spokes geometry needs the ground plane", b);
+      if (!(N >= 1.0 && N <= (double)MH_MAX_SPOKES) || N != (double)(int)N) return fail(MH_ERR_INVALID_ARG, "body %d: number of spokes outside [1, %d]", b, MH_MAX_SPOKES);
+      if (spokes_body >= 0 && (sc->geom_dim[b][0] != sc->geom_dim[spokes_body][0] || N != sc->geom_dim[spokes_body][1]))
+        return fail(MH_ERR_INVALID_ARG, "body %d: all spokes geometries of a scene must share R and N", b);
+      spokes_body = b;
+    }
     if (!(sc->geom_dim[b][0] > 0.0) || !(sc->mass[b] > 0.0)) return fail(MH_ERR_INVALID_ARG, "body %d: radius and mass must be > 0", b);
     for (int k = 0; k < 3; k++) if (!(sc->inertia[b][k] > 0.0)) return fail(MH_ERR_INVALID_ARG, "body %d: inertia must be > 0", b);
   }
@@ -338,11 +369,14 @@ void mh_world_aux_init(mh_world_aux* a, uint32_t seed)
   mh_rand_seed(a->rng, seed);
 }
 
+typedef void (*mh_world_kernel)(const mh_scene*, int, double, int, double*, mh_world_aux*, double*, int, double*, int, unsigned long long*);
+
 struct mh_world_batch {
   mh_scene scene;
   int B;
   int nmax;
-  int small;
+  int variant;               // 0 small, 1 large, 2 wheel
+  mh_world_kernel kernel;
   mh_scene* d_scene;
   double* d_lu_ws;
   double* d_state;
@@ -355,8 +389,7 @@ int mh_world_batch_occupancy(mh_world_batch* wb)
 {
   if (!wb) return fail(MH_ERR_INVALID_ARG, "null batch");
   int n = 0;
-  hipError_t e = wb->small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mh::small::mh_k_world_step, 64, 0)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mh::large::mh_k_world_step, 64, 0);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wb->kernel, 64, 0);
   if (e != hipSuccess) return fail(MH_ERR_HIP, "occupancy query failed: %s", hipGetErrorString(e));
   return n;
 }
@@ -378,15 +411,30 @@ int mh_world_batch_create(const mh_scene* scene, int B, mh_world_batch** out)
     // small variant: <= 4 bodies, <= 6 pairs, islands of <= 4 contacts (12 Jacobian rows); the
     // caller opts in by bounding the LCP size (lcp_n_max <= 56 = 4 contacts x (6 + 16/2) rows).
     // A world that outgrows the variant's limits at run time gets MH_WORLD_UNSUPPORTED.
+    // Spokes geometry or a pair with mu-coulomb >= 100 (=> the no-slip model, ICH:127-135) needs a
+    // variant built with those features: "wheel" for one or two bodies, otherwise "large".
     const int ntot = scene->nb + (scene->has_ground ? 1 : 0), npairs = ntot * (ntot - 1) / 2;
-    wb->small = (scene->nb <= 4 && npairs <= 6 && scene->lcp_n_max > 0 && scene->lcp_n_max <= 56) ? 1 : 0;
+    bool noslip = false;
+    for (int b = 0; b < scene->nb; b++) if (scene->geom_type[b] == MH_GEOM_SPOKES) noslip = true;
+    for (int p = 0; p < npairs; p++) if (scene->pair_enabled[p] && scene->cp_mu_coulomb[p] >= 1e2) noslip = true;
+    if (!noslip && scene->nb <= 4 && npairs <= 6 && scene->lcp_n_max > 0 && scene->lcp_n_max <= 56) { wb->variant = 0; wb->kernel = mh::small::mh_k_world_step; }
+    else if (noslip && scene->nb <= 2 && npairs <= 3) { wb->variant = 2; wb->kernel = mh::wheel::mh_k_world_step; }
+    else { wb->variant = 1; wb->kernel = mh::large::mh_k_world_step; }
   }
   wb->d_scene = nullptr; wb->d_state = nullptr; wb->d_aux = nullptr; wb->d_lu_ws = nullptr;
-  hipError_t e = hipMalloc(&wb->d_scene, sizeof(mh_scene));
+  // device scene record, followed by the spoke-tip table p1 = (cos(theta) R, sin(theta) R), theta = pi i 2 / N
+  // (coldet-plugin.cpp:104-110), evaluated with the host's libm like the oracle does
+  double tips[2 * MH_MAX_SPOKES] = {0.0};
+  for (int b = 0; b < scene->nb; b++) if (scene->geom_type[b] == MH_GEOM_SPOKES) {
+    const double Rr = scene->geom_dim[b][0]; const int N = (int)scene->geom_dim[b][1];
+    for (int i = 0; i < N; i++) { const double theta = M_PI * i * 2.0 / N; tips[2*i] = std::cos(theta) * Rr; tips[2*i+1] = std::sin(theta) * Rr; }
+  }
+  hipError_t e = hipMalloc(&wb->d_scene, sizeof(mh_scene) + sizeof(tips));
   if (e == hipSuccess) e = hipMalloc(&wb->d_lu_ws, (size_t)B * wb->nmax * wb->nmax * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&wb->d_state, (size_t)B * scene->nb * MH_BODY_STATE * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&wb->d_aux, (size_t)B * sizeof(mh_world_aux));
   if (e == hipSuccess) e = hipMemcpy(wb->d_scene, scene, sizeof(mh_scene), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(reinterpret_cast<char*>(wb->d_scene) + sizeof(mh_scene), tips, sizeof(tips), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(wb->d_state, 0, (size_t)B * scene->nb * MH_BODY_STATE * sizeof(double));
   if (e == hipSuccess) {
     std::vector<mh_world_aux> a((size_t)B);
@@ -424,14 +472,9 @@ int mh_world_batch_step(mh_world_batch* wb, void* stream, double dt, int nsteps,
   if (nsteps < 0) return fail(MH_ERR_INVALID_ARG, "negative step count");
   if (nsteps == 0) return MH_OK;
   if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
-  if (wb->small)
-    hipLaunchKernelGGL(mh::small::mh_k_world_step, dim3(wb->B), dim3(64), 0, (hipStream_t)stream,
-                       wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, traj_dev, wb->nmax, wb->d_lu_ws, g_debug_ka,
-                       (unsigned long long*)nullptr);
-  else
-    hipLaunchKernelGGL(mh::large::mh_k_world_step, dim3(wb->B), dim3(64), 0, (hipStream_t)stream,
-                       wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, traj_dev, wb->nmax, wb->d_lu_ws, g_debug_ka,
-                       (unsigned long long*)nullptr);
+  hipLaunchKernelGGL(wb->kernel, dim3(wb->B), dim3(64), 0, (hipStream_t)stream,
+                     (const mh_scene*)wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, traj_dev, wb->nmax, wb->d_lu_ws, g_debug_ka,
+                     (unsigned long long*)nullptr);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
@@ -444,12 +487,8 @@ int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* ph
   const size_t sz = (size_t)wb->B * mh::large::PH_COUNT * sizeof(unsigned long long);
   MH_HIP(hipMalloc(&dprof, sz));
   MH_HIP(hipMemset(dprof, 0, sz));
-  if (wb->small)
-    hipLaunchKernelGGL(mh::small::mh_k_world_step, dim3(wb->B), dim3(64), 0, (hipStream_t)nullptr,
-                       wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, wb->d_lu_ws, g_debug_ka, dprof);
-  else
-    hipLaunchKernelGGL(mh::large::mh_k_world_step, dim3(wb->B), dim3(64), 0, (hipStream_t)nullptr,
-                       wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, wb->d_lu_ws, g_debug_ka, dprof);
+  hipLaunchKernelGGL(wb->kernel, dim3(wb->B), dim3(64), 0, (hipStream_t)nullptr,
+                     (const mh_scene*)wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, wb->d_lu_ws, g_debug_ka, dprof);
   hipError_t e = hipDeviceSynchronize();
   std::vector<unsigned long long> h((size_t)wb->B * mh::large::PH_COUNT);
   if (e == hipSuccess) e = hipMemcpy(h.data(), dprof, sz, hipMemcpyDeviceToHost);

@@ -19,6 +19,9 @@ MH_MAX_PAIRS = 36
 MH_BODY_STATE = 13
 MH_RAND_WORDS = 32
 MH_LCP_MAX_N_WAVE = 64
+MH_NOSLIP_MAX = 16
+MH_MAX_SPOKES = 8
+MH_GEOM_SPHERE, MH_GEOM_SPOKES = 0, 1
 NEAR_ZERO = math.sqrt(np.finfo(np.float64).eps)   # include/Moby/Constants.h:21
 
 MH_WORLD_OK, MH_WORLD_LCP_FAILED, MH_WORLD_IMPACT_TOL, MH_WORLD_UNSUPPORTED, MH_WORLD_STAB_FAILED, MH_WORLD_STALLED = 0, 1, 2, 4, 8, 16
@@ -49,6 +52,7 @@ class mh_world_aux(ctypes.Structure):
         ("rng", ctypes.c_uint32 * MH_RAND_WORDS), ("time", ctypes.c_double),
         ("zlast", ctypes.c_double * MH_LCP_MAX_N_WAVE), ("zbuf", ctypes.c_double * MH_LCP_MAX_N_WAVE),
         ("zlast_size", ctypes.c_int), ("zbuf_size", ctypes.c_int), ("zbuf_cap", ctypes.c_int), ("status", ctypes.c_int),
+        ("vns", ctypes.c_double * MH_NOSLIP_MAX), ("vns_size", ctypes.c_int), ("pad0", ctypes.c_int),
         ("steps", ctypes.c_ulonglong), ("mini_steps", ctypes.c_ulonglong), ("lcp_solves", ctypes.c_ulonglong),
         ("lcp_rows", ctypes.c_ulonglong), ("lcp_pivots", ctypes.c_ulonglong), ("stab_iters", ctypes.c_ulonglong),
         ("lcp_alg_bytes", ctypes.c_ulonglong),
@@ -59,6 +63,7 @@ AUX_DTYPE = np.dtype([
     ("rng", np.uint32, MH_RAND_WORDS), ("time", np.float64),
     ("zlast", np.float64, MH_LCP_MAX_N_WAVE), ("zbuf", np.float64, MH_LCP_MAX_N_WAVE),
     ("zlast_size", np.int32), ("zbuf_size", np.int32), ("zbuf_cap", np.int32), ("status", np.int32),
+    ("vns", np.float64, MH_NOSLIP_MAX), ("vns_size", np.int32), ("pad0", np.int32),
     ("steps", np.uint64), ("mini_steps", np.uint64), ("lcp_solves", np.uint64),
     ("lcp_rows", np.uint64), ("lcp_pivots", np.uint64), ("stab_iters", np.uint64),
     ("lcp_alg_bytes", np.uint64)], align=True)
@@ -189,6 +194,66 @@ def bouncing_ball_state(B=1):
     st[:, 0, 0:3] = (0.0, 1.5, 0.0)
     st[:, 0, 6] = 1.0
     st[:, 0, 10:13] = (0.0, 10.0, 0.0)
+    return st.reshape(B, MH_BODY_STATE)
+
+
+def rimless_wheel_scene(cstab_max_iterations=0xFFFFFFFF):
+    """example/rimless-wheel/wheel.xml + coldet-plugin.cpp + params.h: one free body (m = 1,
+    J = diag(2,1,2)) whose collision geometry is N_SPOKES = 6 spoke tips at R = 1, a plane with
+    rpy = (1.570796326949, 0, 0), gravity (0.099833, 0, -0.995), epsilon 0, mu-coulomb 100
+    (=> the no-slip model, ICH:127-135)."""
+    sc = mh_scene()
+    _defaults(sc)
+    sc.nb = 1
+    sc.has_ground = 1
+    sc.geom_type[0] = MH_GEOM_SPOKES
+    sc.geom_dim[0][0] = 1.0       # R  (params.h:4)
+    sc.geom_dim[0][1] = 6.0       # N_SPOKES (params.h:6)
+    sc.mass[0] = 1.0
+    for k, j in enumerate((2.0, 1.0, 2.0)):
+        sc.inertia[0][k] = j
+    R = rpy_to_R(1.570796326949, 0.0, 0.0)
+    for k in range(9):
+        sc.plane_R[k] = R.flat[k]
+    for k, g in enumerate((0.099833, 0.0, -0.995)):
+        sc.gravity[k] = g
+    p = pair_index(0, 1, 2)
+    sc.cp_epsilon[p] = 0.0
+    sc.cp_mu_coulomb[p] = 100.0
+    sc.cp_nk[p] = 4
+    sc.cstab_max_iterations = cstab_max_iterations
+    sc.lcp_n_max = 8
+    return sc
+
+
+def rimless_wheel_regress_scene(cstab_max_iterations=0xFFFFFFFF):
+    """The scene regress/rimless-wheel.dat was recorded with.  That file predates the wheel.xml in
+    the tree: its trajectory (deceleration -0.152 rad/s^2 while pivoting, first post-impact rate
+    0.2893 rad/s) is reproduced by the commented-out "alpha = 0.05" gravity line of wheel.xml:13-14
+    and an inertia of 2 about the wheel axis, not by the active lines (gravity alpha = 0.1,
+    J = diag(2,1,2)) -- see tests/test_oracle_wheel.py."""
+    sc = rimless_wheel_scene(cstab_max_iterations)
+    for k, g in enumerate((0.049979, 0.0, -0.99875)):
+        sc.gravity[k] = g
+    sc.inertia[0][1] = 2.0
+    return sc
+
+
+def rimless_wheel_state(theta_dots=(0.24,)):
+    """example/rimless-wheel/init.cpp:166-191: theta = 0, z = 0.866025403784439,
+    the SVelocityd built there has a null (= GLOBAL) pose, so its linear part 2 pi R * (theta_dot /
+    2 pi) is the velocity of the body point at the global ORIGIN; the COM moves with
+    v_x = theta_dot R + theta_dot * z.  omega_y = theta_dot (RIMLESS_WHEEL_THETAD, 0.24 in
+    regress/regression-test:58-61)."""
+    B = len(theta_dots)
+    st = np.zeros((B, 1, MH_BODY_STATE))
+    for w, thd in enumerate(theta_dots):
+        dist_per_rev = 2 * math.pi * 1.0
+        rev_per_sec = thd / (math.pi * 2.0)
+        st[w, 0, 2] = 0.866025403784439
+        st[w, 0, 6] = 1.0
+        st[w, 0, 7] = dist_per_rev * rev_per_sec + thd * 0.866025403784439
+        st[w, 0, 11] = thd
     return st.reshape(B, MH_BODY_STATE)
 
 

@@ -129,6 +129,19 @@ double oracle_world_step_batch(const mh_scene* sc, int B, double dt, int nsteps,
   return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
 }
 
+// finds the contacts of the current state and handles impacts in place, without integrating
+// (what ConstraintSimulator::find_unilateral_constraints + calc_impacting_unilateral_constraint_forces
+// do at the end of a mini-step, TSS:206-212); used to start a run from a post-impact state
+void oracle_world_handle_impacts(const mh_scene* sc, double* state, mh_world_aux* aux)
+{
+  World w(sc, state, aux);
+  std::vector<int> pairs; w.broad_phase(0.0, pairs);
+  std::vector<PairDist> pd; w.calc_pairwise_distances(pairs, pd);
+  std::vector<Contact> cs;
+  for (const PairDist& d : pd) if (d.dist < sc->contact_dist_thresh) w.find_contacts(d.pair, sc->contact_dist_thresh, cs);
+  w.handle_impacts(cs);
+}
+
 // the impact LCP (_MM column-major n x n, _qq) the handler would assemble for the
 // current state's contacts (first active island), for cross-checks; returns n
 int oracle_world_impact_lcp(const mh_scene* sc, double* state, mh_world_aux* aux, double* MM, double* qq, int cap)

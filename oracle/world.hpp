@@ -133,6 +133,7 @@ class World {
     for (int i = 0; i < ntot; i++)
       for (int j = i + 1; j < ntot; j++) {
         const int p = pair_index(i, j, ntot);
+        if (is_spokes(i) || is_spokes(j)) continue;   // removed from CCD's body list (coldet-plugin.cpp:58-66)
         bool ov = true;
         for (int k = 0; k < 3; k++) if (!(lo[i][k] <= hi[j][k] && lo[j][k] <= hi[i][k])) ov = false;
         if (!ov) continue;                          // needs overlap on all three axes (CCD.cpp:857)
@@ -140,6 +141,20 @@ class World {
         if (!enabled(i) && !enabled(j)) continue;
         pairs.push_back(p);
       }
+    // BladePlanePlugin::broad_phase appends (ground, wheel) unconditionally (coldet-plugin.cpp:72)
+    if (sc->has_ground)
+      for (int i = 0; i < sc->nb; i++) if (is_spokes(i)) pairs.push_back(pair_index(i, sc->nb, ntot));
+  }
+  bool is_spokes(int b) const { return b < sc->nb && sc->geom_type[b] == MH_GEOM_SPOKES; }
+  // tip of spoke i in the global frame: p1 = (cos(theta) R, W/2, sin(theta) R) in the wheel frame,
+  // theta = pi i 2 / N, W = 0 (coldet-plugin.cpp:104-113, params.h)
+  V3 spoke_tip(int b, int i) const {
+    const double Rr = sc->geom_dim[b][0]; const int N = (int)sc->geom_dim[b][1];
+    const double theta = M_PI * i * 2.0 / N;
+    const double px = std::cos(theta) * Rr, py = 0.0, pz = std::sin(theta) * Rr;
+    double R[9]; rot(b, R);
+    const V3 c = X(b);
+    return v3(c.x + ((R[0]*px + R[1]*py) + R[2]*pz), c.y + ((R[3]*px + R[4]*py) + R[5]*pz), c.z + ((R[6]*px + R[7]*py) + R[8]*pz));
   }
   void pair_bodies(int p, int& a, int& b) const {
     const int ntot = nbodies_all();
@@ -150,6 +165,22 @@ class World {
   // SpherePrimitive.cpp:104-136 / PlanePrimitive.cpp:385-411
   PairDist signed_dist(int p) const {
     PairDist d; d.pair = p; pair_bodies(p, d.a, d.b);
+    if (is_spokes(d.a)) {
+      // BladePlanePlugin::calc_signed_dist_wheel_plane (coldet-plugin.cpp:88-137).  The pair is
+      // (ground, wheel) and the plugin hands back pA = the WHEEL point, pB = the ground point
+      // (:336-339 swap the geometries, not the points): kept, it decides the sign in the
+      // conservative-advancement step and the normal of the stabilisation contact.
+      const int w = d.a;
+      const int N = (int)sc->geom_dim[w][1];
+      double min_dist = INF;
+      for (int i = 0; i < N; i++) {
+        const V3 g = spoke_tip(w, i);
+        const V3 pp = to_plane(g);
+        if (pp.y < min_dist) { min_dist = pp.y; d.pb = from_plane(v3(pp.x, 0.0, pp.z)); d.pa = g; }
+      }
+      d.dist = min_dist; d.a = sc->nb; d.b = w;
+      return d;
+    }
     if (enabled(d.a) && enabled(d.b)) {
       const V3 ca = X(d.a), cb = X(d.b);
       const double ra = sc->geom_dim[d.a][0], rb = sc->geom_dim[d.b][0];
@@ -194,6 +225,22 @@ class World {
   void find_contacts(int p, double TOL, std::vector<Contact>& out) const {
     int a, b; pair_bodies(p, a, b);
     Contact c; c.pair = p;
+    if (is_spokes(a)) {
+      // BladePlanePlugin::find_contacts_wheel_plane (coldet-plugin.cpp:211-288): one contact per
+      // spoke tip below sim->contact_dist_thresh (the TOL argument is ignored, :214)
+      const int N = (int)sc->geom_dim[a][1];
+      for (int i = 0; i < N; i++) {
+        const V3 g = spoke_tip(a, i);
+        const V3 pp = to_plane(g);
+        if (!(pp.y < sc->contact_dist_thresh)) continue;
+        c.p = (g + from_plane(v3(pp.x, 0.0, pp.z))) * 0.5;
+        c.n = plane_n(); c.g1 = a; c.g2 = b; c.dist = pp.y;
+        orthonormal_basis(c.n, c.s, c.t);
+        fill_params(c);
+        out.push_back(c);
+      }
+      return;
+    }
     if (enabled(a) && enabled(b)) {
       const V3 cA = X(a), cB = X(b);
       const double rA = sc->geom_dim[a][0], rB = sc->geom_dim[b][0];
@@ -229,8 +276,12 @@ class World {
     const V3 w0 = Wa(b);
     return dot(n, xd0) + norm(cross(w0, n)) * rmax;
   }
+  // CCD::_rmax (CCD.cpp:739): sphere radius; a spokes body is never seen by CCD::broad_phase, so
+  // the std::map lookup default-constructs 0
+  double rmax_of(int b) const { return (enabled(b) && !is_spokes(b)) ? sc->geom_dim[b][0] : 0.0; }
   // CCD::calc_next_CA_Euler_step_generic (CCD.cpp:238-405) for sphere pairs
   double next_CA_generic(const PairDist& d) const {
+    if (is_spokes(d.b)) return INF;                 // BladePlanePlugin::calc_next_CA_Euler_step (coldet-plugin.cpp:205-208)
     std::vector<Contact> cs; find_contacts(d.pair, NEAR_ZERO, cs);
     if (cs.empty()) return INF;
     for (const Contact& c : cs) if (contact_vel(c, c.n) < -NEAR_ZERO) return 0.0;
@@ -241,8 +292,8 @@ class World {
     if (d.dist <= 0.0) return next_CA_generic(d);
     const V3 d0 = d.pa - d.pb;
     const V3 n0 = d0 / norm(d0);
-    const double tA = calc_max_dist(d.a, -n0, enabled(d.a) ? sc->geom_dim[d.a][0] : 0.0);
-    const double tB = calc_max_dist(d.b, n0, enabled(d.b) ? sc->geom_dim[d.b][0] : 0.0);
+    const double tA = calc_max_dist(d.a, -n0, rmax_of(d.a));
+    const double tB = calc_max_dist(d.b, n0, rmax_of(d.b));
     double total = tA + tB;
     if (total < 0.0) total = 0.0;
     const double cand = d.dist / total;
@@ -250,6 +301,7 @@ class World {
   }
   // CCD::calc_CA_Euler_step_sphere (CCD.cpp:138-166)
   double CA_step(const PairDist& d) const {
+    if (is_spokes(d.b)) return CA_generic(d);       // no SpherePrimitive in the pair (CCD.cpp:127-133)
     if (d.dist > NEAR_ZERO) return CA_generic(d);
     std::vector<Contact> cs; find_contacts(d.pair, NEAR_ZERO, cs);
     if (cs.size() == 1 && std::fabs(contact_vel(cs[0], cs[0].n)) < NEAR_ZERO * 10) return INF;
@@ -577,6 +629,118 @@ class World {
     }
   }
 
+  // ImpactConstraintHandler::apply_no_slip_model (ICH:1009-1417), contacts only (no limits, no
+  // bilateral rows).  Dense products are restated in the order the HIP kernel uses: dot products
+  // accumulate from 0 in ascending index order.
+  bool apply_no_slip_model(ProblemData& pd) {
+    const int nc = pd.nc;
+    if (nc > MH_NOSLIP_MAX) { aux->status |= MH_WORLD_UNSUPPORTED; return false; }
+    std::vector<int> S, T;
+    std::vector<double> Y;
+    auto build_Y = [&](bool skew) -> int {
+      const int ns = (int)S.size(), nt = (int)T.size(), m = ns + nt;
+      Y.assign((size_t)m * m, 0.0);                        // column-major
+      for (int a = 0; a < ns; a++) for (int b = 0; b < ns; b++) Y[a + (size_t)m * b] = pd.G[1][1][(size_t)S[a] * nc + S[b]];
+      for (int a = 0; a < nt; a++) for (int b = 0; b < nt; b++) Y[(ns + a) + (size_t)m * (ns + b)] = pd.G[2][2][(size_t)T[a] * nc + T[b]];
+      for (int a = 0; a < ns; a++) for (int b = 0; b < nt; b++) {
+        const double g = pd.G[1][2][(size_t)S[a] * nc + T[b]];
+        Y[a + (size_t)m * (ns + b)] = g; Y[(ns + b) + (size_t)m * a] = g;
+      }
+      if (skew) for (int j = 0; j < m; j++) Y[j + (size_t)m * j] = Y[j + (size_t)m * j] - NEAR_ZERO;   // ICH:1110-1111
+      return m;
+    };
+    // greedy largest non-singular tangent set (ICH:1087-1145)
+    for (int i = 0; i < nc; i++) {
+      S.push_back(i);
+      int m = build_Y(true);
+      if (!chol_factor(m, Y.data(), m)) S.pop_back();
+      T.push_back(i);
+      m = build_Y(true);
+      if (!chol_factor(m, Y.data(), m)) T.pop_back();
+    }
+    const int ns = (int)S.size(), nt = (int)T.size();
+    const int m = build_Y(false);                            // ICH:1166-1183
+    if (!chol_factor(m, Y.data(), m)) { aux->status |= MH_WORLD_LCP_FAILED; return false; }   // assert(success)
+    // Q X X^T (nc x m): [Cn X Cs^T(:,S)  Cn X Ct^T(:,T)] (ICH:1198-1203)
+    std::vector<double> QX((size_t)nc * m);
+    for (int i = 0; i < nc; i++) {
+      for (int a = 0; a < ns; a++) QX[(size_t)i * m + a] = pd.G[0][1][(size_t)i * nc + S[a]];
+      for (int a = 0; a < nt; a++) QX[(size_t)i * m + ns + a] = pd.G[0][2][(size_t)i * nc + T[a]];
+    }
+    // W = Y^-1 (Q X X^T)^T, column by column (ICH:1210-1211)
+    std::vector<double> W((size_t)m * nc), col(m);
+    for (int j = 0; j < nc; j++) {
+      for (int a = 0; a < m; a++) col[a] = QX[(size_t)j * m + a];
+      chol_solve(m, Y.data(), m, col.data());
+      for (int a = 0; a < m; a++) W[a + (size_t)m * j] = col[a];
+    }
+    // MM = Cn X Cn^T - QX W (ICH:1190-1215)
+    std::vector<double> MM((size_t)nc * nc), qq(nc);
+    for (int i = 0; i < nc; i++) for (int j = 0; j < nc; j++) {
+      double acc = 0.0;
+      for (int a = 0; a < m; a++) acc = acc + QX[(size_t)i * m + a] * W[a + (size_t)m * j];
+      MM[i + (size_t)nc * j] = pd.G[0][0][(size_t)i * nc + j] - acc;
+    }
+    // qq = Cn v - QX Y^-1 [Cs v(S); Ct v(T)] (ICH:1217-1236)
+    std::vector<double> YXv(m);
+    for (int a = 0; a < ns; a++) YXv[a] = pd.Cv[1][S[a]];
+    for (int a = 0; a < nt; a++) YXv[ns + a] = pd.Cv[2][T[a]];
+    chol_solve(m, Y.data(), m, YXv.data());
+    for (int i = 0; i < nc; i++) {
+      double acc = 0.0;
+      for (int a = 0; a < m; a++) acc = acc + QX[(size_t)i * m + a] * YXv[a];
+      qq[i] = pd.Cv[0][i] - acc;
+    }
+    // lcp_fast on the persistent _v, then the Lemke ladder (ICH:1239, 1281)
+    Vec z; z.d.assign(aux->vns, aux->vns + MH_NOSLIP_MAX); z.len = (unsigned)aux->vns_size;
+    oracle_rand_t rs; std::memcpy(&rs, aux->rng, sizeof(rs));
+    LCP lcp; lcp.rng = &rs;
+    Trace tr; tr.buf = trace ? trace + trace_len : nullptr; tr.cap = trace ? std::max(0, trace_cap - trace_len) : 0;
+    lcp.trace = &tr;
+    unsigned piv = 0;
+    bool ok = lcp.lcp_fast(nc, MM.data(), nc, qq.data(), z, -1.0);
+    piv += lcp.pivots;
+    if (!ok) { ok = lcp.lcp_lemke_regularized(nc, MM.data(), nc, qq.data(), z); piv += lcp.pivots; }
+    trace_len += tr.len;
+    std::memcpy(aux->rng, &rs, sizeof(rs));
+    lcp_account(nc, piv);
+    if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; return false; }   // std::runtime_error("Unable to solve constraint LCP!")
+    for (int i = 0; i < nc; i++) aux->vns[i] = z[i];
+    aux->vns_size = nc;
+    // [cs; ct] = -(Y^-1 X v + Y^-1 (QX)^T v) (ICH:1293-1298)
+    std::vector<double> t2(m);
+    for (int a = 0; a < m; a++) {
+      double acc = 0.0;
+      for (int i = 0; i < nc; i++) acc = acc + QX[(size_t)i * m + a] * z[i];
+      t2[a] = acc;
+    }
+    chol_solve(m, Y.data(), m, t2.data());
+    for (int i = 0; i < nc; i++) { pd.cn[i] = z[i]; pd.cs[i] = 0.0; pd.ct[i] = 0.0; }
+    for (int a = 0; a < ns; a++) pd.cs[S[a]] = -(YXv[a] + t2[a]);
+    for (int a = 0; a < nt; a++) pd.ct[T[a]] = -(YXv[ns + a] + t2[ns + a]);
+    apply_impulses(pd);                                              // ICH:1351-1385
+    return true;
+  }
+  // apply_no_slip_model_to_connected_constraints (ICH:236-295)
+  void apply_no_slip_model_to_island(const std::vector<Contact>& all, const Island& isl) {
+    ProblemData pd; compute_problem_data(all, isl, pd, false);
+    const int nc = pd.nc;
+    if (!apply_no_slip_model(pd)) return;
+    update_constraint_vels(pd);                                      // ICH:265
+    const double minv = *std::min_element(pd.Cv[0].begin(), pd.Cv[0].end());
+    bool changed = false;                                            // apply_restitution(q) (ICH:497-525)
+    for (int i = 0; i < nc; i++) { pd.cn[i] = pd.cn[i] * pd.c[i]->eps; if (!changed && pd.cn[i] > NEAR_ZERO) changed = true; }
+    if (changed) {
+      for (int i = 0; i < nc; i++) { pd.cs[i] = 0.0; pd.ct[i] = 0.0; }
+      apply_impulses(pd);                                            // update_from_stacked(q) (ICH:274)
+      update_constraint_vels(pd);
+      const double minv_plus = *std::min_element(pd.Cv[0].begin(), pd.Cv[0].end());
+      // ICH:284-291 would re-solve and then read the D-S solver's _z, which this path never
+      // sized: undefined in the reference, reported here
+      if (minv_plus < 0.0 && minv_plus < minv - NEAR_ZERO) aux->status |= MH_WORLD_UNSUPPORTED;
+    }
+  }
+
   // apply_model_to_connected_constraints (ICH:530-626), Drumwright-Shell path
   void apply_model(const std::vector<Contact>& all, const Island& isl) {
     ProblemData pd; compute_problem_data(all, isl, pd, false);
@@ -631,8 +795,8 @@ class World {
     for (const Island& isl : active) {
       bool all_inf = true;
       for (int ci : isl.contacts) if (cs[ci].mu < 1e2) all_inf = false;
-      if (all_inf) { aux->status |= MH_WORLD_UNSUPPORTED; continue; }   // no-slip model (ICH:1009-1417): not built yet
-      apply_model(cs, isl);
+      if (all_inf) apply_no_slip_model_to_island(cs, isl);              // ICH:134-135
+      else apply_model(cs, isl);
     }
     for (const Island& isl : active)
       for (int ci : isl.contacts) if (contact_vel(cs[ci], cs[ci].n) < -NEAR_ZERO) { aux->status |= MH_WORLD_IMPACT_TOL; }

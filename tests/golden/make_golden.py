@@ -7,6 +7,10 @@ data (run in the build container, where /root/reference exists):
                         then every 25th, and the last row; plus the CPU-seconds
                         footer (regress.cpp:274-277).
 
+  rimless_wheel_dat.npz rows of /root/reference/regress/rimless-wheel.dat (t + the wheel's
+                        [x y z qx qy qz qw]): the first 30 rows, then every 25th, and the
+                        last row (the file ends at t = 6.274 s without a footer).
+
 Only DATA is stored (inputs / expected outputs), never reference source.
 """
 import os
@@ -25,6 +29,12 @@ def main():
     np.savez_compressed(os.path.join(HERE, "sphere_stack_dat.npz"), row_index=np.array(keep), rows=data[keep],
                         n_rows=len(data), cpu_seconds=float(footer[-1]) if footer else np.nan)
     print("sphere-stack.dat: %d rows -> %d kept" % (len(data), len(keep)))
+
+    lines = open(os.path.join(REF, "rimless-wheel.dat")).read().split("\n")
+    data = np.array([[float(x) for x in l.split()] for l in lines if len(l.split()) == 8])
+    keep = sorted(set(list(range(30)) + list(range(0, len(data), 25)) + [len(data) - 1]))
+    np.savez_compressed(os.path.join(HERE, "rimless_wheel_dat.npz"), row_index=np.array(keep), rows=data[keep], n_rows=len(data))
+    print("rimless-wheel.dat: %d rows -> %d kept" % (len(data), len(keep)))
 
 
 if __name__ == "__main__":

@@ -99,6 +99,13 @@ def oracle_world_step_batch(self, scene, state, aux, dt, nsteps):
     return self.lib.oracle_world_step_batch(ctypes.byref(scene), int(B), ctypes.c_double(dt), int(nsteps), P(state), P(aux))
 
 
+def oracle_world_handle_impacts(self, scene, state, aux):
+    _world_protos(self.lib)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    self.lib.oracle_world_handle_impacts.restype = None
+    self.lib.oracle_world_handle_impacts(ctypes.byref(scene), P(state), P(aux))
+
+
 def oracle_world_impact_lcp(self, scene, state, aux, cap=64):
     _world_protos(self.lib)
     MM = np.zeros(cap * cap); qq = np.zeros(cap)
@@ -112,3 +119,4 @@ def oracle_world_impact_lcp(self, scene, state, aux, cap=64):
 Oracle.world_step = oracle_world_step
 Oracle.world_step_batch = oracle_world_step_batch
 Oracle.world_impact_lcp = oracle_world_impact_lcp
+Oracle.world_handle_impacts = oracle_world_handle_impacts
