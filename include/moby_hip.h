@@ -128,6 +128,8 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 #define MH_GEOM_SPOKES 1            /* rimless wheel: N point "spoke tips" at radius R in the body's x-z plane
                                        (example/rimless-wheel/coldet-plugin.cpp:104-137, params.h:4-6); it is
                                        only ever tested against the ground plane, and always (plugin :53-74) */
+#define MH_GEOM_BOX 2               /* BoxPrimitive, tested against the ground plane only (vertex-plane contacts,
+                                       CCD.inl:848-886); box-box / box-sphere pairs must be disabled */
 #define MH_MAX_SPOKES 8
 #define MH_NOSLIP_MAX 16            /* largest no-slip LCP (contacts of one island) whose warm start is kept */
 
@@ -135,7 +137,7 @@ typedef struct mh_scene {
   int    nb;                               /* enabled rigid bodies */
   int    has_ground;                       /* static Plane primitive present */
   int    geom_type[MH_MAX_BODIES];         /* MH_GEOM_* */
-  double geom_dim[MH_MAX_BODIES][3];       /* sphere: radius,-,- ; spokes: R, number of spokes, - */
+  double geom_dim[MH_MAX_BODIES][3];       /* sphere: radius,-,- ; spokes: R, number of spokes, - ; box: xlen, ylen, zlen */
   double mass[MH_MAX_BODIES];
   double inertia[MH_MAX_BODIES][3];        /* body-frame principal inertia (SpherePrimitive.cpp:138-155) */
   double plane_R[9];                       /* row-major rotation of the plane frame; its +Y is the normal (PlanePrimitive) */

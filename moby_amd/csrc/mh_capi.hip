@@ -257,6 +257,7 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 //   large  <= 8 bodies, <= 36 pairs, <= 12 contacts, <= 24 rows, every feature
 #define MHW_NS small
 #define MHW_NOSLIP 0
+#define MHW_BOX 0
 #define MHW_NB 4
 #define MHW_MAX_PAIRS 6
 #define MHW_MAX_CONTACTS 6
@@ -289,8 +290,10 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 #undef MHW_MAX_GROWS
 #undef MHW_WAVES_PER_SIMD
 #undef MHW_NOSLIP
+#undef MHW_BOX
 #define MHW_NS large
 #define MHW_NOSLIP 1
+#define MHW_BOX 1
 #define MHW_NB MH_MAX_BODIES
 #define MHW_MAX_PAIRS MH_MAX_PAIRS
 #define MHW_MAX_CONTACTS 12
@@ -324,8 +327,16 @@ int check_scene(const mh_scene* sc)
   const int ntot = sc->nb + (sc->has_ground ? 1 : 0);
   int spokes_body = -1;
   for (int b = 0; b < sc->nb; b++) {
-    if (sc->geom_type[b] != MH_GEOM_SPHERE && sc->geom_type[b] != MH_GEOM_SPOKES)
-      return fail(MH_ERR_INVALID_ARG, "body %d: geometry type %d is not built (sphere, spokes)", b, sc->geom_type[b]);
+    if (sc->geom_type[b] != MH_GEOM_SPHERE && sc->geom_type[b] != MH_GEOM_SPOKES && sc->geom_type[b] != MH_GEOM_BOX)
+      return fail(MH_ERR_INVALID_ARG, "body %d: geometry type %d is not built (sphere, spokes, box)", b, sc->geom_type[b]);
+    if (sc->geom_type[b] == MH_GEOM_BOX) {
+      if (!(sc->geom_dim[b][1] > 0.0) || !(sc->geom_dim[b][2] > 0.0)) return fail(MH_ERR_INVALID_ARG, "body %d: box edge lengths must be > 0", b);
+      for (int o = 0; o < sc->nb; o++) if (o != b) {
+        const int i = o < b ? o : b, j = o < b ? b : o;
+        if (sc->pair_enabled[i * ntot - (i * (i + 1)) / 2 + (j - i - 1)])
+          return fail(MH_ERR_INVALID_ARG, "bodies %d,%d: box-box / box-sphere contact is not built; disable the pair (only box-plane is)", i, j);
+      }
+    }
     if (sc->geom_type[b] == MH_GEOM_SPOKES) {
       const double N = sc->geom_dim[b][1];
       if (!sc->has_ground) return fail(MH_ERR_INVALID_ARG, "body %d: spokes geometry needs the ground plane", b);
@@ -414,11 +425,12 @@ int mh_world_batch_create(const mh_scene* scene, int B, mh_world_batch** out)
     // Spokes geometry or a pair with mu-coulomb >= 100 (=> the no-slip model, ICH:127-135) needs a
     // variant built with those features: "wheel" for one or two bodies, otherwise "large".
     const int ntot = scene->nb + (scene->has_ground ? 1 : 0), npairs = ntot * (ntot - 1) / 2;
-    bool noslip = false;
+    bool noslip = false, box = false;
     for (int b = 0; b < scene->nb; b++) if (scene->geom_type[b] == MH_GEOM_SPOKES) noslip = true;
+    for (int b = 0; b < scene->nb; b++) if (scene->geom_type[b] == MH_GEOM_BOX) box = true;
     for (int p = 0; p < npairs; p++) if (scene->pair_enabled[p] && scene->cp_mu_coulomb[p] >= 1e2) noslip = true;
-    if (!noslip && scene->nb <= 4 && npairs <= 6 && scene->lcp_n_max > 0 && scene->lcp_n_max <= 56) { wb->variant = 0; wb->kernel = mh::small::mh_k_world_step; }
-    else if (noslip && scene->nb <= 2 && npairs <= 3) { wb->variant = 2; wb->kernel = mh::wheel::mh_k_world_step; }
+    if (!noslip && !box && scene->nb <= 4 && npairs <= 6 && scene->lcp_n_max > 0 && scene->lcp_n_max <= 56) { wb->variant = 0; wb->kernel = mh::small::mh_k_world_step; }
+    else if (noslip && !box && scene->nb <= 2 && npairs <= 3) { wb->variant = 2; wb->kernel = mh::wheel::mh_k_world_step; }
     else { wb->variant = 1; wb->kernel = mh::large::mh_k_world_step; }
   }
   wb->d_scene = nullptr; wb->d_state = nullptr; wb->d_aux = nullptr; wb->d_lu_ws = nullptr;

@@ -21,7 +21,7 @@ MH_RAND_WORDS = 32
 MH_LCP_MAX_N_WAVE = 64
 MH_NOSLIP_MAX = 16
 MH_MAX_SPOKES = 8
-MH_GEOM_SPHERE, MH_GEOM_SPOKES = 0, 1
+MH_GEOM_SPHERE, MH_GEOM_SPOKES, MH_GEOM_BOX = 0, 1, 2
 NEAR_ZERO = math.sqrt(np.finfo(np.float64).eps)   # include/Moby/Constants.h:21
 
 MH_WORLD_OK, MH_WORLD_LCP_FAILED, MH_WORLD_IMPACT_TOL, MH_WORLD_UNSUPPORTED, MH_WORLD_STAB_FAILED, MH_WORLD_STALLED = 0, 1, 2, 4, 8, 16
@@ -255,6 +255,49 @@ def rimless_wheel_state(theta_dots=(0.24,)):
         st[w, 0, 7] = dist_per_rev * rev_per_sec + thd * 0.866025403784439
         st[w, 0, 11] = thd
     return st.reshape(B, MH_BODY_STATE)
+
+
+def box_scene(dims=(1.0, 1.0, 1.0), density=1.0, gravity=(0.0, -9.81, 0.0), ground_rpy=(0.0, 0.0, 0.0), epsilon=0.0,
+              mu_coulomb=0.0, mu_viscous=0.0, nk=8, cstab_max_iterations=0xFFFFFFFF):
+    """example/simple-contact/simplest.xml (a unit box of density 1 on the default plane, NK = 8) and,
+    with mu_coulomb = 0.1, spinning-box-frictional.xml.  Mass properties as BoxPrimitive::
+    calc_mass_properties (BoxPrimitive.cpp:692-712)."""
+    sc = mh_scene()
+    _defaults(sc)
+    sc.nb = 1
+    sc.has_ground = 1
+    sc.geom_type[0] = MH_GEOM_BOX
+    x, y, z = dims
+    for k in range(3):
+        sc.geom_dim[0][k] = dims[k]
+    m = density * (x * y * z)
+    sc.mass[0] = m
+    M = m / 12.0
+    for k, j in enumerate((M * (y * y + z * z), M * (x * x + z * z), M * (x * x + y * y))):
+        sc.inertia[0][k] = j
+    R = rpy_to_R(*ground_rpy)
+    for k in range(9):
+        sc.plane_R[k] = R.flat[k]
+    for k in range(3):
+        sc.gravity[k] = gravity[k]
+    p = pair_index(0, 1, 2)
+    sc.cp_epsilon[p] = epsilon
+    sc.cp_mu_coulomb[p] = mu_coulomb
+    sc.cp_mu_viscous[p] = mu_viscous
+    sc.cp_nk[p] = nk
+    sc.cstab_max_iterations = cstab_max_iterations
+    sc.lcp_n_max = 64
+    return sc
+
+
+def box_state(pos=(0.0, 0.5, 0.0), quat=(0.0, 0.0, 0.0, 1.0), v=(0.0, 0.0, 0.0), w=(0.0, 0.0, 0.0)):
+    st = np.zeros((1, MH_BODY_STATE))
+    st[0, 0:3] = pos
+    q = np.array(quat, dtype=np.float64)
+    st[0, 3:7] = q / np.linalg.norm(q)
+    st[0, 7:10] = v
+    st[0, 10:13] = w
+    return st
 
 
 def new_aux(B, seed=1):

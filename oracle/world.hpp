@@ -122,7 +122,7 @@ class World {
       const V3 vdt = Vl(b) * dt, wdt = Wa(b) * dt;
       const V3 lin = vdt + cross(c, wdt);            // linear part of (v dt) expressed at the global origin
       const V3 p2 = c + lin;
-      const double r = sc->geom_dim[b][0];
+      const double r = bounding_radius(b);
       for (int k = 0; k < 3; k++) {
         const double a = comp(c, k), e = comp(p2, k);
         lo[b][k] = ((a < e) ? a : e) - r;
@@ -134,6 +134,10 @@ class World {
       for (int j = i + 1; j < ntot; j++) {
         const int p = pair_index(i, j, ntot);
         if (is_spokes(i) || is_spokes(j)) continue;   // removed from CCD's body list (coldet-plugin.cpp:58-66)
+        if ((is_box(i) || is_box(j)) && j != sc->nb) {  // box-box (v-clip on a qhull polyhedron) / box-sphere: not built
+          if (sc->pair_enabled[p]) aux->status |= MH_WORLD_UNSUPPORTED;
+          continue;
+        }
         bool ov = true;
         for (int k = 0; k < 3; k++) if (!(lo[i][k] <= hi[j][k] && lo[j][k] <= hi[i][k])) ov = false;
         if (!ov) continue;                          // needs overlap on all three axes (CCD.cpp:857)
@@ -146,6 +150,20 @@ class World {
       for (int i = 0; i < sc->nb; i++) if (is_spokes(i)) pairs.push_back(pair_index(i, sc->nb, ntot));
   }
   bool is_spokes(int b) const { return b < sc->nb && sc->geom_type[b] == MH_GEOM_SPOKES; }
+  bool is_box(int b) const { return b < sc->nb && sc->geom_type[b] == MH_GEOM_BOX; }
+  // radius of the bounding sphere CCD::construct_bounding_sphere builds (CCD.cpp:1040-1063)
+  double bounding_radius(int b) const {
+    if (is_box(b)) { const V3 h = v3(sc->geom_dim[b][0] / 2.0, sc->geom_dim[b][1] / 2.0, sc->geom_dim[b][2] / 2.0); return norm(h); }
+    return sc->geom_dim[b][0];
+  }
+  // BoxPrimitive::get_vertices order (BoxPrimitive.cpp:358-365), global frame
+  V3 box_vertex(int b, int i) const {
+    const double hx = sc->geom_dim[b][0] * 0.5, hy = sc->geom_dim[b][1] * 0.5, hz = sc->geom_dim[b][2] * 0.5;
+    const double px = (i & 4) ? -hx : hx, py = (i & 2) ? -hy : hy, pz = (i & 1) ? -hz : hz;
+    double R[9]; rot(b, R);
+    const V3 c = X(b);
+    return v3(c.x + ((R[0]*px + R[1]*py) + R[2]*pz), c.y + ((R[3]*px + R[4]*py) + R[5]*pz), c.z + ((R[6]*px + R[7]*py) + R[8]*pz));
+  }
   // tip of spoke i in the global frame: p1 = (cos(theta) R, W/2, sin(theta) R) in the wheel frame,
   // theta = pi i 2 / N, W = 0 (coldet-plugin.cpp:104-113, params.h)
   V3 spoke_tip(int b, int i) const {
@@ -179,6 +197,18 @@ class World {
         if (pp.y < min_dist) { min_dist = pp.y; d.pb = from_plane(v3(pp.x, 0.0, pp.z)); d.pa = g; }
       }
       d.dist = min_dist; d.a = sc->nb; d.b = w;
+      return d;
+    }
+    if (is_box(d.a)) {
+      // BoxPrimitive::calc_signed_dist -> PlanePrimitive::calc_signed_dist(polyhedral) (BoxPrimitive.cpp:156-162,
+      // PlanePrimitive.cpp:338-376): lowest vertex in the plane frame, first one wins ties
+      double min_dist = INF;
+      for (int i = 0; i < 8; i++) {
+        const V3 g = box_vertex(d.a, i);
+        const V3 pp = to_plane(g);
+        if (pp.y < min_dist) { min_dist = pp.y; d.pa = g; d.pb = from_plane(v3(pp.x, 0.0, pp.z)); }
+      }
+      d.dist = min_dist;
       return d;
     }
     if (enabled(d.a) && enabled(d.b)) {
@@ -241,6 +271,20 @@ class World {
       }
       return;
     }
+    if (is_box(a)) {
+      // CCD::find_contacts_plane_generic(plane, box) (CCD.inl:848-886): every vertex within TOL (<=) of
+      // the plane; contact point = the vertex, geom1 = plane, geom2 = box, normal = -(plane normal)
+      for (int i = 0; i < 8; i++) {
+        const V3 g = box_vertex(a, i);
+        const V3 pp = to_plane(g);
+        if (!(pp.y <= TOL)) continue;
+        c.p = g; c.n = -plane_n(); c.g1 = b; c.g2 = a; c.dist = pp.y;
+        orthonormal_basis(c.n, c.s, c.t);
+        fill_params(c);
+        out.push_back(c);
+      }
+      return;
+    }
     if (enabled(a) && enabled(b)) {
       const V3 cA = X(a), cB = X(b);
       const double rA = sc->geom_dim[a][0], rB = sc->geom_dim[b][0];
@@ -278,13 +322,56 @@ class World {
   }
   // CCD::_rmax (CCD.cpp:739): sphere radius; a spokes body is never seen by CCD::broad_phase, so
   // the std::map lookup default-constructs 0
-  double rmax_of(int b) const { return (enabled(b) && !is_spokes(b)) ? sc->geom_dim[b][0] : 0.0; }
+  // (box: BoxPrimitive::get_bounding_radius, BoxPrimitive.h:44 -- the FULL diagonal)
+  double rmax_of(int b) const {
+    if (!enabled(b) || is_spokes(b)) return 0.0;
+    if (is_box(b)) { const double x = sc->geom_dim[b][0], y = sc->geom_dim[b][1], z = sc->geom_dim[b][2]; return std::sqrt((x*x + y*y) + z*z); }
+    return sc->geom_dim[b][0];
+  }
+  // CompGeom::collinear / rel_equal (CompGeom.cpp:1923-1931, CompGeom.h:110)
+  static bool rel_equal(double x, double y) { const double m = std::max(std::fabs(x), std::max(std::fabs(y), 1.0)); return std::fabs(x - y) <= NEAR_ZERO * m; }
+  static bool collinear(V3 a, V3 b, V3 c) {
+    return rel_equal((c.z-a.z)*(b.y-a.y), (b.z-a.z)*(c.y-a.y)) && rel_equal((b.z-a.z)*(c.x-a.x), (b.x-a.x)*(c.z-a.z)) &&
+           rel_equal((b.x-a.x)*(c.y-a.y), (b.y-a.y)*(c.x-a.x));
+  }
+  // CCD::calc_next_CA_Euler_step_polyhedron_plane (CCD.cpp:410-468) for box `bx` resting on the
+  // plane: called with normal = -contact_normal = +plane normal, offset0 = -<contact normal, point>
+  double next_CA_box_plane(int bx, V3 normal, double offset0) const {
+    double R[9]; rot(bx, R);
+    auto to_box_vec = [&](V3 v) { return v3((R[0]*v.x + R[3]*v.y) + R[6]*v.z, (R[1]*v.x + R[4]*v.y) + R[7]*v.z, (R[2]*v.x + R[5]*v.y) + R[8]*v.z); };
+    const V3 nP = to_box_vec(normal);
+    const V3 p0 = normal * offset0;
+    const double offset = dot(nP, to_box_vec(p0 - X(bx)));
+    const double av_norm = norm(to_box_vec(Wa(bx)));
+    const double lv_dot_n = -dot(nP, to_box_vec(Vl(bx)));
+    const double hx = sc->geom_dim[bx][0] * 0.5, hy = sc->geom_dim[bx][1] * 0.5, hz = sc->geom_dim[bx][2] * 0.5;
+    double max_step = INF;
+    for (int i = 0; i < 8; i++) {
+      const V3 vtx = v3((i & 4) ? -hx : hx, (i & 2) ? -hy : hy, (i & 1) ? -hz : hz);
+      const double r = norm(vtx);
+      const double dist = dot(nP, vtx) - offset;
+      if (dist < NEAR_ZERO) continue;
+      const double sp = lv_dot_n + av_norm * r;
+      const double speed = (0.0 > sp) ? 0.0 : sp;
+      const double cand = dist / speed;
+      max_step = (cand < max_step) ? cand : max_step;
+    }
+    return max_step;
+  }
   // CCD::calc_next_CA_Euler_step_generic (CCD.cpp:238-405) for sphere pairs
   double next_CA_generic(const PairDist& d) const {
     if (is_spokes(d.b)) return INF;                 // BladePlanePlugin::calc_next_CA_Euler_step (coldet-plugin.cpp:205-208)
     std::vector<Contact> cs; find_contacts(d.pair, NEAR_ZERO, cs);
     if (cs.empty()) return INF;
     for (const Contact& c : cs) if (contact_vel(c, c.n) < -NEAR_ZERO) return 0.0;
+    if (is_box(d.a)) {
+      // CCD.cpp:285-323: three non-collinear contacts (only the FIRST three are ever tested, :313-318) => rest
+      if (cs.size() >= 3 && !collinear(cs[0].p, cs[1].p, cs[2].p)) return INF;
+      // geom1 is the plane: the "planeA / polyhedron B" branch (CCD.cpp:383-397)
+      const Contact& c = cs[0];
+      const double dd = dot(c.n, c.p);
+      return next_CA_box_plane(d.a, -c.n, -dd);
+    }
     return INF;
   }
   // CCD::calc_CA_Euler_step_generic (CCD.cpp:169-235)
@@ -301,7 +388,7 @@ class World {
   }
   // CCD::calc_CA_Euler_step_sphere (CCD.cpp:138-166)
   double CA_step(const PairDist& d) const {
-    if (is_spokes(d.b)) return CA_generic(d);       // no SpherePrimitive in the pair (CCD.cpp:127-133)
+    if (is_spokes(d.b) || is_box(d.a)) return CA_generic(d);   // no SpherePrimitive in the pair (CCD.cpp:127-133)
     if (d.dist > NEAR_ZERO) return CA_generic(d);
     std::vector<Contact> cs; find_contacts(d.pair, NEAR_ZERO, cs);
     if (cs.size() == 1 && std::fabs(contact_vel(cs[0], cs[0].n)) < NEAR_ZERO * 10) return INF;

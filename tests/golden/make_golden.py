@@ -11,6 +11,10 @@ data (run in the build container, where /root/reference exists):
                         [x y z qx qy qz qw]): the first 30 rows, then every 25th, and the
                         last row (the file ends at t = 6.274 s without a footer).
 
+  sitting_box_dat.npz   rows of /root/reference/regress/sitting-box.dat (t + the box's
+                        [x y z qx qy qz qw]; 10001 rows, dt = 1e-3): first 30, every 100th, last;
+                        plus the CPU-seconds footer.
+
 Only DATA is stored (inputs / expected outputs), never reference source.
 """
 import os
@@ -35,6 +39,14 @@ def main():
     keep = sorted(set(list(range(30)) + list(range(0, len(data), 25)) + [len(data) - 1]))
     np.savez_compressed(os.path.join(HERE, "rimless_wheel_dat.npz"), row_index=np.array(keep), rows=data[keep], n_rows=len(data))
     print("rimless-wheel.dat: %d rows -> %d kept" % (len(data), len(keep)))
+
+    lines = open(os.path.join(REF, "sitting-box.dat")).read().split("\n")
+    data = np.array([[float(x) for x in l.split()] for l in lines if len(l.split()) == 8])
+    footer = [l for l in lines if len(l.split()) == 1 and l.strip()]
+    keep = sorted(set(list(range(30)) + list(range(0, len(data), 100)) + [len(data) - 1]))
+    np.savez_compressed(os.path.join(HERE, "sitting_box_dat.npz"), row_index=np.array(keep), rows=data[keep], n_rows=len(data),
+                        cpu_seconds=float(footer[-1]) if footer else np.nan)
+    print("sitting-box.dat: %d rows -> %d kept" % (len(data), len(keep)))
 
 
 if __name__ == "__main__":

@@ -168,3 +168,43 @@ def test_no_slip_spheres_use_the_large_variant_bit_exact(oracle):
     traj = wb.step(1e-3, 150, want_traj=True)
     st_o, aux_o, traj_o = oracle_run(oracle, sc, st0, 150, 1e-3)
     assert_same(wb, traj, st_o, aux_o, traj_o)
+
+
+def test_sitting_box_bit_exact_and_reference_dat(oracle):
+    """example/simple-contact/simplest.xml: 4 vertex-plane contacts (n = 40), against the oracle bit
+    for bit and against regress/sitting-box.dat (tolerances: tests/test_oracle_box.py)."""
+    g = np.load(os.path.join(GOLD, "sitting_box_dat.npz"))
+    sc = S.box_scene()
+    st0 = S.box_state(pos=(0.0, 0.50001, 0.0))
+    n = 2000
+    wb = WorldBatch(sc, st0.copy())
+    traj = wb.step(1e-3, n, want_traj=True)
+    st_o, aux_o, traj_o = oracle_run(oracle, sc, st0, n, 1e-3)
+    assert_same(wb, traj, st_o, aux_o, traj_o)
+    for row, k in zip(g["rows"], g["row_index"]):
+        if 0 < k <= n:
+            np.testing.assert_allclose(traj[0, k - 1, 0], row[1:], rtol=0, atol=(1.1e-5 if k == 1 else 1e-6))
+
+
+def test_tumbling_and_spinning_boxes_bit_exact(oracle):
+    """Dice dropped with spin (edge and vertex contacts, polyhedron-plane conservative advancement,
+    restitution, friction) and the spinning box of spinning-box-frictional.xml."""
+    sc = S.box_scene(mu_coulomb=0.5, epsilon=0.3, nk=4, cstab_max_iterations=10)
+    from moby_amd.synth import world_uniforms
+    sts = []
+    for w in range(8):
+        u = world_uniforms(w, 10)
+        sts.append(S.box_state(pos=(0.0, 0.9 + u[0], 0.0), quat=(u[1] - 0.5, u[2] - 0.5, u[3] - 0.5, 0.5 + u[4]),
+                               v=(u[5] - 0.5, 0.0, u[6] - 0.5), w=(4 * u[7] - 2, 4 * u[8] - 2, 4 * u[9] - 2))[0])
+    st0 = np.array(sts)
+    wb = WorldBatch(sc, st0.copy())
+    traj = wb.step(1e-3, 1200, want_traj=True)
+    st_o, aux_o, traj_o = oracle_run(oracle, sc, st0, 1200, 1e-3)
+    assert_same(wb, traj, st_o, aux_o, traj_o)
+    assert (aux_o["lcp_solves"] >= 10).all()
+    sc2 = S.box_scene(mu_coulomb=0.1)
+    st2 = S.box_state(w=(0.0, 10.0, 0.0))
+    wb2 = WorldBatch(sc2, st2.copy())
+    traj2 = wb2.step(0.01, 200, want_traj=True)
+    st_o, aux_o, traj_o = oracle_run(oracle, sc2, st2, 200, 0.01)
+    assert_same(wb2, traj2, st_o, aux_o, traj_o)
