@@ -37,7 +37,9 @@ extern "C" {
 #define MH_ERR_NO_DEVICE     (-4)
 
 #define MH_RAND_WORDS 32
-#define MH_LCP_MAX_N_WAVE 64       /* one-wavefront-per-world solver limit */
+#define MH_LCP_MAX_N_WAVE 64       /* one-wavefront-per-problem solver (M in LDS); also the many-worlds limit */
+#define MH_LCP_MAX_N_BLOCK 4096    /* n above MH_LCP_MAX_N_WAVE: one 256-thread workgroup per problem, M read in
+                                      place from HBM, LU scratch in an HBM workspace of B (n^2 + 5n) doubles */
 
 /* solver selector: include/Moby/LCP.h:21-27 */
 #define MH_LCP_FAST       0  /* LCP::lcp_fast              src/LCP.cpp:41   */

@@ -8,6 +8,7 @@
 #include <vector>
 #include "../../include/moby_hip.h"
 #include "mh_lcp_wave.h"
+#include "mh_lcp_block.h"
 
 namespace {
 
@@ -109,6 +110,46 @@ void mh_k_lcp_wave(int B, int n, const double* __restrict__ Mg, int ld, long str
 }
 
 // ---------------------------------------------------------------------------
+// n > 64: one 256-thread workgroup per LCP, M read in place from HBM, everything else in a
+// per-problem HBM workspace (mh_lcp_block.h).
+__global__ __launch_bounds__(256)
+void mh_k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strideM,
+                    const double* __restrict__ qg, double* __restrict__ zg,
+                    const int* __restrict__ zsz_in, int* __restrict__ zsz_out,
+                    uint32_t* __restrict__ rngg, int* __restrict__ status, unsigned* __restrict__ pivots_out,
+                    int32_t* __restrict__ trace, int trace_cap, int* __restrict__ trace_len,
+                    mh::LcpParams P, mh::Pow10Table p10, double* __restrict__ wsd, int* __restrict__ wsi)
+{
+  namespace bk = mh::blk;
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int t = bk::tid();
+  bk::Ws W;
+  double* wd = wsd + (size_t)b * bk::ws_doubles(n);
+  int* wi = wsi + (size_t)b * bk::ws_ints(n);
+  W.A = wd; W.b = wd + (size_t)n * n; W.w = W.b + n; W.x = W.w + n; W.d = W.x + n; W.art = W.d + n;
+  W.list = wi; W.flag = wi + n; W.pos = wi + 2 * (size_t)n; W.bv = wi + 3 * (size_t)n;
+  if (t < 32) bk::s_rng[t] = rngg[(size_t)b * MH_RAND_WORDS + t];
+  bk::Mat M; M.M = Mg + (size_t)b * strideM; M.ld = ld; M.n = n;
+  const double* q = qg + (size_t)b * n;
+  double* z = zg + (size_t)b * n;
+  int zsize = zsz_in ? zsz_in[b] : n;
+  if (zsize != n) for (int i = t; i < n; i += bk::T) z[i] = 0.0;
+  bk::sync();
+  bk::Trace2 tr; tr.buf = trace ? trace + (size_t)b * trace_cap : nullptr; tr.cap = trace_cap; tr.len = 0;
+  unsigned piv = 0;
+  const bool ok = bk::lcp_solve(P, p10, M, W, q, z, zsize, piv, tr);
+  bk::sync();
+  if (t < 32) rngg[(size_t)b * MH_RAND_WORDS + t] = bk::s_rng[t];
+  if (t == 0) {
+    status[b] = ok ? 1 : 0;
+    if (pivots_out) pivots_out[b] = piv;
+    if (zsz_out) zsz_out[b] = zsize;
+    if (trace_len) trace_len[b] = tr.len;
+  }
+}
+
+// ---------------------------------------------------------------------------
 extern "C" {
 
 int mh_version(void) { return 100; }
@@ -184,10 +225,25 @@ int mh_lcp_solve_batch_dev(void* stream, int kind, int B, int n,
   if (!M || !q || !z || !rng || !status) return fail(MH_ERR_INVALID_ARG, "null M/q/z/rng/status");
   if (ld < n) return fail(MH_ERR_INVALID_ARG, "ld (%d) < n (%d)", ld, n);
   if (strideM < (long)ld * (n - 1) + n) return fail(MH_ERR_INVALID_ARG, "strideM (%ld) smaller than one matrix", strideM);
-  if (n > MH_LCP_MAX_N_WAVE)
-    return fail(MH_ERR_UNSUPPORTED_N, "n = %d > %d: large-island solver not built yet", n, MH_LCP_MAX_N_WAVE);
+  if (n > MH_LCP_MAX_N_BLOCK)
+    return fail(MH_ERR_UNSUPPORTED_N, "n = %d > %d", n, MH_LCP_MAX_N_BLOCK);
   if (trace && trace_cap <= 0) return fail(MH_ERR_INVALID_ARG, "trace given with trace_cap <= 0");
   static const mh::Pow10Table p10 = make_pow10();
+  if (n > MH_LCP_MAX_N_WAVE) {
+    // workgroup-per-problem solver; its workspace is allocated and freed in stream order
+    double* wsd = nullptr; int* wsi = nullptr;
+    const size_t nd = (size_t)B * ((size_t)n * n + 5 * (size_t)n), ni = (size_t)B * 4 * (size_t)n;
+    MH_HIP(hipMallocAsync((void**)&wsd, nd * sizeof(double), (hipStream_t)stream));
+    hipError_t e = hipMallocAsync((void**)&wsi, ni * sizeof(int), (hipStream_t)stream);
+    if (e != hipSuccess) { (void)hipFreeAsync(wsd, (hipStream_t)stream); return fail(MH_ERR_HIP, "workspace allocation failed: %s", hipGetErrorString(e)); }
+    hipLaunchKernelGGL(mh_k_lcp_block, dim3(B), dim3(256), 0, (hipStream_t)stream,
+                       B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
+                       trace, trace_cap, trace_len, P, p10, wsd, wsi);
+    e = hipGetLastError();
+    (void)hipFreeAsync(wsd, (hipStream_t)stream); (void)hipFreeAsync(wsi, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(MH_ERR_HIP, "block LCP launch failed: %s", hipGetErrorString(e));
+    return MH_OK;
+  }
   const size_t lds = (size_t)(2 * n * n + n) * sizeof(double);
   hipLaunchKernelGGL(mh_k_lcp_wave, dim3(B), dim3(64), lds, (hipStream_t)stream,
                      B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,

@@ -122,6 +122,42 @@ def test_full_batch_properties():
     assert z[good].min() > -1e-9 and w[good].min() > -1e-7 and np.abs(z[good] * w[good]).max() < 1e-7
 
 
+@pytest.mark.parametrize("kind", [FAST, FAST_REG, LEMKE, LEMKE_REG])
+@pytest.mark.parametrize("n,fam", [(65, "pd"), (100, "pd"), (100, "psd"), (130, "copos"), (200, "pd")])
+def test_block_solver_parity(oracle, kind, n, fam):
+    """n > 64: the workgroup-per-problem solver (mh_lcp_block.h, M read in place from HBM) against
+    the oracle, bit for bit like the wave solver."""
+    B = 3
+    M, q = synth.random_lcp(B, n, fam, seed=31 * n + 1)
+    assert_parity(oracle, kind, M, q, z_size=np.zeros(B, dtype=np.int32))
+
+
+def test_block_solver_warm_start_and_rand_consumption(oracle):
+    n = 96
+    M, q = synth.random_lcp(4, n, "pd", seed=5)
+    ok, z, _ = run_gpu(LEMKE, M, q)
+    assert ok.all()
+    q2 = q + 1e-3 * np.random.default_rng(2).standard_normal(q.shape)
+    assert_parity(oracle, FAST, M, q2, z0=z)
+    assert_parity(oracle, FAST_REG, M, q2, z0=z)
+    assert_parity(oracle, LEMKE, M, q, z_size=np.array([n, 0, 2 * n, n], dtype=np.int32))
+
+
+def test_block_solver_large_n(oracle):
+    """n = 768 (between BASELINE config 4's trimmed sizes): parity with the oracle (which finishes
+    one problem in seconds) plus the LCP conditions on the accepted solutions.  Problem 1 makes
+    lcp_fast give up after 2n pivots -- on both sides."""
+    B, n = 2, 768
+    M, q = synth.random_lcp(B, n, "pd", seed=77)
+    ok = assert_parity(oracle, FAST, M, q, z_size=np.zeros(B, dtype=np.int32))
+    assert ok[0] and not ok[1]
+    _, z, lcp = run_gpu(FAST, M, q, z_size=np.zeros(B, dtype=np.int32))
+    w = M[0] @ z[0] + q[0]
+    scale = np.abs(M[0]).max() * n
+    assert z[0].min() >= 0.0 and w.min() > -1e-10 * scale and np.abs(z[0] * w).max() < 1e-10 * scale
+    assert (lcp.pivots <= 2 * n).all()
+
+
 def test_cpp_adapter_example():
     """The Moby::LCP-shaped C++ adapter (moby_amd/cpp/MobyHipLCP.h) links against
     the C ABI and reproduces the KAT."""
