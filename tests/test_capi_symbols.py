@@ -53,7 +53,7 @@ def test_argument_validation_without_gpu():
     rc = lib.mh_lcp_solve_batch_dev(None, 99, 1, 2, buf.ctypes.data, 2, 4, buf.ctypes.data, buf.ctypes.data,
                                     None, None, buf.ctypes.data, buf.ctypes.data, None, None, 0, None, None)
     assert rc == _lib.MH_ERR_INVALID_ARG and b"kind" in lib.mh_last_error()
-    rc = lib.mh_lcp_solve_batch_dev(None, 0, 1, 65, buf.ctypes.data, 65, 65 * 65, buf.ctypes.data, buf.ctypes.data,
+    rc = lib.mh_lcp_solve_batch_dev(None, 0, 1, 4097, buf.ctypes.data, 4097, 4097 * 4097, buf.ctypes.data, buf.ctypes.data,
                                     None, None, buf.ctypes.data, buf.ctypes.data, None, None, 0, None, None)
     assert rc == _lib.MH_ERR_UNSUPPORTED_N
     rc = lib.mh_lcp_solve_batch_dev(None, 0, 1, 4, buf.ctypes.data, 2, 16, buf.ctypes.data, buf.ctypes.data,
