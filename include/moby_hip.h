@@ -117,11 +117,14 @@ int mh_lcp_solve_batch(int kind, int B, int n,
  * Shell QP->LCP model (src/ImpactConstraintHandlerQP.cpp:94-497) and
  * ConstraintStabilization::stabilize (src/ConstraintStabilization.cpp:167).
  *
- * Scene scope of this build: up to MH_MAX_BODIES free rigid bodies with sphere
- * geometry plus one static plane (the closed-form pairs of CCD.inl:804-847,
- * 1164-1207), gravity, per-pair ContactParameters.  Body ids are 0..nb-1 in
- * the order the reference sorts them (by id string); the ground plane, when
- * present, has id nb.  Pair p enumerates (i<j) lexicographically.
+ * Scene scope of this build: up to MH_MAX_BODIES free rigid bodies with sphere,
+ * box (against the plane only) or rimless-wheel spokes geometry plus one static
+ * plane (the closed-form pairs of CCD.inl:804-886, 1164-1207 and of example/
+ * rimless-wheel/coldet-plugin.cpp), gravity, per-pair ContactParameters; impact
+ * models: Drumwright-Shell QP->LCP and, for islands whose contacts all have
+ * mu-coulomb >= 100, the no-slip model (ImpactConstraintHandler.cpp:1009-1417).
+ * Body ids are 0..nb-1 in the order the reference sorts them (by id string); the
+ * ground plane, when present, has id nb.  Pair p enumerates (i<j) lexicographically.
  */
 #define MH_MAX_BODIES 8
 #define MH_MAX_PAIRS  36            /* C(MH_MAX_BODIES + 1, 2) */
