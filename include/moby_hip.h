@@ -168,7 +168,9 @@ typedef struct mh_scene {
 #define MH_WORLD_IMPACT_TOL    2   /* ImpactToleranceException (warned only, ConstraintSimulator.cpp:342) */
 #define MH_WORLD_UNSUPPORTED   4   /* island larger than the wave solver covers / unsupported model */
 #define MH_WORLD_STAB_FAILED   8   /* update_q gave up (ConstraintStabilization.cpp:230-234) */
-#define MH_WORLD_STALLED       16   /* > 100000 zero-length mini-steps in one step (the reference would not return) */
+#define MH_WORLD_STALLED       16   /* > 100000 zero-length mini-steps in one step, or MH_CSTAB_HARD_CAP stabilisation
+                                       iterations in one call (the reference would not return) */
+#define MH_CSTAB_HARD_CAP 10000u
 
 /* persistent per-world solver state (what the reference keeps in the
  * simulator / handler / libc between steps) + counters */

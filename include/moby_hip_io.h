@@ -1,0 +1,56 @@
+/* moby_hip_io.h -- host-side scene and trajectory I/O around libmoby_hip (C ABI).
+ *
+ * The compatibility layer SURVEY 8(f)2 asks for, so that Moby's own scene files
+ * and regression harness drive the GPU stepper unchanged:
+ *
+ *   mh_io_load_xml        the subset of XMLReader::read (src/XMLReader.cpp:151-204) the many-
+ *                         worlds stepper covers: <Sphere> <Box> <Plane> <GravityForce> <RigidBody>
+ *                         (<CollisionGeometry>, <InertiaFromPrimitive>) <TimeSteppingSimulator>
+ *                         (<DynamicBody> <RecurrentForce> <DisabledPair> <ContactParameters>)
+ *                         <CollisionDetectionPlugin> (the rimless-wheel plugin only) and
+ *                         <DRIVER step-size>.  Attribute meaning follows the reference loaders:
+ *                         src/RigidBody.cpp:132-369, src/Primitive.cpp:244-300, src/SpherePrimitive.cpp:
+ *                         138-155,360-380, src/BoxPrimitive.cpp:640-712, src/GravityForce.cpp:74-90,
+ *                         src/ContactParameters.cpp:46-135, src/ConstraintSimulator.cpp:540-708,
+ *                         src/TimeSteppingSimulator.cpp:463-476.
+ *   mh_io_format_row      one row of programs/regress.cpp:82-93: current_time, then the 7 Euler
+ *                         coordinates of every enabled body in id order (ostream default format)
+ *   mh_io_compare_trajs   programs/compare-trajs.cpp: max over rows of the L-inf difference,
+ *                         last line = timing; returns 0 when max_diff <= tol
+ *
+ * Pure host code (libxml2); no GPU needed.  Library: moby_amd/libmoby_hip_io.so.
+ */
+#ifndef MOBY_HIP_IO_H
+#define MOBY_HIP_IO_H
+#include "moby_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_IO_ID_LEN 64
+
+typedef struct mh_io_scene {
+  mh_scene scene;
+  double   state[MH_MAX_BODIES * MH_BODY_STATE];   /* initial state of the enabled bodies, id order */
+  char     body_id[MH_MAX_BODIES + 1][MH_IO_ID_LEN]; /* ids of the enabled bodies, then the ground's */
+  double   step_size;                              /* <DRIVER step-size>, 0 if absent */
+} mh_io_scene;
+
+/* 0 on success; on failure returns nonzero and mh_io_last_error() says what was not understood
+ * (unsupported elements are errors, never silently dropped) */
+int mh_io_load_xml(const char* path, mh_io_scene* out);
+const char* mh_io_last_error(void);
+
+/* writes at most cap bytes (NUL-terminated) and returns the length the full row needs */
+int mh_io_format_row(double t, const double* state, int nb, char* buf, int cap);
+
+/* *max_diff = max over all rows but the last of the L-inf difference; the last line of each file is
+ * its timing (returned in timing[0], timing[1] if timing != NULL).  Returns 0 if max_diff <= tol,
+ * 1 if larger, -1 on I/O / shape errors (as the reference tool's exit code) */
+int mh_io_compare_trajs(const char* file1, const char* file2, double tol, double* max_diff, double* timing);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,313 @@
+// libmoby_hip_io.so: scene loader + regress-row / compare-trajs helpers (include/moby_hip_io.h).
+// Host only (g++ + libxml2).  The loader is written against the attribute semantics of the
+// reference's load_from_xml methods (cited per element below); it is a new parser over libxml2's
+// tree, not the reference's XMLTree/XMLReader.
+#include <libxml/parser.h>
+#include <libxml/tree.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <strings.h>
+#include <vector>
+#include "../../include/moby_hip_io.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+int fail(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap); return 1; }
+
+struct Attrs { std::map<std::string, std::string> kv;
+  bool has(const char* k) const { return kv.count(k) != 0; }
+  const std::string& str(const char* k) const { static const std::string e; auto i = kv.find(k); return i == kv.end() ? e : i->second; } };
+
+Attrs attrs_of(xmlNode* n) {
+  Attrs a;
+  for (xmlAttr* p = n->properties; p; p = p->next) {
+    xmlChar* v = xmlNodeListGetString(n->doc, p->children, 1);
+    a.kv[(const char*)p->name] = v ? (const char*)v : "";
+    if (v) xmlFree(v);
+  }
+  return a;
+}
+// numbers separated by blanks, commas or semicolons (XMLAttrib::get_*_value accept all three)
+std::vector<double> numbers(const std::string& s) {
+  std::vector<double> v; std::string t = s;
+  for (char& c : t) if (c == ',' || c == ';') c = ' ';
+  std::istringstream in(t); std::string w;
+  while (in >> w) v.push_back(std::atof(w.c_str()));
+  return v;
+}
+bool boolean(const std::string& s) { return !(strcasecmp(s.c_str(), "false") == 0 || s == "0"); }
+
+// Rz(yaw) Ry(pitch) Rx(roll), the expression order of moby_amd/scene.py::rpy_to_R
+void rpy_to_R(double roll, double pitch, double yaw, double R[9]) {
+  const double cr = std::cos(roll), sr = std::sin(roll), cp = std::cos(pitch), sp = std::sin(pitch), cy = std::cos(yaw), sy = std::sin(yaw);
+  R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
+  R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
+  R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+}
+void R_to_quat(const double R[9], double q[4]) {   // xyzw; only used for bodies given with rpy
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) { const double s = std::sqrt(tr + 1.0) * 2; q[3] = 0.25 * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; }
+  else if (R[0] > R[4] && R[0] > R[8]) { const double s = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[3] = (R[7] - R[5]) / s; q[0] = 0.25 * s; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s; }
+  else if (R[4] > R[8]) { const double s = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = 0.25 * s; q[2] = (R[5] + R[7]) / s; }
+  else { const double s = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = 0.25 * s; }
+}
+
+struct Prim { int type; double dim[3]; double mass; double J[3]; bool posed; double R[9]; double o[3]; };   // type: 0 sphere, 2 box, 100 plane
+struct Body { std::string id; bool enabled = true; double x[3] = {0, 0, 0}; double q[4] = {0, 0, 0, 1}; double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+              bool rotated = false; double v[3] = {0, 0, 0}, w[3] = {0, 0, 0}; double mass = 0; double J[3] = {0, 0, 0}; std::string geom; bool has_cg = false; };
+struct CP { std::string a, b; double eps = 0, mu = 0, muv = 0, comp = 0; int nk = 4; };
+
+void collect(xmlNode* n, const char* name, std::vector<xmlNode*>& out) {
+  for (xmlNode* c = n; c; c = c->next) {
+    if (c->type == XML_ELEMENT_NODE) { if (strcmp((const char*)c->name, name) == 0) out.push_back(c); collect(c->children, name, out); }
+  }
+}
+xmlNode* first(xmlNode* root, const char* name) { std::vector<xmlNode*> v; collect(root, name, v); return v.empty() ? nullptr : v[0]; }
+
+// Primitive::load_from_xml (Primitive.cpp:244-300): mass | density, pose
+int prim_common(const Attrs& a, Prim& p, double volume, const char* what) {
+  p.mass = 0.0;
+  if (a.has("mass")) p.mass = std::atof(a.str("mass").c_str());
+  else if (a.has("density")) p.mass = std::atof(a.str("density").c_str()) * volume;
+  p.posed = false;
+  for (int i = 0; i < 9; i++) p.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  p.o[0] = p.o[1] = p.o[2] = 0.0;
+  if (a.has("quat") || a.has("aangle")) return fail("%s: quat / aangle poses of primitives are not supported", what);
+  if (a.has("rpy")) { const std::vector<double> r = numbers(a.str("rpy")); if (r.size() != 3) return fail("%s: bad rpy", what); rpy_to_R(r[0], r[1], r[2], p.R); p.posed = true; }
+  if (a.has("position")) { const std::vector<double> r = numbers(a.str("position")); if (r.size() != 3) return fail("%s: bad position", what);
+    for (int i = 0; i < 3; i++) { p.o[i] = r[i]; if (r[i] != 0.0) p.posed = true; } }
+  return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* mh_io_last_error(void) { return g_err; }
+
+int mh_io_load_xml(const char* path, mh_io_scene* out)
+{
+  if (!path || !out) return fail("null argument");
+  xmlDoc* doc = xmlReadFile(path, nullptr, XML_PARSE_NONET | XML_PARSE_NOERROR | XML_PARSE_NOWARNING);
+  if (!doc) return fail("cannot parse %s", path);
+  struct Guard { xmlDoc* d; ~Guard() { xmlFreeDoc(d); } } guard{doc};
+  xmlNode* root = xmlDocGetRootElement(doc);
+  std::memset(out, 0, sizeof(*out));
+  mh_scene& sc = out->scene;
+  // defaults (mh_scene_defaults, duplicated here so that this library does not need the HIP one)
+  sc.min_step_size = std::sqrt(2.220446049250313e-16); sc.contact_dist_thresh = 1e-6; sc.cstab_eps = std::sqrt(2.220446049250313e-16);
+  sc.cstab_max_iterations = 0xFFFFFFFFu; sc.plane_R[0] = sc.plane_R[4] = sc.plane_R[8] = 1.0;
+  for (int p = 0; p < MH_MAX_PAIRS; p++) { sc.pair_enabled[p] = 1; sc.cp_nk[p] = 4; }
+
+  // ---- primitives ----
+  std::map<std::string, Prim> prims;
+  { std::vector<xmlNode*> v; collect(root, "Sphere", v);
+    for (xmlNode* n : v) { const Attrs a = attrs_of(n); Prim p; p.type = MH_GEOM_SPHERE;
+      const double r = a.has("radius") ? std::atof(a.str("radius").c_str()) : 0.0;   // SpherePrimitive.cpp:368
+      p.dim[0] = r; p.dim[1] = p.dim[2] = 0.0;
+      if (prim_common(a, p, M_PI * r * r * r * 4.0 / 3.0, "Sphere")) return 1;       // SpherePrimitive.cpp:144-146
+      const double j = r * r * p.mass * 2.0 / 5.0;                                  // SpherePrimitive.cpp:149
+      p.J[0] = p.J[1] = p.J[2] = j;
+      prims[a.str("id")] = p; } }
+  { std::vector<xmlNode*> v; collect(root, "Box", v);
+    for (xmlNode* n : v) { const Attrs a = attrs_of(n); Prim p; p.type = MH_GEOM_BOX;
+      const double x = std::atof(a.str("xlen").c_str()), y = std::atof(a.str("ylen").c_str()), z = std::atof(a.str("zlen").c_str());
+      p.dim[0] = x; p.dim[1] = y; p.dim[2] = z;
+      if (prim_common(a, p, x * y * z, "Box")) return 1;                             // BoxPrimitive.cpp:692-712
+      const double M = p.mass / 12.0;
+      p.J[0] = M * (y * y + z * z); p.J[1] = M * (x * x + z * z); p.J[2] = M * (x * x + y * y);
+      prims[a.str("id")] = p; } }
+  { std::vector<xmlNode*> v; collect(root, "Plane", v);
+    for (xmlNode* n : v) { const Attrs a = attrs_of(n); Prim p; p.type = 100; p.dim[0] = p.dim[1] = p.dim[2] = 0.0; p.J[0] = p.J[1] = p.J[2] = 0.0;
+      if (prim_common(a, p, 0.0, "Plane")) return 1;
+      prims[a.str("id")] = p; } }
+  // ---- gravity (GravityForce.cpp:74-90) ----
+  std::map<std::string, std::vector<double> > gravs;
+  { std::vector<xmlNode*> v; collect(root, "GravityForce", v);
+    for (xmlNode* n : v) { const Attrs a = attrs_of(n); std::vector<double> g = numbers(a.str("accel")); if (g.size() != 3) return fail("GravityForce %s: bad accel", a.str("id").c_str()); gravs[a.str("id")] = g; } }
+  // ---- collision detection plugin: only the rimless wheel's ----
+  std::map<std::string, std::string> plugins;
+  { std::vector<xmlNode*> v; collect(root, "CollisionDetectionPlugin", v);
+    for (xmlNode* n : v) { const Attrs a = attrs_of(n); plugins[a.str("id")] = a.str("plugin"); } }
+  // ---- rigid bodies (RigidBody.cpp:132-369) ----
+  std::map<std::string, Body> bodies;
+  { std::vector<xmlNode*> v; collect(root, "RigidBody", v);
+    for (xmlNode* n : v) {
+      const Attrs a = attrs_of(n); Body b; b.id = a.str("id");
+      if (a.has("enabled")) b.enabled = boolean(a.str("enabled"));
+      if (a.has("compliant") && boolean(a.str("compliant"))) return fail("RigidBody %s: compliant bodies are not supported", b.id.c_str());
+      if (a.has("articulated-body-id")) return fail("RigidBody %s: articulated bodies are not supported", b.id.c_str());
+      if (a.has("mass")) b.mass = std::atof(a.str("mass").c_str());
+      if (a.has("inertia")) { const std::vector<double> J = numbers(a.str("inertia")); if (J.size() != 9) return fail("RigidBody %s: inertia needs 9 numbers", b.id.c_str());
+        if (J[1] != 0 || J[2] != 0 || J[3] != 0 || J[5] != 0 || J[6] != 0 || J[7] != 0) return fail("RigidBody %s: only diagonal body-frame inertias are supported", b.id.c_str());
+        b.J[0] = J[0]; b.J[1] = J[4]; b.J[2] = J[8]; }
+      if (a.has("position")) { const std::vector<double> p = numbers(a.str("position")); if (p.size() != 3) return fail("RigidBody %s: bad position", b.id.c_str()); for (int i = 0; i < 3; i++) b.x[i] = p[i]; }
+      if (a.has("quat")) { const std::vector<double> q = numbers(a.str("quat")); if (q.size() != 4) return fail("RigidBody %s: bad quat", b.id.c_str());
+        const double nrm = std::sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]); for (int i = 0; i < 4; i++) b.q[i] = q[i] / nrm; b.rotated = true; }
+      else if (a.has("rpy")) { const std::vector<double> r = numbers(a.str("rpy")); if (r.size() != 3) return fail("RigidBody %s: bad rpy", b.id.c_str()); rpy_to_R(r[0], r[1], r[2], b.R); R_to_quat(b.R, b.q); b.rotated = (r[0] != 0 || r[1] != 0 || r[2] != 0); }
+      else if (a.has("aangle")) return fail("RigidBody %s: aangle orientation is not supported", b.id.c_str());
+      if (a.has("linear-velocity")) { const std::vector<double> p = numbers(a.str("linear-velocity")); if (p.size() != 3) return fail("RigidBody %s: bad linear-velocity", b.id.c_str()); for (int i = 0; i < 3; i++) b.v[i] = p[i]; }
+      if (a.has("angular-velocity")) { const std::vector<double> p = numbers(a.str("angular-velocity")); if (p.size() != 3) return fail("RigidBody %s: bad angular-velocity", b.id.c_str()); for (int i = 0; i < 3; i++) b.w[i] = p[i]; }
+      bool from_prim = false; double m = 0, J[3] = {0, 0, 0};
+      for (xmlNode* c = n->children; c; c = c->next) {
+        if (c->type != XML_ELEMENT_NODE) continue;
+        const Attrs ca = attrs_of(c);
+        if (strcmp((const char*)c->name, "CollisionGeometry") == 0) {
+          if (b.has_cg) return fail("RigidBody %s: more than one CollisionGeometry", b.id.c_str());
+          b.has_cg = true; b.geom = ca.str("primitive-id");
+          if (ca.has("rel-origin") || ca.has("rel-rpy") || ca.has("rel-quat")) return fail("RigidBody %s: offset collision geometries are not supported", b.id.c_str());
+        } else if (strcmp((const char*)c->name, "InertiaFromPrimitive") == 0) {           // RigidBody.cpp:246-321: additive, from zero
+          auto it = prims.find(ca.str("primitive-id"));
+          if (it == prims.end()) return fail("RigidBody %s: unknown primitive %s", b.id.c_str(), ca.str("primitive-id").c_str());
+          if (ca.has("relative-origin") || ca.has("relative-rpy") || ca.has("relative-aangle")) return fail("RigidBody %s: offset inertias are not supported", b.id.c_str());
+          from_prim = true; m += it->second.mass; for (int i = 0; i < 3; i++) J[i] += it->second.J[i];
+        }
+      }
+      if (from_prim) { b.mass = m; for (int i = 0; i < 3; i++) b.J[i] = J[i]; }
+      bodies[b.id] = b;
+    } }
+  // ---- the simulator (ConstraintSimulator.cpp:540-708, TimeSteppingSimulator.cpp:463-476, Simulator.cpp:826-950) ----
+  xmlNode* sim = first(root, "TimeSteppingSimulator");
+  if (!sim) return fail("%s: no TimeSteppingSimulator", path);
+  if (first(root, "RCArticulatedBody") || first(root, "MCArticulatedBody")) return fail("articulated bodies are not supported");
+  const Attrs sa = attrs_of(sim);
+  if (sa.has("min-step-size")) sc.min_step_size = std::atof(sa.str("min-step-size").c_str());
+  if (sa.has("contact-dist-thresh")) sc.contact_dist_thresh = std::atof(sa.str("contact-dist-thresh").c_str());
+  if (sa.has("unilateral-stabilization-tol")) sc.cstab_eps = std::atof(sa.str("unilateral-stabilization-tol").c_str());
+  if (sa.has("constraint-stabilization-max-iterations")) sc.cstab_max_iterations = (unsigned)std::strtoul(sa.str("constraint-stabilization-max-iterations").c_str(), nullptr, 10);
+  bool wheel_plugin = false;
+  if (sa.has("collision-detection-plugin")) {
+    const std::string& pl = plugins[sa.str("collision-detection-plugin")];
+    if (pl.find("rimless-wheel-coldet-plugin") == std::string::npos) return fail("collision detection plugin '%s' is not supported", pl.c_str());
+    wheel_plugin = true;
+  }
+  std::vector<std::string> dyn; std::string ground; std::vector<CP> cps; std::vector<std::pair<std::string, std::string> > disabled;
+  bool have_g = false; double g[3] = {0, 0, 0};
+  for (xmlNode* c = sim->children; c; c = c->next) {
+    if (c->type != XML_ELEMENT_NODE) continue;
+    const Attrs ca = attrs_of(c); const char* nm = (const char*)c->name;
+    if (strcmp(nm, "DynamicBody") == 0) {
+      auto it = bodies.find(ca.str("dynamic-body-id"));
+      if (it == bodies.end()) return fail("simulator: unknown body %s", ca.str("dynamic-body-id").c_str());
+      if (it->second.enabled) dyn.push_back(it->first);
+      else { if (!ground.empty()) return fail("more than one disabled body"); ground = it->first; }
+    } else if (strcmp(nm, "RecurrentForce") == 0) {
+      auto it = gravs.find(ca.str("recurrent-force-id"));
+      if (it == gravs.end()) return fail("simulator: only GravityForce recurrent forces are supported (%s)", ca.str("recurrent-force-id").c_str());
+      if (have_g) return fail("more than one gravity force");
+      have_g = true; for (int i = 0; i < 3; i++) g[i] = it->second[i];
+    } else if (strcmp(nm, "DisabledPair") == 0) disabled.push_back(std::make_pair(ca.str("object1-id"), ca.str("object2-id")));
+    else if (strcmp(nm, "ContactParameters") == 0) {                                   // ContactParameters.cpp:46-135
+      CP p; p.a = ca.str("object1-id"); p.b = ca.str("object2-id");
+      if (ca.has("epsilon")) p.eps = std::atof(ca.str("epsilon").c_str());
+      if (ca.has("mu-coulomb")) p.mu = std::atof(ca.str("mu-coulomb").c_str());
+      if (ca.has("mu-viscous")) p.muv = std::atof(ca.str("mu-viscous").c_str());
+      if (ca.has("compliance")) p.comp = std::atof(ca.str("compliance").c_str());
+      if (ca.has("friction-cone-edges")) { p.nk = std::atoi(ca.str("friction-cone-edges").c_str()); if (p.nk < 4) p.nk = 4; }   // :128-135
+      cps.push_back(p);
+    } else if (strcmp(nm, "ImplicitConstraint") == 0 || strcmp(nm, "ExplicitConstraint") == 0) return fail("joints are not supported");
+  }
+  std::sort(dyn.begin(), dyn.end());                                                    // programs/regress.cpp:66-69
+  const int nb = (int)dyn.size();
+  if (nb < 1 || nb > MH_MAX_BODIES) return fail("%d enabled bodies (supported: 1..%d)", nb, MH_MAX_BODIES);
+  sc.nb = nb; sc.has_ground = ground.empty() ? 0 : 1;
+  for (int i = 0; i < 3; i++) sc.gravity[i] = g[i];
+  std::map<std::string, int> index;
+  for (int b = 0; b < nb; b++) {
+    const Body& B = bodies[dyn[b]];
+    index[B.id] = b;
+    snprintf(out->body_id[b], MH_IO_ID_LEN, "%s", B.id.c_str());
+    sc.mass[b] = B.mass; for (int i = 0; i < 3; i++) sc.inertia[b][i] = B.J[i];
+    if (!(B.mass > 0.0) || !(B.J[0] > 0.0) || !(B.J[1] > 0.0) || !(B.J[2] > 0.0)) return fail("RigidBody %s: mass / inertia missing", B.id.c_str());
+    if (B.has_cg && !B.geom.empty()) {
+      auto it = prims.find(B.geom);
+      if (it == prims.end()) return fail("RigidBody %s: unknown primitive %s", B.id.c_str(), B.geom.c_str());
+      const Prim& P = it->second;
+      if (P.type == 100) return fail("RigidBody %s: an enabled body with plane geometry is not supported", B.id.c_str());
+      if (P.posed) return fail("RigidBody %s: primitive %s has a pose of its own (not supported)", B.id.c_str(), B.geom.c_str());
+      sc.geom_type[b] = P.type; for (int i = 0; i < 3; i++) sc.geom_dim[b][i] = P.dim[i];
+    } else if (wheel_plugin) {
+      sc.geom_type[b] = MH_GEOM_SPOKES; sc.geom_dim[b][0] = 1.0; sc.geom_dim[b][1] = 6.0; sc.geom_dim[b][2] = 0.0;   // params.h:4-6
+    } else return fail("RigidBody %s: no collision geometry", B.id.c_str());
+    double* s = out->state + MH_BODY_STATE * b;
+    for (int i = 0; i < 3; i++) { s[i] = B.x[i]; s[7 + i] = B.v[i]; s[10 + i] = B.w[i]; }
+    for (int i = 0; i < 4; i++) s[3 + i] = B.q[i];
+  }
+  if (sc.has_ground) {
+    const Body& G = bodies[ground];
+    index[G.id] = nb;
+    snprintf(out->body_id[nb], MH_IO_ID_LEN, "%s", G.id.c_str());
+    auto it = prims.find(G.geom);
+    if (it == prims.end() || it->second.type != 100) return fail("disabled body %s must carry a Plane", G.id.c_str());
+    if (G.rotated && it->second.posed) return fail("ground %s: pose on both the body and the plane primitive is not supported", G.id.c_str());
+    const double* R = G.rotated ? G.R : it->second.R;
+    for (int i = 0; i < 9; i++) sc.plane_R[i] = R[i];
+    for (int i = 0; i < 3; i++) sc.plane_o[i] = G.x[i] + it->second.o[i];
+  }
+  const int ntot = nb + sc.has_ground;
+  auto pidx = [&](int i, int j) { if (i > j) std::swap(i, j); return i * ntot - (i * (i + 1)) / 2 + (j - i - 1); };
+  for (const CP& p : cps) {
+    if (!index.count(p.a) || !index.count(p.b)) continue;     // parameters for bodies outside the simulator (wheel.xml:40 has one commented out)
+    const int k = pidx(index[p.a], index[p.b]);
+    sc.cp_epsilon[k] = p.eps; sc.cp_mu_coulomb[k] = p.mu; sc.cp_mu_viscous[k] = p.muv; sc.cp_compliance[k] = p.comp; sc.cp_nk[k] = p.nk;
+  }
+  for (const auto& d : disabled) {
+    if (!index.count(d.first) || !index.count(d.second) || d.first == d.second) continue;
+    sc.pair_enabled[pidx(index[d.first], index[d.second])] = 0;
+  }
+  if (xmlNode* drv = first(root, "DRIVER")) { const Attrs da = attrs_of(drv); if (da.has("step-size")) out->step_size = std::atof(da.str("step-size").c_str()); }
+  return 0;
+}
+
+int mh_io_format_row(double t, const double* state, int nb, char* buf, int cap)
+{
+  std::ostringstream o;                                   // ostream default formatting, as regress.cpp:82-93
+  o << t;
+  for (int b = 0; b < nb; b++) for (int k = 0; k < 7; k++) o << " " << state[MH_BODY_STATE * b + k];
+  const std::string s = o.str();
+  if (buf && cap > 0) { snprintf(buf, (size_t)cap, "%s", s.c_str()); }
+  return (int)s.size();
+}
+
+int mh_io_compare_trajs(const char* file1, const char* file2, double tol, double* max_diff, double* timing)
+{
+  std::ifstream a(file1), b(file2);
+  if (a.fail() || b.fail()) { fail("compare-trajs: unable to open one or both files"); return -1; }
+  std::vector<std::string> la, lb; std::string s;
+  while (std::getline(a, s)) la.push_back(s);
+  while (std::getline(b, s)) lb.push_back(s);
+  while (!la.empty() && la.back().find_first_not_of(" \t\r") == std::string::npos) la.pop_back();
+  while (!lb.empty() && lb.back().find_first_not_of(" \t\r") == std::string::npos) lb.pop_back();
+  if (la.size() != lb.size() || la.empty()) { fail("compare-trajs: unequal numbers of lines (%zu vs %zu)", la.size(), lb.size()); return -1; }
+  auto parse = [](const std::string& str) {               // blanks / commas; inf / -inf (compare-trajs.cpp:29-84)
+    std::vector<double> v; std::string t = str; for (char& c : t) if (c == ',') c = ' ';
+    std::istringstream in(t); std::string w;
+    while (in >> w) {
+      if (strcasecmp(w.c_str(), "inf") == 0) v.push_back(INFINITY);
+      else if (strcasecmp(w.c_str(), "-inf") == 0) v.push_back(-INFINITY);
+      else v.push_back(std::atof(w.c_str()));
+    }
+    return v; };
+  double md = 0.0;
+  for (size_t i = 0; i + 1 < la.size(); i++) {
+    const std::vector<double> va = parse(la[i]), vb = parse(lb[i]);
+    if (va.size() != vb.size()) { fail("compare-trajs: row %zu has %zu vs %zu values", i, va.size(), vb.size()); return -1; }
+    for (size_t k = 0; k < va.size(); k++) md = std::max(md, std::fabs(va[k] - vb[k]));
+  }
+  const std::vector<double> ta = parse(la.back()), tb = parse(lb.back());
+  if (ta.size() != 1 || tb.size() != 1) { fail("compare-trajs: last line must hold the timing"); return -1; }
+  if (timing) { timing[0] = ta[0]; timing[1] = tb[0]; }
+  if (max_diff) *max_diff = md;
+  return (md > tol) ? 1 : 0;
+}
+
+} // extern "C"

@@ -1024,6 +1024,8 @@ class World {
     unsigned iterations = 0;
     while (max_uvio < sc->cstab_eps) {
       if (iterations == sc->cstab_max_iterations) break;
+      // the reference's default cap is UINT_MAX: a cycling stabiliser would never return; stop and say so
+      if (iterations == MH_CSTAB_HARD_CAP) { aux->status |= MH_WORLD_STALLED; break; }
       for (int b = 0; b < nb; b++) for (int k = 0; k < 6; k++) st[13*b + 7 + k] = 0.0;
       // compute_problem_data (CStab:347-492): own broad phase with dt = 0, one contact per pair
       std::vector<int> cpairs; broad_phase(0.0, cpairs);

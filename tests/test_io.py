@@ -1,0 +1,109 @@
+"""Host I/O (include/moby_hip_io.h): the Moby XML subset, regress rows, compare-trajs."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from moby_amd import io as mio
+from moby_amd import scene as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENES = os.path.join(ROOT, "tests", "scenes")
+REF = "/root/reference/example"
+
+
+def scene_bytes(sc, skip=()):
+    d = {}
+    for name, _ in S.mh_scene._fields_:
+        if name in skip:
+            continue
+        v = getattr(sc, name)
+        d[name] = np.array(v).tolist() if hasattr(v, "__len__") else v
+    return d
+
+
+def assert_scene_equal(a, b, skip=("lcp_n_max",)):
+    da, db = scene_bytes(a, skip), scene_bytes(b, skip)
+    for k in da:
+        assert da[k] == db[k], k
+
+
+def test_sphere_stack_xml_equals_the_builder():
+    sc, st, ids, step = mio.load_xml(os.path.join(SCENES, "sphere-stack.xml"))
+    assert ids == ["sph1", "sph2", "sph3", "ground"] and step == 0.0
+    assert_scene_equal(sc, S.sphere_stack_scene())
+    np.testing.assert_array_equal(st, S.sphere_stack_state(1))
+
+
+def test_bouncing_ball_xml_equals_the_builder():
+    sc, st, ids, step = mio.load_xml(os.path.join(SCENES, "bouncing-ball.xml"))
+    assert ids == ["ball", "ground"] and step == 0.025
+    assert_scene_equal(sc, S.bouncing_ball_scene())
+    np.testing.assert_array_equal(st, S.bouncing_ball_state(1))
+
+
+def test_rimless_wheel_xml_equals_the_builder():
+    sc, st, ids, _ = mio.load_xml(os.path.join(SCENES, "rimless-wheel.xml"))
+    assert ids == ["WHEEL", "GROUND"]
+    assert_scene_equal(sc, S.rimless_wheel_scene())
+    assert sc.geom_type[0] == S.MH_GEOM_SPOKES
+    np.testing.assert_array_equal(st[0, :7], [0, 0, 1.0, 0, 0, 0, 1])     # the pose the XML gives; the init plugin overrides it
+
+
+def test_sitting_box_xml_equals_the_builder():
+    sc, st, ids, step = mio.load_xml(os.path.join(SCENES, "sitting-box.xml"))
+    assert ids == ["box", "ground"] and step == 0.1
+    assert_scene_equal(sc, S.box_scene())
+    np.testing.assert_array_equal(st, S.box_state(pos=(0.0, 0.50001, 0.0)))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+def test_reference_example_files_load_to_the_same_scenes():
+    """The reference's own example files (read in place, never copied) give the builders' scenes."""
+    sc, st, ids, _ = mio.load_xml(os.path.join(REF, "stacks", "sphere-stack.xml"))
+    assert_scene_equal(sc, S.sphere_stack_scene(), skip=("lcp_n_max", "cstab_max_iterations"))
+    assert sc.cstab_max_iterations == 0xFFFFFFFF
+    np.testing.assert_array_equal(st, S.sphere_stack_state(1))
+    sc, st, _, _ = mio.load_xml(os.path.join(REF, "bouncing-ball", "bouncing-ball.xml"))
+    assert_scene_equal(sc, S.bouncing_ball_scene())
+    sc, _, ids, _ = mio.load_xml(os.path.join(REF, "rimless-wheel", "wheel.xml"))
+    assert ids == ["WHEEL", "GROUND"]            # the BOX body of wheel.xml is not in the simulator
+    assert_scene_equal(sc, S.rimless_wheel_scene())
+    sc, st, _, _ = mio.load_xml(os.path.join(REF, "simple-contact", "simplest.xml"))
+    assert_scene_equal(sc, S.box_scene())
+    np.testing.assert_array_equal(st, S.box_state(pos=(0.0, 0.5, 0.0)))
+    sc, st, _, _ = mio.load_xml(os.path.join(REF, "simple-contact", "spinning-box-frictional.xml"))
+    assert_scene_equal(sc, S.box_scene(mu_coulomb=0.1))
+    np.testing.assert_array_equal(st, S.box_state(w=(0.0, 10.0, 0.0)))
+
+
+def test_unsupported_content_is_an_error(tmp_path):
+    p = tmp_path / "joint.xml"
+    p.write_text('<XML><MOBY><RCArticulatedBody id="a"/><TimeSteppingSimulator/></MOBY></XML>')
+    with pytest.raises(mio.SceneError, match="articulated"):
+        mio.load_xml(str(p))
+    p.write_text('<XML><MOBY><Sphere id="s" radius="1" mass="1" position="0 1 0"/><RigidBody id="b"><InertiaFromPrimitive primitive-id="s"/>'
+                 '<CollisionGeometry primitive-id="s"/></RigidBody><TimeSteppingSimulator><DynamicBody dynamic-body-id="b"/></TimeSteppingSimulator></MOBY></XML>')
+    with pytest.raises(mio.SceneError, match="pose of its own"):
+        mio.load_xml(str(p))
+    with pytest.raises(mio.SceneError):
+        mio.load_xml(str(tmp_path / "missing.xml"))
+
+
+def test_regress_row_format_and_compare_trajs(tmp_path):
+    st = np.zeros(13); st[:7] = [0, 0.50001, 0, 0, 0, 0, 1]
+    assert mio.format_row(0, st, 1) == "0 0 0.50001 0 0 0 0 1"           # regress/sitting-box.dat:1
+    st[:7] = [0.000250481, -1.62086e-14, 0.86617, -3.50766e-15, 0.000144603, 2.22901e-14, 1]
+    assert mio.format_row(0.001, st, 1) == "0.001 0.000250481 -1.62086e-14 0.86617 -3.50766e-15 0.000144603 2.22901e-14 1"
+    a, b = tmp_path / "a.dat", tmp_path / "b.dat"
+    a.write_text("0 1 2\n0.1 1.5 2\n0.5\n")
+    b.write_text("0 1 2\n0.1 1.5 2.25\n0.25\n")
+    rc, md, tm = mio.compare_trajs(str(a), str(b), 1e-6)
+    assert rc == 1 and md == 0.25 and tm == (0.5, 0.25)
+    assert mio.compare_trajs(str(a), str(b), 0.3)[0] == 0
+    b.write_text("0 1 2\n0.25\n")
+    assert mio.compare_trajs(str(a), str(b), 1.0)[0] == -1
+    exe = os.path.join(ROOT, "moby_amd", "bin", "moby-hip-compare-trajs")
+    assert subprocess.call([exe, str(a), str(a), "1e-9"], stdout=subprocess.DEVNULL) == 0

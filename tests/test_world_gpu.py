@@ -208,3 +208,32 @@ def test_tumbling_and_spinning_boxes_bit_exact(oracle):
     traj2 = wb2.step(0.01, 200, want_traj=True)
     st_o, aux_o, traj_o = oracle_run(oracle, sc2, st2, 200, 0.01)
     assert_same(wb2, traj2, st_o, aux_o, traj_o)
+
+
+def test_regress_tool_reproduces_sphere_stack_dat(tmp_path):
+    """moby-hip-regress <options> <xml> <out> (the reference's programs/regress.cpp command line) on
+    the scene file, then the reference's compare-trajs logic against rows rebuilt from the golden."""
+    import subprocess
+    from moby_amd import io as mio
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "moby_amd", "bin", "moby-hip-regress")
+    opts = tmp_path / "stacks.setup"; opts.write_text("-s=0.001\n-mt=0.3\n")
+    outp = tmp_path / "out.dat"
+    subprocess.check_call([exe, str(opts), os.path.join(root, "tests", "scenes", "sphere-stack.xml"), str(outp)])
+    lines = outp.read_text().strip().split("\n")
+    rows = np.array([[float(x) for x in l.split()] for l in lines[:-1]])
+    # rows t = 0 .. 0.299 (the accumulated time 0.30000000000000016 > 0.3 ends the run, just as
+    # -mt=1 gives the 1000 rows of regress/sphere-stack.dat), then the timing line
+    assert rows.shape == (300, 22) and len(lines[-1].split()) == 1
+    g = np.load(os.path.join(GOLD, "sphere_stack_dat.npz"))
+    for row, k in zip(g["rows"], g["row_index"]):
+        if k < 300:
+            np.testing.assert_allclose(rows[k], row, rtol=0, atol=1e-6)
+    # the same run through the Python mirror prints the same text
+    sc, st, _, _ = mio.load_xml(os.path.join(root, "tests", "scenes", "sphere-stack.xml"))
+    wb = WorldBatch(sc, st.copy())
+    traj = wb.step(1e-3, 299, want_traj=True)
+    full = np.zeros(3 * 13)
+    for k in (1, 150, 299):
+        full.reshape(3, 13)[:, :7] = traj[0, k - 1]
+        assert mio.format_row(rows[k, 0], full, 3).split()[1:] == lines[k].split()[1:]
