@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "moby_hip.h")).read()
+def _declared_symbols(header="moby_hip.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", txt)))
 
@@ -25,6 +25,15 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libmoby_hip.so does not export %s" % name
     assert set(declared) == set(_lib.SYMBOLS), "ctypes table out of sync with moby_hip.h"
     assert lib.mh_version() >= 100
+
+
+def test_io_library_exports_every_declared_symbol():
+    from moby_amd import io as mio
+    lib = mio.load()
+    declared = [n for n in _declared_symbols("moby_hip_io.h") if n.startswith("mh_io_")]
+    assert sorted(declared) == ["mh_io_compare_trajs", "mh_io_format_row", "mh_io_last_error", "mh_io_load_xml"]
+    for name in declared:
+        assert hasattr(lib, name), "libmoby_hip_io.so does not export %s" % name
 
 
 def test_rand_seed_matches_libc():
