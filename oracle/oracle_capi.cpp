@@ -117,6 +117,8 @@ double oracle_world_step(const mh_scene* sc, double dt, int nsteps, double* stat
   return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
 }
 
+unsigned long long oracle_dbg_ca_iters(void) { return g_ca_iters; }
+
 // B worlds sequentially on one thread (CPU baseline); returns elapsed seconds
 double oracle_world_step_batch(const mh_scene* sc, int B, double dt, int nsteps, double* state, mh_world_aux* aux)
 {

@@ -64,6 +64,8 @@ struct Contact {            // UnilateralConstraint (eContact)
 
 struct PairDist { int pair, a, b; double dist; V3 pa, pb; };  // PairwiseDistInfo (global points)
 
+static unsigned long long g_ca_iters = 0;   // diagnostic: conservative-advancement sub-steps taken
+
 class World {
  public:
   const mh_scene* sc;
@@ -907,6 +909,7 @@ class World {
     for (int b = 0; b < nb; b++) get_coords(b, qsave[b]);
     double h = 0.0;
     while (h < dt) {
+      g_ca_iters++;
       broad_phase(dt - h, pairs_to_check);
       calc_pairwise_distances(pairs_to_check, pairwise);
       const double CA = next_CA_step();
