@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmoby_hip.so")
+LIB_PATH = os.environ.get("MOBY_HIP_LIB") or os.path.join(_HERE, "libmoby_hip.so")   # override: kernel experiments (tools/variants.sh)
 
 MH_OK = 0
 MH_ERR_INVALID_ARG = -1

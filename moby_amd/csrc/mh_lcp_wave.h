@@ -147,7 +147,8 @@ MH_DEV int rand_min_wave(double v, uint64_t mask, double tol, WaveRand& rng, dou
   } else argmin_first(v, in, vmin, imin);
   const uint64_t qm = ballot(in && lane != imin && v < vmin + tol);
   const int cnt = 1 + popc(qm);
-  const int r = rng.next() % cnt;
+  const int rv = rng.next();                    // always consumed (LCP.cpp:208)
+  const int r = (cnt == 1) ? 0 : rv % cnt;
   const int chosen = (r == 0) ? imin : nth_set_bit(qm, r - 1);
   val = read_lane(v, chosen);
   return chosen;
@@ -225,7 +226,9 @@ MH_DEV int lu_small(const double* A, double& b)
   return 0;
 }
 
-#define MH_COLCACHE 8
+#ifndef MH_COLCACHE
+#define MH_COLCACHE 4     /* 8 cost 36 more spilled VGPRs at the 128-register budget: -5 % */
+#endif
 template <class MatT>
 MH_DEV int gather_and_solve(const MatT& M, double lam, uint64_t nbmask, int k, bool is_nb, int pos, double qi, double* A, double& b,
                             double (&colv)[MH_COLCACHE])

@@ -92,6 +92,13 @@ MH_DEV void argmax_first(double v, bool valid, double& vmax, int& imax) {
   imax = m ? ctz(m) : 0x7fffffff;
 }
 
+// x / d for 0 <= x < 4096 and a small (wave-uniform, run-time) divisor 1 <= d <= 64: one multiply and a
+// shift instead of the ~30-instruction expansion of an integer division by a non-constant.
+// m = floor(2^18 / d) + 1 is exact for x * d < 2^18.
+MH_DEV int small_div(int x, int d) { const unsigned m = (262144u / (unsigned)d) + 1u; return (int)(((unsigned)x * m) >> 18); }
+MH_DEV unsigned small_div_magic(int d) { return (262144u / (unsigned)d) + 1u; }
+MH_DEV int small_div_m(int x, unsigned m) { return (int)(((unsigned)x * m) >> 18); }
+
 // forward permute: every lane sends v to lane dest (dest must be a permutation
 // of 0..63 across the wave)
 MH_DEV double push_to(double v, int dest) {
