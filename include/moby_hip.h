@@ -195,8 +195,8 @@ typedef struct mh_world_aux {
   unsigned long long lcp_alg_bytes;/* sum of 8 (n^2 + 2n): bytes the same solves move through the LCP entry */
 } mh_world_aux;
 
-/* test hooks: key 1 = edge of the LDS-resident LU block of the world kernel (0..8; 0 sends every
- * LU factorisation through the HBM workspace path) */
+/* test hooks: key 1 = edge of the LDS-resident LU block of the world kernel (0..64, clamped to what the
+ * kernel variant holds: 12 or 16; 0 sends every LU factorisation through the HBM workspace path) */
 int  mh_debug_set(int key, int value);
 void mh_scene_defaults(mh_scene* s);   /* zero + the reference's default tolerances */
 void mh_world_aux_init(mh_world_aux* a, uint32_t seed);

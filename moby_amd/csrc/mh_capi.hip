@@ -359,7 +359,7 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 #include "mh_world_wave.inc"
 
 namespace {
-int g_debug_ka = MHW_KA;      // LDS LU block edge; mh_debug_set(1, 0) forces the HBM workspace path
+int g_debug_ka = 64;          // LDS LU block edge (clamped to the variant's MHW_KA_V); mh_debug_set(1, 0) forces the HBM workspace path
 std::once_flag g_tables_once;
 hipError_t g_tables_err = hipSuccess;
 void init_tables()
@@ -415,7 +415,7 @@ extern "C" {
 
 int mh_debug_set(int key, int value)
 {
-  if (key == 1) { if (value < 0 || value > MHW_KA) return fail(MH_ERR_INVALID_ARG, "LU block edge outside [0, %d]", MHW_KA); g_debug_ka = value; return MH_OK; }
+  if (key == 1) { if (value < 0 || value > 64) return fail(MH_ERR_INVALID_ARG, "LU block edge outside [0, 64]"); g_debug_ka = value; return MH_OK; }
   return fail(MH_ERR_INVALID_ARG, "unknown debug key %d", key);
 }
 

@@ -17,7 +17,7 @@ MH_DEV double norm(V3 a) { return sqrt(dot(a, a)); }
 
 
 #define MHW_INF 1.7976931348623157e+308
-#define MHW_KA 8
+#define MHW_KA 16      /* upper bound of the LDS LU block edge over the variants (MHW_KA_V) */
 
 // friction polygon directions cos/sin(j/(kh-1) * pi/2), filled by the host's libm
 // (ImpactConstraintHandlerQP.cpp:466-468) so that device and oracle agree bit for bit

@@ -42,6 +42,8 @@
 #include "linalg.hpp"
 
 namespace oracle {
+static unsigned long long g_lu_hist[130] = {0};   // diagnostic: LU sizes (lcp_fast: [k], Lemke: [65 + n])
+
 
 // Ravelin::VectorNd stand-in: contents survive a shrinking resize.
 struct Vec {
@@ -134,6 +136,7 @@ class LCP {
       for (unsigned c = 0; c < k; c++) for (unsigned r = 0; r < k; r++) _Msub[r + k*c] = Mat(_nonbas[r], _nonbas[c]);
       _z.resize(k);
       for (unsigned r = 0; r < k; r++) _z[r] = -q[_nonbas[r]];
+      g_lu_hist[k < 65 ? k : 64]++;                                            // diagnostic
       if (k > 0 && lu_solve(k, _Msub.data(), k, _z.data()) != 0) return false; // SingularException
       // _Mmix.mult(_z,_w) += _qbas : dgemv then add
       _w.assign(nb, 0.0);
@@ -322,6 +325,7 @@ class LCP {
       }
       _dl = _Be;
       _Al = _Bl;
+      g_lu_hist[65 + (n < 65 ? n : 64)]++;                                     // diagnostic
       if (lu_solve(n, _Al.data(), n, _dl.data()) != 0) return false; // z keeps size 2n (:840-850)
       _j.clear();
       for (unsigned i = 0; i < n; i++) if (_dl[i] > PIV_TOL) _j.push_back(i);

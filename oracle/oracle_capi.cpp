@@ -118,6 +118,7 @@ double oracle_world_step(const mh_scene* sc, double dt, int nsteps, double* stat
 }
 
 unsigned long long oracle_dbg_ca_iters(void) { return g_ca_iters; }
+void oracle_dbg_lu_hist(unsigned long long* out) { for (int i = 0; i < 130; i++) out[i] = g_lu_hist[i]; }
 
 // B worlds sequentially on one thread (CPU baseline); returns elapsed seconds
 double oracle_world_step_batch(const mh_scene* sc, int B, double dt, int nsteps, double* state, mh_world_aux* aux)

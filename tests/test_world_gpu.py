@@ -105,7 +105,7 @@ def test_full_batch_4096_properties():
 
 
 def test_hbm_lu_workspace_path_is_bit_identical(oracle):
-    """k > MHW_KA nonbasic sets and Lemke bases factorise in the per-world HBM
+    """k > 12 nonbasic sets and Lemke bases factorise in the per-world HBM
     workspace instead of LDS; force that path for every LU and compare."""
     from moby_amd import _lib
     lib = _lib.load()
@@ -116,7 +116,7 @@ def test_hbm_lu_workspace_path_is_bit_identical(oracle):
         _lib.check(lib.mh_debug_set(1, 0))
         b = WorldBatch(sc, st0.copy()); b.step(1e-3, 40)
     finally:
-        _lib.check(lib.mh_debug_set(1, 8))
+        _lib.check(lib.mh_debug_set(1, 64))
     np.testing.assert_array_equal(a.state, b.state)
     np.testing.assert_array_equal(a.aux, b.aux)
 
