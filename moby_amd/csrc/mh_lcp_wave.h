@@ -229,7 +229,9 @@ MH_DEV int lu_small(const double* A, double& b)
 #ifndef MH_COLCACHE
 #define MH_COLCACHE 4     /* 8 cost 36 more spilled VGPRs at the 128-register budget: -5 % */
 #endif
-template <class MatT>
+// REGLU: allow the register-resident factorisations for k = 2..4 (the LDS call site; the HBM one keeps
+// the code small and always takes the general routine -- same arithmetic, bit-identical results)
+template <bool REGLU, class MatT>
 MH_DEV int gather_and_solve(const MatT& M, double lam, uint64_t nbmask, int k, bool is_nb, int pos, double qi, double* A, double& b,
                             double (&colv)[MH_COLCACHE])
 {
@@ -270,9 +272,9 @@ MH_DEV int gather_and_solve(const MatT& M, double lam, uint64_t nbmask, int k, b
   lp_tock(LP_GATHER, t0);
   t0 = lp_tick();
   int info;
-  if (k == 2) info = lu_small<2>(A, b);
-  else if (k == 3) info = lu_small<3>(A, b);
-  else if (k == 4) info = lu_small<4>(A, b);
+  if (REGLU && k == 2) info = lu_small<2>(A, b);
+  else if (REGLU && k == 3) info = lu_small<3>(A, b);
+  else if (REGLU && k == 4) info = lu_small<4>(A, b);
   else info = lu_solve_wave(k, A, b);
   lp_tock(LP_LU, t0);
   return info;
@@ -307,8 +309,12 @@ MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, LuScratch S,
     double b = 0.0;
     double colv[MH_COLCACHE];
     if (k > 0) {
-      double* Ause = (k <= S.ka) ? S.small : S.big;
-      if (gather_and_solve(M, lam, nbmask, k, is_nb, pos, qi, Ause, b, colv) != 0) return false;
+      // two call sites on purpose: with the pointers kept apart the LDS block is addressed with ds_ instructions,
+      // a merged (generic) pointer turns every access of the factorisation into a FLAT memory operation
+      int info;
+      if (k <= S.ka) info = gather_and_solve<true>(M, lam, nbmask, k, is_nb, pos, qi, S.small, b, colv);
+      else info = gather_and_solve<false>(M, lam, nbmask, k, is_nb, pos, qi, S.big, b, colv);
+      if (info != 0) return false;
     }
     // w = Mmix * z + qbas on the basic lanes (dgemv column order)
     unsigned long long tg = lp_tick();
@@ -467,8 +473,10 @@ MH_DEV bool lcp_lemke_wave(int n, const MatT& M, double lam, LuScratch S, double
     // gather Al = Bl from the basis description and solve Al d = Be
     double d = be;
     {
-      double* Ause = (n <= S.ka) ? S.small : S.big;
-      if (lemke_gather_and_solve(n, M, lam, bv, t, art, Ause, d) != 0) return false;   // singular basis (:840-850), size stays 2n
+      int info;
+      if (n <= S.ka) info = lemke_gather_and_solve(n, M, lam, bv, t, art, S.small, d);
+      else info = lemke_gather_and_solve(n, M, lam, bv, t, art, S.big, d);
+      if (info != 0) return false;                                  // singular basis (:840-850), size stays 2n
     }
     const uint64_t jm = ballot(valid && d > PIV_TOL);
     if (jm == 0ull) return false;                              // ray termination (:892-903)
