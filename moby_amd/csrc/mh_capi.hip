@@ -310,7 +310,7 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 // three variants of the world kernel (LDS image, occupancy and feature set differ):
 //   small  <= 4 bodies, <= 6 pairs, <= 6 contacts, <= 12 Jacobian rows, spheres + Drumwright-Shell model only
 //   wheel  <= 2 bodies, <= 3 pairs, <= 4 contacts, + spokes geometry and the no-slip model (rimless wheel)
-//   large  <= 8 bodies, <= 36 pairs, <= 12 contacts, <= 24 rows, every feature
+//   large  <= 8 bodies, <= 36 pairs, <= 40 contacts, <= 24 rows per island, every feature
 #define MHW_NS small
 #define MHW_NOSLIP 0
 #define MHW_BOX 0
@@ -352,7 +352,7 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 #define MHW_BOX 1
 #define MHW_NB MH_MAX_BODIES
 #define MHW_MAX_PAIRS MH_MAX_PAIRS
-#define MHW_MAX_CONTACTS 12
+#define MHW_MAX_CONTACTS 40   /* the stabiliser lists one contact per candidate pair (up to 36), a box adds up to 8 */
 #define MHW_MAX_ROWS 24
 #define MHW_MAX_GROWS 24
 #define MHW_WAVES_PER_SIMD 2
@@ -566,6 +566,17 @@ int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* ph
     double acc = 0.0;
     if (p < mh::large::PH_COUNT) for (int b = 0; b < wb->B; b++) acc += (double)h[(size_t)b * mh::large::PH_COUNT + p];
     phase_cycles[p] = acc / wb->B;
+  }
+  // entries PH_COUNT, PH_COUNT+1 (if asked for): the slowest and the fastest world's stamped total --
+  // the launch lasts as long as its slowest world
+  if (nphase >= mh::large::PH_COUNT + 2) {
+    double mx = 0.0, mn = 1e300;
+    for (int b = 0; b < wb->B; b++) {
+      double t = 0.0;
+      for (int p = 0; p < 10; p++) t += (double)h[(size_t)b * mh::large::PH_COUNT + p];
+      mx = t > mx ? t : mx; mn = t < mn ? t : mn;
+    }
+    phase_cycles[mh::large::PH_COUNT] = mx; phase_cycles[mh::large::PH_COUNT + 1] = mn;
   }
   return MH_OK;
 }

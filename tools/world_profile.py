@@ -19,9 +19,10 @@ if __name__ == "__main__":
     wb.step(1e-3, 20); torch.cuda.synchronize()
     t0 = time.perf_counter(); wb.step(1e-3, nsteps); torch.cuda.synchronize(); t = time.perf_counter() - t0
     print("plain launch: %.3f ms for %d steps x %d worlds -> %.1f us per batch step, %.3g world-steps/s" % (t * 1e3, nsteps, B, t / nsteps * 1e6, B * nsteps / t))
-    ph = np.zeros(len(NAMES))
-    _lib.check(lib.mh_world_batch_profile(wb.handle, 1e-3, nsteps, ph.ctypes.data, len(NAMES)))
+    ph = np.zeros(len(NAMES) + 2)
+    _lib.check(lib.mh_world_batch_profile(wb.handle, 1e-3, nsteps, ph.ctypes.data, len(ph)))
     tot = ph[:10].sum()
-    for n, c in zip(NAMES, ph):
+    for n, c in zip(NAMES, ph[:len(NAMES)]):
         print("  %-14s %10.0f cycles/world-step  %5.1f %%" % (n, c / nsteps, 100 * c / tot))
     print("  total stamped  %10.0f cycles/world-step" % (tot / nsteps))
+    print("  slowest world  %10.0f   fastest %10.0f cycles/world-step (the launch lasts as long as the slowest)" % (ph[-2] / nsteps, ph[-1] / nsteps))
