@@ -46,6 +46,78 @@ def pmc_traffic(B, steps):
     return (t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
 
 
+def _cpu_worker(arg):
+    """One process of the all-cores CPU baseline: `passes` x (nw worlds x ns steps) of the oracle."""
+    first, nw, ns, passes = arg
+    from moby_amd import scene as S
+    from tests.oracle_api import Oracle
+    oracle = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+    sc = S.sphere_stack_scene()
+    rows = 0
+    for _ in range(passes):
+        st = S.sphere_stack_state_range(first, nw)
+        aux = S.new_aux(nw)
+        oracle.world_step_batch(sc, st, aux, DT, ns)
+        rows += int(aux["lcp_rows"].sum())
+    return rows, nw * ns * passes
+
+
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, cut down to the cgroup CPU quota when
+    one is set (os.cpu_count() reports the host's 256 hardware threads inside an 8-CPU container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(B, steps, warmup):
+    """The CPU oracle (oracle/world.hpp, `kind: port`) on the host cores, on a bounded sample of the
+    same workload: one thread (the reference is single-threaded), and -- for scale -- one process
+    per core, each stepping its own worlds.  Runs BEFORE anything touches the GPU (the worker pool
+    forks)."""
+    import multiprocessing as mp
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    from moby_amd import scene as S
+    from tests.oracle_api import Oracle
+    oracle = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+    sc = S.sphere_stack_scene()
+    nw, ns = min(B, 256), min(steps + warmup, 200)
+    secs, crow, cstep, passes = 0.0, 0, 0, 0
+    while secs < 8.0 and passes < 40:
+        st = S.sphere_stack_state_range(0, nw)
+        aux = S.new_aux(nw)
+        secs += oracle.world_step_batch(sc, st, aux, DT, ns)
+        crow += int(aux["lcp_rows"].sum()); cstep += nw * ns; passes += 1
+    out = {"value": crow / secs, "unit": "LCP rows/s", "cores": 1, "kind": "port", "world_steps_per_sec": cstep / secs,
+           "sample": "%d worlds x %d steps of the same batch x %d passes, CPU oracle (oracle/world.hpp), 1 thread; host has %d cores"
+                     % (nw, ns, passes, os.cpu_count())}
+    ncores = int(os.environ.get("MH_BENCH_CPU_PROCS", usable_cpus()))
+    if ncores > 1:
+        per = max(1, min(32, B // ncores if B >= ncores else 1))
+        want = max(1, int(4.0 * (cstep / secs) / (per * ns)))           # ~4 s of work per process
+        jobs = [(i * per, per, ns, min(want, 64)) for i in range(ncores)]
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(ncores) as pool:
+            res = pool.map(_cpu_worker, jobs)
+        wall = time.perf_counter() - t0
+        out["all_cores"] = {"value": sum(r[0] for r in res) / wall, "unit": "LCP rows/s", "cores": ncores,
+                            "world_steps_per_sec": sum(r[1] for r in res) / wall,
+                            "sample": "%d processes (usable CPUs of %d hardware threads) x %d worlds x %d steps x %d passes, wall clock incl. process start"
+                                      % (ncores, os.cpu_count() or 1, per, ns, jobs[0][3])}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,11 +127,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu = None
+    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.worlds, args.steps, args.warmup)         # before the GPU is initialised
+    import torch
+    import torch.distributed as dist
     if world_size != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world_size))
     if not torch.cuda.is_available():
@@ -146,20 +221,8 @@ def main():
                      "model": "LCP-entry bytes 8(n^2+2n) per solved LCP (SURVEY 8d); the fused kernel itself only moves %d B of state per launch" % int(fused_bytes)},
     }
 
-    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
-        from tests.oracle_api import Oracle
-        oracle = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
-        nw, ns = min(B, 256), min(args.steps + args.warmup, 200)
-        secs, crow, cstep, passes = 0.0, 0, 0, 0
-        while secs < 10.0 and passes < 40:
-            st = S.sphere_stack_state_range(0, nw)
-            aux = S.new_aux(nw)
-            secs += oracle.world_step_batch(sc, st, aux, DT, ns)
-            crow += int(aux["lcp_rows"].sum()); cstep += nw * ns; passes += 1
-        out["cpu_baseline"] = {"value": crow / secs, "unit": "LCP rows/s", "cores": 1, "kind": "port",
-                               "world_steps_per_sec": cstep / secs,
-                               "sample": "%d worlds x %d steps of the same batch x %d passes, CPU oracle (oracle/world.hpp), 1 thread; host has %d cores"
-                                         % (nw, ns, passes, os.cpu_count())}
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out))
     if world_size > 1:

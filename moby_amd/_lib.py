@@ -6,6 +6,7 @@ infrastructure and is never imported from here.)
 """
 import ctypes
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOBY_HIP_LIB") or os.path.join(_HERE, "libmoby_hip.so")   # override: kernel experiments (tools/variants.sh)
@@ -70,6 +71,14 @@ def load():
         raise ImportError(
             "moby_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    # torch bundles its own HIP runtime: if this library were loaded first it would bring /opt/rocm's
+    # copy into the process and torch's would come second -- two runtimes, and the second one to
+    # initialise sees no device.  Loading torch first makes libmoby_hip bind to the runtime torch uses.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -300,11 +300,31 @@ def box_state(pos=(0.0, 0.5, 0.0), quat=(0.0, 0.0, 0.0, 1.0), v=(0.0, 0.0, 0.0),
     return st
 
 
+def glibc_srand_state(seed=1):
+    """The 32-word rand() state (31-word TYPE_3 ring + index) right after srand(seed), in the layout
+    mh_rand_seed / oracle/glibc_rand.h use.  Pure Python so that host-side helpers never need the
+    HIP library (loading it before torch would bring a second HIP runtime into the process)."""
+    seed = int(seed) & 0xFFFFFFFF
+    if seed == 0:
+        seed = 1
+    r = [0] * 31
+    r[0] = seed if seed < 2 ** 31 else seed - 2 ** 32
+    for i in range(1, 31):
+        hi, lo = int(r[i - 1] / 127773), int(math.fmod(r[i - 1], 127773))     # C division / remainder (truncating)
+        w = 16807 * lo - 2836 * hi
+        if w < 0:
+            w += 2147483647
+        r[i] = w
+    st = [x & 0xFFFFFFFF for x in r]
+    idx = 3
+    for _ in range(34, 344):
+        st[idx] = (st[idx] + st[(idx + 28) % 31]) & 0xFFFFFFFF
+        idx = (idx + 1) % 31
+    return np.array(st + [idx], dtype=np.uint32)
+
+
 def new_aux(B, seed=1):
     """B fresh mh_world_aux records (numpy structured array), rand() at srand(seed)."""
-    from . import _lib
     aux = np.zeros(B, dtype=AUX_DTYPE)
-    st = np.zeros(MH_RAND_WORDS, dtype=np.uint32)
-    _lib.load().mh_rand_seed(st.ctypes.data, seed)
-    aux["rng"][:] = st
+    aux["rng"][:] = glibc_srand_state(seed)
     return aux

@@ -47,6 +47,15 @@ def test_rand_seed_matches_libc():
         assert [libc.rand() for _ in range(1000)] == [lib.mh_rand_next(st.ctypes.data) for _ in range(1000)]
 
 
+def test_python_srand_state_equals_the_library():
+    from moby_amd import _lib, scene as S
+    lib = _lib.load()
+    for seed in (1, 7, 0, 123456789, 2 ** 31 + 5):
+        st = np.zeros(32, dtype=np.uint32)
+        lib.mh_rand_seed(st.ctypes.data, ctypes.c_uint32(seed))
+        np.testing.assert_array_equal(S.glibc_srand_state(seed), st, err_msg=str(seed))
+
+
 def test_rand_state_layout_equals_oracle(oracle):
     from moby_amd import _lib
     lib = _lib.load()
