@@ -15,9 +15,11 @@
 // Mapping: thread t owns rows t, t+256, ...; the sorted index vectors
 // _bas/_nonbas are a flag array + a list rebuilt by a block scan; every control
 // decision is block-uniform (broadcast through LDS), the libc rand() ring lives
-// in LDS and is advanced by thread 0.  The rank-1 update of the LU is spread
-// over all (row, column) pairs of the trailing block, so one factorisation costs
-// k barriers and (2/3) k^3 / 256 flops per thread.
+// in LDS and is advanced by thread 0.  The LU is right-looking in panels of 8
+// columns (trailing matrix touched once per panel); what bounds it is the number
+// of dependent global-memory phases per column (pivot search, swap, scale:
+// ~12 barriers each), not flops -- measured: n = 256 x 256 problems, 220 pivots,
+// 333 ms.  Keeping the panel in LDS is the next step.
 #pragma once
 #include "mh_lcp_wave.h"
 
@@ -114,29 +116,78 @@ MH_DEV int build_list(int n, const Ws& W) {
 }
 
 // dgesv, one rhs: A k x k col-major (ld = k) and b in the workspace.  Returns LAPACK info (uniform).
+//
+// Right-looking LU in panels of NB columns.  Every element receives exactly the updates
+// a <- a - l*u of dgetf2, in the same order (column steps ascending, each product rounded on its own),
+// so the factors are bit-identical to the unblocked routine; what changes is the traffic: the
+// trailing matrix is read and written once per PANEL (with the NB multipliers of its row in registers
+// and the NB pivot rows staged through LDS) instead of once per column.
+constexpr int NB = 8;
+constexpr int UCH = 256;                 // columns of the pivot-row block staged in LDS at a time
+__shared__ double s_u[NB][UCH];
+
 MH_DEV int lu_solve(int k, double* A, double* b) {
   const int t = tid();
-  for (int j = 0; j < k; j++) {
-    double best = -1.0; int bi = 0x7fffffff;
-    for (int r = j + t; r < k; r += T) { const double a = fabs(A[r + (size_t)k * j]); if (a > best) { best = a; bi = r; } }
-    double amax; int jp; red_max_first(best, bi, amax, jp);
-    if (!(amax != 0.0)) return j + 1;
-    if (jp != j) {
-      for (int c = t; c < k; c += T) { const double t0 = A[j + (size_t)k * c], t1 = A[jp + (size_t)k * c]; A[j + (size_t)k * c] = t1; A[jp + (size_t)k * c] = t0; }
-      if (t == 0) { const double t0 = b[j]; b[j] = b[jp]; b[jp] = t0; }
-      sync();
+  for (int j0 = 0; j0 < k; j0 += NB) {
+    const int nbk = (k - j0 < NB) ? k - j0 : NB;
+    // ---- panel: columns j0 .. j0+nbk-1, unblocked, updates confined to the panel ----
+    for (int j = j0; j < j0 + nbk; j++) {
+      double best = -1.0; int bi = 0x7fffffff;
+      for (int r = j + t; r < k; r += T) { const double a = fabs(A[r + (size_t)k * j]); if (a > best) { best = a; bi = r; } }
+      double amax; int jp; red_max_first(best, bi, amax, jp);
+      if (!(amax != 0.0)) return j + 1;
+      if (jp != j) {                                       // full-row swap, as dgetf2 (dlaswp on both sides)
+        for (int c = t; c < k; c += T) { const double t0 = A[j + (size_t)k * c], t1 = A[jp + (size_t)k * c]; A[j + (size_t)k * c] = t1; A[jp + (size_t)k * c] = t0; }
+        if (t == 0) { const double t0 = b[j]; b[j] = b[jp]; b[jp] = t0; }
+        sync();
+      }
+      if (j < k - 1) {
+        const double piv = A[j + (size_t)k * j];
+        const bool big = fabs(piv) >= MH_SFMIN;
+        const double rcp = 1.0 / piv;
+        for (int r = j + 1 + t; r < k; r += T) { double l = A[r + (size_t)k * j]; l = big ? l * rcp : l / piv; A[r + (size_t)k * j] = l; }
+        sync();
+        const int m = k - j - 1, pc = j0 + nbk - j - 1;    // rows below, panel columns to the right
+        const long tot = (long)m * pc;
+        for (long e = t; e < tot; e += T) {
+          const int r = j + 1 + (int)(e % m), c = j + 1 + (int)(e / m);
+          A[r + (size_t)k * c] = A[r + (size_t)k * c] - A[r + (size_t)k * j] * A[j + (size_t)k * c];
+        }
+        sync();
+      }
     }
-    if (j < k - 1) {
-      const double piv = A[j + (size_t)k * j];
-      const bool big = fabs(piv) >= MH_SFMIN;
-      const double rcp = 1.0 / piv;
-      for (int r = j + 1 + t; r < k; r += T) { double l = A[r + (size_t)k * j]; l = big ? l * rcp : l / piv; A[r + (size_t)k * j] = l; }
+    const int c0 = j0 + nbk;                               // first trailing column
+    if (c0 >= k) break;
+    // ---- trailing columns, UCH at a time ----
+    for (int cb = c0; cb < k; cb += UCH) {
+      const int ncb = (k - cb < UCH) ? k - cb : UCH;
+      // pivot-row block U12[s][c] = A[j0+s][c] - sum_{s' < s} L[j0+s][j0+s'] * U12[s'][c]  (updates of steps j0.. in order)
+      for (int c = t; c < ncb; c += T) {
+        double u[NB];
+#pragma unroll
+        for (int s2 = 0; s2 < NB; s2++) {
+          if (s2 < nbk) {
+            double a = A[(j0 + s2) + (size_t)k * (cb + c)];
+#pragma unroll
+            for (int s1 = 0; s1 < NB; s1++) if (s1 < s2) a = a - A[(j0 + s2) + (size_t)k * (j0 + s1)] * u[s1];
+            u[s2] = a;
+            A[(j0 + s2) + (size_t)k * (cb + c)] = a;
+            s_u[s2][c] = a;
+          }
+        }
+      }
       sync();
-      const int m = k - j - 1;
-      const long tot = (long)m * m;
-      for (long e = t; e < tot; e += T) {
-        const int r = j + 1 + (int)(e % m), c = j + 1 + (int)(e / m);
-        A[r + (size_t)k * c] = A[r + (size_t)k * c] - A[r + (size_t)k * j] * A[j + (size_t)k * c];
+      // A22[r][c] -= L[r][j0+s] * U12[s][c], s ascending; one row per thread, its multipliers in registers
+      for (int r = c0 + t; r < k; r += T) {
+        double l[NB];
+#pragma unroll
+        for (int s2 = 0; s2 < NB; s2++) l[s2] = (s2 < nbk) ? A[r + (size_t)k * (j0 + s2)] : 0.0;
+        for (int c = 0; c < ncb; c++) {
+          double a = A[r + (size_t)k * (cb + c)];
+#pragma unroll
+          for (int s2 = 0; s2 < NB; s2++) if (s2 < nbk) a = a - l[s2] * s_u[s2][c];
+          A[r + (size_t)k * (cb + c)] = a;
+        }
       }
       sync();
     }
