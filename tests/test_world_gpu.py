@@ -314,3 +314,38 @@ def test_eight_sphere_pile_bit_exact(oracle):
     st_o, aux_o, traj_o = oracle_run(oracle, sc, st0, 400, 1e-3)
     assert_same(wb, traj, st_o, aux_o, traj_o)
     assert (aux_o["lcp_solves"] > 100).all()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_sphere_scenes_bit_exact(oracle, seed):
+    """Randomised scenes: 2-4 spheres of different radii / masses dropped on a tilted plane with random
+    contact parameters per pair (restitution, Coulomb and viscous friction, compliance, NK in {4, 8, 16}):
+    both kernel variants (lcp_n_max decides), every term of the QP->LCP assembly."""
+    rng = np.random.default_rng(seed)
+    nb = int(rng.integers(2, 5))
+    radii = list(rng.uniform(0.3, 0.7, nb)); masses = list(rng.uniform(0.5, 2.0, nb))
+    params = {}
+    for i in range(nb):
+        for j in range(i + 1, nb + 1):
+            params[(i, j)] = dict(epsilon=float(rng.choice([0.0, 0.0, 0.3, 0.8])), mu_coulomb=float(rng.choice([0.0, 0.2, 0.7])),
+                                  mu_viscous=float(rng.choice([0.0, 0.0, 0.05])), compliance=float(rng.choice([0.0, 0.0, 1e-6])),
+                                  nk=int(rng.choice([4, 8, 16])))
+    tilt = float(rng.uniform(-0.1, 0.1))
+    sc = S.make_scene(radii, masses, (0.3, -9.81, 0.2), ground_rpy=(tilt, 0.0, 0.0), params=params)
+    sc.cstab_max_iterations = 10
+    nkmax = max(p["nk"] for p in params.values())
+    sc.lcp_n_max = 56 if (seed % 2 and nb <= 4 and 4 * (6 + nkmax // 2) <= 56) else 0      # odd seeds opt into the small variant when it fits
+    B = 6
+    st0 = np.zeros((B, nb, 13)); st0[:, :, 6] = 1.0
+    for w in range(B):
+        y = 0.0
+        for b in range(nb):
+            y += radii[b] + (radii[b - 1] if b else 0.0) + rng.uniform(0.0, 0.2)
+            st0[w, b, :3] = (rng.uniform(-0.05, 0.05), y, rng.uniform(-0.05, 0.05))
+            st0[w, b, 7:10] = rng.uniform(-0.3, 0.3, 3); st0[w, b, 10:13] = rng.uniform(-2, 2, 3)
+    st0 = st0.reshape(B, nb * 13)
+    wb = WorldBatch(sc, st0.copy())
+    traj = wb.step(1e-3, 500, want_traj=True)
+    st_o, aux_o, traj_o = oracle_run(oracle, sc, st0, 500, 1e-3)
+    assert_same(wb, traj, st_o, aux_o, traj_o)
+    assert (aux_o["lcp_solves"] > 10).all()
