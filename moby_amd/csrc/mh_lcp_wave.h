@@ -13,10 +13,13 @@
 //   * the sorted index vectors _bas/_nonbas become ONE 64-bit ballot mask in
 //     SGPRs; "position in the list" is a popcount prefix, "r-th element" a
 //     scalar bit scan -- no list maintenance, no insertion sort;
-//   * M (n x n, col-major) and the LU scratch live in LDS; the right-hand
-//     side, q, z, w and Lemke's x/d vectors live one element per lane in
-//     VGPRs; pivot rows/values are broadcast with v_readlane, reductions
-//     (argmin with first-index ties, idamax) are xor-shuffle butterflies;
+//   * M is anything that can produce M(lane, c) for a wave-uniform column c (an
+//     LDS array for the C-ABI entry, an implicit accessor over G = C X C' in the
+//     world kernels); the LU scratch lives in LDS (k <= 4: in registers, held
+//     redundantly by every lane); the right-hand side, q, z, w and Lemke's x/d
+//     vectors live one element per lane in VGPRs; pivot rows/values are broadcast
+//     with v_readlane, reductions (argmin with first-index ties, idamax) are DPP
+//     row operations + one ballot;
 //   * the per-world libc rand() ring is spread over lanes 0..30.
 // Build with -ffp-contract=off: parity with the oracle is bit-exact.
 #pragma once
