@@ -138,8 +138,16 @@ void mh_k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long st
   bk::sync();
   bk::Trace2 tr; tr.buf = trace ? trace + (size_t)b * trace_cap : nullptr; tr.cap = trace_cap; tr.len = 0;
   unsigned piv = 0;
+#ifdef MH_BLK_PROF
+  if (t < bk::BP_COUNT) bk::s_prof[t] = 0ull;
+  bk::sync();
+#endif
   const bool ok = bk::lcp_solve(P, p10, M, W, q, z, zsize, piv, tr);
   bk::sync();
+#ifdef MH_BLK_PROF
+  if (t == 0 && (b == 0 || b == 5)) printf("blk prof (cycles, block %d, %u pivots): list %llu gather %llu panel %llu swap %llu trail %llu solve %llu gemv %llu randmin %llu\n", b, piv,
+                               bk::s_prof[0], bk::s_prof[1], bk::s_prof[2], bk::s_prof[3], bk::s_prof[4], bk::s_prof[5], bk::s_prof[6], bk::s_prof[7]);
+#endif
   if (t < 32) rngg[(size_t)b * MH_RAND_WORDS + t] = bk::s_rng[t];
   if (t == 0) {
     status[b] = ok ? 1 : 0;

@@ -15,11 +15,14 @@
 // Mapping: thread t owns rows t, t+256, ...; the sorted index vectors
 // _bas/_nonbas are a flag array + a list rebuilt by a block scan; every control
 // decision is block-uniform (broadcast through LDS), the libc rand() ring lives
-// in LDS and is advanced by thread 0.  The LU is right-looking in panels of 8
-// columns (trailing matrix touched once per panel); what bounds it is the number
-// of dependent global-memory phases per column (pivot search, swap, scale:
-// ~12 barriers each), not flops -- measured: n = 256 x 256 problems, 220 pivots,
-// 333 ms.  Keeping the panel in LDS is the next step.
+// in LDS and is advanced by thread 0.  The LU is right-looking in panels of 8 columns:
+// the panel lives in LDS and is factorised by ONE wave (wave reductions + wavefront
+// fences, no block barriers), its row swaps reach the rest of the matrix once per
+// panel, the trailing matrix is updated once per panel by a (64 rows x 4 column
+// groups) thread grid with four loads in flight, the triangular solves take 8
+// columns per barrier round with the diagonal blocks on lanes.  Measured (n = 256,
+// 512 pivots in the slowest problem): 296 ms -> 177 ms; per-phase cycles with
+// -DMH_BLK_PROF: panel 30 %, trailing update 27 %, solves 12 %.
 #pragma once
 #include "mh_lcp_wave.h"
 
@@ -49,38 +52,77 @@ __shared__ int s_bi[4];
 __shared__ unsigned s_rng[32];
 
 MH_DEV int tid() { return (int)threadIdx.x; }
+// -DMH_BLK_PROF: per-phase cycle totals of block 0, printed by the kernel (diagnostic builds only)
+enum { BP_LIST = 0, BP_GATHER, BP_PANEL, BP_SWAP, BP_TRAIL, BP_SOLVE, BP_GEMV, BP_RANDMIN, BP_COUNT };
+#ifdef MH_BLK_PROF
+__shared__ unsigned long long s_prof[BP_COUNT];
+MH_DEV unsigned long long bp_tick() { return __builtin_amdgcn_s_memtime(); }
+MH_DEV void bp_tock(int ph, unsigned long long t0) { const unsigned long long d = __builtin_amdgcn_s_memtime() - t0; if (threadIdx.x == 0) s_prof[ph] += d; }
+#else
+MH_DEV unsigned long long bp_tick() { return 0ull; }
+MH_DEV void bp_tock(int, unsigned long long) {}
+#endif
 MH_DEV void sync() { __syncthreads(); }
+// ordering point between the lanes of ONE wave of the block (compiler ordering; ds_ ops of a wave execute in order)
+MH_DEV void wsync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 MH_DEV double inf() { return __longlong_as_double(0x7ff0000000000000ll); }
 
-// lexicographic (value ascending, index ascending) minimum over the block
+__shared__ double s_wd[4];
+__shared__ int s_wi[4];
+MH_DEV int wave_of() { return tid() >> 6; }
+// lexicographic (value ascending, index ascending) minimum over the block: DPP reductions inside each of
+// the four waves, four partials through LDS -- two barriers instead of a nine-level tree
 MH_DEV void red_min_first(double v, int idx, double& vout, int& iout) {
-  const int t = tid();
-  s_rd[t] = v; s_ri[t] = idx; sync();
-  for (int s = T / 2; s > 0; s >>= 1) {
-    if (t < s) { const double v2 = s_rd[t + s]; const int i2 = s_ri[t + s];
-      if (v2 < s_rd[t] || (v2 == s_rd[t] && i2 < s_ri[t])) { s_rd[t] = v2; s_ri[t] = i2; } }
-    sync();
-  }
-  vout = s_rd[0]; iout = s_ri[0]; sync();
+  const double wm = wave_min(v);
+  const double wi = wave_min((v == wm) ? (double)idx : 1.0e300);     // indices are exact in a double
+  if (lane_id() == 0) { s_wd[wave_of()] = wm; s_wi[wave_of()] = (wi < 1.0e299) ? (int)wi : 0x7fffffff; }
+  sync();
+  double bv = s_wd[0]; int bi = s_wi[0];
+#pragma unroll
+  for (int w = 1; w < T / 64; w++) { const double v2 = s_wd[w]; const int i2 = s_wi[w]; if (v2 < bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; } }
+  vout = bv; iout = bi; sync();
 }
 MH_DEV void red_max_first(double v, int idx, double& vout, int& iout) {
-  const int t = tid();
-  s_rd[t] = v; s_ri[t] = idx; sync();
-  for (int s = T / 2; s > 0; s >>= 1) {
-    if (t < s) { const double v2 = s_rd[t + s]; const int i2 = s_ri[t + s];
-      if (v2 > s_rd[t] || (v2 == s_rd[t] && i2 < s_ri[t])) { s_rd[t] = v2; s_ri[t] = i2; } }
-    sync();
-  }
-  vout = s_rd[0]; iout = s_ri[0]; sync();
+  const double wm = wave_max(v);
+  const double wi = wave_min((v == wm) ? (double)idx : 1.0e300);
+  if (lane_id() == 0) { s_wd[wave_of()] = wm; s_wi[wave_of()] = (wi < 1.0e299) ? (int)wi : 0x7fffffff; }
+  sync();
+  double bv = s_wd[0]; int bi = s_wi[0];
+#pragma unroll
+  for (int w = 1; w < T / 64; w++) { const double v2 = s_wd[w]; const int i2 = s_wi[w]; if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; } }
+  vout = bv; iout = bi; sync();
 }
 MH_DEV double red_max(double v) { double o; int i; red_max_first(v, 0, o, i); return o; }
 MH_DEV double red_min(double v) { double o; int i; red_min_first(v, 0, o, i); return o; }
+MH_DEV int wave_sum_int(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
 MH_DEV int red_sum_int(int v) {
-  const int t = tid();
-  s_ri[t] = v; sync();
-  for (int s = T / 2; s > 0; s >>= 1) { if (t < s) s_ri[t] += s_ri[t + s]; sync(); }
-  const int o = s_ri[0]; sync();
+  v = wave_sum_int(v);
+  if (lane_id() == 0) s_wi[wave_of()] = v;
+  sync();
+  int o = 0;
+#pragma unroll
+  for (int w = 0; w < T / 64; w++) o += s_wi[w];
+  sync();
   return o;
+}
+// exclusive prefix sum of one int per thread (thread order); total returned uniformly
+MH_DEV int excl_scan_int(int v, int& total) {
+  const int lane = lane_id();
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+  if (lane == 63) s_wi[wave_of()] = inc;
+  sync();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < T / 64; w++) { const int x = s_wi[w]; if (w < wave_of()) base += x; tot += x; }
+  sync();
+  total = tot;
+  return base + inc - v;
 }
 MH_DEV int bcast_i(int v) { if (tid() == 0) s_bi[0] = v; sync(); const int o = s_bi[0]; sync(); return o; }
 MH_DEV int rand_next() {           // block-uniform; glibc TYPE_3 ring in LDS (oracle/glibc_rand.h layout)
@@ -106,10 +148,8 @@ MH_DEV int build_list(int n, const Ws& W) {
   const int per = (n + T - 1) / T, lo = t * per, hi = (lo + per < n) ? lo + per : n;
   int c = 0;
   for (int i = lo; i < hi; i++) c += W.flag[i] ? 1 : 0;
-  s_ri[t] = c; sync();
-  if (t == 0) { int acc = 0; for (int k = 0; k < T; k++) { const int v = s_ri[k]; s_ri[k] = acc; acc += v; } s_bi[0] = acc; }
-  sync();
-  int o = s_ri[t]; const int total = s_bi[0];
+  int total;
+  int o = excl_scan_int(c, total);
   for (int i = lo; i < hi; i++) { if (W.flag[i]) { W.list[o] = i; W.pos[i] = o; o++; } else W.pos[i] = -1; }
   sync();
   return total;
@@ -119,26 +159,87 @@ MH_DEV int build_list(int n, const Ws& W) {
 //
 // Right-looking LU in panels of NB columns.  Every element receives exactly the updates
 // a <- a - l*u of dgetf2, in the same order (column steps ascending, each product rounded on its own),
-// so the factors are bit-identical to the unblocked routine; what changes is the traffic: the
-// trailing matrix is read and written once per PANEL (with the NB multipliers of its row in registers
-// and the NB pivot rows staged through LDS) instead of once per column.
+// so the factors are bit-identical to the unblocked routine.  What changes is where the work happens:
+//   * the panel (rows below the diagonal block x NB columns) is factorised in LDS when it fits
+//     (PANEL_CAP doubles): pivot search, scaling and the in-panel updates run at LDS latency;
+//   * the trailing matrix is read and written once per PANEL, with the NB multipliers of a row in
+//     registers and the NB pivot rows staged through LDS (s_u), instead of once per column;
+//   * row swaps outside the panel are plain global-memory swaps off the critical path.
 constexpr int NB = 8;
 constexpr int UCH = 256;                 // columns of the pivot-row block staged in LDS at a time
+constexpr int PANEL_CAP = 3584;          // doubles (28 KB): rows x NB of the panel held in LDS
 __shared__ double s_u[NB][UCH];
+__shared__ int s_li[UCH];
+constexpr int LIST_CAP = 1024;
+__shared__ int s_list[LIST_CAP];
+__shared__ double s_panel[PANEL_CAP];
+constexpr int RHS_CAP = 1024;            // the right-hand side stays in LDS for the whole factorisation when k fits
+__shared__ double s_b[RHS_CAP];
+__shared__ int s_ipiv[NB];
 
 MH_DEV int lu_solve(int k, double* A, double* b) {
   const int t = tid();
+  double* bb = b;
+  const bool b_lds = k <= RHS_CAP;
+  if (b_lds) { for (int i = t; i < k; i += T) s_b[i] = b[i]; sync(); bb = s_b; }
   for (int j0 = 0; j0 < k; j0 += NB) {
     const int nbk = (k - j0 < NB) ? k - j0 : NB;
-    // ---- panel: columns j0 .. j0+nbk-1, unblocked, updates confined to the panel ----
-    for (int j = j0; j < j0 + nbk; j++) {
+    const int R = k - j0;                                   // panel rows (global rows j0 .. k-1)
+    const bool in_lds = R * nbk <= PANEL_CAP;
+    // panel element (global row j0 + r, global column j0 + c): LDS s_panel[r + R*c] or A
+    unsigned long long tp = bp_tick();
+    if (in_lds) {
+      for (int c = 0; c < nbk; c++) for (int r = t; r < R; r += T) s_panel[r + R * c] = A[(j0 + r) + (size_t)k * (j0 + c)];
+      sync();
+    }
+    if (in_lds) {
+      // The panel is factorised by wave 0 alone: its columns cost wave-level reductions and wavefront-scope
+      // fences (the LDS unit executes one wave's ds_ operations in order) instead of ~6 block barriers each;
+      // the other three waves wait at the barrier below.
+      if (t == 0) s_bi[0] = 0;
+      sync();
+      if (t < 64) {
+        const int lane = t;
+        for (int jj = 0; jj < nbk; jj++) {
+          const int j = j0 + jj;
+          double best = -1.0; int bi = 0x7fffffff;
+          for (int r = jj + lane; r < R; r += 64) { const double a = fabs(s_panel[r + R * jj]); if (a > best) { best = a; bi = j0 + r; } }
+          const double amax = wave_max(best);
+          const double wi = wave_min((best == amax) ? (double)bi : 1.0e300);
+          const int jp = (wi < 1.0e299) ? (int)wi : 0x7fffffff;
+          if (!(amax != 0.0)) { if (lane == 0) s_bi[0] = j + 1; break; }
+          if (lane == 0) s_ipiv[jj] = jp;
+          if (jp != j) {
+            if (lane < nbk) { const double t0 = s_panel[jj + R * lane], t1 = s_panel[(jp - j0) + R * lane]; s_panel[jj + R * lane] = t1; s_panel[(jp - j0) + R * lane] = t0; }
+            if (lane == 63) { const double t0 = bb[j]; bb[j] = bb[jp]; bb[jp] = t0; }
+            wsync();
+          }
+          if (j < k - 1) {
+            const double piv = s_panel[jj + R * jj];
+            const bool big = fabs(piv) >= MH_SFMIN;
+            const double rcp = 1.0 / piv;
+            for (int r = jj + 1 + lane; r < R; r += 64) { double l = s_panel[r + R * jj]; l = big ? l * rcp : l / piv; s_panel[r + R * jj] = l; }
+            wsync();
+            for (int c = jj + 1; c < nbk; c++) { const double u = s_panel[jj + R * c];
+              for (int r = jj + 1 + lane; r < R; r += 64) s_panel[r + R * c] = s_panel[r + R * c] - s_panel[r + R * jj] * u; }
+            wsync();
+          }
+        }
+      }
+      sync();
+      const int info = s_bi[0];
+      sync();
+      if (info != 0) return info;
+    } else
+    for (int jj = 0; jj < nbk; jj++) {
+      const int j = j0 + jj;
       double best = -1.0; int bi = 0x7fffffff;
       for (int r = j + t; r < k; r += T) { const double a = fabs(A[r + (size_t)k * j]); if (a > best) { best = a; bi = r; } }
       double amax; int jp; red_max_first(best, bi, amax, jp);
       if (!(amax != 0.0)) return j + 1;
       if (jp != j) {                                       // full-row swap, as dgetf2 (dlaswp on both sides)
         for (int c = t; c < k; c += T) { const double t0 = A[j + (size_t)k * c], t1 = A[jp + (size_t)k * c]; A[j + (size_t)k * c] = t1; A[jp + (size_t)k * c] = t0; }
-        if (t == 0) { const double t0 = b[j]; b[j] = b[jp]; b[jp] = t0; }
+        if (t == 0) { const double t0 = bb[j]; bb[j] = bb[jp]; bb[jp] = t0; }
         sync();
       }
       if (j < k - 1) {
@@ -147,15 +248,26 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
         const double rcp = 1.0 / piv;
         for (int r = j + 1 + t; r < k; r += T) { double l = A[r + (size_t)k * j]; l = big ? l * rcp : l / piv; A[r + (size_t)k * j] = l; }
         sync();
-        const int m = k - j - 1, pc = j0 + nbk - j - 1;    // rows below, panel columns to the right
-        const long tot = (long)m * pc;
-        for (long e = t; e < tot; e += T) {
-          const int r = j + 1 + (int)(e % m), c = j + 1 + (int)(e / m);
-          A[r + (size_t)k * c] = A[r + (size_t)k * c] - A[r + (size_t)k * j] * A[j + (size_t)k * c];
+        if (nbk - jj - 1 > 0) {
+          for (int c = j + 1; c < j0 + nbk; c++) { const double u = A[j + (size_t)k * c];
+            for (int r = j + 1 + t; r < k; r += T) A[r + (size_t)k * c] = A[r + (size_t)k * c] - A[r + (size_t)k * j] * u; }
+          sync();
         }
-        sync();
       }
     }
+    bp_tock(BP_PANEL, tp); tp = bp_tick();
+    if (in_lds) {                                           // L and U of the panel back to the workspace (the solves read them)
+      for (int c = 0; c < nbk; c++) for (int r = t; r < R; r += T) A[(j0 + r) + (size_t)k * (j0 + c)] = s_panel[r + R * c];
+      // dlaswp of the columns outside the panel: one column per thread, the panel's swaps in sequence
+      sync();
+      for (int c = t; c < k; c += T) {
+        if (c >= j0 && c < j0 + nbk) continue;
+        for (int jj = 0; jj < nbk; jj++) { const int jp = s_ipiv[jj], j = j0 + jj;
+          if (jp != j) { const double t0 = A[j + (size_t)k * c], t1 = A[jp + (size_t)k * c]; A[j + (size_t)k * c] = t1; A[jp + (size_t)k * c] = t0; } }
+      }
+      sync();
+    }
+    bp_tock(BP_SWAP, tp); tp = bp_tick();
     const int c0 = j0 + nbk;                               // first trailing column
     if (c0 >= k) break;
     // ---- trailing columns, UCH at a time ----
@@ -169,7 +281,7 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
           if (s2 < nbk) {
             double a = A[(j0 + s2) + (size_t)k * (cb + c)];
 #pragma unroll
-            for (int s1 = 0; s1 < NB; s1++) if (s1 < s2) a = a - A[(j0 + s2) + (size_t)k * (j0 + s1)] * u[s1];
+            for (int s1 = 0; s1 < NB; s1++) if (s1 < s2) a = a - (in_lds ? s_panel[s2 + R * s1] : A[(j0 + s2) + (size_t)k * (j0 + s1)]) * u[s1];
             u[s2] = a;
             A[(j0 + s2) + (size_t)k * (cb + c)] = a;
             s_u[s2][c] = a;
@@ -178,33 +290,83 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
       }
       sync();
       // A22[r][c] -= L[r][j0+s] * U12[s][c], s ascending; one row per thread, its multipliers in registers
-      for (int r = c0 + t; r < k; r += T) {
-        double l[NB];
+      // thread (tr, tc): rows c0 + tr + 64 i, columns tc, tc + 4, ... of the chunk -- a wave still reads 64
+      // consecutive rows of a column; four columns are in flight per thread before any is used
+      { const int tr = t & 63, tc = t >> 6;
+        for (int r = c0 + tr; r < k; r += 64) {
+          double l[NB];
 #pragma unroll
-        for (int s2 = 0; s2 < NB; s2++) l[s2] = (s2 < nbk) ? A[r + (size_t)k * (j0 + s2)] : 0.0;
-        for (int c = 0; c < ncb; c++) {
-          double a = A[r + (size_t)k * (cb + c)];
+          for (int s2 = 0; s2 < NB; s2++) l[s2] = (s2 < nbk) ? (in_lds ? s_panel[(r - j0) + R * s2] : A[r + (size_t)k * (j0 + s2)]) : 0.0;
+          for (int cq = tc; cq < ncb; cq += 16) {
+            double a[4];
 #pragma unroll
-          for (int s2 = 0; s2 < NB; s2++) if (s2 < nbk) a = a - l[s2] * s_u[s2][c];
-          A[r + (size_t)k * (cb + c)] = a;
-        }
-      }
+            for (int u4 = 0; u4 < 4; u4++) { const int c = cq + 4 * u4; a[u4] = (c < ncb) ? A[r + (size_t)k * (cb + c)] : 0.0; }
+#pragma unroll
+            for (int u4 = 0; u4 < 4; u4++) {
+              const int c = cq + 4 * u4;
+              if (c < ncb) {
+                double v = a[u4];
+#pragma unroll
+                for (int s2 = 0; s2 < NB; s2++) if (s2 < nbk) v = v - l[s2] * s_u[s2][c];
+                A[r + (size_t)k * (cb + c)] = v;
+              }
+            }
+          }
+        } }
       sync();
     }
+    bp_tock(BP_TRAIL, tp);
   }
-  for (int kk = 0; kk < k; kk++) {                       // unit lower
-    const double bk = b[kk];
+  const unsigned long long ts = bp_tick();
+  // triangular solves (the rhs is in LDS when k <= RHS_CAP)
+  // NB columns per barrier round: the NB x NB diagonal block is staged in LDS and finished by one thread, the
+  // rows outside it then take their NB updates in the same (ascending / descending) column order as dgetrs
+  for (int kb = 0; kb < k; kb += NB) {                   // unit lower
+    const int nbk = (k - kb < NB) ? k - kb : NB;
+    if (t < NB * NB) { const int r = t % NB, c = t / NB; if (r < nbk && c < nbk) s_u[0][t] = A[(kb + r) + (size_t)k * (kb + c)]; }
     sync();
-    for (int i = kk + 1 + t; i < k; i += T) b[i] = b[i] - bk * A[i + (size_t)k * kk];
+    if (t < 64) {                                          // the diagonal block: lane r = row r, values broadcast with v_readlane
+      const int lane = t;
+      double v = (lane < nbk) ? bb[kb + lane] : 0.0, Lr[NB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) Lr[c] = (lane < nbk && c < nbk) ? s_u[0][lane + NB * c] : 0.0;
+#pragma unroll
+      for (int c = 0; c < NB; c++) if (c < nbk) { const double bk = read_lane(v, c); if (lane > c) v = v - bk * Lr[c]; }
+      if (lane < nbk) bb[kb + lane] = v;
+    }
+    sync();
+    for (int i = kb + nbk + t; i < k; i += T) {
+      double v = bb[i];
+#pragma unroll
+      for (int c = 0; c < NB; c++) if (c < nbk) v = v - bb[kb + c] * A[i + (size_t)k * (kb + c)];
+      bb[i] = v;
+    }
     sync();
   }
-  for (int kk = k - 1; kk >= 0; kk--) {                  // upper
-    if (t == 0) b[kk] = b[kk] / A[kk + (size_t)k * kk];
+  for (int ke = k; ke > 0; ke -= NB) {                   // upper, blocks [kb, ke) from the bottom
+    const int kb = (ke - NB > 0) ? ke - NB : 0, nbk = ke - kb;
+    if (t < NB * NB) { const int r = t % NB, c = t / NB; if (r < nbk && c < nbk) s_u[0][t] = A[(kb + r) + (size_t)k * (kb + c)]; }
     sync();
-    const double bk = b[kk];
-    for (int i = t; i < kk; i += T) b[i] = b[i] - bk * A[i + (size_t)k * kk];
+    if (t < 64) {
+      const int lane = t;
+      double v = (lane < nbk) ? bb[kb + lane] : 0.0, Ur[NB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) Ur[c] = (lane < nbk && c < nbk) ? s_u[0][lane + NB * c] : 1.0;
+#pragma unroll
+      for (int c = NB - 1; c >= 0; c--) if (c < nbk) { if (lane == c) v = v / Ur[c]; const double bk = read_lane(v, c); if (lane < c) v = v - bk * Ur[c]; }
+      if (lane < nbk) bb[kb + lane] = v;
+    }
+    sync();
+    for (int i = t; i < kb; i += T) {
+      double v = bb[i];
+#pragma unroll
+      for (int c = NB - 1; c >= 0; c--) if (c < nbk) v = v - bb[kb + c] * A[i + (size_t)k * (kb + c)];
+      bb[i] = v;
+    }
     sync();
   }
+  if (b_lds) { for (int i = t; i < k; i += T) b[i] = s_b[i]; sync(); }
+  bp_tock(BP_SOLVE, ts);
   return 0;
 }
 
@@ -247,21 +409,40 @@ MH_DEV bool lcp_fast(const Mat& M, double lam, const Ws& W, const double* q, dou
   sync();
   const unsigned MAX_PIV = 2u * (unsigned)n;
   for (pivots = 0; pivots < MAX_PIV; pivots++) {
+    unsigned long long tq = bp_tick();
     const int k = build_list(n, W);
+    bp_tock(BP_LIST, tq); tq = bp_tick();
     if (k > 0) {
-      const long kk2 = (long)k * k;
-      for (long e = t; e < kk2; e += T) { const int r = (int)(e % k), c = (int)(e / k); W.A[e] = M.at(W.list[r], W.list[c], lam); }
+      { int r = t % k, c = t / k;                          // element e = t + m T, walked without a division per element
+        const int dr = T % k, dc = T / k;
+        const bool l_lds = k <= LIST_CAP;                   // the index list through LDS: one global load per element, not two dependent ones
+        if (l_lds) { for (int i = t; i < k; i += T) s_list[i] = W.list[i]; sync(); }
+        const int* L = l_lds ? s_list : W.list;
+        for (long e = t; e < (long)k * k; e += T) {
+          W.A[e] = M.at(L[r], L[c], lam);
+          r += dr; c += dc; if (r >= k) { r -= k; c++; }
+        } }
       for (int r = t; r < k; r += T) W.b[r] = -q[W.list[r]];
       sync();
+      bp_tock(BP_GATHER, tq);
       if (lu_solve(k, W.A, W.b) != 0) return false;
     }
+    tq = bp_tick();
     // w = Mmix z + qbas on the basic variables (dgemv column order)
-    for (int i = t; i < n; i += T) if (!W.flag[i]) {
-      double w = 0.0;
-      for (int c = 0; c < k; c++) w = w + W.b[c] * M.at(i, W.list[c], lam);
-      W.w[i] = w + q[i];
+    // (z values and their variables are staged through LDS UCH at a time: the inner loop then has one
+    //  independent global load per term; the running sums stay in the workspace between chunks)
+    for (int cb = 0; cb < k || cb == 0; cb += UCH) {
+      const int ncb = (k - cb < UCH) ? ((k - cb > 0) ? k - cb : 0) : UCH;
+      for (int c = t; c < ncb; c += T) { s_u[0][c] = W.b[cb + c]; s_li[c] = W.list[cb + c]; }
+      sync();
+      for (int i = t; i < n; i += T) if (!W.flag[i]) {
+        double w = (cb == 0) ? 0.0 : W.w[i];
+        for (int c = 0; c < ncb; c++) w = w + s_u[0][c] * M.at(i, s_li[c], lam);
+        W.w[i] = (cb + UCH >= k) ? w + q[i] : w;
+      }
+      sync();
     }
-    sync();
+    bp_tock(BP_GEMV, tq); tq = bp_tick();
     auto wval = [&](int i) { return W.w[i]; };
     auto isb = [&](int i) { return W.flag[i] == 0; };
     auto zval = [&](int i) { return W.b[W.pos[i]]; };
@@ -271,6 +452,7 @@ MH_DEV bool lcp_fast(const Mat& M, double lam, const Ws& W, const double* q, dou
     if (minw < 0 || wsel > -zero_tol) {
       double zsel = 0.0; int minz = -1;
       if (k > 0) minz = rand_min(n, zval, isnb, zero_tol, zsel);
+      bp_tock(BP_RANDMIN, tq);
       if (minz >= 0 && zsel < -zero_tol) {
         if (t == 0) W.flag[minz] = 0;
         tr.push(-(int32_t)(minz + 1));
@@ -285,6 +467,7 @@ MH_DEV bool lcp_fast(const Mat& M, double lam, const Ws& W, const double* q, dou
       tr.push((int32_t)(minw + 1));
       double zsel = 0.0; int minzv = -1;
       if (k > 0) minzv = rand_min(n, zval, isnb, zero_tol, zsel);
+      bp_tock(BP_RANDMIN, tq);
       int idx2 = -1;
       if (minzv >= 0 && zsel < -zero_tol) {
         // LCP.cpp:176-187: the POSITION found in the old _z indexes the NEW, re-sorted _nonbas
