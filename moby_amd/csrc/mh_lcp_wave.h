@@ -134,6 +134,88 @@ MH_DEV int lu_solve_wave(int k, double* A, double& b)
   return 0;
 }
 
+// The same factorisation for a matrix that lives in the HBM workspace (k above the LDS block, every Lemke
+// basis of a 42-row island).  lu_solve_wave costs ~4 dependent memory phases per COLUMN there (~250 us for
+// k = 42, ten times a CPU core).  Here a panel of 8 columns is loaded into registers once (lane r = logical
+// row r), factorised with v_readlane broadcasts, and the trailing columns take the panel's 8 updates 8
+// columns per round trip; rows are never swapped in memory -- lanes exchange their register contents and
+// the index of the physical row they stand for.  Every element still receives dgetf2's updates
+// a <- a - l*u in ascending column order with separately rounded products: bit-identical factors.
+MH_DEV int lu_solve_wave_hbm(int k, double* A, double& b)
+{
+  constexpr int PB = 8;
+  const int lane = lane_id();
+  const bool valid = lane < k;
+  int prow = lane;                                   // physical row this lane's logical row lives in
+  for (int j0 = 0; j0 < k; j0 += PB) {
+    const int nb = (k - j0 < PB) ? k - j0 : PB;
+    double p[PB];
+#pragma unroll
+    for (int c = 0; c < PB; c++) p[c] = (valid && c < nb) ? A[prow + k * (j0 + c)] : 0.0;
+#pragma unroll
+    for (int jj = 0; jj < PB; jj++) {
+      if (jj < nb) {
+        const int j = j0 + jj;
+        const bool mine = (lane >= j) && valid;
+        double amax; int jp;
+        argmax_first(mine ? fabs(p[jj]) : -1.0, mine, amax, jp);
+        if (!(amax != 0.0)) return j + 1;
+        if (jp != j) {                               // logical rows j <-> jp: registers and row index, no memory traffic
+#pragma unroll
+          for (int c = 0; c < PB; c++) { const double vj = read_lane(p[c], j), vp = read_lane(p[c], jp); if (lane == j) p[c] = vp; else if (lane == jp) p[c] = vj; }
+          { const double vj = read_lane(b, j), vp = read_lane(b, jp); if (lane == j) b = vp; else if (lane == jp) b = vj; }
+          { const int rj = read_lane(prow, j), rp = read_lane(prow, jp); if (lane == j) prow = rp; else if (lane == jp) prow = rj; }
+        }
+        if (j < k - 1) {
+          const double piv = read_lane(p[jj], j);
+          const bool below = (lane > j) && valid;
+          if (below) { double l = p[jj]; if (fabs(piv) >= MH_SFMIN) { const double r = 1.0 / piv; l = l * r; } else l = l / piv; p[jj] = l; }
+#pragma unroll
+          for (int c = 0; c < PB; c++) if (c > jj && c < nb) { const double u = read_lane(p[c], j); if (below) p[c] = p[c] - p[jj] * u; }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < PB; c++) if (valid && c < nb) A[prow + k * (j0 + c)] = p[c];
+    // trailing columns, 8 per round trip: element (r, c) takes the updates of the panel's steps in order
+    for (int cb = j0 + nb; cb < k; cb += PB) {
+      double a[PB];
+#pragma unroll
+      for (int u = 0; u < PB; u++) a[u] = (valid && cb + u < k) ? A[prow + k * (cb + u)] : 0.0;
+#pragma unroll
+      for (int u = 0; u < PB; u++) {
+#pragma unroll
+        for (int s2 = 0; s2 < PB; s2++) if (s2 < nb) { const double us = read_lane(a[u], j0 + s2); if (lane > j0 + s2 && valid) a[u] = a[u] - p[s2] * us; }
+      }
+#pragma unroll
+      for (int u = 0; u < PB; u++) if (valid && cb + u < k) A[prow + k * (cb + u)] = a[u];
+    }
+  }
+  wave_sync();
+  // dgetrs: unit lower, then upper; 8 columns of factors per round trip
+  for (int kb = 0; kb < k; kb += PB) {
+    double l[PB];
+#pragma unroll
+    for (int u = 0; u < PB; u++) l[u] = (valid && kb + u < k) ? A[prow + k * (kb + u)] : 0.0;
+#pragma unroll
+    for (int u = 0; u < PB; u++) if (kb + u < k) { const double bk = read_lane(b, kb + u); if (lane > kb + u && valid) b = b - bk * l[u]; }
+  }
+  for (int ke = k; ke > 0; ke -= PB) {
+    const int kb = (ke - PB > 0) ? ke - PB : 0;
+    double uu[PB];
+#pragma unroll
+    for (int u = 0; u < PB; u++) uu[u] = (valid && kb + u < ke) ? A[prow + k * (kb + u)] : 1.0;
+#pragma unroll
+    for (int u = PB - 1; u >= 0; u--) if (kb + u < ke) {
+      const int kk = kb + u;
+      if (lane == kk) b = b / uu[u];
+      const double bk = read_lane(b, kk);
+      if (lane < kk) b = b - bk * uu[u];
+    }
+  }
+  return 0;
+}
+
 // LCP.cpp:199-209: v is defined on the lanes of `mask` (list order = lane
 // order).  Consumes exactly one rand().  Returns the chosen lane.
 MH_DEV int rand_min_wave(double v, uint64_t mask, double tol, WaveRand& rng, double& val)
@@ -278,7 +360,7 @@ MH_DEV int gather_and_solve(const MatT& M, double lam, uint64_t nbmask, int k, b
   if (REGLU && k == 2) info = lu_small<2>(A, b);
   else if (REGLU && k == 3) info = lu_small<3>(A, b);
   else if (REGLU && k == 4) info = lu_small<4>(A, b);
-  else info = lu_solve_wave(k, A, b);
+  else info = REGLU ? lu_solve_wave(k, A, b) : lu_solve_wave_hbm(k, A, b);     // REGLU <=> the LDS call site
   lp_tock(LP_LU, t0);
   return info;
 }
@@ -405,7 +487,7 @@ MH_DEV bool verify_wave(int n, const MatT& M, double lam, double qi, double zi, 
   return ballot(valid && !(zw < ZERO_TOL)) == 0ull;
 }
 
-template <class MatT>
+template <bool HBM, class MatT>
 MH_DEV int lemke_gather_and_solve(int n, const MatT& M, double lam, int bv, int t, const double* art, double* A, double& d)
 {
   const int lane = lane_id();
@@ -420,7 +502,7 @@ MH_DEV int lemke_gather_and_solve(int n, const MatT& M, double lam, int bv, int 
     if (valid) A[lane + n * p] = a;
   }
   wave_sync();
-  return lu_solve_wave(n, A, d);
+  return HBM ? lu_solve_wave_hbm(n, A, d) : lu_solve_wave(n, A, d);
 }
 
 template <class MatT>
@@ -477,8 +559,8 @@ MH_DEV bool lcp_lemke_wave(int n, const MatT& M, double lam, LuScratch S, double
     double d = be;
     {
       int info;
-      if (n <= S.ka) info = lemke_gather_and_solve(n, M, lam, bv, t, art, S.small, d);
-      else info = lemke_gather_and_solve(n, M, lam, bv, t, art, S.big, d);
+      if (n <= S.ka) info = lemke_gather_and_solve<false>(n, M, lam, bv, t, art, S.small, d);
+      else info = lemke_gather_and_solve<true>(n, M, lam, bv, t, art, S.big, d);
       if (info != 0) return false;                                  // singular basis (:840-850), size stays 2n
     }
     const uint64_t jm = ballot(valid && d > PIV_TOL);
