@@ -349,3 +349,18 @@ def test_random_sphere_scenes_bit_exact(oracle, seed):
     st_o, aux_o, traj_o = oracle_run(oracle, sc, st0, 500, 1e-3)
     assert_same(wb, traj, st_o, aux_o, traj_o)
     assert (aux_o["lcp_solves"] > 10).all()
+
+
+def test_cpp_simulator_adapter_example():
+    """moby_amd/cpp/MobyHipSimulator.h (the TimeSteppingSimulator-shaped C++ adapter) on a scene file:
+    100 calls of step(dt) equal one call of step(dt, 100), bit for bit."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = os.path.join(root, "moby_amd", "cpp")
+    exe = os.path.join(cpp, "example_world")
+    subprocess.check_call(["g++", "-std=c++11", os.path.join(cpp, "example_world.cpp"), "-L" + os.path.join(root, "moby_amd"),
+                           "-lmoby_hip", "-lmoby_hip_io", "-Wl,-rpath," + os.path.join(root, "moby_amd"), "-o", exe])
+    out = subprocess.check_output([exe, os.path.join(root, "tests", "scenes", "sphere-stack.xml")]).decode()
+    assert "same=1" in out and "worlds=4 bodies=3" in out and "status=0" in out
+    z = float(out.split("top body:")[1].split()[2])
+    assert abs(z - 5.0) < 1e-6
