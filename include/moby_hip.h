@@ -171,6 +171,7 @@ typedef struct mh_scene {
 #define MH_WORLD_STALLED       16   /* > 100000 zero-length mini-steps in one step, or MH_CSTAB_HARD_CAP stabilisation
                                        iterations in one call (the reference would not return) */
 #define MH_CSTAB_HARD_CAP 10000u
+#define MH_CA_HARD_CAP 10000000u     /* conservative-advancement sub-steps of one mini-step before MH_WORLD_STALLED */
 
 /* persistent per-world solver state (what the reference keeps in the
  * simulator / handler / libc between steps) + counters */

@@ -908,8 +908,11 @@ class World {
     double qsave[MH_MAX_BODIES][7];
     for (int b = 0; b < nb; b++) get_coords(b, qsave[b]);
     double h = 0.0;
+    unsigned long ca_guard = 0;
     while (h < dt) {
       g_ca_iters++;
+      // a conservative step that no longer advances h (tc below h's ulp) would spin forever in the reference
+      if (++ca_guard > MH_CA_HARD_CAP) { aux->status |= MH_WORLD_STALLED; break; }
       broad_phase(dt - h, pairs_to_check);
       calc_pairwise_distances(pairs_to_check, pairwise);
       const double CA = next_CA_step();
