@@ -359,7 +359,9 @@ MH_DEV int gather_and_solve(const MatT& M, double lam, uint64_t nbmask, int k, b
   int info;
   if (REGLU && k == 2) info = lu_small<2>(A, b);
   else if (REGLU && k == 3) info = lu_small<3>(A, b);
+#ifndef MH_NO_LU4
   else if (REGLU && k == 4) info = lu_small<4>(A, b);
+#endif
   else info = REGLU ? lu_solve_wave(k, A, b) : lu_solve_wave_hbm(k, A, b);     // REGLU <=> the LDS call site
   lp_tock(LP_LU, t0);
   return info;
