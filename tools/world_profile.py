@@ -13,8 +13,14 @@ if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     lib = _lib.load()
-    sc = S.sphere_stack_scene()
-    wb = WorldBatchDevice(sc, S.sphere_stack_state_range(0, B))
+    which = sys.argv[3] if len(sys.argv) > 3 else "stack"
+    if which == "wheel":
+        from moby_amd import synth
+        sc = S.rimless_wheel_scene()
+        wb = WorldBatchDevice(sc, S.rimless_wheel_state([0.24 if w == 0 else 0.2 + 0.4 * synth.world_uniforms(w, 1)[0] for w in range(B)]))
+    else:
+        sc = S.sphere_stack_scene()
+        wb = WorldBatchDevice(sc, S.sphere_stack_state_range(0, B))
     print("runtime occupancy query: %d workgroups per CU" % lib.mh_world_batch_occupancy(wb.handle))
     wb.step(1e-3, 20); torch.cuda.synchronize()
     t0 = time.perf_counter(); wb.step(1e-3, nsteps); torch.cuda.synchronize(); t = time.perf_counter() - t0
