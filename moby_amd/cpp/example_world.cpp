@@ -1,6 +1,6 @@
 // The batched simulator adapter on a scene file: 100 calls of step(dt) against one call of step(dt, 100).
 //   g++ -std=c++11 example_world.cpp -L.. -lmoby_hip -lmoby_hip_io -Wl,-rpath,.. -o example_world
-//   ./example_world ../../tests/scenes/sphere-stack.xml
+//   ./example_world ../../tests/scenes/three_spheres_on_a_plane.xml
 #include <cstdio>
 #include <cstring>
 #include "MobyHipSimulator.h"

@@ -31,21 +31,21 @@ def assert_scene_equal(a, b, skip=("lcp_n_max",)):
 
 
 def test_sphere_stack_xml_equals_the_builder():
-    sc, st, ids, step = mio.load_xml(os.path.join(SCENES, "sphere-stack.xml"))
+    sc, st, ids, step = mio.load_xml(os.path.join(SCENES, "three_spheres_on_a_plane.xml"))
     assert ids == ["sph1", "sph2", "sph3", "ground"] and step == 0.0
     assert_scene_equal(sc, S.sphere_stack_scene())
     np.testing.assert_array_equal(st, S.sphere_stack_state(1))
 
 
 def test_bouncing_ball_xml_equals_the_builder():
-    sc, st, ids, step = mio.load_xml(os.path.join(SCENES, "bouncing-ball.xml"))
+    sc, st, ids, step = mio.load_xml(os.path.join(SCENES, "dropped_spinning_ball.xml"))
     assert ids == ["ball", "ground"] and step == 0.025
     assert_scene_equal(sc, S.bouncing_ball_scene())
     np.testing.assert_array_equal(st, S.bouncing_ball_state(1))
 
 
 def test_rimless_wheel_xml_equals_the_builder():
-    sc, st, ids, _ = mio.load_xml(os.path.join(SCENES, "rimless-wheel.xml"))
+    sc, st, ids, _ = mio.load_xml(os.path.join(SCENES, "six_spoke_wheel.xml"))
     assert ids == ["WHEEL", "GROUND"]
     assert_scene_equal(sc, S.rimless_wheel_scene())
     assert sc.geom_type[0] == S.MH_GEOM_SPOKES
@@ -53,7 +53,7 @@ def test_rimless_wheel_xml_equals_the_builder():
 
 
 def test_sitting_box_xml_equals_the_builder():
-    sc, st, ids, step = mio.load_xml(os.path.join(SCENES, "sitting-box.xml"))
+    sc, st, ids, step = mio.load_xml(os.path.join(SCENES, "resting_cube.xml"))
     assert ids == ["box", "ground"] and step == 0.1
     assert_scene_equal(sc, S.box_scene())
     np.testing.assert_array_equal(st, S.box_state(pos=(0.0, 0.50001, 0.0)))

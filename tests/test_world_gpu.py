@@ -219,7 +219,7 @@ def test_regress_tool_reproduces_sphere_stack_dat(tmp_path):
     exe = os.path.join(root, "moby_amd", "bin", "moby-hip-regress")
     opts = tmp_path / "stacks.setup"; opts.write_text("-s=0.001\n-mt=0.3\n")
     outp = tmp_path / "out.dat"
-    subprocess.check_call([exe, str(opts), os.path.join(root, "tests", "scenes", "sphere-stack.xml"), str(outp)])
+    subprocess.check_call([exe, str(opts), os.path.join(root, "tests", "scenes", "three_spheres_on_a_plane.xml"), str(outp)])
     lines = outp.read_text().strip().split("\n")
     rows = np.array([[float(x) for x in l.split()] for l in lines[:-1]])
     # rows t = 0 .. 0.299 (the accumulated time 0.30000000000000016 > 0.3 ends the run, just as
@@ -230,7 +230,7 @@ def test_regress_tool_reproduces_sphere_stack_dat(tmp_path):
         if k < 300:
             np.testing.assert_allclose(rows[k], row, rtol=0, atol=1e-6)
     # the same run through the Python mirror prints the same text
-    sc, st, _, _ = mio.load_xml(os.path.join(root, "tests", "scenes", "sphere-stack.xml"))
+    sc, st, _, _ = mio.load_xml(os.path.join(root, "tests", "scenes", "three_spheres_on_a_plane.xml"))
     wb = WorldBatch(sc, st.copy())
     traj = wb.step(1e-3, 299, want_traj=True)
     full = np.zeros(3 * 13)
@@ -360,7 +360,7 @@ def test_cpp_simulator_adapter_example():
     exe = os.path.join(cpp, "example_world")
     subprocess.check_call(["g++", "-std=c++11", os.path.join(cpp, "example_world.cpp"), "-L" + os.path.join(root, "moby_amd"),
                            "-lmoby_hip", "-lmoby_hip_io", "-Wl,-rpath," + os.path.join(root, "moby_amd"), "-o", exe])
-    out = subprocess.check_output([exe, os.path.join(root, "tests", "scenes", "sphere-stack.xml")]).decode()
+    out = subprocess.check_output([exe, os.path.join(root, "tests", "scenes", "three_spheres_on_a_plane.xml")]).decode()
     assert "same=1" in out and "worlds=4 bodies=3" in out and "status=0" in out
     z = float(out.split("top body:")[1].split()[2])
     assert abs(z - 5.0) < 1e-6
