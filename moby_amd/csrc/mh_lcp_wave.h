@@ -429,12 +429,14 @@ MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, LuScratch S,
     lp_tock(LP_GEMV, tg);
     tg = lp_tick();
     const uint64_t bmask = vmask & ~nbmask;
+    // both draws of the iteration (LCP.cpp:147 then :153/:172): every path takes the w draw when a basic
+    // variable exists and then the z draw when a nonbasic one does, in that order
     double wsel = 0.0; int minw = -1;
     if (bmask != 0ull) minw = rand_min_wave(w, bmask, zero_tol, rng, wsel);
+    double zsel = 0.0; int minz = -1;
+    if (k > 0) minz = rand_min_wave(zv, nbmask, zero_tol, rng, zsel);
+    lp_tock(LP_RANDMIN, tg);
     if (minw < 0 || wsel > -zero_tol) {
-      double zsel = 0.0; int minz = -1;
-      if (k > 0) minz = rand_min_wave(zv, nbmask, zero_tol, rng, zsel);
-      lp_tock(LP_RANDMIN, tg);
       if (minz >= 0 && zsel < -zero_tol) {
         nbmask &= ~bit(minz);
         tr.push(-(int32_t)(minz + 1));
@@ -446,14 +448,11 @@ MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, LuScratch S,
     } else {
       const uint64_t nb_new = nbmask | bit(minw);
       tr.push((int32_t)(minw + 1));
-      double zsel = 0.0; int minzv = -1;
-      if (k > 0) minzv = rand_min_wave(zv, nbmask, zero_tol, rng, zsel);
-      lp_tock(LP_RANDMIN, tg);
       nbmask = nb_new;
-      if (minzv >= 0 && zsel < -zero_tol) {
+      if (minz >= 0 && zsel < -zero_tol) {
         // LCP.cpp:176-187: the POSITION found in the old _z indexes the NEW,
         // re-sorted _nonbas
-        const int posz = popc((nb_new & ~bit(minw)) & lanes_below(minzv));
+        const int posz = popc((nb_new & ~bit(minw)) & lanes_below(minz));
         const int idx2 = nth_set_bit(nb_new, posz);
         nbmask &= ~bit(idx2);
         tr.push(-(int32_t)(idx2 + 1));
