@@ -36,6 +36,17 @@ def test_io_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libmoby_hip_io.so does not export %s" % name
 
 
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: both public headers compile as C99 (-pedantic -Werror) and as C++11."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "moby_hip.h"\n#include "moby_hip_io.h"\n'
+                   'int main(void) { mh_scene s; mh_world_aux a; mh_io_scene io; (void)s; (void)a; (void)io; return (int)sizeof(mh_lcp_opts) == 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + inc, "-fsyntax-only", str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I" + inc, "-fsyntax-only", "-x", "c++", str(src)])
+
+
 def test_rand_seed_matches_libc():
     from moby_amd import _lib
     lib = _lib.load()
