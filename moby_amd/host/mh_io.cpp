@@ -154,7 +154,18 @@ int mh_io_load_xml(const char* path, mh_io_scene* out)
       if (a.has("quat")) { const std::vector<double> q = numbers(a.str("quat")); if (q.size() != 4) return fail("RigidBody %s: bad quat", b.id.c_str());
         const double nrm = std::sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]); for (int i = 0; i < 4; i++) b.q[i] = q[i] / nrm; b.rotated = true; }
       else if (a.has("rpy")) { const std::vector<double> r = numbers(a.str("rpy")); if (r.size() != 3) return fail("RigidBody %s: bad rpy", b.id.c_str()); rpy_to_R(r[0], r[1], r[2], b.R); R_to_quat(b.R, b.q); b.rotated = (r[0] != 0 || r[1] != 0 || r[2] != 0); }
-      else if (a.has("aangle")) return fail("RigidBody %s: aangle orientation is not supported", b.id.c_str());
+      else if (a.has("aangle")) {                                    // axis x y z, angle (RigidBody.cpp:213-219)
+        const std::vector<double> r = numbers(a.str("aangle")); if (r.size() != 4) return fail("RigidBody %s: bad aangle", b.id.c_str());
+        const double nrm = std::sqrt(r[0]*r[0] + r[1]*r[1] + r[2]*r[2]);
+        if (!(nrm > 0.0)) return fail("RigidBody %s: aangle with a zero axis", b.id.c_str());
+        const double sh = std::sin(0.5 * r[3]), ch = std::cos(0.5 * r[3]);
+        b.q[0] = r[0] / nrm * sh; b.q[1] = r[1] / nrm * sh; b.q[2] = r[2] / nrm * sh; b.q[3] = ch;
+        const double x = b.q[0], y = b.q[1], z = b.q[2], w = b.q[3];
+        b.R[0] = 1 - 2 * (y*y + z*z); b.R[1] = 2 * (x*y - z*w); b.R[2] = 2 * (x*z + y*w);
+        b.R[3] = 2 * (x*y + z*w); b.R[4] = 1 - 2 * (x*x + z*z); b.R[5] = 2 * (y*z - x*w);
+        b.R[6] = 2 * (x*z - y*w); b.R[7] = 2 * (y*z + x*w); b.R[8] = 1 - 2 * (x*x + y*y);
+        b.rotated = (r[3] != 0.0);
+      }
       if (a.has("linear-velocity")) { const std::vector<double> p = numbers(a.str("linear-velocity")); if (p.size() != 3) return fail("RigidBody %s: bad linear-velocity", b.id.c_str()); for (int i = 0; i < 3; i++) b.v[i] = p[i]; }
       if (a.has("angular-velocity")) { const std::vector<double> p = numbers(a.str("angular-velocity")); if (p.size() != 3) return fail("RigidBody %s: bad angular-velocity", b.id.c_str()); for (int i = 0; i < 3; i++) b.w[i] = p[i]; }
       bool from_prim = false; double m = 0, J[3] = {0, 0, 0};

@@ -79,6 +79,16 @@ def test_reference_example_files_load_to_the_same_scenes():
     np.testing.assert_array_equal(st, S.box_state(w=(0.0, 10.0, 0.0)))
 
 
+def test_axis_angle_orientation(tmp_path):
+    p = tmp_path / "tilted.xml"
+    p.write_text('<XML><MOBY><Sphere id="s" radius="1" mass="1"/><Plane id="p"/><RigidBody id="b" position="0 2 0" aangle="0 0 2 1.5707963267948966">'
+                 '<InertiaFromPrimitive primitive-id="s"/><CollisionGeometry primitive-id="s"/></RigidBody>'
+                 '<RigidBody id="g" enabled="false"><CollisionGeometry primitive-id="p"/></RigidBody>'
+                 '<TimeSteppingSimulator><DynamicBody dynamic-body-id="b"/><DynamicBody dynamic-body-id="g"/></TimeSteppingSimulator></MOBY></XML>')
+    sc, st, ids, _ = mio.load_xml(str(p))
+    np.testing.assert_allclose(st[0, 3:7], [0.0, 0.0, np.sin(np.pi / 4), np.cos(np.pi / 4)], atol=1e-15)
+
+
 def test_unsupported_content_is_an_error(tmp_path):
     p = tmp_path / "joint.xml"
     p.write_text('<XML><MOBY><RCArticulatedBody id="a"/><TimeSteppingSimulator/></MOBY></XML>')
