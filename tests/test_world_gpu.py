@@ -364,3 +364,27 @@ def test_cpp_simulator_adapter_example():
     assert "same=1" in out and "worlds=4 bodies=3" in out and "status=0" in out
     z = float(out.split("top body:")[1].split()[2])
     assert abs(z - 5.0) < 1e-6
+
+
+def test_full_batch_2048_wheels_properties():
+    """BASELINE config 3 at full size (2048 worlds): size-independent properties -- every world stays in its
+    plane, no spoke tip sinks below the slope, the wheels only lose energy (the slope's potential included),
+    and the result of a world does not depend on where it sits in the batch."""
+    B = 2048
+    rates = wheel_rates(B // 2) * 2                      # worlds w and w + 1024 start identically
+    sc = S.rimless_wheel_scene()
+    st0 = S.rimless_wheel_state(rates)
+    wb = WorldBatch(sc, st0.copy())
+    wb.step(1e-3, 1500)
+    s = wb.state
+    assert (wb.aux["status"] == 0).all()
+    np.testing.assert_array_equal(s[:B // 2], s[B // 2:])
+    assert np.abs(s[:, 1]).max() < 1e-8 and np.abs(s[:, 3]).max() < 1e-8 and np.abs(s[:, 5]).max() < 1e-8
+    assert s[:, 2].min() > 0.866025403784439 - 1e-6
+    g = np.array([sc.gravity[0], sc.gravity[1], sc.gravity[2]])
+    def energy(x):
+        ke = 0.5 * (x[:, 7:10] ** 2).sum(axis=1) + 0.5 * (2.0 * x[:, 10] ** 2 + 1.0 * x[:, 11] ** 2 + 2.0 * x[:, 12] ** 2)   # m = 1, J = diag(2,1,2), planar motion
+        return ke - x[:, 0:3] @ g
+    # the initial state slips (v_x = theta_dot (R + h)); the first no-slip impact removes that energy, later ones remove more
+    assert (energy(s) < energy(st0) + 1e-9).all()
+    assert (wb.aux["lcp_solves"] > 500).all()
