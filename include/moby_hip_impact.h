@@ -1,0 +1,76 @@
+/* moby_hip_impact.h -- C ABI of the batched impact handler (seam B2 of SURVEY.md 8b).
+ *
+ * Replaces, for B independent worlds that each hand over an explicit list of contact
+ * constraints,
+ *   ImpactConstraintHandler::process_constraints      include/Moby/ImpactConstraintHandler.h:47,
+ *                                                      src/ImpactConstraintHandler.cpp:75-168
+ *   ::apply_model_to_connected_constraints             src/ImpactConstraintHandler.cpp:530-626
+ *   ::compute_problem_data / add_contact_*_to_Jacobian src/ImpactConstraintHandler.cpp:1817-2166
+ *   ::solve_qp_work / setup_QP (Drumwright-Shell)      src/ImpactConstraintHandlerQP.cpp:94-497
+ *   ::update_from_stacked, apply_restitution,
+ *     update_constraint_velocities_from_impulses        src/ImpactConstraintHandler.cpp:298-491
+ * for islands of ANY size the LCP entry covers (n = 6 nc + nc nk/2 <= MH_LCP_MAX_N_BLOCK): the caller
+ * is Moby's ConstraintSimulator::calc_impacting_unilateral_constraint_forces
+ * (src/ConstraintSimulator.cpp:298-355), which owns the contact list -- so contact generation for
+ * pairs the many-worlds stepper does not cover (box-box, box-sphere: v-clip on a qhull polyhedron)
+ * stays with the caller.  This is the path of BASELINE config 4 (box stacks: nc ~ 200-256, n ~ 2048).
+ *
+ * Scope of this build: free rigid bodies; contacts only (no joint limits, no bilateral rows); every
+ * world's contacts must form ONE island after UnilateralConstraint::determine_connected_constraints
+ * (src/UnilateralConstraint.cpp:940-1194) and use the Drumwright-Shell model (not all mu >= 100); other
+ * worlds are left untouched and flagged MH_WORLD_UNSUPPORTED -- never approximated.
+ */
+#ifndef MOBY_HIP_IMPACT_H
+#define MOBY_HIP_IMPACT_H
+#include "moby_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* one UnilateralConstraint of type eContact, as CollisionDetection::create_contact
+ * (src/CollisionDetection.cpp:57-95) and ConstraintSimulator::preprocess_constraint
+ * (src/ConstraintSimulator.cpp:390-416) leave it */
+typedef struct mh_contact {
+  double point[3];        /* contact_point, world frame                                   */
+  double normal[3];       /* contact_normal, unit, points from body2 toward body1          */
+  int    body1, body2;    /* contact_geom1 / contact_geom2 body: 0..nb-1, anything else = static */
+  double mu_coulomb, mu_viscous, epsilon, compliance;   /* ContactParameters              */
+  int    nk;              /* friction-cone-edges (NK, even, >= 4)                          */
+  int    pad;
+} mh_contact;
+
+/* B worlds x (nb bodies, nc contacts) resident on the GPU, plus what the reference's handler object
+ * keeps between calls: _zlast / _z (ImpactConstraintHandlerQP.cpp:158-162, 233) and the rand() stream.
+ *   create    mass: nb, inertia: nb x 3 body-frame principal moments (shared by all worlds); every
+ *             contact of every call must use the same nk (so that all LCPs have the same n)
+ *   upload    state: B*nb*MH_BODY_STATE, contacts: B*nc (host)
+ *   process   enqueues process_constraints for every world on `stream`; does not synchronise
+ *   download  synchronises; state (velocities changed), impulses B*nc*3 = accumulated (cn, cs, ct) of each
+ *             contact in the caller's contact order, status B (MH_WORLD_* bits, sticky), pivots B
+ *             (sum of LCP::pivots over the call's solves), solves B (LCPs solved in the last call);
+ *             any pointer may be NULL
+ */
+typedef struct mh_impact_batch mh_impact_batch;
+int mh_impact_batch_create(int B, int nb, int nc, int nk, const double* mass, const double* inertia,
+                           mh_impact_batch** out);
+int mh_impact_batch_destroy(mh_impact_batch* ib);
+int mh_impact_batch_upload(mh_impact_batch* ib, const double* state, const mh_contact* contacts);
+int mh_impact_batch_process(mh_impact_batch* ib, void* stream);
+int mh_impact_batch_download(mh_impact_batch* ib, double* state, double* impulses, int* status,
+                             unsigned* pivots, int* solves);
+/* the dimension n of every world's impact LCP, and (debug / parity tests) device -> host copies of the
+ * assembled _MM (B*n*n, column-major) and _qq (B*n) of the last call */
+int mh_impact_batch_lcp_size(const mh_impact_batch* ib);
+int mh_impact_batch_debug_lcp(mh_impact_batch* ib, double* MM, double* qq);
+/* raw device pointers for zero-copy interop */
+int mh_impact_batch_device_ptrs(mh_impact_batch* ib, double** state_dev, mh_contact** contacts_dev);
+
+/* Host convenience: create + upload + process + download + destroy (fresh handler state). */
+int mh_impact_process_batch(int B, int nb, int nc, int nk, const double* mass, const double* inertia,
+                            double* state, const mh_contact* contacts, double* impulses,
+                            int* status, unsigned* pivots, int* solves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

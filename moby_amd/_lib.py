@@ -57,6 +57,16 @@ SYMBOLS = {
     "mh_world_batch_profile": (_i, [_vp, _d, _i, _vp, _i]),
     "mh_world_batch_device_ptrs": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "mh_world_step_batch": (_i, [_vp, _i, _d, _i, _vp, _vp, _vp]),
+    # include/moby_hip_impact.h
+    "mh_impact_batch_create": (_i, [_i, _i, _i, _i, _vp, _vp, ctypes.POINTER(_vp)]),
+    "mh_impact_batch_destroy": (_i, [_vp]),
+    "mh_impact_batch_upload": (_i, [_vp, _vp, _vp]),
+    "mh_impact_batch_process": (_i, [_vp, _vp]),
+    "mh_impact_batch_download": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "mh_impact_batch_lcp_size": (_i, [_vp]),
+    "mh_impact_batch_debug_lcp": (_i, [_vp, _vp, _vp]),
+    "mh_impact_batch_device_ptrs": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "mh_impact_process_batch": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

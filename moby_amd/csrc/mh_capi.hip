@@ -44,11 +44,12 @@ void mh_k_lcp_wave(int B, int n, const double* __restrict__ Mg, int ld, long str
                    const int* __restrict__ zsz_in, int* __restrict__ zsz_out,
                    uint32_t* __restrict__ rngg, int* __restrict__ status, unsigned* __restrict__ pivots_out,
                    int32_t* __restrict__ trace, int trace_cap, int* __restrict__ trace_len,
-                   mh::LcpParams P, mh::Pow10Table p10)
+                   mh::LcpParams P, mh::Pow10Table p10, const int* __restrict__ run_if)
 {
   extern __shared__ double lds[];
   const int b = blockIdx.x;
   if (b >= B) return;
+  if (run_if && run_if[b] == 0) return;   // masked problem: every output of it is left untouched
   const int lane = mh::lane_id();
   double* Ms = lds;
   double* A = Ms + n * n;
@@ -118,11 +119,13 @@ void mh_k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long st
                     const int* __restrict__ zsz_in, int* __restrict__ zsz_out,
                     uint32_t* __restrict__ rngg, int* __restrict__ status, unsigned* __restrict__ pivots_out,
                     int32_t* __restrict__ trace, int trace_cap, int* __restrict__ trace_len,
-                    mh::LcpParams P, mh::Pow10Table p10, double* __restrict__ wsd, int* __restrict__ wsi)
+                    mh::LcpParams P, mh::Pow10Table p10, double* __restrict__ wsd, int* __restrict__ wsi,
+                    const int* __restrict__ run_if)
 {
   namespace bk = mh::blk;
   const int b = blockIdx.x;
   if (b >= B) return;
+  if (run_if && run_if[b] == 0) return;
   const int t = bk::tid();
   bk::Ws W;
   double* wd = wsd + (size_t)b * bk::ws_doubles(n);
@@ -216,6 +219,16 @@ static int lcp_params(int kind, const mh_lcp_opts* o, mh::LcpParams& P)
   return MH_OK;
 }
 
+// the LCP entry with a per-problem mask (run_if[b] == 0: problem b is skipped, outputs untouched) and an optional
+// caller-owned block-solver workspace; the exported entry is the unmasked case
+static int lcp_solve_dev_masked(void* stream, int kind, int B, int n,
+                           const double* M, int ld, long strideM,
+                           const double* q, double* z,
+                           const int* z_size_in, int* z_size_out,
+                           uint32_t* rng, int* status, unsigned* pivots,
+                           int32_t* trace, int trace_cap, int* trace_len,
+                           const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i);
+
 int mh_lcp_solve_batch_dev(void* stream, int kind, int B, int n,
                            const double* M, int ld, long strideM,
                            const double* q, double* z,
@@ -223,6 +236,18 @@ int mh_lcp_solve_batch_dev(void* stream, int kind, int B, int n,
                            uint32_t* rng, int* status, unsigned* pivots,
                            int32_t* trace, int trace_cap, int* trace_len,
                            const mh_lcp_opts* opts)
+{
+  return lcp_solve_dev_masked(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
+                              trace, trace_cap, trace_len, opts, nullptr, nullptr, nullptr);
+}
+
+static int lcp_solve_dev_masked(void* stream, int kind, int B, int n,
+                           const double* M, int ld, long strideM,
+                           const double* q, double* z,
+                           const int* z_size_in, int* z_size_out,
+                           uint32_t* rng, int* status, unsigned* pivots,
+                           int32_t* trace, int trace_cap, int* trace_len,
+                           const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i)
 {
   mh::LcpParams P;
   int rc = lcp_params(kind, opts, P);
@@ -239,14 +264,21 @@ int mh_lcp_solve_batch_dev(void* stream, int kind, int B, int n,
   static const mh::Pow10Table p10 = make_pow10();
   if (n > MH_LCP_MAX_N_WAVE) {
     // workgroup-per-problem solver; its workspace is allocated and freed in stream order
-    double* wsd = nullptr; int* wsi = nullptr;
+    double* wsd = ws_d; int* wsi = ws_i;
+    if (wsd && wsi) {
+      hipLaunchKernelGGL(mh_k_lcp_block, dim3(B), dim3(256), 0, (hipStream_t)stream,
+                         B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
+                         trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if);
+      MH_HIP(hipGetLastError());
+      return MH_OK;
+    }
     const size_t nd = (size_t)B * ((size_t)n * n + 5 * (size_t)n), ni = (size_t)B * 4 * (size_t)n;
     MH_HIP(hipMallocAsync((void**)&wsd, nd * sizeof(double), (hipStream_t)stream));
     hipError_t e = hipMallocAsync((void**)&wsi, ni * sizeof(int), (hipStream_t)stream);
     if (e != hipSuccess) { (void)hipFreeAsync(wsd, (hipStream_t)stream); return fail(MH_ERR_HIP, "workspace allocation failed: %s", hipGetErrorString(e)); }
     hipLaunchKernelGGL(mh_k_lcp_block, dim3(B), dim3(256), 0, (hipStream_t)stream,
                        B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                       trace, trace_cap, trace_len, P, p10, wsd, wsi);
+                       trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if);
     e = hipGetLastError();
     (void)hipFreeAsync(wsd, (hipStream_t)stream); (void)hipFreeAsync(wsi, (hipStream_t)stream);
     if (e != hipSuccess) return fail(MH_ERR_HIP, "block LCP launch failed: %s", hipGetErrorString(e));
@@ -255,7 +287,7 @@ int mh_lcp_solve_batch_dev(void* stream, int kind, int B, int n,
   const size_t lds = (size_t)(2 * n * n + n) * sizeof(double);
   hipLaunchKernelGGL(mh_k_lcp_wave, dim3(B), dim3(64), lds, (hipStream_t)stream,
                      B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                     trace, trace_cap, trace_len, P, p10);
+                     trace, trace_cap, trace_len, P, p10, run_if);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
@@ -628,3 +660,7 @@ int mh_world_step_batch(const mh_scene* scene, int B, double dt, int nsteps,
 }
 
 } // extern "C"
+
+// ===========================================================================
+// batched impact handler (include/moby_hip_impact.h)
+#include "mh_impact.inc"

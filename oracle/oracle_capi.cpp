@@ -164,4 +164,56 @@ int oracle_world_impact_lcp(const mh_scene* sc, double* state, mh_world_aux* aux
   return n;
 }
 
+// ImpactConstraintHandler::process_constraints (ICH:75-168) on an explicit contact list: the checker of
+// mh_impact_batch_process (include/moby_hip_impact.h).  Bodies / buffers of any size; aux carries the rand()
+// stream, status bits, counters and the _z / _zlast sizes.  order_out (nc ints or NULL) receives the island
+// order of the contacts (position in the LCP -> caller index) of the first active island.
+void oracle_impact_process(int nb, int nc, const double* mass, const double* inertia, double* state,
+                           const mh_contact* contacts, double* impulses, mh_world_aux* aux,
+                           double* zlast, double* zbuf, int lcp_cap, int* order_out)
+{
+  World w(nb, mass, reinterpret_cast<const double (*)[3]>(inertia), state, aux, zlast, zbuf, lcp_cap);
+  std::vector<Contact> cs((size_t)nc);
+  for (int i = 0; i < nc; i++) {
+    const mh_contact& m = contacts[i]; Contact& c = cs[i];
+    c.g1 = (m.body1 >= 0 && m.body1 < nb) ? m.body1 : nb; c.g2 = (m.body2 >= 0 && m.body2 < nb) ? m.body2 : nb;
+    c.pair = 0; c.dist = 0.0;
+    c.p = v3(m.point[0], m.point[1], m.point[2]); c.n = v3(m.normal[0], m.normal[1], m.normal[2]);
+    World::orthonormal_basis(c.n, c.s, c.t);
+    c.mu = m.mu_coulomb; c.muv = m.mu_viscous; c.eps = m.epsilon; c.compliance = m.compliance; c.nk = m.nk;
+  }
+  if (order_out) {
+    std::vector<World::Island> isl; w.find_islands(cs, isl);
+    for (int i = 0; i < nc; i++) order_out[i] = -1;
+    if (!isl.empty()) for (size_t k = 0; k < isl[0].contacts.size() && (int)k < nc; k++) order_out[k] = isl[0].contacts[k];
+  }
+  w.handle_impacts(cs);
+  if (impulses) for (int i = 0; i < nc; i++) for (int d = 0; d < 3; d++) impulses[3 * i + d] = cs[i].imp[d];
+}
+
+// _MM / _qq of the island the contact list forms (first island), column-major; returns n or -n if n > cap
+int oracle_impact_lcp(int nb, int nc, const double* mass, const double* inertia, double* state,
+                      const mh_contact* contacts, double* MM, double* qq, int cap)
+{
+  mh_world_aux aux; std::memset(&aux, 0, sizeof(aux));
+  World w(nb, mass, reinterpret_cast<const double (*)[3]>(inertia), state, &aux, nullptr, nullptr, cap);
+  std::vector<Contact> cs((size_t)nc);
+  for (int i = 0; i < nc; i++) {
+    const mh_contact& m = contacts[i]; Contact& c = cs[i];
+    c.g1 = (m.body1 >= 0 && m.body1 < nb) ? m.body1 : nb; c.g2 = (m.body2 >= 0 && m.body2 < nb) ? m.body2 : nb;
+    c.pair = 0; c.dist = 0.0;
+    c.p = v3(m.point[0], m.point[1], m.point[2]); c.n = v3(m.normal[0], m.normal[1], m.normal[2]);
+    World::orthonormal_basis(c.n, c.s, c.t);
+    c.mu = m.mu_coulomb; c.muv = m.mu_viscous; c.eps = m.epsilon; c.compliance = m.compliance; c.nk = m.nk;
+  }
+  std::vector<World::Island> isl; w.find_islands(cs, isl);
+  if (isl.empty()) return 0;
+  World::ProblemData p; w.compute_problem_data(cs, isl[0], p, false);
+  std::vector<double> M, q; int n; w.build_impact_lcp(p, M, q, n);
+  if (n > cap) return -n;
+  std::memcpy(MM, M.data(), sizeof(double) * (size_t)n * n);
+  std::memcpy(qq, q.data(), sizeof(double) * n);
+  return n;
+}
+
 } // extern "C"

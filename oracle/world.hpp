@@ -35,6 +35,7 @@
 #include <vector>
 #include <algorithm>
 #include "../include/moby_hip.h"
+#include "../include/moby_hip_impact.h"
 #include "lcp.hpp"
 
 namespace oracle {
@@ -60,6 +61,7 @@ struct Contact {            // UnilateralConstraint (eContact)
   V3 p, n, s, t;            // contact_point, normal (from g2 toward g1), tangents
   double dist;              // signed_violation
   double mu, muv, eps, compliance; int nk;
+  mutable double imp[3] = {0.0, 0.0, 0.0};   // accumulated (cn, cs, ct): what update_from_stacked adds to contact_impulse (ICH:298-410)
 };
 
 struct PairDist { int pair, a, b; double dist; V3 pa, pb; };  // PairwiseDistInfo (global points)
@@ -73,7 +75,15 @@ class World {
   mh_world_aux* aux;
   int32_t* trace = nullptr; int trace_cap = 0; int trace_len = 0;  // concatenated LCP traces (tests)
 
-  World(const mh_scene* scene, double* state, mh_world_aux* a) : sc(scene), st(state), aux(a) {}
+  // body table and handler storage: the scene's / the aux record's by default; the impact-handler entry
+  // (oracle_impact_process) points them at caller arrays of any size instead
+  int nb_; const double* mass_; const double (*inertia_)[3];
+  double* zlast_; double* zbuf_; int lcp_cap_;
+
+  World(const mh_scene* scene, double* state, mh_world_aux* a) : sc(scene), st(state), aux(a),
+    nb_(scene->nb), mass_(scene->mass), inertia_(scene->inertia), zlast_(a->zlast), zbuf_(a->zbuf), lcp_cap_(MH_LCP_MAX_N_WAVE) {}
+  World(int nb, const double* mass, const double (*inertia)[3], double* state, mh_world_aux* a, double* zlast, double* zbuf, int lcp_cap)
+    : sc(nullptr), st(state), aux(a), nb_(nb), mass_(mass), inertia_(inertia), zlast_(zlast), zbuf_(zbuf), lcp_cap_(lcp_cap) {}
 
   // ---- state access -------------------------------------------------------
   V3 X(int b) const { return v3(st[13*b], st[13*b+1], st[13*b+2]); }
@@ -82,7 +92,7 @@ class World {
   void setX(int b, V3 v) { st[13*b] = v.x; st[13*b+1] = v.y; st[13*b+2] = v.z; }
   void setV(int b, V3 v) { st[13*b+7] = v.x; st[13*b+8] = v.y; st[13*b+9] = v.z; }
   void setW(int b, V3 v) { st[13*b+10] = v.x; st[13*b+11] = v.y; st[13*b+12] = v.z; }
-  bool enabled(int b) const { return b < sc->nb; }
+  bool enabled(int b) const { return b >= 0 && b < nb_; }
   int nbodies_all() const { return sc->nb + (sc->has_ground ? 1 : 0); }
   static int pair_index(int i, int j, int ntot) { // i<j, lexicographic
     return i * ntot - (i * (i + 1)) / 2 + (j - i - 1);
@@ -401,7 +411,7 @@ class World {
   // world-frame inertia R J R^T and its SPD inverse (inverse_SPD, ICH:1607)
   void inertia_world(int b, double Jw[9]) const {
     double R[9]; rot(b, R);
-    const double* J = sc->inertia[b];
+    const double* J = inertia_[b];
     double T[9];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[3*i+j] = R[3*i+j] * J[j];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
@@ -411,7 +421,7 @@ class World {
   }
   // X block of body b: blockdiag(inv(m I3), inv(Jw)), both via Cholesky (inverse_spd)
   void inv_inertia(int b, double& im, double Ji[9]) const {
-    double Mm[1] = { sc->mass[b] };
+    double Mm[1] = { mass_[b] };
     inverse_spd(1, Mm, 1); im = Mm[0];
     double Jw[9]; inertia_world(b, Jw);
     double A[9]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i + 3*j] = Jw[3*i+j];
@@ -455,7 +465,7 @@ class World {
   // UnilateralConstraint::determine_connected_constraints (UC:940-1194), contacts only
   void find_islands(const std::vector<Contact>& cs, std::vector<Island>& out) const {
     out.clear();
-    const int nb = sc->nb;
+    const int nb = nb_;
     std::vector<char> node(nb, 0), done(cs.size(), 0);
     std::vector<std::vector<int> > adj(nb);           // multimap in insertion order
     for (size_t i = 0; i < cs.size(); i++) {
@@ -467,14 +477,18 @@ class World {
     for (int start = 0; start < nb; start++) {
       if (!node[start]) continue;
       Island isl;
+      // The reference pushes a neighbour once per multimap edge while it is not yet *processed* (UC:1104-1109), so a
+      // node reached over k parallel edges is queued k times and a chain of such nodes 4, 16, 64, ... times: the queue
+      // grows exponentially with the height of a box stack (4 contacts per interface).  Only the FIRST pop of a node
+      // adds constraints, and a later pop can only push nodes that were pushed before, so marking nodes when they
+      // are first pushed gives the same island (contact order, body set) in linear time.
       std::vector<int> queue; queue.push_back(start);
-      std::vector<char> processed(nb, 0);
+      std::vector<char> queued(nb, 0); queued[start] = 1;
       for (size_t qi = 0; qi < queue.size(); qi++) {
         const int nd = queue[qi];
         node[nd] = 0;
-        isl.bodies.push_back(nd);                     // NB: may hold duplicates, as the reference's list does
-        processed[nd] = 1;
-        for (int nbr : adj[nd]) if (!processed[nbr]) queue.push_back(nbr);
+        isl.bodies.push_back(nd);
+        for (int nbr : adj[nd]) if (!queued[nbr]) { queued[nbr] = 1; queue.push_back(nbr); }
         for (size_t i = 0; i < cs.size(); i++)
           if (!done[i] && (cs[i].g1 == nd || cs[i].g2 == nd)) { isl.contacts.push_back((int)i); done[i] = 1; }
       }
@@ -646,9 +660,9 @@ class World {
 
   // solve_qp_work's solver chain (ICH-QP:157-233) on the persistent _z / _zlast
   bool solve_impact_lcp(const std::vector<double>& MM, const std::vector<double>& qq, int n, std::vector<double>& zout) {
-    Vec z; z.d.assign(aux->zbuf, aux->zbuf + aux->zbuf_cap); z.len = (unsigned)aux->zbuf_size;
+    Vec z; z.d.assign(zbuf_, zbuf_ + aux->zbuf_cap); z.len = (unsigned)aux->zbuf_size;
     z.resize((unsigned)n);                                   // ICH-QP:158
-    if ((int)z.size() == aux->zlast_size) for (int i = 0; i < n; i++) z[i] = aux->zlast[i];
+    if ((int)z.size() == aux->zlast_size) for (int i = 0; i < n; i++) z[i] = zlast_[i];
     oracle_rand_t rs; std::memcpy(&rs, aux->rng, sizeof(rs));
     LCP lcp; lcp.rng = &rs;
     Trace tr; tr.buf = trace ? trace + trace_len : nullptr; tr.cap = trace ? trace_cap - trace_len : 0; if (tr.cap < 0) tr.cap = 0;
@@ -667,13 +681,13 @@ class World {
     if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; return false; }   // LCPSolverException
     // _zlast = z (ICH-QP:233)
     aux->zlast_size = n;
-    for (int i = 0; i < n; i++) aux->zlast[i] = z[i];
+    for (int i = 0; i < n; i++) zlast_[i] = z[i];
     zout.assign(z.d.begin(), z.d.begin() + n);
     // persist _z's storage: entries [0,n) are rewritten, entries beyond keep what
     // they held (Ravelin keeps a vector's storage when it shrinks).  Growth of
     // the buffer inside lcp_lemke (z.set_zero(2n)) is not modelled: only reads
     // of [0,n) ever happen (documented deviation).
-    for (int i = 0; i < n; i++) aux->zbuf[i] = z[i];
+    for (int i = 0; i < n; i++) zbuf_[i] = z[i];
     if (aux->zbuf_cap < n) aux->zbuf_cap = n;
     aux->zbuf_size = n;
     return true;
@@ -689,6 +703,10 @@ class World {
       std::fill(tmp.begin(), tmp.end(), 0.0);
       for (int j = 0; j < nc; j++) { const double t = (*imp[d])[j]; for (int r = 0; r < ngc; r++) tmp[r] = tmp[r] + t * pd.XJ[d][(size_t)r + (size_t)ngc * j]; }
       if (d == 0) dv = tmp; else for (int r = 0; r < ngc; r++) dv[r] = dv[r] + tmp[r];
+    }
+    for (int j = 0; j < nc; j++) {
+      pd.c[j]->imp[0] += pd.cn[j];
+      if (!pd.XJ[1].empty()) { pd.c[j]->imp[1] += pd.cs[j]; pd.c[j]->imp[2] += pd.ct[j]; }
     }
     for (size_t bi = 0; bi < pd.bodies.size(); bi++) {
       const int b = pd.bodies[bi]; const double* o = &dv[6 * bi];
@@ -837,23 +855,23 @@ class World {
     std::vector<double> MM, qq, z; int n;
     auto solve_and_store = [&]() -> bool {
       build_impact_lcp(pd, MM, qq, n);
-      if (n > MH_LCP_MAX_N_WAVE) { aux->status |= MH_WORLD_UNSUPPORTED; return false; }
+      if (n > lcp_cap_) { aux->status |= MH_WORLD_UNSUPPORTED; return false; }
       if (!solve_impact_lcp(MM, qq, n, z)) return false;
       // repack z in the epd layout (ICH-QP:236-250): here identical to the first 5 nc entries
-      for (int i = 0; i < 5 * nc; i++) aux->zbuf[i] = z[i];
+      for (int i = 0; i < 5 * nc; i++) zbuf_[i] = z[i];
       aux->zbuf_size = 5 * nc;
       if (aux->zbuf_cap < 5 * nc) aux->zbuf_cap = 5 * nc;
       return true;
     };
     if (!solve_and_store()) return;
-    std::vector<double> zepd(aux->zbuf, aux->zbuf + 5 * nc);
+    std::vector<double> zepd(zbuf_, zbuf_ + 5 * nc);
     from_stacked_qp(pd, zepd); apply_impulses(pd);                  // ICH:569
     update_constraint_vels(pd);                                      // ICH:572
     double minv = *std::min_element(pd.Cv[0].begin(), pd.Cv[0].end());   // ICH:575
     // apply_restitution(_epd, _z) (ICH:470-491): scales z[cn] only
     bool changed = false;
     for (int i = 0; i < nc; i++) { zepd[i] = zepd[i] * pd.c[i]->eps; if (!changed && zepd[i] > NEAR_ZERO) changed = true; }
-    for (int i = 0; i < nc; i++) aux->zbuf[i] = zepd[i];
+    for (int i = 0; i < nc; i++) zbuf_[i] = zepd[i];
     if (changed) {
       from_stacked_qp(pd, zepd); apply_impulses(pd);                // ICH:581
       update_constraint_vels(pd);
@@ -861,7 +879,7 @@ class World {
       if (minv_plus < 0.0 && minv_plus < minv - NEAR_ZERO) {        // ICH:591
         // second solve reuses the problem data with the updated C*v vectors
         if (!solve_and_store()) return;
-        std::vector<double> z2(aux->zbuf, aux->zbuf + 5 * nc);
+        std::vector<double> z2(zbuf_, zbuf_ + 5 * nc);
         from_stacked_qp(pd, z2); apply_impulses(pd);                // ICH:600
       }
     }

@@ -120,3 +120,32 @@ Oracle.world_step = oracle_world_step
 Oracle.world_step_batch = oracle_world_step_batch
 Oracle.world_impact_lcp = oracle_world_impact_lcp
 Oracle.world_handle_impacts = oracle_world_handle_impacts
+
+
+def oracle_impact_process(self, nb, mass, inertia, state, contacts, aux, zlast, zbuf, lcp_cap):
+    """process_constraints on ONE world's contact list (state (nb*13,), contacts structured (nc,), aux 1-element
+    structured array; zlast / zbuf: lcp_cap doubles each), in place.  Returns (impulses (nc, 3), island order (nc,))."""
+    nc = len(contacts)
+    imp = np.zeros((nc, 3)); order = np.zeros(nc, dtype=np.int32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    m = np.ascontiguousarray(mass, dtype=np.float64); J = np.ascontiguousarray(inertia, dtype=np.float64)
+    self.lib.oracle_impact_process.restype = None
+    self.lib.oracle_impact_process(int(nb), int(nc), P(m), P(J), P(state), P(contacts), P(imp), P(aux), P(zlast), P(zbuf),
+                                   int(lcp_cap), P(order))
+    return imp, order
+
+
+def oracle_impact_lcp(self, nb, mass, inertia, state, contacts, cap):
+    nc = len(contacts)
+    MM = np.zeros(cap * cap); qq = np.zeros(cap)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    m = np.ascontiguousarray(mass, dtype=np.float64); J = np.ascontiguousarray(inertia, dtype=np.float64)
+    self.lib.oracle_impact_lcp.restype = ctypes.c_int
+    n = self.lib.oracle_impact_lcp(int(nb), int(nc), P(m), P(J), P(state), P(contacts), P(MM), P(qq), int(cap))
+    if n <= 0:
+        return n, None, None
+    return n, MM[:n * n].reshape(n, n).T.copy(), qq[:n].copy()
+
+
+Oracle.impact_process = oracle_impact_process
+Oracle.impact_lcp = oracle_impact_lcp

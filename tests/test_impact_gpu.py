@@ -1,0 +1,167 @@
+"""GPU parity of the batched impact handler (include/moby_hip_impact.h, through the C ABI) against the oracle's
+restatement of ImpactConstraintHandler::process_constraints: bit-exact states, impulses, pivot counts, status bits,
+rand() streams (via the pivot counts of the following call) and assembled _MM / _qq."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from moby_amd import _lib, impact as I, scene as S
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_batch(oracle, nb, mass, J, state, cs, n, aux, zl, zb):
+    B = state.shape[0]
+    imp = np.zeros((B, cs.shape[1], 3))
+    piv0 = aux["lcp_pivots"].copy(); sol0 = aux["lcp_solves"].copy()
+    for w in range(B):
+        imp[w], _ = oracle.impact_process(nb, mass, J, state[w], cs[w], aux[w:w + 1], zl[w], zb[w], n)
+    return imp, (aux["lcp_pivots"] - piv0).astype(np.uint32), (aux["lcp_solves"] - sol0).astype(np.int32)
+
+
+def assert_same(r, st_o, imp_o, piv_o, sol_o, aux):
+    assert np.array_equal(r["state"], st_o), "max |dv| = %.3e" % np.abs(r["state"] - st_o).max()
+    assert np.array_equal(r["impulses"], imp_o)
+    assert np.array_equal(r["status"], aux["status"])
+    assert np.array_equal(r["pivots"], piv_o)
+    assert np.array_equal(r["solves"], sol_o)
+
+
+@pytest.mark.parametrize("nbx,B,eps,mu", [(1, 4, 0.0, 1e-4), (2, 4, 0.0, 1e-4), (3, 4, 0.0, 0.3), (5, 3, 0.0, 1e-4),
+                                          (2, 4, 0.5, 0.3), (4, 3, 0.3, 0.5)])
+def test_box_stack_calls_match_oracle(oracle, nbx, B, eps, mu):
+    """Cold call, then two warm-started calls (gravity acts for another dt on the same contacts).  eps > 0 exercises
+    apply_restitution and the second solve (ICH:575-600); n = 32 nbx crosses the wave / block solver boundary at 64."""
+    mass, J, st, cs = I.box_stack(nbx, B=B, epsilon=eps, mu=mu)
+    nc = 4 * nbx; n = I.lcp_size(nc, 4)
+    ib = I.ImpactBatch(B, nbx, nc, 4, mass, J)
+    assert ib.n == n
+    aux = S.new_aux(B); zl = np.zeros((B, n)); zb = np.zeros((B, n))
+    st_g = st.copy(); st_o = st.copy()
+    second = 0
+    for call in range(3):
+        r = ib.process(st_g, cs)
+        if call == 0 and eps == 0.0:
+            MMg, qqg = ib.debug_lcp()
+            for w in range(min(B, 2)):
+                nn, MMo, qqo = oracle.impact_lcp(nbx, mass, J, st_o[w].copy(), cs[w], n)
+                assert nn == n and np.array_equal(MMo, MMg[w]) and np.array_equal(qqo, qqg[w])
+        imp_o, piv_o, sol_o = oracle_batch(oracle, nbx, mass, J, st_o, cs, n, aux, zl, zb)
+        assert_same(r, st_o, imp_o, piv_o, sol_o, aux)
+        assert (r["status"] & ~S.MH_WORLD_IMPACT_TOL == 0).all()
+        second += int((r["solves"] == 2).sum())
+        st_g = r["state"].copy()
+        for a in (st_g, st_o):
+            a.reshape(B, nbx, 13)[:, :, 8] += -9.81e-3
+    if eps > 0.0:
+        assert second > 0          # the restitution branch with a second solve was really taken
+    ib.close()
+
+
+def random_island(rng, nb, nc, static_frac=0.3):
+    cs = np.zeros(nc, dtype=I.CONTACT_DTYPE)
+    for i in range(nc):
+        if i < nb - 1:
+            a, b = i + 1, int(rng.integers(0, i + 1))
+        else:
+            a = int(rng.integers(0, nb)); b = nb if rng.random() < static_frac else int(rng.integers(0, nb))
+            while b == a:
+                b = int(rng.integers(0, nb))
+        if rng.random() < 0.5:
+            a, b = b, a
+        cs["body1"][i], cs["body2"][i] = a, b
+    cs = cs[rng.permutation(nc)]
+    nrm = rng.standard_normal((nc, 3)); cs["normal"] = nrm / np.linalg.norm(nrm, axis=1)[:, None]
+    cs["point"] = rng.standard_normal((nc, 3))
+    cs["mu_coulomb"] = rng.uniform(0.0, 1.0, nc); cs["mu_viscous"] = rng.uniform(0.0, 0.1, nc) * (rng.random(nc) < 0.3)
+    cs["epsilon"] = rng.uniform(0.0, 0.8, nc) * (rng.random(nc) < 0.5); cs["compliance"] = 1e-6 * (rng.random(nc) < 0.2)
+    return cs
+
+
+@pytest.mark.parametrize("seed,nb,nc,nk", [(0, 2, 3, 4), (1, 3, 6, 4), (2, 4, 7, 8), (3, 5, 10, 4), (4, 3, 12, 6), (5, 6, 14, 4)])
+def test_random_contact_graphs_match_oracle(oracle, seed, nb, nc, nk):
+    """Random single-island multigraphs (permuted contact lists, static and dynamic pairs, arbitrary normals, rotated
+    bodies, mixed parameters): island order, Jacobian rows, X blocks and the whole solve chain."""
+    rng = np.random.default_rng(seed)
+    B = 4
+    n = I.lcp_size(nc, nk)
+    mass = rng.uniform(0.5, 3.0, nb); J = rng.uniform(0.2, 2.0, (nb, 3))
+    cs = np.stack([random_island(rng, nb, nc) for _ in range(B)]); cs["nk"] = nk
+    st = np.zeros((B, nb, 13)); st[:, :, 0:3] = rng.standard_normal((B, nb, 3))
+    q = rng.standard_normal((B, nb, 4)); st[:, :, 3:7] = q / np.linalg.norm(q, axis=2)[:, :, None]
+    st[:, :, 7:13] = rng.standard_normal((B, nb, 6))
+    st = st.reshape(B, -1)
+    ib = I.ImpactBatch(B, nb, nc, nk, mass, J)
+    aux = S.new_aux(B); zl = np.zeros((B, n)); zb = np.zeros((B, n))
+    st_o = st.copy(); st_g = st.copy()
+    for call in range(2):
+        r = ib.process(st_g, cs)
+        imp_o, piv_o, sol_o = oracle_batch(oracle, nb, mass, J, st_o, cs, n, aux, zl, zb)
+        assert_same(r, st_o, imp_o, piv_o, sol_o, aux)
+        st_g = r["state"].copy()
+        st_g.reshape(B, nb, 13)[:, :, 7:13] += 0.1 * rng.standard_normal((B, nb, 6)); st_o[:] = st_g
+    assert (r["solves"] >= 1).any()
+    ib.close()
+
+
+def test_unsupported_and_idle_worlds_are_left_untouched(oracle):
+    """World 0: two islands; world 1: every mu >= 100 (no-slip model); world 2: nothing impacting; world 3: ordinary."""
+    nbx, B = 2, 4
+    mass, J, st, cs = I.box_stack(nbx, B=B, perturb=False)
+    cs["body2"][0, 4:] = 99                              # box 1 now rests on something static: two islands
+    cs["mu_coulomb"][1] = 100.0
+    st.reshape(B, nbx, 13)[2, :, 8] = 0.5                # separating
+    r = I.ImpactBatch(B, nbx, 8, 4, mass, J).process(st, cs)
+    assert list(r["status"]) == [S.MH_WORLD_UNSUPPORTED, S.MH_WORLD_UNSUPPORTED, 0, 0]
+    assert np.array_equal(r["state"][:3], st[:3]) and not np.array_equal(r["state"][3], st[3])
+    assert list(r["solves"]) == [0, 0, 0, 1]
+    assert np.abs(r["impulses"][:3]).max() == 0.0 and r["impulses"][3, :, 0].sum() > 0
+    # the oracle agrees on what it can express: idle world untouched, ordinary world identical
+    n = I.lcp_size(8, 4)
+    for w in (2, 3):
+        aux = S.new_aux(1); s = st[w].copy()
+        oracle.impact_process(nbx, mass, J, s, cs[w], aux, np.zeros(n), np.zeros(n), n)
+        assert np.array_equal(s, r["state"][w]) and aux["status"][0] == r["status"][w]
+    # ... and flags the no-slip world the same way (its no-slip path keeps at most MH_NOSLIP_MAX contacts: here it runs)
+    aux = S.new_aux(1); s = st[0].copy()
+    oracle.impact_process(nbx, mass, J, s, cs[0], aux, np.zeros(n), np.zeros(n), n)
+    assert not np.array_equal(s, st[0])                  # the reference handles islands one by one; this entry does not (flagged)
+
+
+def test_upload_rejects_malformed_contacts():
+    lib = _lib.load()
+    mass, J, st, cs = I.box_stack(2, B=1)
+    ib = I.ImpactBatch(1, 2, 8, 4, mass, J)
+    for field, value in (("nk", 6), ("body2", 0)):
+        bad = cs.copy(); bad[field][0, 0] = value        # nk differs from the batch's; body1 == body2
+        assert lib.mh_impact_batch_upload(ib.handle, st.ctypes.data, bad.ctypes.data) == _lib.MH_ERR_INVALID_ARG
+    bad = cs.copy(); bad["normal"][0, 3] = (0.0, 0.0, 0.0)
+    assert lib.mh_impact_batch_upload(ib.handle, st.ctypes.data, bad.ctypes.data) == _lib.MH_ERR_INVALID_ARG
+    bad = cs.copy(); bad["body1"][0, 0] = -1                # body2 of contact 0 is the ground already: static-static
+    assert lib.mh_impact_batch_upload(ib.handle, st.ctypes.data, bad.ctypes.data) == _lib.MH_ERR_INVALID_ARG
+    ib.close()
+
+
+def test_host_convenience_entry_equals_object_api():
+    lib = _lib.load()
+    B, nbx = 3, 3
+    mass, J, st, cs = I.box_stack(nbx, B=B)
+    r = I.ImpactBatch(B, nbx, 12, 4, mass, J).process(st, cs)
+    s2 = st.copy(); imp = np.zeros((B, 12, 3)); status = np.zeros(B, dtype=np.int32); piv = np.zeros(B, dtype=np.uint32)
+    sol = np.zeros(B, dtype=np.int32)
+    _lib.check(lib.mh_impact_process_batch(B, nbx, 12, 4, mass.ctypes.data, J.ctypes.data, s2.ctypes.data, cs.ctypes.data,
+                                           imp.ctypes.data, status.ctypes.data, piv.ctypes.data, sol.ctypes.data))
+    assert np.array_equal(s2, r["state"]) and np.array_equal(imp, r["impulses"]) and np.array_equal(piv, r["pivots"])
+
+
+def test_tall_stack_properties_at_scale():
+    """64 worlds x 8 boxes (n = 256, block solver, Lemke fallback): every box at rest after the impact, normal impulses
+    of the ground interface carry the stack's momentum, identical worlds give identical results in any slot."""
+    nbx, B = 8, 64
+    mass, J, st, cs = I.box_stack(nbx, B=B, mu=0.0, perturb=False)
+    r = I.ImpactBatch(B, nbx, 32, 4, mass, J).process(st, cs)
+    assert (r["status"] == 0).all() and (r["solves"] == 1).all()
+    assert np.abs(r["state"].reshape(B, nbx, 13)[:, :, 7:13]).max() < 1e-9
+    np.testing.assert_allclose(r["impulses"][:, :4, 0].sum(axis=1), 9.81e-3 * mass.sum(), rtol=1e-8)
+    assert (r["state"] == r["state"][0]).all() and (r["pivots"] == r["pivots"][0]).all()
