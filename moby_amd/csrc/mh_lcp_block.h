@@ -176,6 +176,15 @@ __shared__ double s_panel[PANEL_CAP];
 constexpr int RHS_CAP = 1024;            // the right-hand side stays in LDS for the whole factorisation when k fits
 __shared__ double s_b[RHS_CAP];
 __shared__ int s_ipiv[NB];
+// Exact skips of the trailing update.  a <- a - l*u leaves a as it is (up to the sign of a zero) when l == 0 or
+// u == 0 and the other factor is finite.  The matrices this solver sees are mostly zeros -- Lemke's basis is identity
+// columns plus a few columns of M, and the impact LCP's M is block-sparse (two contacts couple only through a shared
+// body) -- so per panel: rows whose NB multipliers are all zero and columns whose NB pivot-row entries are all zero
+// are neither read nor written.  Flags: [0] every multiplier of the panel below its diagonal block is zero,
+// [1] ... is finite, [2 + parity] every pivot-row entry of the current column chunk is finite.
+__shared__ int s_sk[4];
+__shared__ unsigned char s_nz[UCH];
+MH_DEV bool finite_d(double x) { return fabs(x) <= 1.7976931348623157e308; }
 
 MH_DEV int lu_solve(int k, double* A, double* b) {
   const int t = tid();
@@ -270,12 +279,27 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
     bp_tock(BP_SWAP, tp); tp = bp_tick();
     const int c0 = j0 + nbk;                               // first trailing column
     if (c0 >= k) break;
+    if (t == 0) { s_sk[0] = 1; s_sk[1] = 1; s_sk[2] = 1; s_sk[3] = 1; }
+    sync();
+    { bool z = true, f = true;
+      for (int s2 = 0; s2 < nbk; s2++)
+        for (int r = c0 + t; r < k; r += T) {
+          const double l = in_lds ? s_panel[(r - j0) + R * s2] : A[r + (size_t)k * (j0 + s2)];
+          if (l != 0.0) z = false;
+          if (!finite_d(l)) f = false;
+        }
+      if (!z) s_sk[0] = 0;
+      if (!f) s_sk[1] = 0; }
+    sync();
+    const bool Lz = s_sk[0] != 0, Lfin = s_sk[1] != 0;
+    int par = 0;
     // ---- trailing columns, UCH at a time ----
-    for (int cb = c0; cb < k; cb += UCH) {
+    for (int cb = c0; cb < k; cb += UCH, par ^= 1) {
       const int ncb = (k - cb < UCH) ? k - cb : UCH;
       // pivot-row block U12[s][c] = A[j0+s][c] - sum_{s' < s} L[j0+s][j0+s'] * U12[s'][c]  (updates of steps j0.. in order)
       for (int c = t; c < ncb; c += T) {
         double u[NB];
+        bool nz = false, fin = true;
 #pragma unroll
         for (int s2 = 0; s2 < NB; s2++) {
           if (s2 < nbk) {
@@ -285,10 +309,17 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
             u[s2] = a;
             A[(j0 + s2) + (size_t)k * (cb + c)] = a;
             s_u[s2][c] = a;
+            nz = nz || (a != 0.0);
+            fin = fin && finite_d(a);
           }
         }
+        s_nz[c] = (nz || !Lfin) ? 1 : 0;                   // 0: this column's update is an exact no-op
+        if (!fin) s_sk[2 + par] = 0;
       }
       sync();
+      const bool Ufin = s_sk[2 + par] != 0;
+      if (t == 0) s_sk[2 + (par ^ 1)] = 1;                 // re-arm the other chunk's flag (idle during this phase)
+      if (!(Lz && Ufin))
       // A22[r][c] -= L[r][j0+s] * U12[s][c], s ascending; one row per thread, its multipliers in registers
       // thread (tr, tc): rows c0 + tr + 64 i, columns tc, tc + 4, ... of the chunk -- a wave still reads 64
       // consecutive rows of a column; four columns are in flight per thread before any is used
@@ -297,14 +328,20 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
           double l[NB];
 #pragma unroll
           for (int s2 = 0; s2 < NB; s2++) l[s2] = (s2 < nbk) ? (in_lds ? s_panel[(r - j0) + R * s2] : A[r + (size_t)k * (j0 + s2)]) : 0.0;
-          for (int cq = tc; cq < ncb; cq += 16) {
-            double a[4];
+          if (Ufin) {
+            bool lz = true;
 #pragma unroll
-            for (int u4 = 0; u4 < 4; u4++) { const int c = cq + 4 * u4; a[u4] = (c < ncb) ? A[r + (size_t)k * (cb + c)] : 0.0; }
+            for (int s2 = 0; s2 < NB; s2++) lz = lz && (l[s2] == 0.0);
+            if (lz) continue;                              // this row's multipliers are all zero
+          }
+          for (int cq = tc; cq < ncb; cq += 16) {
+            double a[4]; bool go[4];
+#pragma unroll
+            for (int u4 = 0; u4 < 4; u4++) { const int c = cq + 4 * u4; go[u4] = (c < ncb) && s_nz[c]; a[u4] = go[u4] ? A[r + (size_t)k * (cb + c)] : 0.0; }
 #pragma unroll
             for (int u4 = 0; u4 < 4; u4++) {
               const int c = cq + 4 * u4;
-              if (c < ncb) {
+              if (go[u4]) {
                 double v = a[u4];
 #pragma unroll
                 for (int s2 = 0; s2 < NB; s2++) if (s2 < nbk) v = v - l[s2] * s_u[s2][c];
