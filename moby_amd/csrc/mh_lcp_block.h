@@ -167,6 +167,10 @@ MH_DEV int build_list(int n, const Ws& W) {
 //   * row swaps outside the panel are plain global-memory swaps off the critical path.
 constexpr int NB = 8;
 constexpr int UCH = 256;                 // columns of the pivot-row block staged in LDS at a time
+#ifndef MH_BLK_TCOLS
+#define MH_BLK_TCOLS 8
+#endif
+constexpr int TCOLS = MH_BLK_TCOLS;      // trailing-update columns a thread has in flight
 constexpr int PANEL_CAP = 3584;          // doubles (28 KB): rows x NB of the panel held in LDS
 __shared__ double s_u[NB][UCH];
 __shared__ int s_li[UCH];
@@ -185,6 +189,45 @@ __shared__ int s_ipiv[NB];
 __shared__ int s_sk[4];
 __shared__ unsigned char s_nz[UCH];
 MH_DEV bool finite_d(double x) { return fabs(x) <= 1.7976931348623157e308; }
+
+// A22[r][c] -= L[r][j0+s] * U12[s][c], s ascending; one row per thread, its multipliers in registers.
+// Thread (tr, tc): rows c0 + tr + 64 i, columns tc, tc + 4, ... of the chunk -- a wave still reads 64 consecutive
+// rows of a column; TCOLS columns are in flight per thread before any is used.  FULL (a whole panel of NB columns,
+// every panel but the last) and INLDS are compile-time so that the NB updates of an element are straight-line code:
+// with the `s < nbk` tests left in, every update was a ds_read + s_waitcnt + branch chain.  (Tried on top: requesting the
+// next TCOLS columns before updating the current ones -- 3 % slower; TCOLS 4 / 8 / 16 -- within 1 %.)
+template <bool FULL, bool INLDS>
+MH_DEV void trail_update(double* __restrict__ A, int k, int j0, int c0, int cb, int ncb, int nbk, int R, bool Ufin)
+{
+  const int t = tid();
+  const int tr = t & 63, tc = t >> 6;
+  for (int r = c0 + tr; r < k; r += 64) {
+    double l[NB];
+#pragma unroll
+    for (int s2 = 0; s2 < NB; s2++) l[s2] = (FULL || s2 < nbk) ? (INLDS ? s_panel[(r - j0) + R * s2] : A[r + (size_t)k * (j0 + s2)]) : 0.0;
+    if (Ufin) {
+      bool lz = true;
+#pragma unroll
+      for (int s2 = 0; s2 < NB; s2++) lz = lz && (l[s2] == 0.0);
+      if (lz) continue;                              // this row's multipliers are all zero
+    }
+    for (int cq = tc; cq < ncb; cq += 4 * TCOLS) {
+      double a[TCOLS]; bool go[TCOLS];
+#pragma unroll
+      for (int u4 = 0; u4 < TCOLS; u4++) { const int c = cq + 4 * u4; go[u4] = (c < ncb) && s_nz[c]; a[u4] = go[u4] ? A[r + (size_t)k * (cb + c)] : 0.0; }
+#pragma unroll
+      for (int u4 = 0; u4 < TCOLS; u4++) {
+        const int c = cq + 4 * u4;
+        if (go[u4]) {
+          double v = a[u4];
+#pragma unroll
+          for (int s2 = 0; s2 < NB; s2++) if (FULL || s2 < nbk) v = v - l[s2] * s_u[s2][c];
+          A[r + (size_t)k * (cb + c)] = v;
+        }
+      }
+    }
+  }
+}
 
 MH_DEV int lu_solve(int k, double* A, double* b) {
   const int t = tid();
@@ -227,9 +270,12 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
             const double piv = s_panel[jj + R * jj];
             const bool big = fabs(piv) >= MH_SFMIN;
             const double rcp = 1.0 / piv;
-            for (int r = jj + 1 + lane; r < R; r += 64) { double l = s_panel[r + R * jj]; l = big ? l * rcp : l / piv; s_panel[r + R * jj] = l; }
+            bool lfin = true;
+            for (int r = jj + 1 + lane; r < R; r += 64) { double l = s_panel[r + R * jj]; l = big ? l * rcp : l / piv; s_panel[r + R * jj] = l; lfin = lfin && finite_d(l); }
             wsync();
+            const bool all_fin = mh::ballot(!lfin) == 0ull;
             for (int c = jj + 1; c < nbk; c++) { const double u = s_panel[jj + R * c];
+              if (u == 0.0 && all_fin) continue;              // a - l*0 = a: exact no-op (see s_sk above)
               for (int r = jj + 1 + lane; r < R; r += 64) s_panel[r + R * c] = s_panel[r + R * c] - s_panel[r + R * jj] * u; }
             wsync();
           }
@@ -302,7 +348,7 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
         bool nz = false, fin = true;
 #pragma unroll
         for (int s2 = 0; s2 < NB; s2++) {
-          if (s2 < nbk) {
+          {                                                // nbk == NB here (see trail_update)
             double a = A[(j0 + s2) + (size_t)k * (cb + c)];
 #pragma unroll
             for (int s1 = 0; s1 < NB; s1++) if (s1 < s2) a = a - (in_lds ? s_panel[s2 + R * s1] : A[(j0 + s2) + (size_t)k * (j0 + s1)]) * u[s1];
@@ -319,37 +365,10 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
       sync();
       const bool Ufin = s_sk[2 + par] != 0;
       if (t == 0) s_sk[2 + (par ^ 1)] = 1;                 // re-arm the other chunk's flag (idle during this phase)
-      if (!(Lz && Ufin))
-      // A22[r][c] -= L[r][j0+s] * U12[s][c], s ascending; one row per thread, its multipliers in registers
-      // thread (tr, tc): rows c0 + tr + 64 i, columns tc, tc + 4, ... of the chunk -- a wave still reads 64
-      // consecutive rows of a column; four columns are in flight per thread before any is used
-      { const int tr = t & 63, tc = t >> 6;
-        for (int r = c0 + tr; r < k; r += 64) {
-          double l[NB];
-#pragma unroll
-          for (int s2 = 0; s2 < NB; s2++) l[s2] = (s2 < nbk) ? (in_lds ? s_panel[(r - j0) + R * s2] : A[r + (size_t)k * (j0 + s2)]) : 0.0;
-          if (Ufin) {
-            bool lz = true;
-#pragma unroll
-            for (int s2 = 0; s2 < NB; s2++) lz = lz && (l[s2] == 0.0);
-            if (lz) continue;                              // this row's multipliers are all zero
-          }
-          for (int cq = tc; cq < ncb; cq += 16) {
-            double a[4]; bool go[4];
-#pragma unroll
-            for (int u4 = 0; u4 < 4; u4++) { const int c = cq + 4 * u4; go[u4] = (c < ncb) && s_nz[c]; a[u4] = go[u4] ? A[r + (size_t)k * (cb + c)] : 0.0; }
-#pragma unroll
-            for (int u4 = 0; u4 < 4; u4++) {
-              const int c = cq + 4 * u4;
-              if (go[u4]) {
-                double v = a[u4];
-#pragma unroll
-                for (int s2 = 0; s2 < NB; s2++) if (s2 < nbk) v = v - l[s2] * s_u[s2][c];
-                A[r + (size_t)k * (cb + c)] = v;
-              }
-            }
-          }
-        } }
+      if (!(Lz && Ufin)) {
+        // a trailing matrix exists only behind a full panel (nbk < NB is the last panel, c0 == k)
+        if (in_lds) trail_update<true, true>(A, k, j0, c0, cb, ncb, nbk, R, Ufin); else trail_update<true, false>(A, k, j0, c0, cb, ncb, nbk, R, Ufin);
+      }
       sync();
     }
     bp_tock(BP_TRAIL, tp);
@@ -595,6 +614,7 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
     if (leaving < n) { entering = n + leaving; for (int p = t; p < n; p += T) W.d[p] = (p == leaving) ? -1.0 : 0.0; }
     else { entering = leaving - n; for (int p = t; p < n; p += T) W.d[p] = M.at(p, entering, lam); }
     // Al = Bl from the basis description; solve Al d = Be
+    const unsigned long long tq = bp_tick();
     const long nn = (long)n * n;
     for (long e = t; e < nn; e += T) {
       const int r = (int)(e % n), p = (int)(e / n);
@@ -606,6 +626,7 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
       W.A[e] = a;
     }
     sync();
+    bp_tock(BP_GATHER, tq);
     if (lu_solve(n, W.A, W.d) != 0) return false;                   // singular basis (:840-850), size stays 2n
     double th = inf(); int any = 0;
     for (int p = t; p < n; p += T) { const double dp = W.d[p]; if (dp > PIV_TOL) { any = 1; const double r = (W.x[p] + zero_tol) / dp; th = (r < th) ? r : th; } }
