@@ -165,3 +165,19 @@ def test_tall_stack_properties_at_scale():
     assert np.abs(r["state"].reshape(B, nbx, 13)[:, :, 7:13]).max() < 1e-9
     np.testing.assert_allclose(r["impulses"][:, :4, 0].sum(axis=1), 9.81e-3 * mass.sum(), rtol=1e-8)
     assert (r["state"] == r["state"][0]).all() and (r["pivots"] == r["pivots"][0]).all()
+
+
+def test_cpp_impact_handler_adapter_example():
+    """moby_amd/cpp/MobyHipImpactHandler.h (the process_constraints-shaped C++ adapter, plain g++): a 3-box stack comes
+    to rest, the ground contacts carry the stack's momentum, both worlds of the batch agree."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = os.path.join(root, "moby_amd", "cpp")
+    exe = os.path.join(cpp, "example_impact")
+    subprocess.check_call(["g++", "-std=c++11", os.path.join(cpp, "example_impact.cpp"), "-L" + os.path.join(root, "moby_amd"),
+                           "-lmoby_hip", "-Wl,-rpath," + os.path.join(root, "moby_amd"), "-o", exe])
+    out = subprocess.check_output([exe, "3"]).decode()
+    assert "n=96 status=0 solves=1" in out and "same=1" in out
+    assert float(out.split("vmax=")[1].split()[0]) < 1e-9
+    assert abs(float(out.split("weight_dt=")[1].split()[0]) - 1.0) < 1e-9
