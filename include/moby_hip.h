@@ -198,7 +198,8 @@ typedef struct mh_world_aux {
 
 /* test hooks: key 1 = edge of the LDS-resident LU block of the world kernel (0..64, clamped to what the
  * kernel variant holds: 12 or 16; 0 sends every LU factorisation through the HBM workspace path) */
-int  mh_debug_set(int key, int value);
+int  mh_debug_set(int key, int value);   /* key 2: block LCP solver (n > 64) thread geometry -- 0 choose by n and B,
+                                            1 = 256 threads per problem, 2 = 1024 threads per problem */
 void mh_scene_defaults(mh_scene* s);   /* zero + the reference's default tolerances */
 void mh_world_aux_init(mh_world_aux* a, uint32_t seed);
 

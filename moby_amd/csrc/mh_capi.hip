@@ -8,7 +8,19 @@
 #include <vector>
 #include "../../include/moby_hip.h"
 #include "mh_lcp_wave.h"
+// the workgroup-per-problem solver in two thread geometries: 256 threads (two problems per CU: throughput when the
+// batch is larger than the chip) and 1024 threads (one problem per CU with 16 waves to hide its round trips:
+// 1.2x / 1.4x faster per problem at n = 256 / 512, slower at n = 128)
+#define MH_BLK_NS blk
+#define MH_BLK_T 256
 #include "mh_lcp_block.h"
+#undef MH_BLK_NS
+#undef MH_BLK_T
+#define MH_BLK_NS blkw
+#define MH_BLK_T 1024
+#include "mh_lcp_block.h"
+#undef MH_BLK_NS
+#undef MH_BLK_T
 
 namespace {
 
@@ -111,56 +123,6 @@ void mh_k_lcp_wave(int B, int n, const double* __restrict__ Mg, int ld, long str
 }
 
 // ---------------------------------------------------------------------------
-// n > 64: one 256-thread workgroup per LCP, M read in place from HBM, everything else in a
-// per-problem HBM workspace (mh_lcp_block.h).
-__global__ __launch_bounds__(256)
-void mh_k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strideM,
-                    const double* __restrict__ qg, double* __restrict__ zg,
-                    const int* __restrict__ zsz_in, int* __restrict__ zsz_out,
-                    uint32_t* __restrict__ rngg, int* __restrict__ status, unsigned* __restrict__ pivots_out,
-                    int32_t* __restrict__ trace, int trace_cap, int* __restrict__ trace_len,
-                    mh::LcpParams P, mh::Pow10Table p10, double* __restrict__ wsd, int* __restrict__ wsi,
-                    const int* __restrict__ run_if)
-{
-  namespace bk = mh::blk;
-  const int b = blockIdx.x;
-  if (b >= B) return;
-  if (run_if && run_if[b] == 0) return;
-  const int t = bk::tid();
-  bk::Ws W;
-  double* wd = wsd + (size_t)b * bk::ws_doubles(n);
-  int* wi = wsi + (size_t)b * bk::ws_ints(n);
-  W.A = wd; W.b = wd + (size_t)n * n; W.w = W.b + n; W.x = W.w + n; W.d = W.x + n; W.art = W.d + n;
-  W.list = wi; W.flag = wi + n; W.pos = wi + 2 * (size_t)n; W.bv = wi + 3 * (size_t)n;
-  if (t < 32) bk::s_rng[t] = rngg[(size_t)b * MH_RAND_WORDS + t];
-  bk::Mat M; M.M = Mg + (size_t)b * strideM; M.ld = ld; M.n = n;
-  const double* q = qg + (size_t)b * n;
-  double* z = zg + (size_t)b * n;
-  int zsize = zsz_in ? zsz_in[b] : n;
-  if (zsize != n) for (int i = t; i < n; i += bk::T) z[i] = 0.0;
-  bk::sync();
-  bk::Trace2 tr; tr.buf = trace ? trace + (size_t)b * trace_cap : nullptr; tr.cap = trace_cap; tr.len = 0;
-  unsigned piv = 0;
-#ifdef MH_BLK_PROF
-  if (t < bk::BP_COUNT) bk::s_prof[t] = 0ull;
-  bk::sync();
-#endif
-  const bool ok = bk::lcp_solve(P, p10, M, W, q, z, zsize, piv, tr);
-  bk::sync();
-#ifdef MH_BLK_PROF
-  if (t == 0 && (b == 0 || b == 5)) printf("blk prof (cycles, block %d, %u pivots): list %llu gather %llu panel %llu swap %llu trail %llu solve %llu gemv %llu randmin %llu\n", b, piv,
-                               bk::s_prof[0], bk::s_prof[1], bk::s_prof[2], bk::s_prof[3], bk::s_prof[4], bk::s_prof[5], bk::s_prof[6], bk::s_prof[7]);
-#endif
-  if (t < 32) rngg[(size_t)b * MH_RAND_WORDS + t] = bk::s_rng[t];
-  if (t == 0) {
-    status[b] = ok ? 1 : 0;
-    if (pivots_out) pivots_out[b] = piv;
-    if (zsz_out) zsz_out[b] = zsize;
-    if (trace_len) trace_len[b] = tr.len;
-  }
-}
-
-// ---------------------------------------------------------------------------
 extern "C" {
 
 int mh_version(void) { return 100; }
@@ -202,6 +164,14 @@ int mh_rand_next(uint32_t* st)
   st[idx] = v;
   st[31] = (idx + 1) % 31;
   return (int)(v >> 1);
+}
+
+static int g_debug_blk = 0;      // mh_debug_set(2, v): 0 = choose, 1 = 256-thread block solver, 2 = 1024-thread block solver
+static int g_cu_count()
+{
+  static int cus = 0;
+  if (cus == 0) { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount; if (cus <= 0) cus = 256; }
+  return cus;
 }
 
 static int lcp_params(int kind, const mh_lcp_opts* o, mh::LcpParams& P)
@@ -265,8 +235,15 @@ static int lcp_solve_dev_masked(void* stream, int kind, int B, int n,
   if (n > MH_LCP_MAX_N_WAVE) {
     // workgroup-per-problem solver; its workspace is allocated and freed in stream order
     double* wsd = ws_d; int* wsi = ws_i;
+    // thread geometry: wide when a problem is large enough to feed 16 waves and the batch does not fill the chip twice
+    // over with the narrow one (measured: n = 128 x 1024 problems 17 % slower wide; n = 256 x 256: 1.22x, n = 512 x 64: 1.44x faster)
+    bool wide = n >= 192 && B <= 2 * g_cu_count();
+    if (g_debug_blk == 1) wide = false; else if (g_debug_blk == 2) wide = true;
     if (wsd && wsi) {
-      hipLaunchKernelGGL(mh_k_lcp_block, dim3(B), dim3(256), 0, (hipStream_t)stream,
+      if (wide) hipLaunchKernelGGL(mh::blkw::k_lcp_block, dim3(B), dim3(mh::blkw::T), 0, (hipStream_t)stream,
+                         B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
+                         trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if);
+      else hipLaunchKernelGGL(mh::blk::k_lcp_block, dim3(B), dim3(mh::blk::T), 0, (hipStream_t)stream,
                          B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
                          trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if);
       MH_HIP(hipGetLastError());
@@ -276,7 +253,10 @@ static int lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     MH_HIP(hipMallocAsync((void**)&wsd, nd * sizeof(double), (hipStream_t)stream));
     hipError_t e = hipMallocAsync((void**)&wsi, ni * sizeof(int), (hipStream_t)stream);
     if (e != hipSuccess) { (void)hipFreeAsync(wsd, (hipStream_t)stream); return fail(MH_ERR_HIP, "workspace allocation failed: %s", hipGetErrorString(e)); }
-    hipLaunchKernelGGL(mh_k_lcp_block, dim3(B), dim3(256), 0, (hipStream_t)stream,
+    if (wide) hipLaunchKernelGGL(mh::blkw::k_lcp_block, dim3(B), dim3(mh::blkw::T), 0, (hipStream_t)stream,
+                       B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
+                       trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if);
+    else hipLaunchKernelGGL(mh::blk::k_lcp_block, dim3(B), dim3(mh::blk::T), 0, (hipStream_t)stream,
                        B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
                        trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if);
     e = hipGetLastError();
@@ -456,6 +436,7 @@ extern "C" {
 int mh_debug_set(int key, int value)
 {
   if (key == 1) { if (value < 0 || value > 64) return fail(MH_ERR_INVALID_ARG, "LU block edge outside [0, 64]"); g_debug_ka = value; return MH_OK; }
+  if (key == 2) { if (value < 0 || value > 2) return fail(MH_ERR_INVALID_ARG, "block solver geometry outside {0, 1, 2}"); g_debug_blk = value; return MH_OK; }
   return fail(MH_ERR_INVALID_ARG, "unknown debug key %d", key);
 }
 

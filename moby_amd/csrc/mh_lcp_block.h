@@ -23,12 +23,16 @@
 // columns per barrier round with the diagonal blocks on lanes.  Measured (n = 256,
 // 512 pivots in the slowest problem): 296 ms -> 177 ms; per-phase cycles with
 // -DMH_BLK_PROF: panel 30 %, trailing update 27 %, solves 12 %.
-#pragma once
+// No include guard: mh_capi.hip includes this file once per thread geometry (MH_BLK_NS / MH_BLK_T).
 #include "mh_lcp_wave.h"
 
-namespace mh { namespace blk {
+#if !defined(MH_BLK_NS) || !defined(MH_BLK_T)
+#error "define MH_BLK_NS and MH_BLK_T before including mh_lcp_block.h"
+#endif
+namespace mh { namespace MH_BLK_NS {
 
-constexpr int T = 256;
+constexpr int T = MH_BLK_T;              // threads per problem (a multiple of 64)
+constexpr int NW = T / 64;               // waves per problem
 
 struct Ws {
   double* A;      // n x n LU scratch (col-major, ld = k)
@@ -67,8 +71,8 @@ MH_DEV void sync() { __syncthreads(); }
 MH_DEV void wsync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 MH_DEV double inf() { return __longlong_as_double(0x7ff0000000000000ll); }
 
-__shared__ double s_wd[4];
-__shared__ int s_wi[4];
+__shared__ double s_wd[NW];
+__shared__ int s_wi[NW];
 MH_DEV int wave_of() { return tid() >> 6; }
 // lexicographic (value ascending, index ascending) minimum over the block: DPP reductions inside each of
 // the four waves, four partials through LDS -- two barriers instead of a nine-level tree
@@ -211,13 +215,13 @@ MH_DEV void trail_update(double* __restrict__ A, int k, int j0, int c0, int cb, 
       for (int s2 = 0; s2 < NB; s2++) lz = lz && (l[s2] == 0.0);
       if (lz) continue;                              // this row's multipliers are all zero
     }
-    for (int cq = tc; cq < ncb; cq += 4 * TCOLS) {
+    for (int cq = tc; cq < ncb; cq += NW * TCOLS) {
       double a[TCOLS]; bool go[TCOLS];
 #pragma unroll
-      for (int u4 = 0; u4 < TCOLS; u4++) { const int c = cq + 4 * u4; go[u4] = (c < ncb) && s_nz[c]; a[u4] = go[u4] ? A[r + (size_t)k * (cb + c)] : 0.0; }
+      for (int u4 = 0; u4 < TCOLS; u4++) { const int c = cq + NW * u4; go[u4] = (c < ncb) && s_nz[c]; a[u4] = go[u4] ? A[r + (size_t)k * (cb + c)] : 0.0; }
 #pragma unroll
       for (int u4 = 0; u4 < TCOLS; u4++) {
-        const int c = cq + 4 * u4;
+        const int c = cq + NW * u4;
         if (go[u4]) {
           double v = a[u4];
 #pragma unroll
@@ -697,4 +701,51 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
   return false;
 }
 
-} } // namespace mh::blk
+// n > 64: one T-thread workgroup per LCP, M read in place from HBM, everything else in a per-problem HBM workspace.
+__global__ __launch_bounds__(T)
+void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strideM,
+                    const double* __restrict__ qg, double* __restrict__ zg,
+                    const int* __restrict__ zsz_in, int* __restrict__ zsz_out,
+                    uint32_t* __restrict__ rngg, int* __restrict__ status, unsigned* __restrict__ pivots_out,
+                    int32_t* __restrict__ trace, int trace_cap, int* __restrict__ trace_len,
+                    LcpParams P, Pow10Table p10, double* __restrict__ wsd, int* __restrict__ wsi,
+                    const int* __restrict__ run_if)
+{
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  if (run_if && run_if[b] == 0) return;
+  const int t = tid();
+  Ws W;
+  double* wd = wsd + (size_t)b * ws_doubles(n);
+  int* wi = wsi + (size_t)b * ws_ints(n);
+  W.A = wd; W.b = wd + (size_t)n * n; W.w = W.b + n; W.x = W.w + n; W.d = W.x + n; W.art = W.d + n;
+  W.list = wi; W.flag = wi + n; W.pos = wi + 2 * (size_t)n; W.bv = wi + 3 * (size_t)n;
+  if (t < 32) s_rng[t] = rngg[(size_t)b * MH_RAND_WORDS + t];
+  Mat M; M.M = Mg + (size_t)b * strideM; M.ld = ld; M.n = n;
+  const double* q = qg + (size_t)b * n;
+  double* z = zg + (size_t)b * n;
+  int zsize = zsz_in ? zsz_in[b] : n;
+  if (zsize != n) for (int i = t; i < n; i += T) z[i] = 0.0;
+  sync();
+  Trace2 tr; tr.buf = trace ? trace + (size_t)b * trace_cap : nullptr; tr.cap = trace_cap; tr.len = 0;
+  unsigned piv = 0;
+#ifdef MH_BLK_PROF
+  if (t < BP_COUNT) s_prof[t] = 0ull;
+  sync();
+#endif
+  const bool ok = lcp_solve(P, p10, M, W, q, z, zsize, piv, tr);
+  sync();
+#ifdef MH_BLK_PROF
+  if (t == 0 && (b == 0 || b == 5)) printf("blk prof (cycles, block %d, %u pivots): list %llu gather %llu panel %llu swap %llu trail %llu solve %llu gemv %llu randmin %llu\n", b, piv,
+                               s_prof[0], s_prof[1], s_prof[2], s_prof[3], s_prof[4], s_prof[5], s_prof[6], s_prof[7]);
+#endif
+  if (t < 32) rngg[(size_t)b * MH_RAND_WORDS + t] = s_rng[t];
+  if (t == 0) {
+    status[b] = ok ? 1 : 0;
+    if (pivots_out) pivots_out[b] = piv;
+    if (zsz_out) zsz_out[b] = zsize;
+    if (trace_len) trace_len[b] = tr.len;
+  }
+}
+
+} } // namespace mh::MH_BLK_NS

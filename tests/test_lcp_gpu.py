@@ -171,3 +171,20 @@ def test_cpp_adapter_example():
     vals = [float(x) for x in out.splitlines()[0].split("z=")[1].split()]
     np.testing.assert_allclose(vals, 9.81e-3 * np.array([3.0, 2.0, 1.0]), rtol=1e-13)
     assert "lemke ok=1" in out
+
+
+@pytest.mark.parametrize("geometry", [1, 2])
+@pytest.mark.parametrize("kind,n,fam", [(FAST, 100, "pd"), (LEMKE, 100, "psd"), (FAST_REG, 300, "copos"), (LEMKE_REG, 300, "pd"), (LEMKE, 260, "pd")])
+def test_block_solver_both_thread_geometries(oracle, geometry, kind, n, fam):
+    """The workgroup-per-problem solver exists with 256 and with 1024 threads per problem (chosen by n and B,
+    mh_capi.hip); mh_debug_set(2, .) forces one: both reproduce the oracle bit for bit at sizes on either side of
+    the switch."""
+    from moby_amd import _lib
+    lib = _lib.load()
+    B = 2
+    M, q = synth.random_lcp(B, n, fam, seed=17 * n + geometry)
+    _lib.check(lib.mh_debug_set(2, geometry))
+    try:
+        assert_parity(oracle, kind, M, q, z_size=np.zeros(B, dtype=np.int32))
+    finally:
+        _lib.check(lib.mh_debug_set(2, 0))
