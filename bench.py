@@ -16,6 +16,8 @@ leaves the GPU between steps); inputs are resident in HBM before the clock start
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel) and
 `cpu_baseline` (the CPU oracle on the host cores; rank 0, N = 1 only).
+`config4_impact_handler` (rank 0, N = 1; informational, outside the timed region): BASELINE config 4 in the small --
+4-box stacks x1024 through the impact-handler entry (include/moby_hip_impact.h), one cold and one warm call.
 """
 import argparse
 import json
@@ -118,6 +120,33 @@ def cpu_baseline(B, steps, warmup):
     return out
 
 
+def config4_leg(torch, nboxes=4, B=1024):
+    """BASELINE config 4 in the small: B stacks of `nboxes` boxes through the impact-handler entry
+    (include/moby_hip_impact.h), one cold and one warm-started process_constraints call on every world, timed with
+    events on the launch stream.  Not part of `value`; never allowed to break the headline line."""
+    try:
+        from moby_amd import impact as I
+        mass, J, st, cs = I.box_stack(nboxes, B=B)
+        ib = I.ImpactBatch(B, nboxes, 4 * nboxes, 4, mass, J)
+        ib.upload(st, cs)
+        stream = torch.cuda.current_stream().cuda_stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        res = {"workload": "box stack of %d (n = %d) x%d worlds, 4 corner contacts per interface" % (nboxes, ib.n, B)}
+        for tag in ("cold", "warm"):
+            e0.record(); ib.process_async(stream); e1.record(); torch.cuda.synchronize()
+            r = ib.download()
+            ms = e0.elapsed_time(e1)
+            res[tag] = {"ms": ms, "lcp_rows_per_sec": ib.n * float(r["solves"].sum()) / (ms * 1e-3),
+                        "pivots_mean": float(r["pivots"].mean()), "pivots_max": int(r["pivots"].max()),
+                        "worlds_with_errors": int(((r["status"] & ~2) != 0).sum())}
+            s2 = r["state"].reshape(B, nboxes, 13); s2[:, :, 8] += -9.81e-3      # gravity acts for another dt
+            ib.upload(s2.reshape(B, -1), cs)
+        ib.close()
+        return res
+    except Exception as e:          # noqa: BLE001 -- informational leg
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,6 +154,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--worlds", type=int, default=WORLDS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config4", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -223,6 +253,8 @@ def main():
 
     if cpu is not None:
         out["cpu_baseline"] = cpu
+    if rank == 0 and world_size == 1 and not args.no_config4:
+        out["config4_impact_handler"] = config4_leg(torch)             # after the timed region; informational
     if rank == 0:
         print(json.dumps(out))
     if world_size > 1:
