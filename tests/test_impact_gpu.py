@@ -181,3 +181,19 @@ def test_cpp_impact_handler_adapter_example():
     assert "n=96 status=0 solves=1" in out and "same=1" in out
     assert float(out.split("vmax=")[1].split()[0]) < 1e-9
     assert abs(float(out.split("weight_dt=")[1].split()[0]) - 1.0) < 1e-9
+
+
+def test_twelve_box_stack_matches_oracle(oracle):
+    """n = 384: the 1024-thread block solver; in the perturbed world lcp_fast fails on all four rungs and the Lemke ladder solves it --
+    the regime of BASELINE config 4 -- bit for bit against the oracle (0.8 s per world on the CPU)."""
+    nbx, B = 12, 2
+    mass, J, st, cs = I.box_stack(nbx, B=B)
+    nc = 4 * nbx; n = I.lcp_size(nc, 4)
+    ib = I.ImpactBatch(B, nbx, nc, 4, mass, J)
+    aux = S.new_aux(B); zl = np.zeros((B, n)); zb = np.zeros((B, n))
+    st_o = st.copy()
+    r = ib.process(st, cs)
+    imp_o, piv_o, sol_o = oracle_batch(oracle, nbx, mass, J, st_o, cs, n, aux, zl, zb)
+    assert_same(r, st_o, imp_o, piv_o, sol_o, aux)
+    assert r["pivots"].max() > 4 * n and (r["status"] == 0).all()      # world 1: all four lcp_fast rungs fail, Lemke solves
+    ib.close()
