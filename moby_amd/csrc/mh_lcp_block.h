@@ -620,15 +620,17 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
     // Al = Bl from the basis description; solve Al d = Be
     const unsigned long long tq = bp_tick();
     const long nn = (long)n * n;
-    for (long e = t; e < nn; e += T) {
-      const int r = (int)(e % n), p = (int)(e / n);
-      const int id = W.bv[p];
-      double a;
-      if (id == tt) a = W.art[r];
-      else if (id >= n) a = (r == id - n) ? -1.0 : 0.0;
-      else a = M.at(r, id, lam);
-      W.A[e] = a;
-    }
+    { int r = t % n, p = t / n;                             // element e = t + m T, walked without a division per element
+      const int dr = T % n, dp = T / n;
+      for (long e = t; e < nn; e += T) {
+        const int id = W.bv[p];
+        double a;
+        if (id == tt) a = W.art[r];
+        else if (id >= n) a = (r == id - n) ? -1.0 : 0.0;
+        else a = M.at(r, id, lam);
+        W.A[e] = a;
+        r += dr; p += dp; if (r >= n) { r -= n; p++; }
+      } }
     sync();
     bp_tock(BP_GATHER, tq);
     if (lu_solve(n, W.A, W.d) != 0) return false;                   // singular basis (:840-850), size stays 2n
