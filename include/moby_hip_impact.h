@@ -62,6 +62,12 @@ int mh_impact_batch_download(mh_impact_batch* ib, double* state, double* impulse
  * assembled _MM (B*n*n, column-major) and _qq (B*n) of the last call */
 int mh_impact_batch_lcp_size(const mh_impact_batch* ib);
 int mh_impact_batch_debug_lcp(mh_impact_batch* ib, double* MM, double* qq);
+/* checkpoint / resume: what the handler keeps between calls -- _zlast (B*n), its size (B), the rand()
+ * streams (B*MH_RAND_WORDS) and the sticky status bits (B).  The reference's XML pickle drops _zlast, so a resumed run
+ * there diverges in its pivot sequence; a batch restored with load_solver_state continues bit for bit. */
+int mh_impact_batch_save_solver_state(mh_impact_batch* ib, double* zlast, int* zlast_size, uint32_t* rng, int* status);
+int mh_impact_batch_load_solver_state(mh_impact_batch* ib, const double* zlast, const int* zlast_size, const uint32_t* rng,
+                                      const int* status);
 /* raw device pointers for zero-copy interop */
 int mh_impact_batch_device_ptrs(mh_impact_batch* ib, double** state_dev, mh_contact** contacts_dev);
 

@@ -65,6 +65,8 @@ SYMBOLS = {
     "mh_impact_batch_download": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mh_impact_batch_lcp_size": (_i, [_vp]),
     "mh_impact_batch_debug_lcp": (_i, [_vp, _vp, _vp]),
+    "mh_impact_batch_save_solver_state": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mh_impact_batch_load_solver_state": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mh_impact_batch_device_ptrs": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "mh_impact_process_batch": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }

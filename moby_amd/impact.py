@@ -89,6 +89,19 @@ class ImpactBatch:
         _lib.check(_lib.load().mh_impact_batch_debug_lcp(self.handle, MM.ctypes.data, qq.ctypes.data))
         return np.transpose(MM, (0, 2, 1)).copy(), qq          # row-major M[b, r, c]
 
+    def solver_state(self):
+        """What a checkpoint must keep besides the body states: _zlast, its size, the rand() streams, status bits."""
+        zl = np.zeros((self.B, self.n)); zs = np.zeros(self.B, dtype=np.int32)
+        rng = np.zeros((self.B, S.MH_RAND_WORDS), dtype=np.uint32); status = np.zeros(self.B, dtype=np.int32)
+        _lib.check(_lib.load().mh_impact_batch_save_solver_state(self.handle, zl.ctypes.data, zs.ctypes.data, rng.ctypes.data, status.ctypes.data))
+        return dict(zlast=zl, zlast_size=zs, rng=rng, status=status)
+
+    def load_solver_state(self, ss):
+        zl = np.ascontiguousarray(ss["zlast"], dtype=np.float64); zs = np.ascontiguousarray(ss["zlast_size"], dtype=np.int32)
+        rng = np.ascontiguousarray(ss["rng"], dtype=np.uint32); status = np.ascontiguousarray(ss["status"], dtype=np.int32)
+        assert zl.shape == (self.B, self.n) and rng.shape == (self.B, S.MH_RAND_WORDS)
+        _lib.check(_lib.load().mh_impact_batch_load_solver_state(self.handle, zl.ctypes.data, zs.ctypes.data, rng.ctypes.data, status.ctypes.data))
+
     def close(self):
         if self.handle:
             _lib.load().mh_impact_batch_destroy(self.handle)

@@ -42,14 +42,14 @@ class WorldBatchDevice:
     """Same, with state/aux resident in HBM behind an ``mh_world_batch`` handle;
     ``step`` is asynchronous on the given (torch) stream."""
 
-    def __init__(self, scene, state, seed=1):
+    def __init__(self, scene, state, seed=1, aux=None):
         lib = _lib.load()
         self.scene = scene
         self.B = state.shape[0]
         self.handle = ctypes.c_void_p()
         _lib.check(lib.mh_world_batch_create(ctypes.addressof(scene), self.B, ctypes.byref(self.handle)))
         st = np.ascontiguousarray(state, dtype=np.float64)
-        aux = S.new_aux(self.B, seed)
+        aux = S.new_aux(self.B, seed) if aux is None else np.ascontiguousarray(aux)      # aux given: resume from a checkpoint
         _lib.check(lib.mh_world_batch_upload(self.handle, st.ctypes.data, aux.ctypes.data))
 
     def step(self, dt, nsteps=1, stream=None, traj_ptr=None):
@@ -71,3 +71,21 @@ class WorldBatchDevice:
             self.close()
         except Exception:
             pass
+
+
+
+def save_checkpoint(path, scene, state, aux):
+    """Everything a resumed run needs: the scene record, the body states and the per-world solver state
+    (``mh_world_aux``: rand() stream, _zlast / _z / _v with their sizes, current_time, status, counters).  The reference's
+    XML pickle (programs/driver.cpp:224-232) keeps none of the solver state, so its resumed runs diverge in pivot sequence."""
+    np.savez(path, scene=np.frombuffer(bytes(scene), dtype=np.uint8), state=np.ascontiguousarray(state, dtype=np.float64),
+             aux=np.frombuffer(np.ascontiguousarray(aux).tobytes(), dtype=np.uint8), nworlds=np.int64(len(aux)))
+
+
+def load_checkpoint(path):
+    """Returns (scene, state, aux) as ``save_checkpoint`` stored them."""
+    z = np.load(path)
+    scene = S.mh_scene.from_buffer_copy(z["scene"].tobytes())
+    aux = np.frombuffer(z["aux"].tobytes(), dtype=S.AUX_DTYPE).copy()
+    assert len(aux) == int(z["nworlds"])
+    return scene, z["state"].copy(), aux

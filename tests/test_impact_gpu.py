@@ -197,3 +197,26 @@ def test_twelve_box_stack_matches_oracle(oracle):
     assert_same(r, st_o, imp_o, piv_o, sol_o, aux)
     assert r["pivots"].max() > 4 * n and (r["status"] == 0).all()      # world 1: all four lcp_fast rungs fail, Lemke solves
     ib.close()
+
+
+def test_solver_state_checkpoint_resumes_bit_exact():
+    """_zlast and the rand() streams of a handler saved and loaded into a new batch: the next call equals the call an
+    uninterrupted handler makes; a fresh handler (what the reference's pickle amounts to) pivots differently."""
+    nbx, B = 3, 4
+    mass, J, st, cs = I.box_stack(nbx, B=B, mu=0.3)
+    a = I.ImpactBatch(B, nbx, 12, 4, mass, J)
+    r1 = a.process(st, cs)
+    s2 = r1["state"].copy(); s2.reshape(B, nbx, 13)[:, :, 8] += -9.81e-3
+    ss = a.solver_state()
+    assert (ss["zlast_size"] == a.n).all()
+    r2 = a.process(s2, cs)
+    b = I.ImpactBatch(B, nbx, 12, 4, mass, J); b.load_solver_state(ss)
+    r2b = b.process(s2, cs)
+    assert np.array_equal(r2b["state"], r2["state"]) and np.array_equal(r2b["pivots"], r2["pivots"]) and np.array_equal(r2b["impulses"], r2["impulses"])
+    sb = b.solver_state(); sa = a.solver_state()
+    assert np.array_equal(sb["rng"], sa["rng"]) and np.array_equal(sb["zlast"], sa["zlast"])
+    fresh = I.ImpactBatch(B, nbx, 12, 4, mass, J).process(s2, cs)
+    assert not np.array_equal(fresh["pivots"], r2["pivots"])
+    bad = dict(ss); bad["zlast_size"] = ss["zlast_size"] + 1
+    with pytest.raises(_lib.MobyHipError):
+        b.load_solver_state(bad)

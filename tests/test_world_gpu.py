@@ -388,3 +388,27 @@ def test_full_batch_2048_wheels_properties():
     # the initial state slips (v_x = theta_dot (R + h)); the first no-slip impact removes that energy, later ones remove more
     assert (energy(s) < energy(st0) + 1e-9).all()
     assert (wb.aux["lcp_solves"] > 500).all()
+
+
+def test_checkpoint_resume_is_bit_exact(tmp_path):
+    """a run resumed from (scene, body states, mh_world_aux) continues bit for bit -- states, rand()
+    streams, warm starts, counters -- while a resume from the body states alone (all the reference's XML pickle keeps,
+    programs/driver.cpp:224-232) takes a different pivot sequence."""
+    from moby_amd import world as W
+    sc = S.sphere_stack_scene()
+    st0 = S.sphere_stack_state(16)
+    straight = WorldBatch(sc, st0.copy()); straight.step(1e-3, 120)
+    first = WorldBatch(sc, st0.copy()); first.step(1e-3, 60)
+    path = str(tmp_path / "ck.npz")
+    W.save_checkpoint(path, sc, first.state, first.aux)
+    sc2, st2, aux2 = W.load_checkpoint(path)
+    resumed = WorldBatch(sc2, st2.copy(), aux=aux2.copy()); resumed.step(1e-3, 60)      # WorldBatch steps its arrays in place
+    assert np.array_equal(resumed.state, straight.state)
+    for f in S.AUX_DTYPE.names:
+        assert np.array_equal(resumed.aux[f], straight.aux[f]), f
+    # the device-resident batch resumes the same way
+    dev = W.WorldBatchDevice(sc2, st2, aux=aux2); dev.step(1e-3, 60)
+    st_d, aux_d = dev.download(); dev.close()
+    assert np.array_equal(st_d, straight.state) and np.array_equal(aux_d["rng"], straight.aux["rng"])
+    bodies_only = WorldBatch(sc, first.state.copy()); bodies_only.step(1e-3, 60)
+    assert not np.array_equal(bodies_only.aux["lcp_pivots"], straight.aux["lcp_pivots"] - first.aux["lcp_pivots"])
