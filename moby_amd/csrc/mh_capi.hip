@@ -11,16 +11,31 @@
 // the workgroup-per-problem solver in two thread geometries: 256 threads (two problems per CU: throughput when the
 // batch is larger than the chip) and 1024 threads (one problem per CU with 16 waves to hide its round trips:
 // 1.2x / 1.4x faster per problem at n = 256 / 512, slower at n = 128)
+// The 256-thread geometry is the throughput one (batches larger than the chip): half the LDS staging (panel 14 KB,
+// pivot-row chunk 128 columns) and a 128-VGPR budget let FOUR problems share a CU instead of two -- 4-box stacks x8192:
+// 8.4 s -> 5.6 s per cold call; a single problem is 3 % slower.
 #define MH_BLK_NS blk
 #define MH_BLK_T 256
+#define MH_BLK_UCH 128
+#define MH_BLK_PANEL_CAP 1792
+#define MH_BLK_KATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #include "mh_lcp_block.h"
 #undef MH_BLK_NS
 #undef MH_BLK_T
+#undef MH_BLK_UCH
+#undef MH_BLK_PANEL_CAP
+#undef MH_BLK_KATTR
 #define MH_BLK_NS blkw
 #define MH_BLK_T 1024
+#define MH_BLK_UCH 256
+#define MH_BLK_PANEL_CAP 3584
+#define MH_BLK_KATTR
 #include "mh_lcp_block.h"
 #undef MH_BLK_NS
 #undef MH_BLK_T
+#undef MH_BLK_UCH
+#undef MH_BLK_PANEL_CAP
+#undef MH_BLK_KATTR
 
 namespace {
 

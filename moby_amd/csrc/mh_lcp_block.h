@@ -26,8 +26,8 @@
 // No include guard: mh_capi.hip includes this file once per thread geometry (MH_BLK_NS / MH_BLK_T).
 #include "mh_lcp_wave.h"
 
-#if !defined(MH_BLK_NS) || !defined(MH_BLK_T)
-#error "define MH_BLK_NS and MH_BLK_T before including mh_lcp_block.h"
+#if !defined(MH_BLK_NS) || !defined(MH_BLK_T) || !defined(MH_BLK_UCH) || !defined(MH_BLK_PANEL_CAP) || !defined(MH_BLK_KATTR)
+#error "define MH_BLK_NS, MH_BLK_T, MH_BLK_UCH, MH_BLK_PANEL_CAP and MH_BLK_KATTR before including mh_lcp_block.h"
 #endif
 namespace mh { namespace MH_BLK_NS {
 
@@ -170,12 +170,12 @@ MH_DEV int build_list(int n, const Ws& W) {
 //     registers and the NB pivot rows staged through LDS (s_u), instead of once per column;
 //   * row swaps outside the panel are plain global-memory swaps off the critical path.
 constexpr int NB = 8;
-constexpr int UCH = 256;                 // columns of the pivot-row block staged in LDS at a time
+constexpr int UCH = MH_BLK_UCH;          // columns of the pivot-row block staged in LDS at a time
 #ifndef MH_BLK_TCOLS
 #define MH_BLK_TCOLS 8
 #endif
 constexpr int TCOLS = MH_BLK_TCOLS;      // trailing-update columns a thread has in flight
-constexpr int PANEL_CAP = 3584;          // doubles (28 KB): rows x NB of the panel held in LDS
+constexpr int PANEL_CAP = MH_BLK_PANEL_CAP;   // doubles (14 / 28 KB): rows x NB of the panel held in LDS
 __shared__ double s_u[NB][UCH];
 __shared__ int s_li[UCH];
 constexpr int LIST_CAP = 1024;
@@ -704,7 +704,7 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
 }
 
 // n > 64: one T-thread workgroup per LCP, M read in place from HBM, everything else in a per-problem HBM workspace.
-__global__ __launch_bounds__(T)
+__global__ __launch_bounds__(T) MH_BLK_KATTR
 void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strideM,
                     const double* __restrict__ qg, double* __restrict__ zg,
                     const int* __restrict__ zsz_in, int* __restrict__ zsz_out,
