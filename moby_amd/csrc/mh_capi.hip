@@ -250,9 +250,10 @@ static int lcp_solve_dev_masked(void* stream, int kind, int B, int n,
   if (n > MH_LCP_MAX_N_WAVE) {
     // workgroup-per-problem solver; its workspace is allocated and freed in stream order
     double* wsd = ws_d; int* wsi = ws_i;
-    // thread geometry: wide when a problem is large enough to feed 16 waves and the batch does not fill the chip twice
-    // over with the narrow one (measured: n = 128 x 1024 problems 17 % slower wide; n = 256 x 256: 1.22x, n = 512 x 64: 1.44x faster)
-    bool wide = n >= 192 && B <= 2 * g_cu_count();
+    // thread geometry: wide when a problem is large enough to feed 16 waves -- always from n = 384 up (n = 512: 1.6x at 256
+    // problems, still 1.09x at 1024), below that only while the batch does not fill the chip twice over with the narrow one
+    // (n = 256: 1.34x at 256 problems, 1.07x at 512, 0.80x at 1024; n = 128 x 1024: 0.85x)
+    bool wide = n >= 384 || (n >= 192 && B <= 2 * g_cu_count());
     if (g_debug_blk == 1) wide = false; else if (g_debug_blk == 2) wide = true;
     if (wsd && wsi) {
       if (wide) hipLaunchKernelGGL(mh::blkw::k_lcp_block, dim3(B), dim3(mh::blkw::T), 0, (hipStream_t)stream,
