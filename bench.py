@@ -14,6 +14,11 @@ lcp_fast_regularized and the Lemke ladder, restitution, constraint
 stabilisation.  The K timed steps run inside ONE persistent launch (state never
 leaves the GPU between steps); inputs are resident in HBM before the clock starts.
 
+N > 1 started as plain `python bench.py --gpus N ...` (no RANK in the environment) re-launches itself under
+`python -m torch.distributed.run` as a CHILD process before anything touches the GPU and returns the child's exit code.
+`scaling` is "weak" (`--worlds` per GPU, the headline `value`); for N > 1 the same line also carries `strong_scaling`:
+ONE batch of `--worlds` split N ways (4096 / 8 = 512 worlds per GPU = 2 waves per CU), timed the same way.
+
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel) and
 `cpu_baseline` (the CPU oracle on the host cores; rank 0, N = 1 only).
 `config4_impact_handler` (rank 0, N = 1; informational, outside the timed region): BASELINE config 4 in the small --
@@ -36,16 +41,16 @@ DT = 1e-3
 
 
 def pmc_traffic(B, steps):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/pmc_traffic.json, written from profiles/r01_*_pmc.csv); None when the
-    configuration differs from the profiled one (counters cannot be read in-process)."""
+    """HBM bytes of one launch of B worlds x `steps` steps, from the committed rocprofv3 PMC passes of this same
+    command (profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE of the timed launch, separate passes, normalised per
+    world-step -- the kernel's traffic is per-world scratch + state, so it scales with worlds x steps).  Counters cannot
+    be read in-process; None when no profile of this kernel is committed."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    except OSError:
+        per_world_step = (t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0 / (t["worlds"] * t["steps"])
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
-    if t.get("worlds") != B or t.get("steps") != steps:
-        return None
-    return (t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
+    return per_world_step * B * steps
 
 
 def _cpu_worker(arg):
@@ -147,6 +152,55 @@ def config4_leg(torch, nboxes=4, B=1024):
         return {"error": repr(e)}
 
 
+def strong_leg(torch, dist, mdist, S, WorldBatchDevice, sc, B_total, rank, world_size, dev, args):
+    """Strong scaling: ONE batch of `B_total` worlds split over the ranks (rank r owns worlds [r B/N, (r+1) B/N) of the
+    same batch the N = 1 run steps), W warmup + K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+    first, count = mdist.split_range(rank, world_size, B_total)
+    wb = WorldBatchDevice(sc, S.sphere_stack_state_range(first, count))
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    if args.warmup > 0:
+        wb.step(DT, args.warmup, stream)
+    torch.cuda.synchronize()
+    _, aux0 = wb.download()
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wb.step(DT, args.steps, stream)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _, aux1 = wb.download()
+    tot = mdist.counter_vector(aux0, aux1, (aux1["status"] & ~S.MH_WORLD_IMPACT_TOL) != 0)
+    elapsed, tot = mdist.reduce_interval(elapsed, tot, dist, dev)
+    wb.close()
+    return {"scaling": "strong", "worlds_total": B_total, "worlds_per_gpu": count, "value": float(tot[0]) / elapsed, "unit": "LCP rows/s",
+            "world_steps_per_sec": B_total * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+            "note": "%d worlds per GPU = %.1f waves per CU: below the 16 resident waves per CU the kernel needs to hide LDS latency"
+                    % (count, count / 256.0)}
+
+
+def long_horizon_leg(torch, wb, stream, B, args):
+    """The same batch far from t = 0: advance to step `--long-horizon-start` (untimed), then time 200 steps.  After ~3000
+    steps a few worlds per thousand cycle lcp_fast to its pivot cap on every rung of the regularisation ladder
+    ("Long horizons"); a lockstep launch lasts as long as its slowest world."""
+    try:
+        done = args.warmup + args.steps
+        skip = max(0, args.long_horizon_start - done)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        while skip > 0:
+            k = min(skip, 1000); wb.step(DT, k, stream); torch.cuda.synchronize(); skip -= k
+        _, a0 = wb.download()
+        e0.record(); wb.step(DT, 200, stream); e1.record(); torch.cuda.synchronize()
+        _, a1 = wb.download()
+        ms = e0.elapsed_time(e1)
+        rows = float(a1["lcp_rows"].astype(np.int64).sum() - a0["lcp_rows"].astype(np.int64).sum())
+        piv = float(a1["lcp_pivots"].astype(np.int64).sum() - a0["lcp_pivots"].astype(np.int64).sum())
+        return {"steps_from": max(done, args.long_horizon_start), "steps": 200, "ms_per_step": ms / 200.0,
+                "lcp_rows_per_sec": rows / (ms * 1e-3), "world_steps_per_sec": B * 200 / (ms * 1e-3),
+                "pivots_per_world_step": piv / (B * 200.0),
+                "worlds_flagged": int((a1["status"] != 0).sum())}
+    except Exception as e:          # noqa: BLE001 -- informational leg
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,7 +209,19 @@ def main():
     ap.add_argument("--worlds", type=int, default=WORLDS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config4", action="store_true")
+    ap.add_argument("--no-long-horizon", action="store_true")
+    ap.add_argument("--long-horizon-start", type=int, default=4000)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  The ranks are CHILD processes started before this
+        # process has made any GPU call (never an exec from a process that initialised the GPU).
+        import socket
+        import subprocess
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -251,8 +317,12 @@ def main():
                      "model": "LCP-entry bytes 8(n^2+2n) per solved LCP (SURVEY 8d); the fused kernel itself only moves %d B of state per launch" % int(fused_bytes)},
     }
 
+    if world_size > 1:
+        out["strong_scaling"] = strong_leg(torch, dist, mdist, S, WorldBatchDevice, sc, B, rank, world_size, dev, args)
     if cpu is not None:
         out["cpu_baseline"] = cpu
+    if rank == 0 and world_size == 1 and not args.no_long_horizon:
+        out["long_horizon"] = long_horizon_leg(torch, wb, stream, B, args)   # after the timed region; informational
     if rank == 0 and world_size == 1 and not args.no_config4:
         out["config4_impact_handler"] = config4_leg(torch)             # after the timed region; informational
     if rank == 0:

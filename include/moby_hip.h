@@ -157,7 +157,7 @@ typedef struct mh_scene {
   double min_step_size;                    /* TimeSteppingSimulator.cpp:48  (sqrt eps) */
   double contact_dist_thresh;              /* ConstraintSimulator.cpp:56    (1e-6)     */
   double cstab_eps;                        /* ConstraintStabilization.cpp:59 (sqrt eps) */
-  unsigned cstab_max_iterations;           /* ConstraintStabilization.cpp:56 (UINT_MAX) */
+  unsigned cstab_max_iterations;           /* ConstraintStabilization.cpp:56 (reference: UINT_MAX; here MH_CSTAB_DEFAULT_MAX_ITERATIONS) */
   int    lcp_n_max;                        /* largest LCP the wave solver must hold in LDS (0 = 64); worlds
                                               that exceed it get MH_WORLD_UNSUPPORTED */
 } mh_scene;
@@ -171,6 +171,12 @@ typedef struct mh_scene {
 #define MH_WORLD_STALLED       16   /* > 100000 zero-length mini-steps in one step, or MH_CSTAB_HARD_CAP stabilisation
                                        iterations in one call (the reference would not return) */
 #define MH_CSTAB_HARD_CAP 10000u
+/* Default of mh_scene.cstab_max_iterations in EVERY entry path (mh_scene_defaults, the XML loader when the attribute
+ * constraint-stabilization-max-iterations is absent, moby_amd/scene.py).  The reference's default is UINT_MAX
+ * (ConstraintStabilization.cpp:56); with the restated arithmetic its loop 2-cycles on resting stacks (DESIGN.md 2,
+ * deviation 1) and would not return, so the documented default is a cap the loop reaches about once in 1000 steps.
+ * A scene that sets the attribute explicitly (e.g. ur10.xml: 0) is honoured as written. */
+#define MH_CSTAB_DEFAULT_MAX_ITERATIONS 10u
 #define MH_CA_HARD_CAP 10000000u     /* conservative-advancement sub-steps of one mini-step before MH_WORLD_STALLED */
 
 /* persistent per-world solver state (what the reference keeps in the

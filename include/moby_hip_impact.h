@@ -68,7 +68,10 @@ int mh_impact_batch_debug_lcp(mh_impact_batch* ib, double* MM, double* qq);
 int mh_impact_batch_save_solver_state(mh_impact_batch* ib, double* zlast, int* zlast_size, uint32_t* rng, int* status);
 int mh_impact_batch_load_solver_state(mh_impact_batch* ib, const double* zlast, const int* zlast_size, const uint32_t* rng,
                                       const int* status);
-/* raw device pointers for zero-copy interop */
+/* raw device pointers for zero-copy interop.  Contacts written straight to contacts_dev skip upload()'s host
+ * checks; the device repeats them (nk of the batch, unit normal, two distinct bodies with at least one dynamic) and
+ * flags a world with a malformed contact MH_WORLD_UNSUPPORTED instead of processing it.  The restitution round
+ * (epsilon > 0, src/ImpactConstraintHandler.cpp:578-602) is decided on the device per world, not from upload(). */
 int mh_impact_batch_device_ptrs(mh_impact_batch* ib, double** state_dev, mh_contact** contacts_dev);
 
 /* Host convenience: create + upload + process + download + destroy (fresh handler state). */

@@ -13,8 +13,12 @@
 //   Vector: size(), data(), resize(n) (contents kept when shrinking), set_zero(n)
 // Conventions kept from the reference: returns true/false, never throws for a solver
 // failure (only for a broken library / device), `z` is warm-start in and solution out,
-// `pivots` counts pivots of the last call, the object owns the libc rand() stream the
-// reference takes from the process (srand(1) state at construction).
+// `pivots` counts pivots of the last call.  rand(): the reference draws from the PROCESS-global libc stream
+// (src/LCP.cpp:208,620), so ImpactConstraintHandler::_lcp and ConstraintStabilization::_lcp interleave their
+// draws.  By default every MobyHip::LCP object therefore shares ONE stream per process (process_rng(), srand(1)
+// state on first use), which is what a Moby build with two adapters needs to pivot like the fused kernel
+// (one stream per world).  A batched caller that steps several worlds from one process gives each world's
+// solver objects their own stream with use_rng(state).
 #ifndef MOBY_HIP_LCP_ADAPTER_H
 #define MOBY_HIP_LCP_ADAPTER_H
 #include <stdexcept>
@@ -28,7 +32,17 @@ namespace MobyHip {
 template <class Matrix, class Vector>
 class LCP {
  public:
-  LCP() : pivots(0) { mh_rand_seed(_rng, 1); }
+  LCP() : pivots(0), _rng(process_rng()) {}
+
+  // the stream every adapter object of this process shares unless told otherwise (libc rand() after srand(1))
+  static uint32_t* process_rng() {
+    static uint32_t* st = 0;
+    static uint32_t storage[MH_RAND_WORDS];
+    if (!st) { mh_rand_seed(storage, 1); st = storage; }
+    return st;
+  }
+  // draw from a caller-owned stream instead (MH_RAND_WORDS words, mh_rand_seed); one per simulated world
+  void use_rng(uint32_t* state) { _rng = state ? state : process_rng(); }
 
   bool lcp_fast(const Matrix& M, const Vector& q, Vector& z, double zero_tol = -1.0) {
     return solve(MH_LCP_FAST, M, q, z, -20, 1, 1, -1.0, zero_tol);
@@ -48,7 +62,7 @@ class LCP {
   unsigned pivots;   // LCP.h:30 (private there; exposed for diagnostics)
 
  private:
-  uint32_t _rng[MH_RAND_WORDS];
+  uint32_t* _rng;
   std::vector<double> _zbuf;
 
   bool solve(int kind, const Matrix& M, const Vector& q, Vector& z, int min_exp, unsigned step_exp, int max_exp,

@@ -1,0 +1,49 @@
+// Host-side internals shared by the translation units of libmoby_hip.so (hidden visibility: none of this is ABI).
+// Each .hip file is its own code object (no relocatable device code): kernels never call across files, only the
+// host functions below do.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include "../../include/moby_hip.h"
+
+#define MH_HIDDEN __attribute__((visibility("hidden")))
+
+extern "C" {   // C linkage only so that definitions may sit inside the extern "C" blocks of the ABI files
+
+// sets the thread-local message mh_last_error() returns, and hands `code` back
+MH_HIDDEN int mh_fail(int code, const char* fmt, ...);
+#define fail mh_fail
+
+#define MH_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  return mh_fail(MH_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+MH_HIDDEN int mh_cu_count();
+
+// the LCP entry with a per-problem mask (run_if[b] == 0: problem b is skipped, outputs untouched) and an optional
+// caller-owned block-solver workspace (ws_d: B (n^2 + 5n) doubles, ws_i: B 4n ints); the exported entry
+// mh_lcp_solve_batch_dev is the unmasked case
+MH_HIDDEN int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
+                                      const double* M, int ld, long strideM,
+                                      const double* q, double* z,
+                                      const int* z_size_in, int* z_size_out,
+                                      uint32_t* rng, int* status, unsigned* pivots,
+                                      int32_t* trace, int trace_cap, int* trace_len,
+                                      const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i);
+
+// the three size variants of the many-worlds kernel, one translation unit each (mh_world_{small,wheel,large}.hip)
+typedef void (*mh_world_kernel)(const mh_scene*, int, double, int, double*, mh_world_aux*, double*, int, double*, int, unsigned long long*);
+struct mh_world_variant {
+  mh_world_kernel kernel;
+  int ph_count;                                        // per-phase cycle accumulators of the profiling launch
+  hipError_t (*upload_tables)(const void* fric, size_t fric_bytes, const void* pow10, size_t pow10_bytes);
+};
+MH_HIDDEN const mh_world_variant* mh_world_variant_small();
+MH_HIDDEN const mh_world_variant* mh_world_variant_wheel();
+MH_HIDDEN const mh_world_variant* mh_world_variant_large();
+
+// mh_debug_set keys 1 / 2 (test hooks; defined in mh_capi.hip)
+extern MH_HIDDEN int mh_g_debug_ka;
+extern MH_HIDDEN int mh_g_debug_blk;
+
+}  // extern "C"

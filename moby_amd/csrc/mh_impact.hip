@@ -1,5 +1,5 @@
 // mh_impact.inc -- batched ImpactConstraintHandler::process_constraints on explicit contact lists
-// (include/moby_hip_impact.h; seam B2 of SURVEY.md 8b).  Included at the end of mh_capi.hip.
+// (include/moby_hip_impact.h; seam B2 of SURVEY.md 8b).
 //
 // One world = one island of up to IMP_MAXC contacts over up to IMP_MAXB free bodies.  Everything a world
 // needs lives in HBM (the LCP matrix alone is n^2 doubles: 33.5 MB at n = 2048); the pipeline of one call is
@@ -14,7 +14,13 @@
 // and, only when some contact has epsilon > 0, a second round (mm with new _qq, LCP, post) for the worlds that asked.
 // Arithmetic order follows oracle/world.hpp (compute_problem_data, build_impact_lcp, apply_impulses,
 // update_constraint_vels), which restates the reference's SparseJacobian products.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <vector>
 #include "../../include/moby_hip_impact.h"
+#include "mh_host.h"
+#define MH_DEV __device__ __forceinline__
 
 namespace mh { namespace imp {
 
@@ -107,10 +113,10 @@ void mh_k_imp_prep(Dev d)
   __shared__ unsigned char s_done[MAXC], s_node[MAXB], s_queued[MAXB];
   __shared__ int s_queue[MAXB];
   __shared__ double s_xinv[MAXB * 10];
-  __shared__ int s_flag[4];   // 0: some contact impacting, 1: some mu < 100, 2: single island, 3: need
+  __shared__ int s_flag[5];   // 0: some contact impacting, 1: some mu < 100, 2: single island, 3: need, 4: malformed contact
   const mh_contact* C = d.contacts + (size_t)b * nc;
   const double* st = d.state + (size_t)b * nb * 13;
-  if (t < 4) s_flag[t] = 0;
+  if (t < 5) s_flag[t] = 0;
   for (int i = t; i < nb; i += T) { s_node[i] = 0; s_queued[i] = 0; }
   __syncthreads();
   for (int i = t; i < nc; i += T) {
@@ -124,6 +130,10 @@ void mh_k_imp_prep(Dev d)
     const double vn = dot3(n, point_vel(st, g1, p) - point_vel(st, g2, p));     // calc_constraint_vel (UC:695-747)
     if (vn < -NEAR_ZERO_) s_flag[0] = 1;
     if (C[i].mu_coulomb < 1e2) s_flag[1] = 1;                                    // ICH:127
+    // contacts may have been written through mh_impact_batch_device_ptrs, past upload()'s host checks: the same
+    // checks here (nk of the batch, unit normal, two different bodies of which one is dynamic)
+    const double nn = dot3(n, n);
+    if (C[i].nk != d.nk || !(nn > 0.25 && nn < 4.0) || g1 == g2) s_flag[4] = 1;
   }
   for (int i = t; i < nb; i += T) inv_inertia(st + 13 * i, d.inertia + 3 * i, d.mass[i], s_xinv + 10 * i);
   __syncthreads();
@@ -150,11 +160,11 @@ void mh_k_imp_prep(Dev d)
     }
     const int single = (cnt == nc);
     s_flag[2] = single;
-    const int need = s_flag[0] && single && s_flag[1];
+    const int need = s_flag[0] && single && s_flag[1] && !s_flag[4];
     s_flag[3] = need;
     d.need[b] = need; d.need2[b] = 0; d.again[b] = 0; d.lst1[b] = 1; d.lst2[b] = 1; d.piv1[b] = 0u; d.piv2[b] = 0u;
     d.pivots[b] = 0u; d.solves[b] = 0;
-    if (s_flag[0] && !need) d.status[b] |= MH_WORLD_UNSUPPORTED;     // several islands / the no-slip model: not built here
+    if ((s_flag[0] && !need) || s_flag[4]) d.status[b] |= MH_WORLD_UNSUPPORTED;     // several islands / the no-slip model: not built here; malformed contact
   }
   __syncthreads();
   for (int i = t; i < nc * 3; i += T) d.imp[(size_t)b * nc * 3 + i] = 0.0;
@@ -425,7 +435,6 @@ void mh_k_imp_post(Dev d, const int* __restrict__ run_if, int* __restrict__ agai
 
 struct mh_impact_batch {
   int B, nb, nc, nk, n;
-  bool any_eps;
   mh::imp::Dev d;
   std::vector<void*> allocs;
   double* ws_d; int* ws_i;
@@ -460,7 +469,7 @@ int mh_impact_batch_create(int B, int nb, int nc, int nk, const double* mass, co
   }
   if (mh_device_count() <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
   mh_impact_batch* ib = new mh_impact_batch();
-  ib->B = B; ib->nb = nb; ib->nc = nc; ib->nk = nk; ib->n = (int)n; ib->any_eps = false; ib->ws_d = nullptr; ib->ws_i = nullptr;
+  ib->B = B; ib->nb = nb; ib->nc = nc; ib->nk = nk; ib->n = (int)n; ib->ws_d = nullptr; ib->ws_i = nullptr;
   im::Dev& d = ib->d;
   std::memset(&d, 0, sizeof(d));
   d.B = B; d.nb = nb; d.nc = nc; d.nk = nk; d.kh = nk / 2; d.n = (int)n;
@@ -518,7 +527,6 @@ int mh_impact_batch_upload(mh_impact_batch* ib, const double* state, const mh_co
 {
   if (!ib || !state || !contacts) return fail(MH_ERR_INVALID_ARG, "null batch/state/contacts");
   const size_t ncon = (size_t)ib->B * ib->nc;
-  bool any_eps = false;
   for (size_t i = 0; i < ncon; i++) {
     const mh_contact& c = contacts[i];
     if (c.nk != ib->nk) return fail(MH_ERR_INVALID_ARG, "contact %zu has nk = %d, the batch was created for nk = %d", i, c.nk, ib->nk);
@@ -527,9 +535,7 @@ int mh_impact_batch_upload(mh_impact_batch* ib, const double* state, const mh_co
     const bool s1 = c.body1 < 0 || c.body1 >= ib->nb, s2 = c.body2 < 0 || c.body2 >= ib->nb;
     if (!s1 && c.body1 == c.body2) return fail(MH_ERR_INVALID_ARG, "contact %zu: body1 == body2", i);
     if (s1 && s2) return fail(MH_ERR_INVALID_ARG, "contact %zu joins two static bodies", i);
-    if (c.epsilon > 0.0) any_eps = true;
   }
-  ib->any_eps = any_eps;
   MH_HIP(hipMemcpy(ib->d.state, state, (size_t)ib->B * ib->nb * 13 * 8, hipMemcpyHostToDevice));
   MH_HIP(hipMemcpy(const_cast<mh_contact*>(ib->d.contacts), contacts, ncon * sizeof(mh_contact), hipMemcpyHostToDevice));
   return MH_OK;
@@ -541,12 +547,12 @@ static int impact_solve_round(mh_impact_batch* ib, hipStream_t s, const int* run
   im::Dev& d = ib->d;
   const int B = ib->B, n = ib->n;
   mh_lcp_opts o1; o1.min_exp = -20; o1.step_exp = 4u; o1.max_exp = -8; o1.piv_tol = -1.0; o1.zero_tol = -1.0;   // ICH-QP:219
-  int rc = lcp_solve_dev_masked(s, MH_LCP_FAST_REG, B, n, d.MM, n, (long)n * n, d.qq, d.z, d.zsz, nullptr, d.rng, d.lst1, d.piv1,
+  int rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST_REG, B, n, d.MM, n, (long)n * n, d.qq, d.z, d.zsz, nullptr, d.rng, d.lst1, d.piv1,
                                 nullptr, 0, nullptr, &o1, run_if, ib->ws_d, ib->ws_i);
   if (rc != MH_OK) return rc;
   hipLaunchKernelGGL(im::mh_k_imp_lemke_prep, dim3(B), dim3(im::T), 0, s, d, run_if);
   MH_HIP(hipGetLastError());
-  rc = lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, d.MM, n, (long)n * n, d.qq, d.z, d.zsz, nullptr, d.rng, d.lst2, d.piv2,
+  rc = mh_lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, d.MM, n, (long)n * n, d.qq, d.z, d.zsz, nullptr, d.rng, d.lst2, d.piv2,
                             nullptr, 0, nullptr, nullptr, d.need2, ib->ws_d, ib->ws_i);                                    // ICH-QP:224
   return rc;
 }
@@ -566,8 +572,10 @@ int mh_impact_batch_process(mh_impact_batch* ib, void* stream)
   if (rc != MH_OK) return rc;
   hipLaunchKernelGGL(im::mh_k_imp_post, dim3(B), dim3(im::T), 0, s, d, (const int*)d.need, d.again, 0);
   MH_HIP(hipGetLastError());
-  if (ib->any_eps) {
-    // second solve for the worlds whose restitution impulses left a contact approaching (ICH:591-600): same _MM, new _qq
+  {
+    // second solve for the worlds whose restitution impulses left a contact approaching (ICH:591-600): same _MM, new _qq.
+    // The mask `again` is computed on the device (mh_k_imp_post, phase 0) and the round is always enqueued -- masked
+    // workgroups exit at once -- so contacts written through device_ptrs() get it too (no host-side epsilon scan).
     hipLaunchKernelGGL(im::mh_k_imp_mm, dim3(1, B), dim3(im::T), 0, s, d, (const int*)d.again, 1);
     MH_HIP(hipGetLastError());
     rc = impact_solve_round(ib, s, d.again);

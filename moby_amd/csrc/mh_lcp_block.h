@@ -49,8 +49,6 @@ struct Ws {
 MH_DEV size_t ws_doubles(int n) { return (size_t)n * n + 5 * (size_t)n; }
 MH_DEV size_t ws_ints(int n) { return 4 * (size_t)n; }
 
-__shared__ double s_rd[T];
-__shared__ int s_ri[T];
 __shared__ double s_bd[4];
 __shared__ int s_bi[4];
 __shared__ unsigned s_rng[32];

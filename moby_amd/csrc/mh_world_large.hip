@@ -1,0 +1,29 @@
+// The "large" variant of the many-worlds kernel (mh_world_wave.inc): <= 8 bodies, <= 36 pairs, <= 40 contacts, <= 24 rows per island, every feature.
+// One translation unit per variant: the LDS image, occupancy and feature set differ, and the three compile in parallel.
+#include <hip/hip_runtime.h>
+#include "../../include/moby_hip.h"
+#include "mh_host.h"
+#define MHW_NS large
+#define MHW_NOSLIP 1
+#define MHW_BOX 1
+#define MHW_NB MH_MAX_BODIES
+#define MHW_MAX_PAIRS MH_MAX_PAIRS
+#define MHW_MAX_CONTACTS 40   /* the stabiliser lists one contact per candidate pair (up to 36), a box adds up to 8 */
+#define MHW_MAX_ROWS 24
+#define MHW_MAX_GROWS 24
+#define MHW_WAVES_PER_SIMD 2
+#include "mh_world_wave.inc"
+
+static hipError_t upload_tables(const void* fric, size_t fric_bytes, const void* pow10, size_t pow10_bytes)
+{
+  if (fric_bytes != sizeof(mh::FricTable) || pow10_bytes != sizeof(mh::Pow10Table)) return hipErrorInvalidValue;
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(mh::c_fric), fric, fric_bytes);
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(mh::c_pow10), pow10, pow10_bytes);
+  return e;
+}
+
+const mh_world_variant* mh_world_variant_large()
+{
+  static const mh_world_variant v = { mh::large::mh_k_world_step, mh::large::PH_COUNT, upload_tables };
+  return &v;
+}

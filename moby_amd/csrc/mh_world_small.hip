@@ -1,0 +1,29 @@
+// The "small" variant of the many-worlds kernel (mh_world_wave.inc): <= 4 bodies, <= 6 pairs, <= 6 contacts, <= 12 Jacobian rows, spheres + Drumwright-Shell model only.
+// One translation unit per variant: the LDS image, occupancy and feature set differ, and the three compile in parallel.
+#include <hip/hip_runtime.h>
+#include "../../include/moby_hip.h"
+#include "mh_host.h"
+#define MHW_NS small
+#define MHW_NOSLIP 0
+#define MHW_BOX 0
+#define MHW_NB 4
+#define MHW_MAX_PAIRS 6
+#define MHW_MAX_CONTACTS 6
+#define MHW_MAX_ROWS 12
+#define MHW_MAX_GROWS 12
+#define MHW_WAVES_PER_SIMD 4
+#include "mh_world_wave.inc"
+
+static hipError_t upload_tables(const void* fric, size_t fric_bytes, const void* pow10, size_t pow10_bytes)
+{
+  if (fric_bytes != sizeof(mh::FricTable) || pow10_bytes != sizeof(mh::Pow10Table)) return hipErrorInvalidValue;
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(mh::c_fric), fric, fric_bytes);
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(mh::c_pow10), pow10, pow10_bytes);
+  return e;
+}
+
+const mh_world_variant* mh_world_variant_small()
+{
+  static const mh_world_variant v = { mh::small::mh_k_world_step, mh::small::PH_COUNT, upload_tables };
+  return &v;
+}

@@ -1,0 +1,29 @@
+// The "wheel" variant of the many-worlds kernel (mh_world_wave.inc): <= 2 bodies, <= 3 pairs, <= 4 contacts, + spokes geometry and the no-slip model (rimless wheel).
+// One translation unit per variant: the LDS image, occupancy and feature set differ, and the three compile in parallel.
+#include <hip/hip_runtime.h>
+#include "../../include/moby_hip.h"
+#include "mh_host.h"
+#define MHW_NS wheel
+#define MHW_NOSLIP 1
+#define MHW_BOX 0
+#define MHW_NB 2
+#define MHW_MAX_PAIRS 3
+#define MHW_MAX_CONTACTS 4
+#define MHW_MAX_ROWS 12
+#define MHW_MAX_GROWS 12
+#define MHW_WAVES_PER_SIMD 2
+#include "mh_world_wave.inc"
+
+static hipError_t upload_tables(const void* fric, size_t fric_bytes, const void* pow10, size_t pow10_bytes)
+{
+  if (fric_bytes != sizeof(mh::FricTable) || pow10_bytes != sizeof(mh::Pow10Table)) return hipErrorInvalidValue;
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(mh::c_fric), fric, fric_bytes);
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(mh::c_pow10), pow10, pow10_bytes);
+  return e;
+}
+
+const mh_world_variant* mh_world_variant_wheel()
+{
+  static const mh_world_variant v = { mh::wheel::mh_k_world_step, mh::wheel::PH_COUNT, upload_tables };
+  return &v;
+}

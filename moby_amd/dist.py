@@ -11,6 +11,14 @@ def shard_range(rank, worlds_per_rank):
     return rank * worlds_per_rank, worlds_per_rank
 
 
+def split_range(rank, world_size, total):
+    """Strong scaling: first world id and count of `rank`'s contiguous share of ONE batch of `total` worlds
+    ([g B/G, (g+1) B/G) of SURVEY 8e; the remainder goes to the lowest ranks)."""
+    base, rem = divmod(total, world_size)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
 def counter_vector(aux_before, aux_after, bad_mask):
     """Per-rank totals over an interval: deltas of the counter fields + number of failed worlds."""
     d = [float(aux_after[f].astype(np.int64).sum() - aux_before[f].astype(np.int64).sum()) for f in COUNTER_FIELDS]

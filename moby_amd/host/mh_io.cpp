@@ -53,6 +53,12 @@ void rpy_to_R(double roll, double pitch, double yaw, double R[9]) {
   R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
   R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
 }
+void quat_to_R(const double q[4], double R[9]) {     // q = x y z w, row-major R (the kernels' / oracle's rot())
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y*y + z*z); R[1] = 2 * (x*y - z*w); R[2] = 2 * (x*z + y*w);
+  R[3] = 2 * (x*y + z*w); R[4] = 1 - 2 * (x*x + z*z); R[5] = 2 * (y*z - x*w);
+  R[6] = 2 * (x*z - y*w); R[7] = 2 * (y*z + x*w); R[8] = 1 - 2 * (x*x + y*y);
+}
 void R_to_quat(const double R[9], double q[4]) {   // xyzw; only used for bodies given with rpy
   const double tr = R[0] + R[4] + R[8];
   if (tr > 0) { const double s = std::sqrt(tr + 1.0) * 2; q[3] = 0.25 * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; }
@@ -105,7 +111,7 @@ int mh_io_load_xml(const char* path, mh_io_scene* out)
   mh_scene& sc = out->scene;
   // defaults (mh_scene_defaults, duplicated here so that this library does not need the HIP one)
   sc.min_step_size = std::sqrt(2.220446049250313e-16); sc.contact_dist_thresh = 1e-6; sc.cstab_eps = std::sqrt(2.220446049250313e-16);
-  sc.cstab_max_iterations = 0xFFFFFFFFu; sc.plane_R[0] = sc.plane_R[4] = sc.plane_R[8] = 1.0;
+  sc.cstab_max_iterations = MH_CSTAB_DEFAULT_MAX_ITERATIONS; sc.plane_R[0] = sc.plane_R[4] = sc.plane_R[8] = 1.0;
   for (int p = 0; p < MH_MAX_PAIRS; p++) { sc.pair_enabled[p] = 1; sc.cp_nk[p] = 4; }
 
   // ---- primitives ----
@@ -152,7 +158,12 @@ int mh_io_load_xml(const char* path, mh_io_scene* out)
         b.J[0] = J[0]; b.J[1] = J[4]; b.J[2] = J[8]; }
       if (a.has("position")) { const std::vector<double> p = numbers(a.str("position")); if (p.size() != 3) return fail("RigidBody %s: bad position", b.id.c_str()); for (int i = 0; i < 3; i++) b.x[i] = p[i]; }
       if (a.has("quat")) { const std::vector<double> q = numbers(a.str("quat")); if (q.size() != 4) return fail("RigidBody %s: bad quat", b.id.c_str());
-        const double nrm = std::sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]); for (int i = 0; i < 4; i++) b.q[i] = q[i] / nrm; b.rotated = true; }
+        // the attribute is written and read as w x y z (XMLTree.cpp:89-94, 407-419); the state keeps x y z w
+        const double nrm = std::sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+        if (!(nrm > 0.0)) return fail("RigidBody %s: zero quat", b.id.c_str());
+        b.q[0] = q[1] / nrm; b.q[1] = q[2] / nrm; b.q[2] = q[3] / nrm; b.q[3] = q[0] / nrm;
+        quat_to_R(b.q, b.R);
+        b.rotated = !(b.q[0] == 0.0 && b.q[1] == 0.0 && b.q[2] == 0.0); }
       else if (a.has("rpy")) { const std::vector<double> r = numbers(a.str("rpy")); if (r.size() != 3) return fail("RigidBody %s: bad rpy", b.id.c_str()); rpy_to_R(r[0], r[1], r[2], b.R); R_to_quat(b.R, b.q); b.rotated = (r[0] != 0 || r[1] != 0 || r[2] != 0); }
       else if (a.has("aangle")) {                                    // axis x y z, angle (RigidBody.cpp:213-219)
         const std::vector<double> r = numbers(a.str("aangle")); if (r.size() != 4) return fail("RigidBody %s: bad aangle", b.id.c_str());
@@ -160,10 +171,7 @@ int mh_io_load_xml(const char* path, mh_io_scene* out)
         if (!(nrm > 0.0)) return fail("RigidBody %s: aangle with a zero axis", b.id.c_str());
         const double sh = std::sin(0.5 * r[3]), ch = std::cos(0.5 * r[3]);
         b.q[0] = r[0] / nrm * sh; b.q[1] = r[1] / nrm * sh; b.q[2] = r[2] / nrm * sh; b.q[3] = ch;
-        const double x = b.q[0], y = b.q[1], z = b.q[2], w = b.q[3];
-        b.R[0] = 1 - 2 * (y*y + z*z); b.R[1] = 2 * (x*y - z*w); b.R[2] = 2 * (x*z + y*w);
-        b.R[3] = 2 * (x*y + z*w); b.R[4] = 1 - 2 * (x*x + z*z); b.R[5] = 2 * (y*z - x*w);
-        b.R[6] = 2 * (x*z - y*w); b.R[7] = 2 * (y*z + x*w); b.R[8] = 1 - 2 * (x*x + y*y);
+        quat_to_R(b.q, b.R);
         b.rotated = (r[3] != 0.0);
       }
       if (a.has("linear-velocity")) { const std::vector<double> p = numbers(a.str("linear-velocity")); if (p.size() != 3) return fail("RigidBody %s: bad linear-velocity", b.id.c_str()); for (int i = 0; i < 3; i++) b.v[i] = p[i]; }

@@ -20,6 +20,7 @@ MH_BODY_STATE = 13
 MH_RAND_WORDS = 32
 MH_LCP_MAX_N_WAVE = 64
 MH_NOSLIP_MAX = 16
+MH_CSTAB_DEFAULT_MAX_ITERATIONS = 10   # include/moby_hip.h
 MH_MAX_SPOKES = 8
 MH_GEOM_SPHERE, MH_GEOM_SPOKES, MH_GEOM_BOX = 0, 1, 2
 NEAR_ZERO = math.sqrt(np.finfo(np.float64).eps)   # include/Moby/Constants.h:21
@@ -86,7 +87,7 @@ def _defaults(sc):
     sc.min_step_size = NEAR_ZERO          # TimeSteppingSimulator.cpp:48
     sc.contact_dist_thresh = 1e-6         # ConstraintSimulator.cpp:56
     sc.cstab_eps = NEAR_ZERO              # ConstraintStabilization.cpp:59
-    sc.cstab_max_iterations = 0xFFFFFFFF  # ConstraintStabilization.cpp:56
+    sc.cstab_max_iterations = MH_CSTAB_DEFAULT_MAX_ITERATIONS  # ConstraintStabilization.cpp:56 is UINT_MAX: see moby_hip.h
     for p in range(MH_MAX_PAIRS):
         sc.pair_enabled[p] = 1
         sc.cp_nk[p] = 4                   # ContactParameters.cpp:26
@@ -124,7 +125,7 @@ def make_scene(radii, masses, gravity, ground_rpy=None, ground_o=(0.0, 0.0, 0.0)
     return sc
 
 
-def sphere_stack_scene(cstab_max_iterations=10):
+def sphere_stack_scene(cstab_max_iterations=MH_CSTAB_DEFAULT_MAX_ITERATIONS):
     """example/stacks/sphere-stack.xml:11-51.
 
     ``constraint-stabilization-max-iterations`` is not set in the XML (default
@@ -197,7 +198,7 @@ def bouncing_ball_state(B=1):
     return st.reshape(B, MH_BODY_STATE)
 
 
-def rimless_wheel_scene(cstab_max_iterations=0xFFFFFFFF):
+def rimless_wheel_scene(cstab_max_iterations=MH_CSTAB_DEFAULT_MAX_ITERATIONS):
     """example/rimless-wheel/wheel.xml + coldet-plugin.cpp + params.h: one free body (m = 1,
     J = diag(2,1,2)) whose collision geometry is N_SPOKES = 6 spoke tips at R = 1, a plane with
     rpy = (1.570796326949, 0, 0), gravity (0.099833, 0, -0.995), epsilon 0, mu-coulomb 100
@@ -226,7 +227,7 @@ def rimless_wheel_scene(cstab_max_iterations=0xFFFFFFFF):
     return sc
 
 
-def rimless_wheel_regress_scene(cstab_max_iterations=0xFFFFFFFF):
+def rimless_wheel_regress_scene(cstab_max_iterations=MH_CSTAB_DEFAULT_MAX_ITERATIONS):
     """The scene regress/rimless-wheel.dat was recorded with.  That file predates the wheel.xml in
     the tree: its trajectory (deceleration -0.152 rad/s^2 while pivoting, first post-impact rate
     0.2893 rad/s) is reproduced by the commented-out "alpha = 0.05" gravity line of wheel.xml:13-14
@@ -258,7 +259,7 @@ def rimless_wheel_state(theta_dots=(0.24,)):
 
 
 def box_scene(dims=(1.0, 1.0, 1.0), density=1.0, gravity=(0.0, -9.81, 0.0), ground_rpy=(0.0, 0.0, 0.0), epsilon=0.0,
-              mu_coulomb=0.0, mu_viscous=0.0, nk=8, cstab_max_iterations=0xFFFFFFFF):
+              mu_coulomb=0.0, mu_viscous=0.0, nk=8, cstab_max_iterations=MH_CSTAB_DEFAULT_MAX_ITERATIONS):
     """example/simple-contact/simplest.xml (a unit box of density 1 on the default plane, NK = 8) and,
     with mu_coulomb = 0.1, spinning-box-frictional.xml.  Mass properties as BoxPrimitive::
     calc_mass_properties (BoxPrimitive.cpp:692-712)."""

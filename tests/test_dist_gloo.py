@@ -51,3 +51,30 @@ def test_two_rank_sharding_and_reduction():
         assert elapsed == 1.5                                           # MAX over ranks
         assert red[0] == sum(range(1, world * B + 1))                   # SUM of rows over all worlds
         assert red[1] == 2 * world * B
+
+
+def test_split_range_covers_the_batch_once():
+    """Strong scaling (one batch split N ways): contiguous, disjoint, complete; remainder on the lowest ranks."""
+    for total in (4096, 4097, 7, 1):
+        for n in (1, 2, 3, 8):
+            got = [mdist.split_range(r, n, total) for r in range(n)]
+            assert got[0][0] == 0 and sum(c for _, c in got) == total
+            for (f0, c0), (f1, _) in zip(got, got[1:]):
+                assert f1 == f0 + c0
+            assert max(c for _, c in got) - min(c for _, c in got) <= 1
+
+
+def test_bench_launches_its_own_ranks_when_started_as_plain_python():
+    """`python bench.py --gpus 2` with no RANK in the environment must start torch.distributed.run as a child (the
+    driver's scaling run does exactly this).  Without a GPU every rank stops at "needs a GPU" -- after the rendezvous
+    environment was set up, which is what is checked here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.is_available():
+        return      # on a GPU box the scaling run itself is the driver's job
+    assert p.returncode != 0
+    assert "needs a GPU" in p.stderr and "WORLD_SIZE=1" not in p.stderr, p.stderr[-2000:]

@@ -64,7 +64,7 @@ def test_reference_example_files_load_to_the_same_scenes():
     """The reference's own example files (read in place, never copied) give the builders' scenes."""
     sc, st, ids, _ = mio.load_xml(os.path.join(REF, "stacks", "sphere-stack.xml"))
     assert_scene_equal(sc, S.sphere_stack_scene(), skip=("lcp_n_max", "cstab_max_iterations"))
-    assert sc.cstab_max_iterations == 0xFFFFFFFF
+    assert sc.cstab_max_iterations == S.MH_CSTAB_DEFAULT_MAX_ITERATIONS      # one documented default in every entry path
     np.testing.assert_array_equal(st, S.sphere_stack_state(1))
     sc, st, _, _ = mio.load_xml(os.path.join(REF, "bouncing-ball", "bouncing-ball.xml"))
     assert_scene_equal(sc, S.bouncing_ball_scene())
@@ -87,6 +87,25 @@ def test_axis_angle_orientation(tmp_path):
                  '<TimeSteppingSimulator><DynamicBody dynamic-body-id="b"/><DynamicBody dynamic-body-id="g"/></TimeSteppingSimulator></MOBY></XML>')
     sc, st, ids, _ = mio.load_xml(str(p))
     np.testing.assert_allclose(st[0, 3:7], [0.0, 0.0, np.sin(np.pi / 4), np.cos(np.pi / 4)], atol=1e-15)
+
+
+def test_quat_attribute_is_w_x_y_z(tmp_path):
+    """XMLTree.cpp:407-419 reads `quat` as w x y z (and :89-94 writes it so): quat="1 0 0 0" is the identity, and a
+    ground body posed with `quat` must rotate the plane (30 degrees about x: the plane's +Y normal tilts toward +Z)."""
+    h = np.sqrt(0.5)
+    c15, s15 = np.cos(np.pi / 12), np.sin(np.pi / 12)
+    p = tmp_path / "quat.xml"
+    p.write_text('<XML><MOBY><Sphere id="s" radius="1" mass="1"/><Plane id="p"/>'
+                 '<RigidBody id="a" position="0 2 0" quat="1 0 0 0"><InertiaFromPrimitive primitive-id="s"/><CollisionGeometry primitive-id="s"/></RigidBody>'
+                 '<RigidBody id="b" position="3 2 0" quat="%r 0 0 %r"><InertiaFromPrimitive primitive-id="s"/><CollisionGeometry primitive-id="s"/></RigidBody>'
+                 '<RigidBody id="g" enabled="false" quat="%r %r 0 0"><CollisionGeometry primitive-id="p"/></RigidBody>'
+                 '<TimeSteppingSimulator><DynamicBody dynamic-body-id="a"/><DynamicBody dynamic-body-id="b"/><DynamicBody dynamic-body-id="g"/>'
+                 '<DisabledPair object1-id="a" object2-id="b"/></TimeSteppingSimulator></MOBY></XML>' % (float(h), float(h), float(c15), float(s15)))
+    sc, st, ids, _ = mio.load_xml(str(p))
+    np.testing.assert_allclose(st.reshape(-1, 13)[0, 3:7], [0.0, 0.0, 0.0, 1.0], atol=1e-15)          # identity, not a flip about x
+    np.testing.assert_allclose(st.reshape(-1, 13)[1, 3:7], [0.0, 0.0, h, h], atol=1e-15)              # 90 degrees about z
+    R = np.array(sc.plane_R).reshape(3, 3)
+    np.testing.assert_allclose(R[:, 1], [0.0, np.cos(np.pi / 6), np.sin(np.pi / 6)], atol=1e-15)   # the plane normal
 
 
 def test_unsupported_content_is_an_error(tmp_path):

@@ -158,6 +158,60 @@ def test_block_solver_large_n(oracle):
     assert (lcp.pivots <= 2 * n).all()
 
 
+def _pd_problem(B, n, seed, active):
+    """M = A A' / n + I (PD, dense), q chosen so that exactly the first `active` variables are positive at the solution
+    (z = 1 there, w = 1 elsewhere): sizes of the nonbasic block are known without solving."""
+    rng = np.random.default_rng(seed)
+    M = np.empty((B, n, n)); q = np.empty((B, n))
+    for b in range(B):
+        A = rng.standard_normal((n, n))
+        M[b] = A @ A.T / n + np.eye(n)
+        zs = np.zeros(n); zs[:active] = 1.0
+        ws = np.ones(n); ws[:active] = 0.0
+        q[b] = ws - M[b] @ zs
+    return M, q
+
+
+def test_block_solver_lists_beyond_the_lds_caps(oracle):
+    """k > 1024: the nonbasic index list and the right-hand side no longer fit the solver's LDS staging (LIST_CAP /
+    RHS_CAP in mh_lcp_block.h) and live in the HBM workspace.  n = 1100: a warm-started lcp_fast whose nonbasic block
+    is 1060 x 1060, and a Lemke run (its basis is always n x n) that needs a handful of pivots -- both bit for bit."""
+    n = 1100
+    M, q = _pd_problem(1, n, seed=3, active=1060)
+    z0 = np.zeros((1, n)); z0[0, :1060] = 1.0 + 1e-3 * np.random.default_rng(4).standard_normal(1060)
+    ok = assert_parity(oracle, FAST, M, q, z0=z0)
+    assert ok[0]
+    M, q = _pd_problem(1, n, seed=5, active=3)
+    ok = assert_parity(oracle, LEMKE, M, q, z_size=np.array([n], dtype=np.int32))
+    assert ok[0]
+
+
+@pytest.mark.parametrize("n", [1024, 2048])
+def test_block_solver_config4_sizes_properties(n):
+    """The sizes BASELINE config 4 rests on (n = 1024: 32-box stacks, n = 2048: 64-box stacks), beyond what the oracle
+    finishes in seconds: the LCP conditions on every accepted solution, the known solution recovered, identical
+    problems giving identical answers (batch-order independence), for lcp_fast (warm) and lcp_lemke (cold)."""
+    B = 2
+    M1, q1 = _pd_problem(1, n, seed=n, active=n - 40)
+    M = np.repeat(M1, B, axis=0); q = np.repeat(q1, B, axis=0)
+    z0 = np.zeros((B, n)); z0[:, :n - 40] = 1.0
+    ok, z, lcp = run_gpu(FAST, M, q, z0=z0)
+    assert ok.all()
+    np.testing.assert_array_equal(z[0], z[1])
+    w = M[0] @ z[0] + q[0]
+    scale = np.abs(M[0]).max() * n
+    assert z[0].min() >= 0.0 and w.min() > -1e-10 * scale and np.abs(z[0] * w).max() < 1e-10 * scale
+    np.testing.assert_allclose(z[0, :n - 40], 1.0, atol=1e-9); assert (z[0, n - 40:] == 0.0).all()
+    M1, q1 = _pd_problem(1, n, seed=n + 1, active=4)
+    M = np.repeat(M1, B, axis=0); q = np.repeat(q1, B, axis=0)
+    ok, z, lcp = run_gpu(LEMKE, M, q, z_size=np.full(B, n, dtype=np.int32))
+    assert ok.all() and (lcp.pivots <= 50).all()
+    np.testing.assert_array_equal(z[0], z[1])
+    w = M[0] @ z[0] + q[0]
+    assert z[0].min() >= 0.0 and w.min() > -1e-10 * scale and np.abs(z[0] * w).max() < 1e-10 * scale
+    np.testing.assert_allclose(z[0, :4], 1.0, atol=1e-9)
+
+
 def test_cpp_adapter_example():
     """The Moby::LCP-shaped C++ adapter (moby_amd/cpp/MobyHipLCP.h) links against
     the C ABI and reproduces the KAT."""
