@@ -1,0 +1,89 @@
+/* moby_hip_stack.h -- C ABI of the many-worlds stepper for LARGE worlds (BASELINE config 4: box stacks,
+ * tens of bodies, impact LCPs of 1000+ rows), seams B5 and B3 of SURVEY.md 8b for worlds the one-wavefront
+ * kernel of moby_hip.h (<= 8 bodies, <= 64 LCP rows) does not hold.
+ *
+ * Replaces, per world,
+ *   TimeSteppingSimulator::step / do_mini_step / calc_next_CA_Euler_step   src/TimeSteppingSimulator.cpp:52-222, 272-331
+ *   ConstraintSimulator::{broad_phase, calc_pairwise_distances, find_unilateral_constraints,
+ *     calc_impacting_unilateral_constraint_forces}                          src/ConstraintSimulator.cpp:298-537
+ *   CCD::broad_phase, calc_CA_Euler_step_generic, calc_next_CA_Euler_step_generic / _polyhedron_plane,
+ *     find_contacts_plane_generic                                           src/CCD.cpp:169-468, 702-876; include/Moby/CCD.inl:848-886
+ *   ImpactConstraintHandler::process_constraints with its island loop       src/ImpactConstraintHandler.cpp:75-168, 530-626
+ *   ConstraintStabilization::stabilize (+ compute_problem_data, determine_dq, update_q, ridders_unilateral)
+ *                                                                           src/ConstraintStabilization.cpp:167-254, 347-492, 932-970, 1056-1379
+ *   Simulator::calc_fwd_dyn for free bodies                                 src/Simulator.cpp:482-602
+ * Every world is stepped by its own workgroup (geometry, islands, problem data, impulse application, Ridders line
+ * search) and its LCPs go through the LCP entry of moby_hip.h with per-island sizes; nothing runs on the host but
+ * the loop that asks "does any world have another mini-step / island / stabilisation iteration".
+ *
+ * Geometry scope: boxes and spheres against ONE static plane (the closed forms of moby_hip.h), plus box-on-box pairs
+ * declared MH_PAIR_VERTEX_FACE: the pair is handled exactly like box-plane (CCD.inl:848-886, PlanePrimitive.cpp:338-376,
+ * CCD.cpp:383-397, 410-468), the plane being the +Y face of the lower-id box ("support") and the polyhedron the
+ * higher-id box, with the polyhedron's velocity taken relative to the support.  The reference's box-box path (v-clip on
+ * a qhull polyhedron, contact order qhull-dependent: SURVEY a18) is not reproducible and is not built; the model
+ * is the build's documented order for stacked pairs and is valid while the upper box's vertices project inside the
+ * support face (the stack generator shrinks boxes with height).  Any other box-box / box-sphere pair must be left out of
+ * the candidate list (= a <DisabledPair>).
+ */
+#ifndef MOBY_HIP_STACK_H
+#define MOBY_HIP_STACK_H
+#include "moby_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_PAIR_CLOSED_FORM 0   /* sphere-sphere, sphere-plane, box-plane */
+#define MH_PAIR_VERTEX_FACE 1   /* box (higher id) on the +Y face of a box (lower id) */
+
+#define MH_BIG_MAX_BODIES 128
+#define MH_BIG_MAX_PAIRS  256
+#define MH_BIG_MAX_CONTACTS 512   /* per world, impact or stabilisation list */
+
+/* A scene of any size: body tables + the candidate pairs (everything not listed is a <DisabledPair>).  Pairs are
+ * (a < b) body ids, the ground plane is id nb, sorted lexicographically (the canonical order of SURVEY 7 / a18).
+ * All contacts of a scene share one friction-cone-edges value nk (so a world's LCP size is 6 nc + nc nk/2). */
+typedef struct mh_big_scene {
+  int nb, has_ground;
+  const int*    geom_type;      /* nb: MH_GEOM_SPHERE / MH_GEOM_BOX                 */
+  const double* geom_dim;       /* nb x 3                                            */
+  const double* mass;           /* nb                                                */
+  const double* inertia;        /* nb x 3 body-frame principal moments               */
+  double plane_R[9], plane_o[3], gravity[3];
+  int npairs;
+  const int*    pair_a;         /* npairs                                            */
+  const int*    pair_b;
+  const int*    pair_model;     /* MH_PAIR_*                                         */
+  const double* cp_epsilon;     /* npairs each: ContactParameters                    */
+  const double* cp_mu_coulomb;
+  const double* cp_mu_viscous;
+  const double* cp_compliance;
+  int    nk;                    /* friction-cone-edges of every pair (even, >= 4)    */
+  double min_step_size, contact_dist_thresh, cstab_eps;
+  unsigned cstab_max_iterations;
+  int    lcp_n_max;             /* capacity of the handlers' LCPs (0 = as large as the pair list allows, <= MH_LCP_MAX_N_BLOCK);
+                                   an island that needs more flags its world MH_WORLD_UNSUPPORTED */
+} mh_big_scene;
+
+/* B worlds resident on the GPU.  mh_world_aux carries the rand() stream, time, status bits and counters; the
+ * handlers' _zlast / _z vectors (up to lcp_n_max doubles each) live in the batch (solver_state below).
+ *   step        nsteps x TimeSteppingSimulator::step(dt) for every world (seam B5); host loop + device kernels,
+ *               returns when the device work is enqueued AND the last control read-back is done (the loop needs them)
+ *   stabilize   ConstraintStabilization::stabilize alone on the resident states (seam B3,
+ *               include/Moby/ConstraintStabilization.h:24): configurations change, velocities are restored
+ */
+typedef struct mh_big_batch mh_big_batch;
+int mh_big_batch_create(const mh_big_scene* scene, int B, mh_big_batch** out);
+int mh_big_batch_destroy(mh_big_batch* bb);
+int mh_big_batch_upload(mh_big_batch* bb, const double* state, const mh_world_aux* aux);
+int mh_big_batch_step(mh_big_batch* bb, void* stream, double dt, int nsteps);
+int mh_big_batch_stabilize(mh_big_batch* bb, void* stream);
+int mh_big_batch_download(mh_big_batch* bb, double* state, mh_world_aux* aux);
+int mh_big_batch_lcp_capacity(const mh_big_batch* bb);
+/* checkpoint / resume: _zlast, _z (B x capacity each) and their sizes (B each: zlast_size, zbuf_size, zbuf_cap) */
+int mh_big_batch_save_solver_state(mh_big_batch* bb, double* zlast, double* zbuf, int* sizes3);
+int mh_big_batch_load_solver_state(mh_big_batch* bb, const double* zlast, const double* zbuf, const int* sizes3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

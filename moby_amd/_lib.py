@@ -69,6 +69,16 @@ SYMBOLS = {
     "mh_impact_batch_load_solver_state": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mh_impact_batch_device_ptrs": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "mh_impact_process_batch": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    # include/moby_hip_stack.h
+    "mh_big_batch_create": (_i, [_vp, _i, ctypes.POINTER(_vp)]),
+    "mh_big_batch_destroy": (_i, [_vp]),
+    "mh_big_batch_upload": (_i, [_vp, _vp, _vp]),
+    "mh_big_batch_step": (_i, [_vp, _vp, _d, _i]),
+    "mh_big_batch_stabilize": (_i, [_vp, _vp]),
+    "mh_big_batch_download": (_i, [_vp, _vp, _vp]),
+    "mh_big_batch_lcp_capacity": (_i, [_vp]),
+    "mh_big_batch_save_solver_state": (_i, [_vp, _vp, _vp, _vp]),
+    "mh_big_batch_load_solver_state": (_i, [_vp, _vp, _vp, _vp]),
 }
 
 _lib = None

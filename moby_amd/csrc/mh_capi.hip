@@ -69,12 +69,16 @@ void mh_k_lcp_wave(int B, int n, const double* __restrict__ Mg, int ld, long str
                    const int* __restrict__ zsz_in, int* __restrict__ zsz_out,
                    uint32_t* __restrict__ rngg, int* __restrict__ status, unsigned* __restrict__ pivots_out,
                    int32_t* __restrict__ trace, int trace_cap, int* __restrict__ trace_len,
-                   mh::LcpParams P, mh::Pow10Table p10, const int* __restrict__ run_if)
+                   mh::LcpParams P, mh::Pow10Table p10, const int* __restrict__ run_if, const int* __restrict__ n_arr)
 {
   extern __shared__ double lds[];
   const int b = blockIdx.x;
   if (b >= B) return;
   if (run_if && run_if[b] == 0) return;   // masked problem: every output of it is left untouched
+  // per-problem sizes (islands of different worlds): q / z / M keep the strides of the largest problem, M is
+  // compact (ld = its own n); problems this kernel does not cover belong to the block solver of the same call
+  const int nstride = n;
+  if (n_arr) { n = mh::uni(n_arr[b]); ld = n; if (n < 1 || n > MH_LCP_MAX_N_WAVE) return; }
   const int lane = mh::lane_id();
   double* Ms = lds;
   double* A = Ms + n * n;
@@ -114,9 +118,9 @@ void mh_k_lcp_wave(int B, int n, const double* __restrict__ Mg, int ld, long str
   mh::wave_sync();
   const bool valid = lane < n;
   const double dii = valid ? Ms[lane + n * lane] : 0.0;
-  const double qi = valid ? qg[(size_t)b * n + lane] : 0.0;
+  const double qi = valid ? qg[(size_t)b * nstride + lane] : 0.0;
   int zsize = zsz_in ? mh::uni(zsz_in[b]) : n;
-  double zi = (valid && zsize == n) ? zg[(size_t)b * n + lane] : 0.0;
+  double zi = (valid && zsize == n) ? zg[(size_t)b * nstride + lane] : 0.0;
   if (lane == 0) mh::g_lcp_prof_on = 0;
   mh::wave_sync();
   mh::WaveRand rng; rng.load(rngg + (size_t)b * MH_RAND_WORDS);
@@ -125,7 +129,7 @@ void mh_k_lcp_wave(int B, int n, const double* __restrict__ Mg, int ld, long str
   mh::DenseLds Md; Md.M = Ms; Md.n = n;
   mh::LuScratch S; S.small = A; S.ka = n; S.big = A;
   const bool ok = mh::lcp_solve_wave(P, p10, n, Md, S, art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
-  if (valid) zg[(size_t)b * n + lane] = zi;
+  if (valid) zg[(size_t)b * nstride + lane] = zi;
   rng.store(rngg + (size_t)b * MH_RAND_WORDS);
   if (lane == 0) {
     status[b] = ok ? 1 : 0;
@@ -212,7 +216,7 @@ int mh_lcp_solve_batch_dev(void* stream, int kind, int B, int n,
                            const mh_lcp_opts* opts)
 {
   return mh_lcp_solve_dev_masked(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                              trace, trace_cap, trace_len, opts, nullptr, nullptr, nullptr);
+                              trace, trace_cap, trace_len, opts, nullptr, nullptr, nullptr, nullptr);
 }
 
 int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
@@ -221,7 +225,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
                            const int* z_size_in, int* z_size_out,
                            uint32_t* rng, int* status, unsigned* pivots,
                            int32_t* trace, int trace_cap, int* trace_len,
-                           const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i)
+                           const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i, const int* n_arr)
 {
   mh::LcpParams P;
   int rc = lcp_params(kind, opts, P);
@@ -247,23 +251,31 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     if (wsd && wsi) {
       if (wide) hipLaunchKernelGGL(mh::blkw::k_lcp_block, dim3(B), dim3(mh::blkw::T), 0, (hipStream_t)stream,
                          B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                         trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if);
+                         trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr);
       else hipLaunchKernelGGL(mh::blk::k_lcp_block, dim3(B), dim3(mh::blk::T), 0, (hipStream_t)stream,
                          B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                         trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if);
+                         trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr);
       MH_HIP(hipGetLastError());
+      if (n_arr) {          // the problems of this call that fit one wavefront (n_arr[b] <= 64) take the wave solver
+        const size_t ldsw = (size_t)(2 * MH_LCP_MAX_N_WAVE * MH_LCP_MAX_N_WAVE + MH_LCP_MAX_N_WAVE) * sizeof(double);
+        hipLaunchKernelGGL(mh_k_lcp_wave, dim3(B), dim3(64), ldsw, (hipStream_t)stream,
+                           B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
+                           trace, trace_cap, trace_len, P, p10, run_if, n_arr);
+        MH_HIP(hipGetLastError());
+      }
       return MH_OK;
     }
+    if (n_arr) return fail(MH_ERR_INVALID_ARG, "per-problem sizes need a caller-owned workspace");
     const size_t nd = (size_t)B * ((size_t)n * n + 5 * (size_t)n), ni = (size_t)B * 4 * (size_t)n;
     MH_HIP(hipMallocAsync((void**)&wsd, nd * sizeof(double), (hipStream_t)stream));
     hipError_t e = hipMallocAsync((void**)&wsi, ni * sizeof(int), (hipStream_t)stream);
     if (e != hipSuccess) { (void)hipFreeAsync(wsd, (hipStream_t)stream); return fail(MH_ERR_HIP, "workspace allocation failed: %s", hipGetErrorString(e)); }
     if (wide) hipLaunchKernelGGL(mh::blkw::k_lcp_block, dim3(B), dim3(mh::blkw::T), 0, (hipStream_t)stream,
                        B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                       trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if);
+                       trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr);
     else hipLaunchKernelGGL(mh::blk::k_lcp_block, dim3(B), dim3(mh::blk::T), 0, (hipStream_t)stream,
                        B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                       trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if);
+                       trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr);
     e = hipGetLastError();
     (void)hipFreeAsync(wsd, (hipStream_t)stream); (void)hipFreeAsync(wsi, (hipStream_t)stream);
     if (e != hipSuccess) return fail(MH_ERR_HIP, "block LCP launch failed: %s", hipGetErrorString(e));
@@ -272,7 +284,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
   const size_t lds = (size_t)(2 * n * n + n) * sizeof(double);
   hipLaunchKernelGGL(mh_k_lcp_wave, dim3(B), dim3(64), lds, (hipStream_t)stream,
                      B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                     trace, trace_cap, trace_len, P, p10, run_if);
+                     trace, trace_cap, trace_len, P, p10, run_if, n_arr);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }

@@ -29,7 +29,8 @@ MH_HIDDEN int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
                                       const int* z_size_in, int* z_size_out,
                                       uint32_t* rng, int* status, unsigned* pivots,
                                       int32_t* trace, int trace_cap, int* trace_len,
-                                      const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i);
+                                      const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i,
+                                      const int* n_arr);   // n_arr: per-problem sizes (<= n, M compact with ld = its n) or NULL
 
 // the three size variants of the many-worlds kernel, one translation unit each (mh_world_{small,wheel,large}.hip)
 typedef void (*mh_world_kernel)(const mh_scene*, int, double, int, double*, mh_world_aux*, double*, int, double*, int, unsigned long long*);

@@ -1,0 +1,48 @@
+// The island pipeline shared by the impact-handler entry (mh_impact.hip, seam B2) and the large-world stepper
+// (mh_big.hip, seams B5 / B3): device buffers of B worlds x up to ncmax contacts x up to nb bodies, and the host
+// functions that run ImpactConstraintHandler::process_constraints (mode IMPACT) or ConstraintStabilization's
+// compute_problem_data + determine_dq (mode STAB) over every island of every world.  Host-only header: the kernels
+// live in mh_impact.hip.
+#pragma once
+#include "mh_host.h"
+#include "../../include/moby_hip_impact.h"
+
+enum { MH_CORE_IMPACT = 0, MH_CORE_STAB = 1 };
+
+struct mh_imp_core {
+  int B, nb, ncmax, nk, kh, nmax, islmax;
+  // inputs owned by the caller of the pipeline
+  const double* mass; const double* inertia;        // nb, nb x 3 (shared by all worlds)
+  double* state;                                    // B x nb x 13
+  const mh_contact* contacts;                       // B x ncmax
+  const int* ncount;                                // B contacts in use, or NULL (= ncmax)
+  const double* cdist;                              // MH_CORE_STAB: signed_violation of each contact (B x ncmax)
+  double stab_eps;                                  // ConstraintStabilization::eps
+  uint32_t* rng;                                    // B x MH_RAND_WORDS
+  int* status;                                      // B, MH_WORLD_* bits (sticky)
+  // island tables and per-contact problem data, in island order
+  int* order; int* cbody; double* cpar; double* W; double* XJ; double* Cv; double* xinv;
+  int* nisl; int* isl_start; int* isl_len; int* maxisl;      // maxisl: one int, max over worlds of nisl
+  // the LCP of the current round
+  double* G; double* MM; double* qq; double* z; int* zsz; int* ncur;
+  // what the handler object keeps between solves: _zlast and the storage of _z (ICH-QP:158-162, 233)
+  double* zlast; double* zbuf; int* zlast_size; int* zbuf_size; int* zbuf_cap;
+  int* run; int* need2; int* again; int* lst1; int* lst2; unsigned* piv1; unsigned* piv2;
+  double* imp;                                      // B x ncmax x 3 accumulated (cn, cs, ct), caller order
+  unsigned long long* cnt;                          // B x 4: LCPs solved, rows, pivots, LCP-entry bytes 8 (n^2 + 2n)
+  const double* fcos; const double* fsin;           // kh each (host libm)
+  double* ws_d; int* ws_i;                          // block-solver workspace (nmax > 64)
+  int* hmax;                                        // pinned host copy of maxisl
+  void* allocs[48]; int nallocs;
+};
+
+extern "C" {
+// allocates every buffer the pipeline owns (everything but mass / inertia / state / contacts / ncount / cdist / rng /
+// status, which the caller points at its own memory) and uploads the friction-polygon table
+MH_HIDDEN int mh_imp_core_create(mh_imp_core* c, int B, int nb, int ncmax, int nk, int nmax);
+MH_HIDDEN void mh_imp_core_destroy(mh_imp_core* c);
+// prep (islands, rows, X C^T, C v) + one round per island (gram, LCP matrix, solver chain, impulse application,
+// restitution / second solve) + the impact-tolerance check.  Synchronises `stream` once, after the island search, to
+// learn how many rounds the batch needs.
+MH_HIDDEN int mh_imp_core_process(mh_imp_core* c, void* stream, int mode);
+}

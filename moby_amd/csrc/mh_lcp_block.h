@@ -709,7 +709,7 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
                     uint32_t* __restrict__ rngg, int* __restrict__ status, unsigned* __restrict__ pivots_out,
                     int32_t* __restrict__ trace, int trace_cap, int* __restrict__ trace_len,
                     LcpParams P, Pow10Table p10, double* __restrict__ wsd, int* __restrict__ wsi,
-                    const int* __restrict__ run_if)
+                    const int* __restrict__ run_if, const int* __restrict__ n_arr)
 {
   const int b = blockIdx.x;
   if (b >= B) return;
@@ -718,12 +718,16 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   Ws W;
   double* wd = wsd + (size_t)b * ws_doubles(n);
   int* wi = wsi + (size_t)b * ws_ints(n);
+  // per-problem sizes: strides of q / z / M / the workspace stay those of the largest problem (the launch's n), M is
+  // compact (ld = its own n); problems of at most 64 rows belong to the wave solver of the same call
+  const int nstride = n;
+  if (n_arr) { n = n_arr[b]; ld = n; if (n <= MH_LCP_MAX_N_WAVE) return; }
   W.A = wd; W.b = wd + (size_t)n * n; W.w = W.b + n; W.x = W.w + n; W.d = W.x + n; W.art = W.d + n;
   W.list = wi; W.flag = wi + n; W.pos = wi + 2 * (size_t)n; W.bv = wi + 3 * (size_t)n;
   if (t < 32) s_rng[t] = rngg[(size_t)b * MH_RAND_WORDS + t];
   Mat M; M.M = Mg + (size_t)b * strideM; M.ld = ld; M.n = n;
-  const double* q = qg + (size_t)b * n;
-  double* z = zg + (size_t)b * n;
+  const double* q = qg + (size_t)b * nstride;
+  double* z = zg + (size_t)b * nstride;
   int zsize = zsz_in ? zsz_in[b] : n;
   if (zsize != n) for (int i = t; i < n; i += T) z[i] = 0.0;
   sync();

@@ -1,0 +1,171 @@
+"""Host-side mirror of the large-world stepper (include/moby_hip_stack.h).
+
+``BigScene`` holds the body tables and the candidate-pair list of one scene topology (any number of free
+boxes / spheres over one static plane); ``box_stack_scene`` generates BASELINE config 4's scene -- the pattern of
+/root/reference/example/stacks/stack.xml:6-12,36-96 extended to any height; ``BigBatch`` plays the
+role of B ``TimeSteppingSimulator`` objects (``step``) and of ``ConstraintStabilization::stabilize`` (``stabilize``).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from . import scene as S
+
+MH_PAIR_CLOSED_FORM, MH_PAIR_VERTEX_FACE = 0, 1
+_dp, _ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+
+
+class mh_big_scene(ctypes.Structure):
+    _fields_ = [
+        ("nb", ctypes.c_int), ("has_ground", ctypes.c_int),
+        ("geom_type", _ip), ("geom_dim", _dp), ("mass", _dp), ("inertia", _dp),
+        ("plane_R", ctypes.c_double * 9), ("plane_o", ctypes.c_double * 3), ("gravity", ctypes.c_double * 3),
+        ("npairs", ctypes.c_int),
+        ("pair_a", _ip), ("pair_b", _ip), ("pair_model", _ip),
+        ("cp_epsilon", _dp), ("cp_mu_coulomb", _dp), ("cp_mu_viscous", _dp), ("cp_compliance", _dp),
+        ("nk", ctypes.c_int),
+        ("min_step_size", ctypes.c_double), ("contact_dist_thresh", ctypes.c_double), ("cstab_eps", ctypes.c_double),
+        ("cstab_max_iterations", ctypes.c_uint), ("lcp_n_max", ctypes.c_int),
+    ]
+
+
+class BigScene:
+    """numpy tables + the ctypes record pointing into them (keep this object alive while the record is in use)."""
+
+    def __init__(self, geom_type, geom_dim, mass, inertia, pairs, gravity, plane_R=None, plane_o=(0.0, 0.0, 0.0), has_ground=True,
+                 nk=4, epsilon=0.0, mu_coulomb=0.0, mu_viscous=0.0, compliance=0.0,
+                 cstab_max_iterations=S.MH_CSTAB_DEFAULT_MAX_ITERATIONS, lcp_n_max=0):
+        self.geom_type = np.ascontiguousarray(geom_type, dtype=np.int32)
+        self.nb = len(self.geom_type)
+        self.geom_dim = np.ascontiguousarray(geom_dim, dtype=np.float64).reshape(self.nb, 3)
+        self.mass = np.ascontiguousarray(mass, dtype=np.float64)
+        self.inertia = np.ascontiguousarray(inertia, dtype=np.float64).reshape(self.nb, 3)
+        pairs = sorted(pairs)                                  # (a, b, model), a < b, lexicographic = canonical order
+        self.pair_a = np.array([p[0] for p in pairs], dtype=np.int32)
+        self.pair_b = np.array([p[1] for p in pairs], dtype=np.int32)
+        self.pair_model = np.array([p[2] for p in pairs], dtype=np.int32)
+        npairs = len(pairs)
+        full = lambda v: np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64), (npairs,)))
+        self.cp_epsilon, self.cp_mu_coulomb = full(epsilon), full(mu_coulomb)
+        self.cp_mu_viscous, self.cp_compliance = full(mu_viscous), full(compliance)
+        c = mh_big_scene()
+        c.nb, c.has_ground, c.npairs, c.nk = self.nb, 1 if has_ground else 0, npairs, int(nk)
+        P = lambda a, t: a.ctypes.data_as(t)
+        c.geom_type, c.geom_dim, c.mass, c.inertia = P(self.geom_type, _ip), P(self.geom_dim, _dp), P(self.mass, _dp), P(self.inertia, _dp)
+        c.pair_a, c.pair_b, c.pair_model = P(self.pair_a, _ip), P(self.pair_b, _ip), P(self.pair_model, _ip)
+        c.cp_epsilon, c.cp_mu_coulomb = P(self.cp_epsilon, _dp), P(self.cp_mu_coulomb, _dp)
+        c.cp_mu_viscous, c.cp_compliance = P(self.cp_mu_viscous, _dp), P(self.cp_compliance, _dp)
+        R = np.eye(3) if plane_R is None else np.asarray(plane_R, dtype=np.float64).reshape(3, 3)
+        for k in range(9):
+            c.plane_R[k] = R.flat[k]
+        for k in range(3):
+            c.plane_o[k] = plane_o[k]; c.gravity[k] = gravity[k]
+        c.min_step_size = S.NEAR_ZERO; c.contact_dist_thresh = 1e-6; c.cstab_eps = S.NEAR_ZERO
+        c.cstab_max_iterations = int(cstab_max_iterations); c.lcp_n_max = int(lcp_n_max)
+        self.c = c
+
+    @property
+    def npairs(self):
+        return len(self.pair_a)
+
+    def lcp_capacity(self):
+        """Largest LCP a world of this scene can ask for: every candidate pair with 4 contacts (a box face) -- the
+        bound mh_big_batch_create uses when lcp_n_max is 0."""
+        if self.c.lcp_n_max:
+            return int(self.c.lcp_n_max)
+        per = [4 if (m == MH_PAIR_VERTEX_FACE or self.geom_type[a] == S.MH_GEOM_BOX) else 1
+               for a, m in zip(self.pair_a, self.pair_model)]
+        nc = int(sum(per))
+        return min(4096, max(64, 6 * nc + nc * (self.c.nk // 2)))
+
+
+def box_dims(k):
+    """Box k of the stack: (1 - 0.005 k) x 1 x (1 - 0.005 k) (stack.xml:6-12 extended)."""
+    s = 1.0 - 0.005 * k
+    return s, 1.0, s
+
+
+def box_stack_scene(nboxes, mu=1e-4, epsilon=0.0, nk=4, cstab_max_iterations=S.MH_CSTAB_DEFAULT_MAX_ITERATIONS, lcp_n_max=None):
+    """nboxes boxes, density 10, centre y = 0.5 + k, on the plane y = 0, gravity (0, -9.81, 0).  Candidate pairs: the
+    ground with every box (its DummyBV is infinite, CCD.cpp:1091-1094) and each box with the one above it (the only
+    box pairs whose bounding spheres of radius ~0.87 can overlap at a centre distance of 1), as vertex-face pairs."""
+    gt = np.full(nboxes, S.MH_GEOM_BOX, dtype=np.int32)
+    dims = np.array([box_dims(k) for k in range(nboxes)])
+    mass = 10.0 * dims.prod(axis=1)                                              # BoxPrimitive.cpp:692-712
+    M = mass / 12.0
+    x, y, z = dims.T
+    inertia = np.stack([M * (y * y + z * z), M * (x * x + z * z), M * (x * x + y * y)], axis=1)
+    if lcp_n_max is None:
+        # every interface (ground-box 0 and box k - box k+1) with its 4 corner contacts: n = nboxes * 4 * (6 + nk/2)
+        lcp_n_max = max(64, nboxes * 4 * (6 + nk // 2))
+    pairs = [(k, nboxes, MH_PAIR_CLOSED_FORM) for k in range(nboxes)] + [(k, k + 1, MH_PAIR_VERTEX_FACE) for k in range(nboxes - 1)]
+    return BigScene(gt, dims, mass, inertia, pairs, gravity=(0.0, -9.81, 0.0), nk=nk, epsilon=epsilon, mu_coulomb=mu,
+                    cstab_max_iterations=cstab_max_iterations, lcp_n_max=lcp_n_max)
+
+
+def box_stack_state(nboxes, B=1, perturb=True, seed0=0x4D4F4259):
+    """Boxes at rest, exactly touching; worlds > 0 get small seeded velocity perturbations."""
+    st = np.zeros((B, nboxes, S.MH_BODY_STATE))
+    st[:, :, 1] = 0.5 + np.arange(nboxes)
+    st[:, :, 6] = 1.0
+    if perturb and B > 1:
+        rng = np.random.default_rng(seed0)
+        st[1:, :, 7] += rng.uniform(-1e-3, 1e-3, (B - 1, nboxes))
+        st[1:, :, 9] += rng.uniform(-1e-3, 1e-3, (B - 1, nboxes))
+        st[1:, :, 8] += rng.uniform(-1e-3, 0.0, (B - 1, nboxes))
+        st[1:, :, 10:13] += rng.uniform(-1e-3, 1e-3, (B - 1, nboxes, 3))
+    return st.reshape(B, nboxes * S.MH_BODY_STATE)
+
+
+class BigBatch:
+    """B large worlds behind an ``mh_big_batch`` handle."""
+
+    def __init__(self, scene, state, aux=None):
+        lib = _lib.load()
+        self.scene = scene
+        st = np.ascontiguousarray(state, dtype=np.float64)
+        self.B = st.shape[0]
+        assert st.shape == (self.B, scene.nb * S.MH_BODY_STATE)
+        self.handle = ctypes.c_void_p()
+        _lib.check(lib.mh_big_batch_create(ctypes.byref(scene.c), self.B, ctypes.byref(self.handle)))
+        self.cap = lib.mh_big_batch_lcp_capacity(self.handle)
+        self.upload(st, aux)
+
+    def upload(self, state, aux=None):
+        st = np.ascontiguousarray(state, dtype=np.float64)
+        a = None if aux is None else np.ascontiguousarray(aux)
+        _lib.check(_lib.load().mh_big_batch_upload(self.handle, st.ctypes.data, None if a is None else a.ctypes.data))
+
+    def step(self, dt, nsteps=1, stream=None):
+        _lib.check(_lib.load().mh_big_batch_step(self.handle, stream, float(dt), int(nsteps)))
+
+    def stabilize(self, stream=None):
+        _lib.check(_lib.load().mh_big_batch_stabilize(self.handle, stream))
+
+    def download(self):
+        st = np.zeros((self.B, self.scene.nb * S.MH_BODY_STATE)); aux = np.zeros(self.B, dtype=S.AUX_DTYPE)
+        _lib.check(_lib.load().mh_big_batch_download(self.handle, st.ctypes.data, aux.ctypes.data))
+        return st, aux
+
+    def solver_state(self):
+        zl = np.zeros((self.B, self.cap)); zb = np.zeros((self.B, self.cap)); sz = np.zeros((self.B, 3), dtype=np.int32)
+        _lib.check(_lib.load().mh_big_batch_save_solver_state(self.handle, zl.ctypes.data, zb.ctypes.data, sz.ctypes.data))
+        return dict(zlast=zl, zbuf=zb, sizes=sz)
+
+    def load_solver_state(self, ss):
+        zl = np.ascontiguousarray(ss["zlast"], dtype=np.float64); zb = np.ascontiguousarray(ss["zbuf"], dtype=np.float64)
+        sz = np.ascontiguousarray(ss["sizes"], dtype=np.int32)
+        assert zl.shape == (self.B, self.cap) and zb.shape == (self.B, self.cap) and sz.shape == (self.B, 3)
+        _lib.check(_lib.load().mh_big_batch_load_solver_state(self.handle, zl.ctypes.data, zb.ctypes.data, sz.ctypes.data))
+
+    def close(self):
+        if self.handle:
+            _lib.load().mh_big_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

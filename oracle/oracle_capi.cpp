@@ -216,4 +216,35 @@ int oracle_impact_lcp(int nb, int nc, const double* mass, const double* inertia,
   return n;
 }
 
+
+// ---- big scenes (include/moby_hip_stack.h) ----------------------------------------------------------
+static SceneView view_of(const mh_big_scene* s, const std::vector<int>& enabled_all)
+{
+  return SceneView{ s->nb, s->has_ground, s->geom_type, reinterpret_cast<const double (*)[3]>(s->geom_dim), s->mass,
+                    reinterpret_cast<const double (*)[3]>(s->inertia), s->plane_R, s->plane_o, s->gravity,
+                    s->npairs, s->pair_a, s->pair_b, s->pair_model, enabled_all.data(),
+                    s->cp_epsilon, s->cp_mu_coulomb, s->cp_mu_viscous, s->cp_compliance, nullptr,
+                    s->min_step_size, s->contact_dist_thresh, s->cstab_eps, s->cstab_max_iterations };
+}
+
+// nsteps x TimeSteppingSimulator::step (mode 0) or one ConstraintStabilization::stabilize (mode 1) of ONE big world.
+// zlast / zbuf: the handler's _zlast / _z storage (lcp_cap doubles each); their sizes live in aux (zlast_size, zbuf_size,
+// zbuf_cap).  Returns elapsed seconds.
+double oracle_big_step(const mh_big_scene* s, double dt, int nsteps, double* state, mh_world_aux* aux,
+                       double* zlast, double* zbuf, int lcp_cap, int mode)
+{
+  timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+  std::vector<int> en((size_t)s->npairs, 1), nk((size_t)s->npairs, s->nk);
+  SceneView v = view_of(s, en);
+  v.cp_nk = nk.data();
+  World w(v, state, aux, zlast, zbuf, lcp_cap);
+  if (mode == 1) {
+    w.broad_phase(0.0, w.pairs_to_check);              // the simulator's pair list of the step that just ended
+    w.calc_pairwise_distances(w.pairs_to_check, w.pairwise);
+    w.stabilize();
+  } else for (int k = 0; k < nsteps; k++) w.step(dt);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}
+
 } // extern "C"

@@ -36,6 +36,7 @@
 #include <algorithm>
 #include "../include/moby_hip.h"
 #include "../include/moby_hip_impact.h"
+#include "../include/moby_hip_stack.h"
 #include "lcp.hpp"
 
 namespace oracle {
@@ -68,22 +69,45 @@ struct PairDist { int pair, a, b; double dist; V3 pa, pb; };  // PairwiseDistInf
 
 static unsigned long long g_ca_iters = 0;   // diagnostic: conservative-advancement sub-steps taken
 
+// What the stepper reads of a scene: the members of mh_scene under the same names, as pointers, so that scenes of any
+// size (include/moby_hip_stack.h: mh_big_scene, explicit candidate-pair list) run through the same code.  Pair p of a
+// small scene is the lexicographic (i<j) index over nb (+ ground) bodies, as before.
+struct SceneView {
+  int nb, has_ground;
+  const int* geom_type; const double (*geom_dim)[3]; const double* mass; const double (*inertia)[3];
+  const double* plane_R; const double* plane_o; const double* gravity;
+  int npairs; const int* pair_a; const int* pair_b; const int* pair_model;     // pair_a == nullptr: all (i<j), lexicographic
+  const int* pair_enabled; const double* cp_epsilon; const double* cp_mu_coulomb; const double* cp_mu_viscous;
+  const double* cp_compliance; const int* cp_nk;
+  double min_step_size, contact_dist_thresh, cstab_eps; unsigned cstab_max_iterations;
+};
+
 class World {
  public:
-  const mh_scene* sc;
+  SceneView view_;
+  const SceneView* sc;
   double* st;               // nb * 13
   mh_world_aux* aux;
   int32_t* trace = nullptr; int trace_cap = 0; int trace_len = 0;  // concatenated LCP traces (tests)
 
   // body table and handler storage: the scene's / the aux record's by default; the impact-handler entry
-  // (oracle_impact_process) points them at caller arrays of any size instead
+  // (oracle_impact_process) and the big-scene stepper point them at caller arrays of any size instead
   int nb_; const double* mass_; const double (*inertia_)[3];
   double* zlast_; double* zbuf_; int lcp_cap_;
 
-  World(const mh_scene* scene, double* state, mh_world_aux* a) : sc(scene), st(state), aux(a),
-    nb_(scene->nb), mass_(scene->mass), inertia_(scene->inertia), zlast_(a->zlast), zbuf_(a->zbuf), lcp_cap_(MH_LCP_MAX_N_WAVE) {}
+  World(const mh_scene* s, double* state, mh_world_aux* a) : sc(&view_), st(state), aux(a),
+    nb_(s->nb), mass_(s->mass), inertia_(s->inertia), zlast_(a->zlast), zbuf_(a->zbuf), lcp_cap_(MH_LCP_MAX_N_WAVE) {
+    const int ntot = s->nb + (s->has_ground ? 1 : 0);
+    view_ = SceneView{ s->nb, s->has_ground, s->geom_type, s->geom_dim, s->mass, s->inertia, s->plane_R, s->plane_o, s->gravity,
+                       ntot * (ntot - 1) / 2, nullptr, nullptr, nullptr,
+                       s->pair_enabled, s->cp_epsilon, s->cp_mu_coulomb, s->cp_mu_viscous, s->cp_compliance, s->cp_nk,
+                       s->min_step_size, s->contact_dist_thresh, s->cstab_eps, s->cstab_max_iterations };
+  }
   World(int nb, const double* mass, const double (*inertia)[3], double* state, mh_world_aux* a, double* zlast, double* zbuf, int lcp_cap)
     : sc(nullptr), st(state), aux(a), nb_(nb), mass_(mass), inertia_(inertia), zlast_(zlast), zbuf_(zbuf), lcp_cap_(lcp_cap) {}
+  // a big scene: the view is the caller's, the handler vectors _zlast / _z are caller arrays of lcp_cap doubles
+  World(const SceneView& v, double* state, mh_world_aux* a, double* zlast, double* zbuf, int lcp_cap)
+    : view_(v), sc(&view_), st(state), aux(a), nb_(v.nb), mass_(v.mass), inertia_(v.inertia), zlast_(zlast), zbuf_(zbuf), lcp_cap_(lcp_cap) {}
 
   // ---- state access -------------------------------------------------------
   V3 X(int b) const { return v3(st[13*b], st[13*b+1], st[13*b+2]); }
@@ -127,9 +151,9 @@ class World {
   // DummyBV (DummyBV.h:53-56).
   void broad_phase(double dt, std::vector<int>& pairs) const {
     const int ntot = nbodies_all();
-    double lo[MH_MAX_BODIES + 1][3], hi[MH_MAX_BODIES + 1][3];
+    std::vector<double> lo(3 * (size_t)ntot), hi(3 * (size_t)ntot);
     for (int b = 0; b < ntot; b++) {
-      if (!enabled(b)) { for (int k = 0; k < 3; k++) { lo[b][k] = -INF; hi[b][k] = INF; } continue; }
+      if (!enabled(b)) { for (int k = 0; k < 3; k++) { lo[3*b+k] = -INF; hi[3*b+k] = INF; } continue; }
       const V3 c = X(b);
       const V3 vdt = Vl(b) * dt, wdt = Wa(b) * dt;
       const V3 lin = vdt + cross(c, wdt);            // linear part of (v dt) expressed at the global origin
@@ -137,30 +161,32 @@ class World {
       const double r = bounding_radius(b);
       for (int k = 0; k < 3; k++) {
         const double a = comp(c, k), e = comp(p2, k);
-        lo[b][k] = ((a < e) ? a : e) - r;
-        hi[b][k] = ((a > e) ? a : e) + r;
+        lo[3*b+k] = ((a < e) ? a : e) - r;
+        hi[3*b+k] = ((a > e) ? a : e) + r;
       }
     }
     pairs.clear();
-    for (int i = 0; i < ntot; i++)
-      for (int j = i + 1; j < ntot; j++) {
-        const int p = pair_index(i, j, ntot);
+    for (int p = 0; p < sc->npairs; p++) {
+        int i, j; pair_bodies(p, i, j);
         if (is_spokes(i) || is_spokes(j)) continue;   // removed from CCD's body list (coldet-plugin.cpp:58-66)
-        if ((is_box(i) || is_box(j)) && j != sc->nb) {  // box-box (v-clip on a qhull polyhedron) / box-sphere: not built
+        if ((is_box(i) || is_box(j)) && j != sc->nb && !vertex_face(p)) {  // box-box (v-clip on a qhull polyhedron) / box-sphere: not built
           if (sc->pair_enabled[p]) aux->status |= MH_WORLD_UNSUPPORTED;
           continue;
         }
         bool ov = true;
-        for (int k = 0; k < 3; k++) if (!(lo[i][k] <= hi[j][k] && lo[j][k] <= hi[i][k])) ov = false;
+        for (int k = 0; k < 3; k++) if (!(lo[3*i+k] <= hi[3*j+k] && lo[3*j+k] <= hi[3*i+k])) ov = false;
         if (!ov) continue;                          // needs overlap on all three axes (CCD.cpp:857)
         if (!sc->pair_enabled[p]) continue;
         if (!enabled(i) && !enabled(j)) continue;
         pairs.push_back(p);
       }
     // BladePlanePlugin::broad_phase appends (ground, wheel) unconditionally (coldet-plugin.cpp:72)
-    if (sc->has_ground)
+    if (sc->has_ground && !sc->pair_a)
       for (int i = 0; i < sc->nb; i++) if (is_spokes(i)) pairs.push_back(pair_index(i, sc->nb, ntot));
   }
+  // MH_PAIR_VERTEX_FACE (include/moby_hip_stack.h): a box-box pair handled like box-plane, the plane being the +Y face of
+  // the lower-id box ("support") and the polyhedron the higher-id box -- the build's documented model of a stacked pair
+  bool vertex_face(int p) const { return sc->pair_model && sc->pair_model[p] == MH_PAIR_VERTEX_FACE; }
   bool is_spokes(int b) const { return b < sc->nb && sc->geom_type[b] == MH_GEOM_SPOKES; }
   bool is_box(int b) const { return b < sc->nb && sc->geom_type[b] == MH_GEOM_BOX; }
   // radius of the bounding sphere CCD::construct_bounding_sphere builds (CCD.cpp:1040-1063)
@@ -187,10 +213,14 @@ class World {
     return v3(c.x + ((R[0]*px + R[1]*py) + R[2]*pz), c.y + ((R[3]*px + R[4]*py) + R[5]*pz), c.z + ((R[6]*px + R[7]*py) + R[8]*pz));
   }
   void pair_bodies(int p, int& a, int& b) const {
+    if (sc->pair_a) { a = sc->pair_a[p]; b = sc->pair_b[p]; return; }
     const int ntot = nbodies_all();
     for (int i = 0; i < ntot; i++) for (int j = i + 1; j < ntot; j++) if (pair_index(i, j, ntot) == p) { a = i; b = j; return; }
     a = b = -1;
   }
+  // the support plane of a vertex-face pair: through the centre of body L's +Y face, normal = L's +Y axis (world)
+  V3 face_n(int L) const { double R[9]; rot(L, R); return v3(R[1], R[4], R[7]); }
+  double face_height(int L, V3 p) const { return dot(face_n(L), p - X(L)) - sc->geom_dim[L][1] * 0.5; }
   // CollisionGeometry::calc_signed_dist (CollisionGeometry.cpp:236-250) ->
   // SpherePrimitive.cpp:104-136 / PlanePrimitive.cpp:385-411
   PairDist signed_dist(int p) const {
@@ -209,6 +239,19 @@ class World {
         if (pp.y < min_dist) { min_dist = pp.y; d.pb = from_plane(v3(pp.x, 0.0, pp.z)); d.pa = g; }
       }
       d.dist = min_dist; d.a = sc->nb; d.b = w;
+      return d;
+    }
+    if (vertex_face(p)) {
+      // PlanePrimitive::calc_signed_dist(polyhedral) (PlanePrimitive.cpp:338-376) with the support face as the plane:
+      // lowest vertex of the upper box over the face, first one wins ties; pa on the support, pb the vertex
+      double min_dist = INF;
+      const V3 nL = face_n(d.a);
+      for (int i = 0; i < 8; i++) {
+        const V3 g = box_vertex(d.b, i);
+        const double h = face_height(d.a, g);
+        if (h < min_dist) { min_dist = h; d.pb = g; d.pa = g - nL * h; }
+      }
+      d.dist = min_dist;
       return d;
     }
     if (is_box(d.a)) {
@@ -283,6 +326,21 @@ class World {
       }
       return;
     }
+    if (vertex_face(p)) {
+      // find_contacts_plane_generic (CCD.inl:848-886) with the support face as the plane: every vertex of the upper
+      // box within TOL (<=) of it; contact point = the vertex, geom1 = support, geom2 = upper box, normal = -(face normal)
+      const V3 nL = face_n(a);
+      for (int i = 0; i < 8; i++) {
+        const V3 g = box_vertex(b, i);
+        const double h = face_height(a, g);
+        if (!(h <= TOL)) continue;
+        c.p = g; c.n = -nL; c.g1 = a; c.g2 = b; c.dist = h;
+        orthonormal_basis(c.n, c.s, c.t);
+        fill_params(c);
+        out.push_back(c);
+      }
+      return;
+    }
     if (is_box(a)) {
       // CCD::find_contacts_plane_generic(plane, box) (CCD.inl:848-886): every vertex within TOL (<=) of
       // the plane; contact point = the vertex, geom1 = plane, geom2 = box, normal = -(plane normal)
@@ -348,14 +406,18 @@ class World {
   }
   // CCD::calc_next_CA_Euler_step_polyhedron_plane (CCD.cpp:410-468) for box `bx` resting on the
   // plane: called with normal = -contact_normal = +plane normal, offset0 = -<contact normal, point>
-  double next_CA_box_plane(int bx, V3 normal, double offset0) const {
+  double next_CA_box_plane(int bx, V3 normal, double offset0, int support = -1) const {
     double R[9]; rot(bx, R);
     auto to_box_vec = [&](V3 v) { return v3((R[0]*v.x + R[3]*v.y) + R[6]*v.z, (R[1]*v.x + R[4]*v.y) + R[7]*v.z, (R[2]*v.x + R[5]*v.y) + R[8]*v.z); };
     const V3 nP = to_box_vec(normal);
     const V3 p0 = normal * offset0;
     const double offset = dot(nP, to_box_vec(p0 - X(bx)));
-    const double av_norm = norm(to_box_vec(Wa(bx)));
-    const double lv_dot_n = -dot(nP, to_box_vec(Vl(bx)));
+    // rv = velocity of the polyhedron relative to the plane's body, at the polyhedron's pose (CCD.cpp:388-394); the
+    // ground plane does not move, a support box does
+    const V3 wrel = enabled(support) ? Wa(bx) - Wa(support) : Wa(bx);
+    const V3 vrel = enabled(support) ? Vl(bx) - point_vel(support, X(bx)) : Vl(bx);
+    const double av_norm = norm(to_box_vec(wrel));
+    const double lv_dot_n = -dot(nP, to_box_vec(vrel));
     const double hx = sc->geom_dim[bx][0] * 0.5, hy = sc->geom_dim[bx][1] * 0.5, hz = sc->geom_dim[bx][2] * 0.5;
     double max_step = INF;
     for (int i = 0; i < 8; i++) {
@@ -382,6 +444,7 @@ class World {
       // geom1 is the plane: the "planeA / polyhedron B" branch (CCD.cpp:383-397)
       const Contact& c = cs[0];
       const double dd = dot(c.n, c.p);
+      if (vertex_face(d.pair)) return next_CA_box_plane(d.b, -c.n, -dd, d.a);
       return next_CA_box_plane(d.a, -c.n, -dd);
     }
     return INF;
@@ -923,7 +986,8 @@ class World {
   // TimeSteppingSimulator::do_mini_step (TSS:114-222)
   double do_mini_step(double dt) {
     const int nb = sc->nb;
-    double qsave[MH_MAX_BODIES][7];
+    std::vector<double> qsave_v(7 * (size_t)nb);
+    double (*qsave)[7] = reinterpret_cast<double (*)[7]>(qsave_v.data());
     for (int b = 0; b < nb; b++) get_coords(b, qsave[b]);
     double h = 0.0;
     unsigned long ca_guard = 0;
@@ -1040,7 +1104,8 @@ class World {
   void stabilize() {
     if (sc->cstab_max_iterations == 0) return;
     const int nb = sc->nb;
-    double vsave[MH_MAX_BODIES][6];
+    std::vector<double> vsave_v(6 * (size_t)nb);
+    double (*vsave)[6] = reinterpret_cast<double (*)[6]>(vsave_v.data());
     for (int b = 0; b < nb; b++) for (int k = 0; k < 6; k++) vsave[b][k] = st[13*b + 7 + k];
     std::vector<double> q; get_q(q);
     std::vector<double> uC;
@@ -1072,7 +1137,7 @@ class World {
         const int nc = pd.nc;
         for (int i = 0; i < nc; i++) pd.Cv[0][i] = pd.c[i]->dist - std::fabs(sc->cstab_eps) - NEAR_ZERO;   // CStab:431
         // determine_dq (CStab:932-970): MM = Cn X Cn', cold lcp_fast then Lemke ladder
-        if (nc > MH_LCP_MAX_N_WAVE) { aux->status |= MH_WORLD_UNSUPPORTED; continue; }
+        if (nc > lcp_cap_) { aux->status |= MH_WORLD_UNSUPPORTED; continue; }
         std::vector<double> MM((size_t)nc * nc);
         for (int i = 0; i < nc; i++) for (int j = 0; j < nc; j++) MM[(size_t)i + (size_t)nc * j] = pd.G[0][0][(size_t)i * nc + j];
         Vec z;                                                       // fresh local: size 0 -> cold start

@@ -149,3 +149,19 @@ def oracle_impact_lcp(self, nb, mass, inertia, state, contacts, cap):
 
 Oracle.impact_process = oracle_impact_process
 Oracle.impact_lcp = oracle_impact_lcp
+
+
+def oracle_big_step(self, scene, state, aux, dt, nsteps=1, zlast=None, zbuf=None, cap=None, mode=0):
+    """nsteps x step(dt) (mode 0) or one stabilize() (mode 1) of ONE large world (moby_amd.stack.BigScene), in place.
+    state (nb*13,), aux 1-element structured array, zlast / zbuf: the handler's _zlast / _z storage (cap doubles)."""
+    cap = scene.lcp_capacity() if cap is None else int(cap)
+    zlast = np.zeros(cap) if zlast is None else zlast
+    zbuf = np.zeros(cap) if zbuf is None else zbuf
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    self.lib.oracle_big_step.restype = ctypes.c_double
+    secs = self.lib.oracle_big_step(ctypes.byref(scene.c), ctypes.c_double(dt), int(nsteps), P(state), P(aux), P(zlast), P(zbuf),
+                                    int(cap), int(mode))
+    return dict(seconds=secs, zlast=zlast, zbuf=zbuf)
+
+
+Oracle.big_step = oracle_big_step

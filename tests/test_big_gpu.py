@@ -1,0 +1,153 @@
+"""GPU parity of the large-world stepper (include/moby_hip_stack.h, through the C ABI) against the oracle: bit-exact
+body states, rand() streams, status bits and counters after full TimeSteppingSimulator::step calls (conservative
+advancement, contact generation, the island loop of process_constraints, stabilisation with Ridders), and of
+ConstraintStabilization::stabilize alone (seam B3)."""
+import numpy as np
+import pytest
+
+from moby_amd import scene as S
+from moby_amd import stack as K
+from tests.test_oracle_big import big_from_small
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "stab_iters", "lcp_alg_bytes",
+          "zlast_size", "zbuf_size", "zbuf_cap")
+
+
+def run_both(oracle, sc, st0, dt, nsteps, chunks=1, mode=0):
+    """GPU batch vs one oracle world at a time; returns (gpu state, gpu aux, oracle state, oracle aux)."""
+    B = st0.shape[0]
+    bb = K.BigBatch(sc, st0)
+    cap = bb.cap
+    st_o = st0.copy(); aux_o = S.new_aux(B); zl = np.zeros((B, cap)); zb = np.zeros((B, cap))
+    for _ in range(chunks):
+        if mode == 0:
+            bb.step(dt, nsteps)
+        else:
+            bb.stabilize()
+        for w in range(B):
+            oracle.big_step(sc, st_o[w], aux_o[w:w + 1], dt, nsteps, zlast=zl[w], zbuf=zb[w], cap=cap, mode=mode)
+    st_g, aux_g = bb.download()
+    ss = bb.solver_state()
+    bb.close()
+    return st_g, aux_g, st_o, aux_o, ss, zl, zb
+
+
+def assert_parity(st_g, aux_g, st_o, aux_o, ss=None, zl=None, zb=None):
+    for f in FIELDS:
+        assert np.array_equal(aux_g[f], aux_o[f]), "%s: gpu %r oracle %r" % (f, aux_g[f], aux_o[f])
+    assert np.array_equal(st_g, st_o), "max |diff| = %.3e" % np.abs(st_g - st_o).max()
+    if ss is not None:
+        for w in range(st_g.shape[0]):
+            n = int(aux_o["zlast_size"][w]); c = int(aux_o["zbuf_cap"][w])
+            assert np.array_equal(ss["zlast"][w, :n], zl[w, :n]) and np.array_equal(ss["zbuf"][w, :c], zb[w, :c])
+
+
+@pytest.mark.parametrize("nboxes,B,nsteps", [(1, 4, 6), (2, 4, 6), (3, 4, 5), (5, 3, 4)])
+def test_box_stacks_step_like_the_oracle(oracle, nboxes, B, nsteps):
+    """Config 4 in the small (n = 32 nboxes: wave solver at 1-2 boxes, block solver above), perturbed worlds."""
+    sc = K.box_stack_scene(nboxes)
+    st0 = K.box_stack_state(nboxes, B)
+    r = run_both(oracle, sc, st0, 1e-3, nsteps)
+    assert_parity(*r)
+    assert (r[1]["lcp_rows"] > 0).all() and (r[1]["steps"] == nsteps).all()
+
+
+def test_sphere_stack_through_the_large_world_path(oracle):
+    """BASELINE config 2's scene through this stepper: the same trajectories, bit for bit, as the oracle -- and hence as
+    the one-wavefront kernel of moby_hip.h, which the same oracle checks (tests/test_world_gpu.py)."""
+    sc = big_from_small(S.sphere_stack_scene())
+    st0 = S.sphere_stack_state_range(0, 6)
+    r = run_both(oracle, sc, st0, 1e-3, 20, chunks=2)
+    assert_parity(*r)
+    assert (r[1]["stab_iters"] > 0).any() and (r[1]["lcp_rows"] > 0).all()
+
+
+def test_dropped_boxes_conservative_advancement_and_restitution(oracle):
+    """A tumbling box dropped on a box lying on the plane (vertex-face pair), mu = 0.4, epsilon = 0.3: conservative-
+    advancement sub-steps, intermittent contacts, second solves."""
+    dims = [(2.0, 1.0, 2.0), (0.8, 0.6, 0.7)]
+    mass = [20.0, 3.0]
+    inertia = [[m / 12.0 * (y * y + z * z), m / 12.0 * (x * x + z * z), m / 12.0 * (x * x + y * y)] for m, (x, y, z) in zip(mass, dims)]
+    sc = K.BigScene([S.MH_GEOM_BOX] * 2, dims, mass, inertia, [(0, 2, 0), (1, 2, 0), (0, 1, K.MH_PAIR_VERTEX_FACE)], gravity=(0, -9.81, 0),
+                    mu_coulomb=0.4, epsilon=0.3, lcp_n_max=192)
+    B = 4
+    rng = np.random.default_rng(5)
+    st = np.zeros((B, 2, 13)); st[:, :, 6] = 1.0
+    st[:, 0, 1] = 0.5
+    st[:, 1, 1] = 1.0 + 0.3 + 0.05 + 0.02 * rng.random(B); st[:, 1, 8] = -1.0
+    q = np.concatenate([0.05 * rng.standard_normal((B, 3)), np.ones((B, 1))], axis=1); st[:, 1, 3:7] = q / np.linalg.norm(q, axis=1)[:, None]
+    st[:, 1, 10:13] = 0.5 * rng.standard_normal((B, 3))
+    r = run_both(oracle, sc, st.reshape(B, -1), 1e-3, 40, chunks=3)
+    assert_parity(*r)
+    assert (r[1]["mini_steps"] > r[1]["steps"]).all() and (r[1]["lcp_solves"] > 0).all()
+
+
+def test_two_stacks_in_one_world_are_two_islands(oracle):
+    """The island loop of process_constraints (ICH:105-151) and of the stabiliser: two stacks of two boxes side by side share
+    no body, so every step solves two impact LCPs of 64 rows instead of one of 128 -- in the reference's island order."""
+    dims = [K.box_dims(0), K.box_dims(1), K.box_dims(0), K.box_dims(1)]
+    mass = [10.0 * x * y * z for x, y, z in dims]
+    inertia = [[m / 12.0 * (y * y + z * z), m / 12.0 * (x * x + z * z), m / 12.0 * (x * x + y * y)] for m, (x, y, z) in zip(mass, dims)]
+    pairs = [(b, 4, 0) for b in range(4)] + [(0, 1, K.MH_PAIR_VERTEX_FACE), (2, 3, K.MH_PAIR_VERTEX_FACE)]
+    sc = K.BigScene([S.MH_GEOM_BOX] * 4, dims, mass, inertia, pairs, gravity=(0, -9.81, 0), mu_coulomb=0.2, lcp_n_max=128)
+    B = 3
+    st = np.zeros((B, 4, 13)); st[:, :, 6] = 1.0
+    st[:, :, 1] = (0.5, 1.5, 0.5, 1.5); st[:, 2:, 0] = 5.0
+    rng = np.random.default_rng(2)
+    st[1:, :, 7:13] += 1e-3 * rng.standard_normal((B - 1, 4, 6))
+    r = run_both(oracle, sc, st.reshape(B, -1), 1e-3, 5)
+    assert_parity(*r)
+    assert (r[1]["lcp_solves"] >= 2 * 5).all()                 # two islands per step (+ the stabiliser's)
+    assert (r[1]["lcp_rows"] <= r[1]["lcp_solves"] * 64).all()  # and none of them the 128-row LCP of a single island
+
+
+def test_stabilize_alone_is_the_b3_seam(oracle):
+    """ConstraintStabilization::stabilize (include/Moby/ConstraintStabilization.h:24) on interpenetrating stacks:
+    configurations change, velocities come back as they were, the violation is gone -- and every bit equals the oracle."""
+    N, B = 3, 4
+    sc = K.box_stack_scene(N, cstab_max_iterations=50)
+    st = K.box_stack_state(N, B).reshape(B, N, 13)
+    rng = np.random.default_rng(9)
+    st[:, :, 1] -= 1e-4 * (1 + np.arange(N)) * (1.0 + rng.random((B, 1)))          # every interface penetrates by ~1e-4
+    st[:, :, 7:13] = rng.standard_normal((B, N, 6))
+    st0 = st.reshape(B, -1).copy()
+    r = run_both(oracle, sc, st0, 0.0, 0, mode=1)
+    assert_parity(*r)
+    g = r[0].reshape(B, N, 13)
+    assert np.array_equal(g[:, :, 7:13], st[:, :, 7:13])                                 # velocities restored
+    gaps = np.diff(np.concatenate([np.zeros((B, 1)), g[:, :, 1] - 0.5], axis=1), axis=1) - np.array([0.0] + [1.0] * (N - 1))
+    assert (gaps > -1e-9).all() and (r[1]["stab_iters"] >= 1).all()
+
+
+def test_sixteen_box_stack_one_step_matches_oracle(oracle):
+    """n = 512 impact LCP (the wide block solver, Lemke fallback) inside a full step."""
+    N, B = 16, 2
+    sc = K.box_stack_scene(N)
+    st0 = K.box_stack_state(N, B)
+    r = run_both(oracle, sc, st0, 1e-3, 1)
+    assert_parity(*r)
+    assert (r[1]["lcp_rows"] >= 512).all()
+
+
+CONFIG4_BOXES = 16        # the size bench.py's config-4 leg names (n = 512 impact LCP per world); see DESIGN.md 4
+
+
+def test_config4_stated_size_properties():
+    """BASELINE config 4 at the size bench.py names, many worlds, one full step: no world fails, the stack stays put,
+    and identical worlds give identical results wherever they sit in the batch."""
+    N, B = CONFIG4_BOXES, 128
+    sc = K.box_stack_scene(N)
+    st0 = K.box_stack_state(N, B)
+    st0[B // 2:] = st0[:B // 2]                                   # second half = copy of the first
+    bb = K.BigBatch(sc, st0)
+    bb.step(1e-3, 1)
+    st, aux = bb.download()
+    bb.close()
+    assert np.array_equal(st[B // 2:], st[:B // 2]) and np.array_equal(aux["lcp_pivots"][B // 2:], aux["lcp_pivots"][:B // 2])
+    assert ((aux["status"] & ~S.MH_WORLD_IMPACT_TOL) == 0).all()
+    assert (aux["steps"] == 1).all() and (aux["lcp_rows"] >= 32 * N).all()
+    b = st.reshape(B, N, 13)
+    assert np.abs(b[:, :, 1] - 0.5 - np.arange(N)).max() < 1e-4     # nothing sank or flew
+    assert np.abs(b[:, :, 7:13]).max() < 5e-2

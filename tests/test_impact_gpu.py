@@ -105,28 +105,71 @@ def test_random_contact_graphs_match_oracle(oracle, seed, nb, nc, nk):
     ib.close()
 
 
-def test_unsupported_and_idle_worlds_are_left_untouched(oracle):
-    """World 0: two islands; world 1: every mu >= 100 (no-slip model); world 2: nothing impacting; world 3: ordinary."""
+def test_islands_loop_noslip_flag_and_idle_worlds(oracle):
+    """World 0: two islands (ICH:105-151 handles them one after the other -- so does this entry); world 1: every
+    mu >= 100 (the no-slip model: flagged, untouched); world 2: nothing impacting; world 3: ordinary."""
     nbx, B = 2, 4
     mass, J, st, cs = I.box_stack(nbx, B=B, perturb=False)
     cs["body2"][0, 4:] = 99                              # box 1 now rests on something static: two islands
     cs["mu_coulomb"][1] = 100.0
     st.reshape(B, nbx, 13)[2, :, 8] = 0.5                # separating
     r = I.ImpactBatch(B, nbx, 8, 4, mass, J).process(st, cs)
-    assert list(r["status"]) == [S.MH_WORLD_UNSUPPORTED, S.MH_WORLD_UNSUPPORTED, 0, 0]
-    assert np.array_equal(r["state"][:3], st[:3]) and not np.array_equal(r["state"][3], st[3])
-    assert list(r["solves"]) == [0, 0, 0, 1]
-    assert np.abs(r["impulses"][:3]).max() == 0.0 and r["impulses"][3, :, 0].sum() > 0
-    # the oracle agrees on what it can express: idle world untouched, ordinary world identical
+    assert list(r["status"]) == [0, S.MH_WORLD_UNSUPPORTED, 0, 0]
+    assert np.array_equal(r["state"][1:3], st[1:3]) and not np.array_equal(r["state"][3], st[3])
+    assert list(r["solves"]) == [2, 0, 0, 1]
+    assert np.abs(r["impulses"][1:3]).max() == 0.0 and r["impulses"][3, :, 0].sum() > 0
     n = I.lcp_size(8, 4)
-    for w in (2, 3):
+    for w in (0, 2, 3):
         aux = S.new_aux(1); s = st[w].copy()
-        oracle.impact_process(nbx, mass, J, s, cs[w], aux, np.zeros(n), np.zeros(n), n)
+        imp, _ = oracle.impact_process(nbx, mass, J, s, cs[w], aux, np.zeros(n), np.zeros(n), n)
         assert np.array_equal(s, r["state"][w]) and aux["status"][0] == r["status"][w]
-    # ... and flags the no-slip world the same way (its no-slip path keeps at most MH_NOSLIP_MAX contacts: here it runs)
-    aux = S.new_aux(1); s = st[0].copy()
-    oracle.impact_process(nbx, mass, J, s, cs[0], aux, np.zeros(n), np.zeros(n), n)
-    assert not np.array_equal(s, st[0])                  # the reference handles islands one by one; this entry does not (flagged)
+        assert np.array_equal(imp, r["impulses"][w]) and aux["lcp_solves"][0] == r["solves"][w] and aux["lcp_pivots"][0] == r["pivots"][w]
+
+
+def random_forest(rng, nb, nc):
+    """Contacts over nb bodies that fall into several islands: bodies are split into groups, every group gets a random
+    connected multigraph, the lists are interleaved."""
+    ngroups = int(rng.integers(2, 4))
+    groups = np.array_split(rng.permutation(nb), ngroups)
+    per = np.maximum(1, np.diff(np.linspace(0, nc, ngroups + 1).astype(int)))
+    parts = []
+    for g, k in zip(groups, per):
+        c = random_island(rng, len(g), int(k), static_frac=1.0 if len(g) == 1 else 0.4)
+        for f in ("body1", "body2"):
+            c[f] = [int(g[v]) if v < len(g) else nb for v in c[f]]
+        parts.append(c)
+    cs = np.concatenate(parts)[:nc]
+    if len(cs) < nc:
+        cs = np.concatenate([cs, cs[:nc - len(cs)]])
+    return cs[rng.permutation(nc)]
+
+
+@pytest.mark.parametrize("seed,nb,nc,nk", [(10, 4, 6, 4), (11, 6, 9, 4), (12, 7, 12, 6), (13, 9, 14, 4)])
+def test_random_multi_island_graphs_match_oracle(oracle, seed, nb, nc, nk):
+    """Random contact lists over several islands of different sizes (one-body islands against static geometry included),
+    two calls: island order, per-island LCP sizes, the _zlast / _z hand-over from one island's solve to the next."""
+    rng = np.random.default_rng(seed)
+    B = 4
+    n = I.lcp_size(nc, nk)
+    mass = rng.uniform(0.5, 3.0, nb); J = rng.uniform(0.2, 2.0, (nb, 3))
+    cs = np.stack([random_forest(rng, nb, nc) for _ in range(B)]); cs["nk"] = nk
+    st = np.zeros((B, nb, 13)); st[:, :, 0:3] = rng.standard_normal((B, nb, 3))
+    q = rng.standard_normal((B, nb, 4)); st[:, :, 3:7] = q / np.linalg.norm(q, axis=2)[:, :, None]
+    st[:, :, 7:13] = rng.standard_normal((B, nb, 6))
+    st = st.reshape(B, -1)
+    ib = I.ImpactBatch(B, nb, nc, nk, mass, J)
+    aux = S.new_aux(B); zl = np.zeros((B, n)); zb = np.zeros((B, n))
+    st_o = st.copy(); st_g = st.copy()
+    most = 0
+    for call in range(2):
+        r = ib.process(st_g, cs)
+        imp_o, piv_o, sol_o = oracle_batch(oracle, nb, mass, J, st_o, cs, n, aux, zl, zb)
+        assert_same(r, st_o, imp_o, piv_o, sol_o, aux)
+        most = max(most, int(r["solves"].max()))
+        st_g = r["state"].copy()
+        st_g.reshape(B, nb, 13)[:, :, 7:13] += 0.1 * rng.standard_normal((B, nb, 6)); st_o[:] = st_g
+    assert most >= 2                                       # some world really had several active islands
+    ib.close()
 
 
 def test_upload_rejects_malformed_contacts():
