@@ -1,0 +1,78 @@
+/* moby_hip_artic.h -- C ABI of the many-worlds stepper for ARTICULATED bodies (BASELINE config 5: the ur10 arm of
+ * example/ur10/model.sdf x8192 initial states): reduced-coordinate forward dynamics by the composite-rigid-body
+ * algorithm + Cholesky, and joint limits as unilateral constraints.
+ *
+ * Replaces, per world (one Moby::RCArticulatedBody with a fixed base and 1-DOF revolute / prismatic joints, which is
+ * what SDFReader::read_model builds: eCRB + eLinkCOM, src/SDFReader.cpp:934-935),
+ *   TimeSteppingSimulator::step / do_mini_step                        src/TimeSteppingSimulator.cpp:52-222
+ *   Ravelin::RCArticulatedBodyd::calc_fwd_dyn (CRB)  [seam B4]         call site src/Simulator.cpp:552 -- Ravelin's source is
+ *                                                                      NOT in the reference tree: the algorithm is
+ *                                                                      Featherstone's (CRBA for H, RNEA for the bias), "parity unpinned"
+ *   ArticulatedBody::find_limit_constraints                            include/Moby/ArticulatedBody.inl:9-43
+ *   ImpactConstraintHandler::compute_problem_data / compute_X /
+ *     compute_limit_components for limit rows                          src/ImpactConstraintHandler.cpp:1590-1695, 1755-1781
+ *   ::apply_no_slip_model[_to_connected_constraints] with NC = 0       src/ImpactConstraintHandler.cpp:236-295, 1009-1417
+ *     (an island without contacts has all_inf == true, ICH:123-135: LCP  L X L' l + L v >= 0  with X = H^-1)
+ *   ::update_from_stacked, update_constraint_velocities_from_impulses, apply_restitution   src/ImpactConstraintHandler.cpp:298-525
+ * One wavefront per world; H, its Cholesky factor, H^-1 and the limit LCP live in LDS.
+ *
+ * Scope: no collision geometry on the links (the robot alone, self-collision disabled as in ur10.xml:12; so no contact
+ * rows and one mini-step per step), no actuator torques (controller plugins stay on the host side of the seam: add them
+ * through qdd = H^-1 (tau - C) by passing tau), constraint stabilisation off (ur10.xml:11 sets
+ * constraint-stabilization-max-iterations = 0).
+ */
+#ifndef MOBY_HIP_ARTIC_H
+#define MOBY_HIP_ARTIC_H
+#include "moby_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_ARTIC_MAX_JOINTS 16
+#define MH_JOINT_REVOLUTE 0
+#define MH_JOINT_PRISMATIC 1
+
+/* Joint i carries link i; joints are listed parents first.  All quantities are LOCAL (constant), as a reader of
+ * model.sdf derives them once at q = 0 (mh_io_load_sdf, moby_amd/host/mh_io.cpp):
+ *   Rrel, trel   pose of link i's frame in its parent link's frame at q = 0 (row-major rotation; parent -1 = model frame)
+ *   axis         joint axis in link i's frame, unit (revolute: rotation about it through the link origin; prismatic:
+ *                translation along it)
+ *   com, inertia centre of mass in link i's frame; inertia about the COM in link i's axes (row-major 3 x 3, symmetric) */
+typedef struct mh_artic_model {
+  int    nj;
+  int    parent[MH_ARTIC_MAX_JOINTS];
+  int    jtype[MH_ARTIC_MAX_JOINTS];
+  double Rrel[MH_ARTIC_MAX_JOINTS][9];
+  double trel[MH_ARTIC_MAX_JOINTS][3];
+  double axis[MH_ARTIC_MAX_JOINTS][3];
+  double com[MH_ARTIC_MAX_JOINTS][3];
+  double inertia[MH_ARTIC_MAX_JOINTS][9];
+  double mass[MH_ARTIC_MAX_JOINTS];
+  double lolimit[MH_ARTIC_MAX_JOINTS];     /* Joint::lolimit / hilimit (src/Joint.cpp:201-262); +-DBL_MAX = none */
+  double hilimit[MH_ARTIC_MAX_JOINTS];
+  double limit_restitution[MH_ARTIC_MAX_JOINTS];   /* restitution-coeff, default 0 (src/Joint.cpp:33) */
+  double gravity[3];
+} mh_artic_model;
+
+/* B worlds resident on the GPU: joint positions q and velocities qd (B x nj each) + mh_world_aux (rand() stream, time,
+ * status, counters; vns / vns_size hold ImpactConstraintHandler::_v, the warm start of the limit LCP).
+ *   step      nsteps x TimeSteppingSimulator::step(dt) in ONE launch
+ *   fwd_dyn   seam B4: qdd = H(q)^-1 (tau - C(q, qd)) for the resident states (tau: B x nj device-side copy of host
+ *             values, or NULL = 0); H_out (B x nj x nj, row-major) optional -- the generalized inertia
+ *             (get_generalized_inertia, used by compute_X)
+ */
+typedef struct mh_artic_batch mh_artic_batch;
+int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** out);
+int mh_artic_batch_destroy(mh_artic_batch* ab);
+int mh_artic_batch_upload(mh_artic_batch* ab, const double* q, const double* qd, const mh_world_aux* aux);
+int mh_artic_batch_step(mh_artic_batch* ab, void* stream, double dt, int nsteps);
+int mh_artic_batch_fwd_dyn(mh_artic_batch* ab, const double* tau, double* qdd_out, double* H_out);
+int mh_artic_batch_download(mh_artic_batch* ab, double* q, double* qd, mh_world_aux* aux);
+/* link poses of the resident states (B x nj x 12: row-major R (9), origin (3), model frame): what a viewer or a
+ * collision front end on the host needs */
+int mh_artic_batch_link_poses(mh_artic_batch* ab, double* poses);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

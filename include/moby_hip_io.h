@@ -23,6 +23,7 @@
 #ifndef MOBY_HIP_IO_H
 #define MOBY_HIP_IO_H
 #include "moby_hip.h"
+#include "moby_hip_artic.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -41,6 +42,21 @@ typedef struct mh_io_scene {
  * (unsupported elements are errors, never silently dropped) */
 int mh_io_load_xml(const char* path, mh_io_scene* out);
 const char* mh_io_last_error(void);
+
+/* SDF models (example/ur10/model.sdf): the subset of SDFReader::read_model / read_link / read_joint / read_inertial
+ * (src/SDFReader.cpp:880-1000, 432-610, 1288-1330) an articulated-body batch needs -- <link> (pose, inertial: pose, mass,
+ * inertia), <joint type="revolute|prismatic"> (parent, child, axis: xyz, use_parent_model_frame, limit lower / upper).
+ * As in the reference a joint whose parent is "world" makes the body fixed-base, a joint sits at its child link's origin
+ * (no <pose> under <joint> in the scope here), and the axis is given in the parent LINK's frame when
+ * use_parent_model_frame is 1 (SDFReader.cpp:559-562), else in the child link's.  Joints are ordered parents first
+ * (file order within a level); names of the links the joints carry come back in link_id.  Collision geometry, visuals,
+ * surfaces and plugins are skipped (out of scope: SURVEY 2).  0 on success. */
+typedef struct mh_io_artic {
+  mh_artic_model model;
+  char link_id[MH_ARTIC_MAX_JOINTS][MH_IO_ID_LEN];
+  char joint_id[MH_ARTIC_MAX_JOINTS][MH_IO_ID_LEN];
+} mh_io_artic;
+int mh_io_load_sdf(const char* path, const double gravity[3], mh_io_artic* out);
 
 /* writes at most cap bytes (NUL-terminated) and returns the length the full row needs */
 int mh_io_format_row(double t, const double* state, int nb, char* buf, int cap);

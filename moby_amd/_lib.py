@@ -79,6 +79,14 @@ SYMBOLS = {
     "mh_big_batch_lcp_capacity": (_i, [_vp]),
     "mh_big_batch_save_solver_state": (_i, [_vp, _vp, _vp, _vp]),
     "mh_big_batch_load_solver_state": (_i, [_vp, _vp, _vp, _vp]),
+    # include/moby_hip_artic.h
+    "mh_artic_batch_create": (_i, [_vp, _i, ctypes.POINTER(_vp)]),
+    "mh_artic_batch_destroy": (_i, [_vp]),
+    "mh_artic_batch_upload": (_i, [_vp, _vp, _vp, _vp]),
+    "mh_artic_batch_step": (_i, [_vp, _vp, _d, _i]),
+    "mh_artic_batch_fwd_dyn": (_i, [_vp, _vp, _vp, _vp]),
+    "mh_artic_batch_download": (_i, [_vp, _vp, _vp, _vp]),
+    "mh_artic_batch_link_poses": (_i, [_vp, _vp]),
 }
 
 _lib = None

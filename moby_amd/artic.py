@@ -1,0 +1,130 @@
+"""Host-side mirror of the articulated-body stepper (include/moby_hip_artic.h).
+
+``ArticBatch(model, q, qd)`` plays the role of B simulators that each hold one fixed-base ``RCArticulatedBody``
+(``step``), and of ``RCArticulatedBodyd::calc_fwd_dyn`` / ``get_generalized_inertia`` on their states (``fwd_dyn``);
+``load_sdf`` reads example/ur10/model.sdf through the C++ loader of libmoby_hip_io.so; ``model_from_links`` builds a
+model from global link poses the way that loader does (synthetic chains for the tests).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from . import io as mio
+from . import scene as S
+
+MH_ARTIC_MAX_JOINTS = 16
+MH_JOINT_REVOLUTE, MH_JOINT_PRISMATIC = 0, 1
+_NJ = MH_ARTIC_MAX_JOINTS
+
+
+class mh_artic_model(ctypes.Structure):
+    _fields_ = [("nj", ctypes.c_int), ("parent", ctypes.c_int * _NJ), ("jtype", ctypes.c_int * _NJ),
+                ("Rrel", (ctypes.c_double * 9) * _NJ), ("trel", (ctypes.c_double * 3) * _NJ), ("axis", (ctypes.c_double * 3) * _NJ),
+                ("com", (ctypes.c_double * 3) * _NJ), ("inertia", (ctypes.c_double * 9) * _NJ), ("mass", ctypes.c_double * _NJ),
+                ("lolimit", ctypes.c_double * _NJ), ("hilimit", ctypes.c_double * _NJ), ("limit_restitution", ctypes.c_double * _NJ),
+                ("gravity", ctypes.c_double * 3)]
+
+
+class mh_io_artic(ctypes.Structure):
+    _fields_ = [("model", mh_artic_model), ("link_id", (ctypes.c_char * mio.MH_IO_ID_LEN) * _NJ),
+                ("joint_id", (ctypes.c_char * mio.MH_IO_ID_LEN) * _NJ)]
+
+
+def load_sdf(path, gravity=(0.0, 0.0, -9.81)):
+    """-> (mh_artic_model, link names, joint names): SDFReader::read_model's articulated-body branch (SDFReader.cpp:928-996)."""
+    lib = mio.load()
+    lib.mh_io_load_sdf.restype = ctypes.c_int
+    lib.mh_io_load_sdf.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(mh_io_artic)]
+    io = mh_io_artic()
+    g = (ctypes.c_double * 3)(*gravity)
+    if lib.mh_io_load_sdf(os.fsencode(path), g, ctypes.byref(io)) != 0:
+        raise mio.SceneError(lib.mh_io_last_error().decode("utf-8", "replace"))
+    m = mh_artic_model()
+    ctypes.memmove(ctypes.addressof(m), ctypes.addressof(io.model), ctypes.sizeof(mh_artic_model))
+    return m, [io.link_id[i].value.decode() for i in range(m.nj)], [io.joint_id[i].value.decode() for i in range(m.nj)]
+
+
+def model_from_links(links, gravity=(0.0, 0.0, -9.81)):
+    """links: dicts (parents first) with parent (-1 = base), type, R0 (3x3, model frame at q = 0), x0, axis (model frame),
+    com (link frame), inertia (3x3 about the COM, link axes), mass, lo, hi, restitution."""
+    m = mh_artic_model()
+    m.nj = len(links)
+    for i, L in enumerate(links):
+        p = L["parent"]
+        Rp = np.eye(3) if p < 0 else np.asarray(links[p]["R0"], dtype=float)
+        xp = np.zeros(3) if p < 0 else np.asarray(links[p]["x0"], dtype=float)
+        Rc = np.asarray(L["R0"], dtype=float); xc = np.asarray(L["x0"], dtype=float)
+        Rrel = Rp.T @ Rc; trel = Rp.T @ (xc - xp)
+        al = Rc.T @ np.asarray(L["axis"], dtype=float); al = al / np.linalg.norm(al)
+        m.parent[i] = p; m.jtype[i] = L.get("type", MH_JOINT_REVOLUTE)
+        for k in range(9):
+            m.Rrel[i][k] = Rrel.flat[k]; m.inertia[i][k] = np.asarray(L["inertia"], dtype=float).flat[k]
+        for k in range(3):
+            m.trel[i][k] = trel[k]; m.axis[i][k] = al[k]; m.com[i][k] = L["com"][k]
+        m.mass[i] = L["mass"]
+        m.lolimit[i] = L.get("lo", -np.finfo(float).max); m.hilimit[i] = L.get("hi", np.finfo(float).max)
+        m.limit_restitution[i] = L.get("restitution", 0.0)
+    for k in range(3):
+        m.gravity[k] = gravity[k]
+    return m
+
+
+def chain_model(n, length=0.5, mass=1.0, lo=-1.0, hi=1.0, restitution=0.0, gravity=(0.0, 0.0, -9.81), prismatic_last=False):
+    """n rods hanging along -z from the origin, hinged about y (a planar n-pendulum); optionally the last joint slides."""
+    links = []
+    for i in range(n):
+        I = mass * length * length / 12.0
+        links.append(dict(parent=i - 1, type=MH_JOINT_PRISMATIC if (prismatic_last and i == n - 1) else MH_JOINT_REVOLUTE,
+                          R0=np.eye(3), x0=(0.0, 0.0, -length * i), axis=(0.0, 0.0, 1.0) if (prismatic_last and i == n - 1) else (0.0, 1.0, 0.0),
+                          com=(0.0, 0.0, -0.5 * length), inertia=np.diag([I, I, 1e-3 * I]), mass=mass, lo=lo, hi=hi, restitution=restitution))
+    return model_from_links(links, gravity)
+
+
+class ArticBatch:
+    def __init__(self, model, q, qd, aux=None):
+        lib = _lib.load()
+        self.model = model
+        self.nj = model.nj
+        q = np.ascontiguousarray(q, dtype=np.float64); qd = np.ascontiguousarray(qd, dtype=np.float64)
+        self.B = q.shape[0]
+        assert q.shape == (self.B, self.nj) and qd.shape == q.shape
+        self.handle = ctypes.c_void_p()
+        _lib.check(lib.mh_artic_batch_create(ctypes.byref(model), self.B, ctypes.byref(self.handle)))
+        self.upload(q, qd, aux)
+
+    def upload(self, q=None, qd=None, aux=None):
+        P = lambda a: None if a is None else np.ascontiguousarray(a).ctypes.data
+        _lib.check(_lib.load().mh_artic_batch_upload(self.handle, P(q), P(qd), P(aux)))
+
+    def step(self, dt, nsteps=1, stream=None):
+        _lib.check(_lib.load().mh_artic_batch_step(self.handle, stream, float(dt), int(nsteps)))
+
+    def fwd_dyn(self, tau=None, want_H=True):
+        qdd = np.zeros((self.B, self.nj)); H = np.zeros((self.B, self.nj, self.nj)) if want_H else None
+        t = None if tau is None else np.ascontiguousarray(tau, dtype=np.float64)
+        _lib.check(_lib.load().mh_artic_batch_fwd_dyn(self.handle, None if t is None else t.ctypes.data, qdd.ctypes.data,
+                                                      None if H is None else H.ctypes.data))
+        return qdd, H
+
+    def link_poses(self):
+        P = np.zeros((self.B, self.nj, 12))
+        _lib.check(_lib.load().mh_artic_batch_link_poses(self.handle, P.ctypes.data))
+        return P
+
+    def download(self):
+        q = np.zeros((self.B, self.nj)); qd = np.zeros((self.B, self.nj)); aux = np.zeros(self.B, dtype=S.AUX_DTYPE)
+        _lib.check(_lib.load().mh_artic_batch_download(self.handle, q.ctypes.data, qd.ctypes.data, aux.ctypes.data))
+        return q, qd, aux
+
+    def close(self):
+        if self.handle:
+            _lib.load().mh_artic_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,573 @@
+// mh_artic.hip -- many-worlds stepper for fixed-base articulated bodies (include/moby_hip_artic.h; BASELINE config 5).
+//
+// One wavefront per world.  Per step (TimeSteppingSimulator::do_mini_step with no collision geometry, TSS:114-222):
+//   q += dt qd (old velocity)  ->  link frames (chain walk, 12 lanes per link), motion subspaces and spatial inertias
+//   about the world origin (lane = link)  ->  bias C(q, qd) by recursive Newton-Euler (6 lanes per link, gravity as a
+//   base acceleration)  ->  composite inertias (36 lanes) and H = S' Ic S (lane = matrix entry)  ->  Cholesky
+//   (lane = row) and  qdd = H^-1 (tau - C)  ->  qd += dt qdd  ->  joint limits (ballot masks -> the reference's
+//   constraint order, ArticulatedBody.inl:9-43)  ->  X = H^-1 (lane = column), the limit LCP  L X L' l + L v >= 0  through
+//   the wave solver of mh_lcp_wave.h (lcp_fast on the persistent _v, then the Lemke ladder: ICH:1239-1283)  ->  impulses,
+//   restitution (ICH:298-525).
+// H, its factor, H^-1, the LCP and all link quantities live in LDS (dynamic, sized by the joint count: 13 KB at
+// 10 joints => 12 worlds per CU); HBM sees q, qd and the aux record once per launch.
+// The dynamics algorithm is Featherstone's (Ravelin's source is not in the reference tree: SURVEY F2); operation
+// order = oracle/artic.hpp, checked bit for bit.  sin / cos: the same explicit kernel as the oracle (no libm call).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "../../include/moby_hip_artic.h"
+#include "mh_host.h"
+#include "mh_lcp_wave.h"
+
+namespace mh { namespace artic {
+
+constexpr int NJ = MH_ARTIC_MAX_JOINTS;
+constexpr int NLMAX = MH_NOSLIP_MAX;
+constexpr double NEAR_ZERO_ = 1.4901161193847656e-08;
+
+struct Model {            // mh_artic_model + what the kernel wants precomputed: ancestor masks
+  mh_artic_model m;
+  unsigned anc[NJ];       // bit j: joint j lies on the path from joint i to the base (i itself included)
+};
+
+__constant__ Pow10Table c_pow10a;
+
+MH_DEV void sincos_kernel(double x, double& s, double& c)
+{
+  const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+  const double kf = floor(x * invpio2 + 0.5);
+  const double r = (x - kf * pio2_1) - kf * pio2_1t;
+  const double z = r * r;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double v = z * r;
+  const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  const double ks = r + v * (S1 + z * rs);
+  const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double kc = 1.0 - (0.5 * z - z * rc);
+  const long long k = (long long)kf;
+  const int n = (int)(((k % 4) + 4) % 4);
+  if (n == 0) { s = ks; c = kc; } else if (n == 1) { s = kc; c = -ks; } else if (n == 2) { s = -ks; c = -kc; } else { s = -kc; c = ks; }
+}
+
+MH_DEV double dot3(const double* a, const double* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+MH_DEV void cross3(const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+MH_DEV void mat3mul(const double* A, const double* B, double* C) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[3*i+j] = (A[3*i] * B[j] + A[3*i+1] * B[3+j]) + A[3*i+2] * B[6+j];
+}
+MH_DEV void mat3vec(const double* A, const double* v, double* y) { for (int i = 0; i < 3; i++) y[i] = (A[3*i] * v[0] + A[3*i+1] * v[1]) + A[3*i+2] * v[2]; }
+MH_DEV double dot6(const double* a, const double* b) { double acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + a[k] * b[k]; return acc; }
+// component k of the spatial cross products ([angular; linear]), operands in LDS
+MH_DEV double cross_c(const double* a, const double* b, int k) { const int k1 = (k + 1) % 3, k2 = (k + 2) % 3; return a[k1] * b[k2] - a[k2] * b[k1]; }
+MH_DEV double crm_c(const double* v, const double* m, int k) { return (k < 3) ? cross_c(v, m, k) : cross_c(v, m + 3, k - 3) + cross_c(v + 3, m, k - 3); }
+MH_DEV double crf_c(const double* v, const double* f, int k) { return (k < 3) ? cross_c(v, f, k) + cross_c(v + 3, f + 3, k) : cross_c(v, f + 3, k - 3); }
+
+// the LDS image of one world (doubles), nj = number of joints
+struct Lay {
+  int nj;
+  int q, qd, qdd, C, R, x, Rl, tl, S, I6, v, a, f, F, Iv, H, L, X, MM, A, art, Lv, l, idx, total;
+  MH_DEV Lay(int n) : nj(n) {
+    int o = 0;
+    q = o; o += n; qd = o; o += n; qdd = o; o += n; C = o; o += n;
+    R = o; o += 9 * n; x = o; o += 3 * n; Rl = o; o += 9 * n; tl = o; o += 3 * n;
+    S = o; o += 6 * n; I6 = o; o += 36 * n; v = o; o += 6 * n; a = o; o += 6 * n; f = o; o += 6 * n; F = o; o += 6 * n; Iv = o; o += 12;
+    H = o; o += n * n; L = o; o += n * n; X = o; o += n * n;
+    MM = o; o += NLMAX * NLMAX; A = o; o += NLMAX * NLMAX; art = o; o += NLMAX; Lv = o; o += NLMAX; l = o; o += NLMAX;
+    idx = o; o += NLMAX;           // ints stored as doubles' slots (one int each, low half)
+    total = o;
+  }
+};
+static size_t lds_bytes(int nj) {
+  const int n = nj;
+  return sizeof(double) * (size_t)(4 * n + 9 * n + 3 * n + 9 * n + 3 * n + 6 * n + 36 * n + 24 * n + 12 + 3 * n * n + 2 * NLMAX * NLMAX + 4 * NLMAX);
+}
+
+// kinematics + spatial inertias + bias + H + Cholesky + qdd for the q / qd in LDS.  Returns false if H is not PD.
+MH_DEV bool dynamics(const Model& M, const Lay& Y, double* g, const double* tau_w)
+{
+  const mh_artic_model& m = M.m;
+  const int nj = Y.nj, lane = lane_id();
+  // local transforms: lane = link
+  if (lane < nj) {
+    const int i = lane;
+    const double* ax = m.axis[i];
+    double Rl[9], tl[3];
+    const double qi = g[Y.q + i];
+    if (m.jtype[i] == MH_JOINT_REVOLUTE) {
+      double s, c; sincos_kernel(qi, s, c);
+      const double t = 1.0 - c;
+      const double K[9] = { 0.0, -ax[2], ax[1], ax[2], 0.0, -ax[0], -ax[1], ax[0], 0.0 };
+      double Rq[9];
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Rq[3*a+b] = (((a == b) ? c : 0.0) + (t * ax[a]) * ax[b]) + s * K[3*a+b];
+      mat3mul(m.Rrel[i], Rq, Rl);
+      for (int k = 0; k < 3; k++) tl[k] = m.trel[i][k];
+    } else {
+      for (int k = 0; k < 9; k++) Rl[k] = m.Rrel[i][k];
+      double d[3], Rd[3];
+      for (int k = 0; k < 3; k++) d[k] = ax[k] * qi;
+      mat3vec(m.Rrel[i], d, Rd);
+      for (int k = 0; k < 3; k++) tl[k] = m.trel[i][k] + Rd[k];
+    }
+    for (int k = 0; k < 9; k++) g[Y.Rl + 9 * i + k] = Rl[k];
+    for (int k = 0; k < 3; k++) g[Y.tl + 3 * i + k] = tl[k];
+  }
+  wave_sync();
+  // chain walk: lanes 0..8 = entries of R_i, lanes 9..11 = x_i
+  for (int i = 0; i < nj; i++) {
+    const int p = m.parent[i];
+    if (lane < 9) {
+      const int a = lane / 3, b = lane - 3 * a;
+      double e;
+      if (p < 0) e = g[Y.Rl + 9 * i + lane];
+      else { const double* Rp = g + Y.R + 9 * p; const double* Rl = g + Y.Rl + 9 * i; e = (Rp[3*a] * Rl[b] + Rp[3*a+1] * Rl[3+b]) + Rp[3*a+2] * Rl[6+b]; }
+      g[Y.R + 9 * i + lane] = e;
+    } else if (lane < 12) {
+      const int k = lane - 9;
+      double e;
+      if (p < 0) e = g[Y.tl + 3 * i + k];
+      else { const double* Rp = g + Y.R + 9 * p; const double* tl = g + Y.tl + 3 * i; e = g[Y.x + 3 * p + k] + ((Rp[3*k] * tl[0] + Rp[3*k+1] * tl[1]) + Rp[3*k+2] * tl[2]); }
+      g[Y.x + 3 * i + k] = e;
+    }
+    wave_sync();
+  }
+  // motion subspace and spatial inertia about the world origin: lane = link
+  if (lane < nj) {
+    const int i = lane;
+    double R[9], x[3];
+    for (int k = 0; k < 9; k++) R[k] = g[Y.R + 9 * i + k];
+    for (int k = 0; k < 3; k++) x[k] = g[Y.x + 3 * i + k];
+    double aw[3]; mat3vec(R, m.axis[i], aw);
+    double* S = g + Y.S + 6 * i;
+    if (m.jtype[i] == MH_JOINT_REVOLUTE) { double xa[3]; cross3(x, aw, xa); for (int k = 0; k < 3; k++) { S[k] = aw[k]; S[3+k] = xa[k]; } }
+    else for (int k = 0; k < 3; k++) { S[k] = 0.0; S[3+k] = aw[k]; }
+    double rc[3], r[3]; mat3vec(R, m.com[i], rc);
+    for (int k = 0; k < 3; k++) r[k] = x[k] + rc[k];
+    double T[9], Iw[9];
+    mat3mul(R, m.inertia[i], T);
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Iw[3*a+b] = (T[3*a] * R[3*b] + T[3*a+1] * R[3*b+1]) + T[3*a+2] * R[3*b+2];
+    Iw[1] = Iw[3]; Iw[2] = Iw[6]; Iw[5] = Iw[7];
+    const double mass = m.mass[i];
+    const double rr = dot3(r, r);
+    const double rx[9] = { 0.0, -r[2], r[1], r[2], 0.0, -r[0], -r[1], r[0], 0.0 };
+    double* I6 = g + Y.I6 + 36 * i;
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+      I6[6*a+b] = Iw[3*a+b] + mass * (((a == b) ? rr : 0.0) - r[a] * r[b]);
+      I6[6*a+3+b] = mass * rx[3*a+b];
+      I6[6*(3+a)+b] = mass * rx[3*b+a];
+      I6[6*(3+a)+3+b] = (a == b) ? mass : 0.0;
+    }
+  }
+  wave_sync();
+  // recursive Newton-Euler with qdd = 0 (the links' OWN inertias): lanes 0..5 = spatial components
+  for (int i = 0; i < nj; i++) {
+    const int p = m.parent[i];
+    const double* S = g + Y.S + 6 * i;
+    const double qdi = g[Y.qd + i];
+    double* vj = g + Y.Iv;                        // S_i qd_i (6), then I v (6)
+    if (lane < 6) { const double e = S[lane] * qdi; vj[lane] = e; g[Y.v + 6 * i + lane] = (p < 0) ? e : g[Y.v + 6 * p + lane] + e; }
+    wave_sync();
+    if (lane < 6) {
+      const double cv = crm_c(g + Y.v + 6 * i, vj, lane);
+      const double ap = (p < 0) ? ((lane < 3) ? 0.0 : -m.gravity[lane - 3]) : g[Y.a + 6 * p + lane];
+      g[Y.a + 6 * i + lane] = ap + cv;
+    }
+    wave_sync();
+    double Ia = 0.0;
+    if (lane < 6) {
+      const double* I6 = g + Y.I6 + 36 * i + 6 * lane;
+      const double* a = g + Y.a + 6 * i; const double* v = g + Y.v + 6 * i;
+      double acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + I6[k] * a[k];
+      Ia = acc;
+      acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + I6[k] * v[k];
+      g[Y.Iv + 6 + lane] = acc;
+    }
+    wave_sync();
+    if (lane < 6) g[Y.f + 6 * i + lane] = Ia + crf_c(g + Y.v + 6 * i, g + Y.Iv + 6, lane);
+    wave_sync();
+  }
+  for (int i = nj - 1; i >= 0; i--) {
+    const int p = m.parent[i];
+    if (lane == 6) g[Y.C + i] = dot6(g + Y.S + 6 * i, g + Y.f + 6 * i);
+    if (p >= 0 && lane < 6) g[Y.f + 6 * p + lane] = g[Y.f + 6 * p + lane] + g[Y.f + 6 * i + lane];
+    wave_sync();
+  }
+  // composite inertias, in place: lanes 0..35 = entries
+  for (int i = nj - 1; i >= 0; i--) {
+    const int p = m.parent[i];
+    if (p >= 0 && lane < 36) g[Y.I6 + 36 * p + lane] = g[Y.I6 + 36 * p + lane] + g[Y.I6 + 36 * i + lane];
+    wave_sync();
+  }
+  // F_i = Ic_i S_i: lanes (i, r)
+  for (int e = lane; e < 6 * nj; e += 64) {
+    const int i = e / 6, r = e - 6 * i;
+    const double* I6 = g + Y.I6 + 36 * i + 6 * r; const double* S = g + Y.S + 6 * i;
+    double acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + I6[k] * S[k];
+    g[Y.F + e] = acc;
+  }
+  wave_sync();
+  // H(i, j) = S_j' F_i for j on i's path to the base (and its mirror); 0 elsewhere: lanes = entries
+  for (int e = lane; e < nj * nj; e += 64) {
+    const int i = e / nj, j = e - nj * i;
+    double h = 0.0;
+    if ((M.anc[i] >> j) & 1u) h = dot6(g + Y.S + 6 * j, g + Y.F + 6 * i);
+    else if ((M.anc[j] >> i) & 1u) h = dot6(g + Y.S + 6 * i, g + Y.F + 6 * j);
+    g[Y.H + e] = h;
+  }
+  wave_sync();
+  // dpotf2('L') on a copy: lane = row
+  for (int e = lane; e < nj * nj; e += 64) g[Y.L + e] = g[Y.H + e];
+  wave_sync();
+  double* L = g + Y.L;                             // symmetric: row-major == column-major; L(i, k) at L[i + nj k]
+  bool pd = true;
+  for (int j = 0; j < nj; j++) {
+    if (lane == j) {
+      double ajj = L[j + nj * j];
+      for (int k = 0; k < j; k++) ajj = ajj - L[j + nj * k] * L[j + nj * k];
+      g[Y.Iv] = ajj;
+    }
+    wave_sync();
+    const double ajj0 = g[Y.Iv];
+    if (!(ajj0 > 0.0)) { pd = false; break; }
+    const double ajj = sqrt(ajj0);
+    if (lane == j) L[j + nj * j] = ajj;
+    if (lane > j && lane < nj) {
+      double s = L[lane + nj * j];
+      for (int k = 0; k < j; k++) s = s - L[lane + nj * k] * L[j + nj * k];
+      L[lane + nj * j] = s / ajj;
+    }
+    wave_sync();
+  }
+  if (!pd) return false;
+  // dpotrs: lane = row for the column sweeps
+  double* b = g + Y.qdd;
+  if (lane < nj) b[lane] = (tau_w ? tau_w[lane] : 0.0) - g[Y.C + lane];
+  wave_sync();
+  for (int k = 0; k < nj; k++) {
+    if (lane == k) b[k] = b[k] / L[k + nj * k];
+    wave_sync();
+    const double bk = b[k];
+    if (lane > k && lane < nj) b[lane] = b[lane] - bk * L[lane + nj * k];
+    wave_sync();
+  }
+  for (int k = nj - 1; k >= 0; k--) {
+    if (lane == k) { double s = b[k]; for (int i = k + 1; i < nj; i++) s = s - L[i + nj * k] * b[i]; b[k] = s / L[k + nj * k]; }
+    wave_sync();
+  }
+  return true;
+}
+
+// X = inverse_SPD(H) from the factor in Y.L (linalg.hpp inverse_spd): lane = column
+MH_DEV void inverse_from_factor(const Lay& Y, double* g)
+{
+  const int nj = Y.nj, lane = lane_id();
+  const double* L = g + Y.L;
+  if (lane < nj) {
+    double e[NJ];
+    for (int i = 0; i < nj; i++) e[i] = (i == lane) ? 1.0 : 0.0;
+    for (int k = 0; k < nj; k++) { e[k] = e[k] / L[k + nj * k]; const double bk = e[k]; for (int i = k + 1; i < nj; i++) e[i] = e[i] - bk * L[i + nj * k]; }
+    for (int k = nj - 1; k >= 0; k--) { double s = e[k]; for (int i = k + 1; i < nj; i++) s = s - L[i + nj * k] * e[i]; e[k] = s / L[k + nj * k]; }
+    for (int i = 0; i < nj; i++) g[Y.X + i + nj * lane] = e[i];          // column `lane`
+  }
+  wave_sync();
+  // mirror the lower triangle into the upper one: A(c, i) = A(i, c), i > c
+  for (int e2 = lane; e2 < nj * nj; e2 += 64) { const int r = e2 % nj, c = e2 / nj; if (r < c) g[Y.X + r + nj * c] = g[Y.X + c + nj * r]; }
+  wave_sync();
+}
+
+// find_limit_constraints + the impact handler's no-slip path with NC = 0 (oracle Artic::handle_limits)
+MH_DEV void handle_limits(const Model& M, const Lay& Y, double* g, mh_world_aux* aux, WaveRand& rng, int& status,
+                          unsigned long long& solves, unsigned long long& rows, unsigned long long& pivs, unsigned long long& bytes)
+{
+  const mh_artic_model& m = M.m;
+  const int nj = Y.nj, lane = lane_id();
+  const double qi = (lane < nj) ? g[Y.q + lane] : 0.0;
+  const bool up = lane < nj && qi >= m.hilimit[lane], lo = lane < nj && qi <= m.lolimit[lane];
+  const uint64_t mu = ballot(up), ml = ballot(lo);
+  const int nl = popc(mu) + popc(ml);
+  if (nl == 0) return;
+  int* idx = reinterpret_cast<int*>(g + Y.idx);                  // idx[k] = joint | (upper << 8)
+  if (lane < nj) {
+    const int base = popc(mu & lanes_below(lane)) + popc(ml & lanes_below(lane));
+    if (nl <= NLMAX) { if (up) idx[base] = lane | 256; if (lo) idx[base + (up ? 1 : 0)] = lane; }
+  }
+  const double qdi = (lane < nj) ? g[Y.qd + lane] : 0.0;
+  const bool impacting = ballot((up && -qdi < -NEAR_ZERO_) || (lo && qdi < -NEAR_ZERO_)) != 0ull;   // CSim:313-323
+  if (!impacting) return;
+  if (nl > NLMAX) { status |= MH_WORLD_UNSUPPORTED; return; }
+  wave_sync();
+  inverse_from_factor(Y, g);                                     // compute_X (ICH:1607)
+  const double* X = g + Y.X;
+  // compute_limit_components (ICH:1755-1781): L_X_LT(a, b) = X(idx_a, idx_b) for b >= a, mirrored; L_v = +-qd
+  double* MM = g + Y.MM;
+  for (int e = lane; e < nl * nl; e += 64) {
+    const int a = e % nl, b2 = e / nl;
+    const int ia = idx[a] & 255, ib = idx[b2] & 255;
+    MM[e] = (b2 >= a) ? X[ia * nj + ib] : X[ib * nj + ia];
+  }
+  const bool valid = lane < nl;
+  const int my = valid ? idx[lane] : 0;
+  const int myj = my & 255; const bool myup = (my & 256) != 0;
+  double Lv = 0.0;
+  if (valid) { Lv = g[Y.qd + myj]; if (myup) Lv = -Lv; }
+  wave_sync();
+  // lcp_fast on the persistent _v, then the Lemke ladder (ICH:1239, 1281)
+  double nrm0 = 0.0;
+  for (int e = lane; e < nl * nl; e += 64) { const double a = fabs(MM[e]); nrm0 = (a > nrm0) ? a : nrm0; }
+  nrm0 = wave_max(nrm0);
+  const double dii = valid ? MM[lane + nl * lane] : 0.0;
+  int zsize = uni(aux->vns_size);
+  double zi = (valid && zsize == nl) ? aux->vns[lane] : 0.0;
+  DenseLds Md; Md.M = MM; Md.n = nl;
+  LuScratch S; S.small = g + Y.A; S.ka = nl; S.big = g + Y.A;
+  Trace tr; tr.buf = nullptr; tr.cap = 0; tr.len = 0;
+  LcpParams P; P.kind = MH_LCP_FAST; P.min_exp = -20; P.step_exp = 1u; P.max_exp = 1; P.piv_tol = -1.0; P.zero_tol = -1.0;
+  unsigned piv = 0, total = 0;
+  bool ok = lcp_solve_wave(P, c_pow10a, nl, Md, S, g + Y.art, nrm0, dii, Lv, zi, zsize, rng, piv, tr);
+  total += piv;
+  if (!ok) {
+    P.kind = MH_LCP_LEMKE_REG;
+    ok = lcp_solve_wave(P, c_pow10a, nl, Md, S, g + Y.art, nrm0, dii, Lv, zi, zsize, rng, piv, tr);
+    total += piv;
+  }
+  solves += 1ull; rows += (unsigned long long)nl; pivs += total; bytes += 8ull * ((unsigned long long)nl * nl + 2ull * nl);
+  if (!ok) { status |= MH_WORLD_LCP_FAILED; return; }           // std::runtime_error("Unable to solve constraint LCP!")
+  if (valid) aux->vns[lane] = zi;
+  if (lane == 0) aux->vns_size = nl;
+  double li = zi;
+  double* lv = g + Y.Lv; double* ll = g + Y.l;
+  auto apply = [&]() {                                           // update_from_stacked (ICH:298-397) + ICH:452
+    if (valid) ll[lane] = li;
+    wave_sync();
+    if (lane < nj) {
+      double dv = 0.0;
+      for (int k = 0; k < nl; k++) { const int c = idx[k]; const double ls = (c & 256) ? -ll[k] : ll[k]; dv = dv + ls * X[(c & 255) * nj + lane]; }
+      g[Y.qd + lane] = g[Y.qd + lane] + dv;
+    }
+    if (valid) { double t = 0.0; for (int k = 0; k < nl; k++) t = t + ll[k] * MM[lane + nl * k]; Lv = Lv + t; }
+    wave_sync();
+  };
+  auto minv_of = [&]() -> double {                               // first-minimum over rows 0 .. nl-1, like the oracle's scan
+    if (valid) lv[lane] = Lv;
+    wave_sync();
+    double mn = lv[0];
+    for (int k = 1; k < nl; k++) mn = (lv[k] < mn) ? lv[k] : mn;
+    wave_sync();
+    return mn;
+  };
+  apply();
+  const double minv = minv_of();
+  if (valid) li = li * m.limit_restitution[myj];
+  const bool changed = ballot(valid && li > NEAR_ZERO_) != 0ull;   // apply_restitution(q) (ICH:497-525)
+  if (changed) {
+    apply();
+    const double minv_plus = minv_of();
+    if (minv_plus < 0.0 && minv_plus < minv - NEAR_ZERO_) status |= MH_WORLD_UNSUPPORTED;   // ICH:284-291 reads an unsized _z
+  }
+  const double qd2 = valid ? g[Y.qd + myj] : 0.0;
+  if (ballot(valid && ((myup ? -qd2 : qd2) < -NEAR_ZERO_)) != 0ull) status |= MH_WORLD_IMPACT_TOL;   // ICH:157-167
+}
+
+__global__ __launch_bounds__(64)
+void k_artic_step(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
+                  mh_world_aux* __restrict__ auxg)
+{
+  extern __shared__ double g[];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const Model& M = *Mg;
+  const int nj = M.m.nj, lane = lane_id();
+  const Lay Y(nj);
+  mh_world_aux* aux = auxg + b;
+  if (lane < nj) { g[Y.q + lane] = qg[(size_t)b * nj + lane]; g[Y.qd + lane] = qdg[(size_t)b * nj + lane]; }
+  WaveRand rng; rng.load(aux->rng);
+  if (lane == 0) g_lcp_prof_on = 0;
+  int status = uni(aux->status);
+  unsigned long long solves = 0, rows = 0, pivs = 0, bytes = 0;
+  wave_sync();
+  for (int s = 0; s < nsteps; s++) {
+    // positions with the OLD velocity (TSS:156-164)
+    if (lane < nj) { double qn = g[Y.qd + lane] * dt; qn = qn + g[Y.q + lane]; g[Y.q + lane] = qn; }
+    wave_sync();
+    const bool ok = dynamics(M, Y, g, nullptr);
+    if (!ok) status |= MH_WORLD_LCP_FAILED;
+    if (lane < nj) { const double qdd = ok ? g[Y.qdd + lane] : 0.0; g[Y.qd + lane] = g[Y.qd + lane] + qdd * dt; }   // TSS:182-192
+    wave_sync();
+    if (ok) handle_limits(M, Y, g, aux, rng, status, solves, rows, pivs, bytes);
+    wave_sync();
+  }
+  if (lane < nj) { qg[(size_t)b * nj + lane] = g[Y.q + lane]; qdg[(size_t)b * nj + lane] = g[Y.qd + lane]; }
+  rng.store(aux->rng);
+  if (lane == 0) {
+    double tm = aux->time; for (int s = 0; s < nsteps; s++) tm += dt;
+    aux->time = tm; aux->status = status;
+    aux->steps += (unsigned long long)nsteps; aux->mini_steps += (unsigned long long)nsteps;
+    aux->lcp_solves += solves; aux->lcp_rows += rows; aux->lcp_pivots += pivs; aux->lcp_alg_bytes += bytes;
+  }
+}
+
+// seam B4: qdd = H^-1 (tau - C), H, link poses of the resident states
+__global__ __launch_bounds__(64)
+void k_artic_fwd_dyn(const Model* __restrict__ Mg, int B, const double* __restrict__ qg, const double* __restrict__ qdg,
+                     const double* __restrict__ tau, double* __restrict__ qdd_out, double* __restrict__ H_out, double* __restrict__ poses,
+                     int* __restrict__ okflag)
+{
+  extern __shared__ double g[];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const Model& M = *Mg;
+  const int nj = M.m.nj, lane = lane_id();
+  const Lay Y(nj);
+  if (lane < nj) { g[Y.q + lane] = qg[(size_t)b * nj + lane]; g[Y.qd + lane] = qdg[(size_t)b * nj + lane]; }
+  wave_sync();
+  const bool ok = dynamics(M, Y, g, tau ? tau + (size_t)b * nj : nullptr);
+  if (qdd_out && lane < nj) qdd_out[(size_t)b * nj + lane] = ok ? g[Y.qdd + lane] : 0.0;
+  if (H_out) for (int e = lane; e < nj * nj; e += 64) H_out[(size_t)b * nj * nj + e] = g[Y.H + e];
+  if (poses) for (int e = lane; e < 12 * nj; e += 64) { const int i = e / 12, k = e - 12 * i; poses[(size_t)b * 12 * nj + e] = (k < 9) ? g[Y.R + 9 * i + k] : g[Y.x + 3 * i + k - 9]; }
+  if (okflag && lane == 0) okflag[b] = ok ? 1 : 0;
+}
+
+}} // namespace mh::artic
+
+struct mh_artic_batch {
+  int B, nj;
+  mh::artic::Model* d_model;
+  double* d_q; double* d_qd; mh_world_aux* d_aux;
+};
+
+extern "C" {
+
+int mh_artic_batch_destroy(mh_artic_batch* ab)
+{
+  if (!ab) return MH_OK;
+  (void)hipDeviceSynchronize();
+  void* ps[] = { ab->d_model, ab->d_q, ab->d_qd, ab->d_aux };
+  for (void* p : ps) if (p) (void)hipFree(p);
+  delete ab;
+  return MH_OK;
+}
+
+int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** out)
+{
+  namespace ar = mh::artic;
+  if (!out) return fail(MH_ERR_INVALID_ARG, "null out");
+  *out = nullptr;
+  if (!model) return fail(MH_ERR_INVALID_ARG, "null model");
+  if (B <= 0) return fail(MH_ERR_INVALID_ARG, "batch must be > 0");
+  const int nj = model->nj;
+  if (nj < 1 || nj > MH_ARTIC_MAX_JOINTS) return fail(MH_ERR_INVALID_ARG, "nj = %d outside [1, %d]", nj, MH_ARTIC_MAX_JOINTS);
+  ar::Model hm; std::memset(&hm, 0, sizeof(hm)); hm.m = *model;
+  for (int i = 0; i < nj; i++) {
+    const int p = model->parent[i];
+    if (p >= i || p < -1) return fail(MH_ERR_INVALID_ARG, "joint %d: parent %d must come before it (-1 = base)", i, p);
+    if (model->jtype[i] != MH_JOINT_REVOLUTE && model->jtype[i] != MH_JOINT_PRISMATIC) return fail(MH_ERR_INVALID_ARG, "joint %d: type %d is not built (revolute, prismatic)", i, model->jtype[i]);
+    if (!(model->mass[i] > 0.0)) return fail(MH_ERR_INVALID_ARG, "link %d: mass must be > 0", i);
+    const double* a = model->axis[i]; const double nn = a[0]*a[0] + a[1]*a[1] + a[2]*a[2];
+    if (!(nn > 0.999999 && nn < 1.000001)) return fail(MH_ERR_INVALID_ARG, "joint %d: axis is not a unit vector", i);
+    if (!(model->lolimit[i] <= model->hilimit[i])) return fail(MH_ERR_INVALID_ARG, "joint %d: lower limit above the upper one", i);
+    hm.anc[i] = (1u << i) | (p >= 0 ? hm.anc[p] : 0u);
+  }
+  if (mh_device_count() <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
+  {
+    static bool once = false;
+    if (!once) {
+      mh::Pow10Table p10; for (int i = 0; i < 64; i++) p10.v[i] = std::pow(10.0, (double)(i - 32));   // LCP.cpp:285
+      MH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ar::c_pow10a), &p10, sizeof(p10)));
+      once = true;
+    }
+  }
+  mh_artic_batch* ab = new mh_artic_batch();
+  ab->B = B; ab->nj = nj; ab->d_model = nullptr; ab->d_q = nullptr; ab->d_qd = nullptr; ab->d_aux = nullptr;
+  const size_t sB = (size_t)B;
+  bool ok = hipMalloc((void**)&ab->d_model, sizeof(ar::Model)) == hipSuccess && hipMalloc((void**)&ab->d_q, sB * nj * 8) == hipSuccess
+         && hipMalloc((void**)&ab->d_qd, sB * nj * 8) == hipSuccess && hipMalloc((void**)&ab->d_aux, sB * sizeof(mh_world_aux)) == hipSuccess;
+  if (ok) {
+    std::vector<mh_world_aux> a(sB);
+    mh_world_aux_init(&a[0], 1);
+    for (int b = 1; b < B; b++) a[b] = a[0];
+    ok = hipMemcpy(ab->d_model, &hm, sizeof(hm), hipMemcpyHostToDevice) == hipSuccess
+      && hipMemset(ab->d_q, 0, sB * nj * 8) == hipSuccess && hipMemset(ab->d_qd, 0, sB * nj * 8) == hipSuccess
+      && hipMemcpy(ab->d_aux, a.data(), sB * sizeof(mh_world_aux), hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (!ok) { mh_artic_batch_destroy(ab); return fail(MH_ERR_HIP, "device allocation / upload failed"); }
+  *out = ab;
+  return MH_OK;
+}
+
+int mh_artic_batch_upload(mh_artic_batch* ab, const double* q, const double* qd, const mh_world_aux* aux)
+{
+  if (!ab) return fail(MH_ERR_INVALID_ARG, "null batch");
+  const size_t n = (size_t)ab->B * ab->nj * 8;
+  if (q) MH_HIP(hipMemcpy(ab->d_q, q, n, hipMemcpyHostToDevice));
+  if (qd) MH_HIP(hipMemcpy(ab->d_qd, qd, n, hipMemcpyHostToDevice));
+  if (aux) MH_HIP(hipMemcpy(ab->d_aux, aux, (size_t)ab->B * sizeof(mh_world_aux), hipMemcpyHostToDevice));
+  return MH_OK;
+}
+
+int mh_artic_batch_step(mh_artic_batch* ab, void* stream, double dt, int nsteps)
+{
+  namespace ar = mh::artic;
+  if (!ab) return fail(MH_ERR_INVALID_ARG, "null batch");
+  if (nsteps < 0) return fail(MH_ERR_INVALID_ARG, "negative step count");
+  if (nsteps == 0) return MH_OK;
+  if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
+  hipLaunchKernelGGL(ar::k_artic_step, dim3(ab->B), dim3(64), ar::lds_bytes(ab->nj), (hipStream_t)stream,
+                     (const ar::Model*)ab->d_model, ab->B, dt, nsteps, ab->d_q, ab->d_qd, ab->d_aux);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+int mh_artic_batch_fwd_dyn(mh_artic_batch* ab, const double* tau, double* qdd_out, double* H_out)
+{
+  namespace ar = mh::artic;
+  if (!ab) return fail(MH_ERR_INVALID_ARG, "null batch");
+  const size_t B = (size_t)ab->B, nj = (size_t)ab->nj;
+  double *d_tau = nullptr, *d_qdd = nullptr, *d_H = nullptr; int* d_ok = nullptr;
+  auto cleanup = [&]() { void* ps[] = { d_tau, d_qdd, d_H, d_ok }; for (void* p : ps) if (p) (void)hipFree(p); };
+  bool ok = hipMalloc((void**)&d_qdd, B * nj * 8) == hipSuccess && hipMalloc((void**)&d_ok, B * 4) == hipSuccess;
+  if (ok && tau) ok = hipMalloc((void**)&d_tau, B * nj * 8) == hipSuccess && hipMemcpy(d_tau, tau, B * nj * 8, hipMemcpyHostToDevice) == hipSuccess;
+  if (ok && H_out) ok = hipMalloc((void**)&d_H, B * nj * nj * 8) == hipSuccess;
+  if (!ok) { cleanup(); return fail(MH_ERR_HIP, "device allocation failed"); }
+  hipLaunchKernelGGL(ar::k_artic_fwd_dyn, dim3(ab->B), dim3(64), ar::lds_bytes(ab->nj), (hipStream_t)nullptr,
+                     (const ar::Model*)ab->d_model, ab->B, (const double*)ab->d_q, (const double*)ab->d_qd, (const double*)d_tau, d_qdd, d_H, (double*)nullptr, d_ok);
+  hipError_t e = hipDeviceSynchronize();
+  std::vector<int> hok(B);
+  if (e == hipSuccess && qdd_out) e = hipMemcpy(qdd_out, d_qdd, B * nj * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && H_out) e = hipMemcpy(H_out, d_H, B * nj * nj * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(hok.data(), d_ok, B * 4, hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) return fail(MH_ERR_HIP, "forward dynamics launch failed: %s", hipGetErrorString(e));
+  for (size_t b = 0; b < B; b++) if (!hok[b]) return fail(MH_ERR_INVALID_ARG, "world %zu: the generalized inertia is not positive definite", b);
+  return MH_OK;
+}
+
+int mh_artic_batch_link_poses(mh_artic_batch* ab, double* poses)
+{
+  namespace ar = mh::artic;
+  if (!ab || !poses) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  const size_t bytes = (size_t)ab->B * ab->nj * 12 * 8;
+  double* d_p = nullptr;
+  MH_HIP(hipMalloc((void**)&d_p, bytes));
+  hipLaunchKernelGGL(ar::k_artic_fwd_dyn, dim3(ab->B), dim3(64), ar::lds_bytes(ab->nj), (hipStream_t)nullptr,
+                     (const ar::Model*)ab->d_model, ab->B, (const double*)ab->d_q, (const double*)ab->d_qd, (const double*)nullptr, (double*)nullptr, (double*)nullptr, d_p, (int*)nullptr);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(poses, d_p, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(d_p);
+  if (e != hipSuccess) return fail(MH_ERR_HIP, "link pose launch failed: %s", hipGetErrorString(e));
+  return MH_OK;
+}
+
+int mh_artic_batch_download(mh_artic_batch* ab, double* q, double* qd, mh_world_aux* aux)
+{
+  if (!ab) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_HIP(hipDeviceSynchronize());
+  const size_t n = (size_t)ab->B * ab->nj * 8;
+  if (q) MH_HIP(hipMemcpy(q, ab->d_q, n, hipMemcpyDeviceToHost));
+  if (qd) MH_HIP(hipMemcpy(qd, ab->d_qd, n, hipMemcpyDeviceToHost));
+  if (aux) MH_HIP(hipMemcpy(aux, ab->d_aux, (size_t)ab->B * sizeof(mh_world_aux), hipMemcpyDeviceToHost));
+  return MH_OK;
+}
+
+} // extern "C"

@@ -96,6 +96,147 @@ int prim_common(const Attrs& a, Prim& p, double volume, const char* what) {
 
 } // namespace
 
+// ---- SDF (src/SDFReader.cpp) -----------------------------------------------------------------------------
+namespace {
+xmlNode* child_named(xmlNode* n, const char* name) {
+  for (xmlNode* c = n ? n->children : nullptr; c; c = c->next)
+    if (c->type == XML_ELEMENT_NODE && strcasecmp((const char*)c->name, name) == 0) return c;
+  return nullptr;
+}
+std::string text_of(xmlNode* n) {
+  if (!n) return std::string();
+  xmlChar* v = xmlNodeGetContent(n);
+  std::string s = v ? (const char*)v : "";
+  if (v) xmlFree(v);
+  const size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+  return (a == std::string::npos) ? std::string() : s.substr(a, b - a + 1);
+}
+struct Pose { double R[9]; double x[3]; };
+Pose identity_pose() { Pose p; for (int i = 0; i < 9; i++) p.R[i] = (i % 4 == 0) ? 1.0 : 0.0; p.x[0] = p.x[1] = p.x[2] = 0.0; return p; }
+// SDFReader::read_pose (SDFReader.cpp:1272-1286): x y z roll pitch yaw, Quatd::rpy
+bool read_pose(xmlNode* parent, Pose& p) {
+  xmlNode* n = child_named(parent, "pose");
+  p = identity_pose();
+  if (!n) return true;
+  const std::vector<double> v = numbers(text_of(n));
+  if (v.size() != 6) return false;
+  for (int i = 0; i < 3; i++) p.x[i] = v[i];
+  rpy_to_R(v[3], v[4], v[5], p.R);
+  return true;
+}
+void mat3mul(const double* A, const double* B, double* C) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[3*i+j] = A[3*i] * B[j] + A[3*i+1] * B[3+j] + A[3*i+2] * B[6+j]; }
+void mat3Tmul(const double* A, const double* B, double* C) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[3*i+j] = A[i] * B[j] + A[3+i] * B[3+j] + A[6+i] * B[6+j]; }
+void mat3vec(const double* A, const double* v, double* y) { for (int i = 0; i < 3; i++) y[i] = A[3*i] * v[0] + A[3*i+1] * v[1] + A[3*i+2] * v[2]; }
+void mat3Tvec(const double* A, const double* v, double* y) { for (int i = 0; i < 3; i++) y[i] = A[i] * v[0] + A[3+i] * v[1] + A[6+i] * v[2]; }
+struct SdfLink { std::string name; Pose pose; Pose inertial; double mass; double I[9]; };
+struct SdfJoint { std::string name, parent, child; int type; double xyz[3]; bool parent_frame; double lo, hi; };
+}  // namespace
+
+extern "C" int mh_io_load_sdf(const char* path, const double gravity[3], mh_io_artic* out)
+{
+  if (!path || !out) return fail("null argument");
+  xmlDoc* doc = xmlReadFile(path, nullptr, XML_PARSE_NONET | XML_PARSE_NOERROR | XML_PARSE_NOWARNING);
+  if (!doc) return fail("cannot parse %s", path);
+  struct Guard { xmlDoc* d; ~Guard() { xmlFreeDoc(d); } } guard{doc};
+  std::vector<xmlNode*> models; collect(xmlDocGetRootElement(doc), "model", models);
+  if (models.size() != 1) return fail("%s: expected exactly one <model>, found %zu", path, models.size());
+  xmlNode* model = models[0];
+  std::vector<SdfLink> links; std::vector<SdfJoint> joints;
+  for (xmlNode* c = model->children; c; c = c->next) {
+    if (c->type != XML_ELEMENT_NODE) continue;
+    if (strcasecmp((const char*)c->name, "link") == 0) {                       // read_link / read_inertial
+      SdfLink L; L.name = attrs_of(c).str("name");
+      if (!read_pose(c, L.pose)) return fail("link %s: bad <pose>", L.name.c_str());
+      xmlNode* in = child_named(c, "inertial");
+      if (!in) return fail("link %s: no <inertial>", L.name.c_str());
+      if (!read_pose(in, L.inertial)) return fail("link %s: bad inertial <pose>", L.name.c_str());
+      L.mass = std::atof(text_of(child_named(in, "mass")).c_str());
+      xmlNode* im = child_named(in, "inertia");
+      if (!im) return fail("link %s: no <inertia>", L.name.c_str());
+      auto g = [&](const char* k) { return std::atof(text_of(child_named(im, k)).c_str()); };
+      const double ixx = g("ixx"), ixy = g("ixy"), ixz = g("ixz"), iyy = g("iyy"), iyz = g("iyz"), izz = g("izz");
+      const double I[9] = { ixx, ixy, ixz, ixy, iyy, iyz, ixz, iyz, izz };
+      // the tensor is given in the inertial frame: bring it into the link's axes (about the COM)
+      double T[9]; mat3mul(L.inertial.R, I, T);
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) L.I[3*i+j] = T[3*i] * L.inertial.R[3*j] + T[3*i+1] * L.inertial.R[3*j+1] + T[3*i+2] * L.inertial.R[3*j+2];
+      links.push_back(L);
+    } else if (strcasecmp((const char*)c->name, "joint") == 0) {                // read_joint
+      SdfJoint J; const Attrs a = attrs_of(c); J.name = a.str("name");
+      std::string type = a.str("type"); for (char& ch : type) ch = (char)tolower(ch);
+      if (type == "revolute") J.type = MH_JOINT_REVOLUTE; else if (type == "prismatic") J.type = MH_JOINT_PRISMATIC;
+      else return fail("joint %s: type '%s' is not supported (revolute, prismatic)", J.name.c_str(), type.c_str());
+      J.parent = text_of(child_named(c, "parent")); J.child = text_of(child_named(c, "child"));
+      if (child_named(c, "pose")) return fail("joint %s: a <pose> under <joint> is not supported", J.name.c_str());
+      xmlNode* ax = child_named(c, "axis");
+      if (!ax) return fail("joint %s: no <axis>", J.name.c_str());
+      const std::vector<double> v = numbers(text_of(child_named(ax, "xyz")));
+      if (v.size() != 3) return fail("joint %s: bad <xyz>", J.name.c_str());
+      for (int i = 0; i < 3; i++) J.xyz[i] = v[i];
+      xmlNode* pf = child_named(ax, "use_parent_model_frame");
+      J.parent_frame = pf && boolean(text_of(pf));
+      J.lo = -1.7976931348623157e308; J.hi = 1.7976931348623157e308;            // Joint::lolimit / hilimit defaults (Joint.cpp:33-54)
+      if (xmlNode* lim = child_named(ax, "limit")) {
+        if (xmlNode* l = child_named(lim, "lower")) J.lo = std::atof(text_of(l).c_str());
+        if (xmlNode* u = child_named(lim, "upper")) J.hi = std::atof(text_of(u).c_str());
+      }
+      joints.push_back(J);
+    }
+  }
+  if (joints.empty()) return fail("%s: a model without joints is a single rigid body, not an articulated one", path);
+  if ((int)joints.size() > MH_ARTIC_MAX_JOINTS) return fail("%zu joints > %d", joints.size(), MH_ARTIC_MAX_JOINTS);
+  std::map<std::string, int> link_of;
+  for (size_t i = 0; i < links.size(); i++) link_of[links[i].name] = (int)i;
+  // parents first: repeatedly take, in file order, the joints whose parent is the world or already placed
+  std::vector<int> order; std::map<std::string, int> joint_of_link;             // child link -> position in `order`
+  std::vector<char> used(joints.size(), 0);
+  bool fixed_base = false;
+  while (order.size() < joints.size()) {
+    bool progress = false;
+    for (size_t j = 0; j < joints.size(); j++) {
+      if (used[j]) continue;
+      const bool world = strcasecmp(joints[j].parent.c_str(), "world") == 0;
+      if (!world && !joint_of_link.count(joints[j].parent)) continue;
+      if (!link_of.count(joints[j].child)) return fail("joint %s: child link '%s' not found", joints[j].name.c_str(), joints[j].child.c_str());
+      if (joint_of_link.count(joints[j].child)) return fail("link %s is the child of two joints (closed chains are not supported)", joints[j].child.c_str());
+      if (world) fixed_base = true;
+      joint_of_link[joints[j].child] = (int)order.size();
+      order.push_back((int)j); used[j] = 1; progress = true;
+    }
+    if (!progress) return fail("%s: joints that do not hang from the world (floating bases are not supported)", path);
+  }
+  if (!fixed_base) return fail("%s: no joint attaches the model to the world", path);
+  if (joint_of_link.size() != links.size()) return fail("%s: %zu links but %zu are carried by joints", path, links.size(), joint_of_link.size());
+  std::memset(out, 0, sizeof(*out));
+  mh_artic_model& m = out->model;
+  m.nj = (int)order.size();
+  for (int k = 0; k < 3; k++) m.gravity[k] = gravity ? gravity[k] : 0.0;
+  for (int i = 0; i < m.nj; i++) {
+    const SdfJoint& J = joints[order[i]];
+    const SdfLink& L = links[link_of[J.child]];
+    const bool world = strcasecmp(J.parent.c_str(), "world") == 0;
+    const Pose Pp = world ? identity_pose() : links[link_of[J.parent]].pose;
+    m.parent[i] = world ? -1 : joint_of_link[J.parent];
+    m.jtype[i] = J.type;
+    mat3Tmul(Pp.R, L.pose.R, m.Rrel[i]);                                        // R_p' R_c
+    const double d[3] = { L.pose.x[0] - Pp.x[0], L.pose.x[1] - Pp.x[1], L.pose.x[2] - Pp.x[2] };
+    mat3Tvec(Pp.R, d, m.trel[i]);
+    double ag[3];                                                                // the axis in the model frame at q = 0 ...
+    if (J.parent_frame) mat3vec(Pp.R, J.xyz, ag); else mat3vec(L.pose.R, J.xyz, ag);
+    double al[3]; mat3Tvec(L.pose.R, ag, al);                                    // ... and in the child link's frame
+    const double nrm = std::sqrt(al[0]*al[0] + al[1]*al[1] + al[2]*al[2]);
+    if (!(nrm > 0.0)) return fail("joint %s: zero axis", J.name.c_str());
+    for (int k = 0; k < 3; k++) m.axis[i][k] = al[k] / nrm;
+    for (int k = 0; k < 3; k++) m.com[i][k] = L.inertial.x[k];
+    for (int k = 0; k < 9; k++) m.inertia[i][k] = L.I[k];
+    m.mass[i] = L.mass;
+    m.lolimit[i] = J.lo; m.hilimit[i] = J.hi; m.limit_restitution[i] = 0.0;
+    snprintf(out->link_id[i], MH_IO_ID_LEN, "%s", L.name.c_str());
+    snprintf(out->joint_id[i], MH_IO_ID_LEN, "%s", J.name.c_str());
+  }
+  return 0;
+}
+
+
 extern "C" {
 
 const char* mh_io_last_error(void) { return g_err; }

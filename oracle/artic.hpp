@@ -1,0 +1,250 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU restatement of one Moby world that holds ONE fixed-base RCArticulatedBody with 1-DOF joints (BASELINE config 5,
+// example/ur10): TimeSteppingSimulator::step -> forward dynamics (CRB algorithm) -> joint-limit constraints -> the
+// impact handler's no-slip path with NC = 0.
+//
+// PARITY UNPINNED for the dynamics: Ravelin::RCArticulatedBodyd (calc_fwd_dyn, get_generalized_inertia) is not in the
+// reference tree and no reference artefact holds an articulated trajectory of a scene this build covers
+// (regress/fixed-articulated-table.dat and contact-constrained-pendulum.dat need contact + bilateral rows).  The
+// algorithm is Featherstone's, in world coordinates about the world origin, spatial vectors angular-first:
+//   composite-rigid-body algorithm for H(q), recursive Newton-Euler with qdd = 0 for the bias C(q, qd) (gravity as a
+//   base acceleration), Cholesky for H qdd = tau - C (LinAlgd::factor_chol / solve_chol_fast semantics, linalg.hpp).
+// It is pinned by physics instead (tests/test_oracle_artic.py): H against the Jacobian form sum_i J_i' M_i J_i in numpy,
+// energy conservation, the pendulum's period.  What IS restated from the reference, line by line: the limit
+// constraints (include/Moby/ArticulatedBody.inl:9-43), compute_limit_components (src/ImpactConstraintHandler.cpp:
+// 1755-1781 -- including its missing sign product between an upper and a lower limit), apply_no_slip_model with no
+// contacts (ICH:1009-1417), update_from_stacked / update_constraint_velocities_from_impulses / apply_restitution
+// (ICH:298-525), the stepping order of TimeSteppingSimulator::do_mini_step (TSS:114-222).
+// sin / cos: an explicit fdlibm-style kernel (sincos below), because the HIP kernels must reproduce every bit.
+#ifndef ORACLE_ARTIC_HPP
+#define ORACLE_ARTIC_HPP
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "../include/moby_hip_artic.h"
+#include "lcp.hpp"
+#include "linalg.hpp"
+
+namespace oracle {
+
+static const double A_NEAR_ZERO = 1.4901161193847656e-08;
+
+// sin and cos of x: Cody-Waite reduction by pi/2 (two terms: |x| < ~1e5 keeps full accuracy), then the fdlibm kernel
+// polynomials on [-pi/4, pi/4]
+static inline void sincos_kernel(double x, double& s, double& c)
+{
+  const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+  const double kf = std::floor(x * invpio2 + 0.5);
+  const double r = (x - kf * pio2_1) - kf * pio2_1t;
+  const double z = r * r;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double v = z * r;
+  const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  const double ks = r + v * (S1 + z * rs);
+  const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double kc = 1.0 - (0.5 * z - z * rc);
+  long long k = (long long)kf;
+  const int n = (int)(((k % 4) + 4) % 4);
+  if (n == 0) { s = ks; c = kc; } else if (n == 1) { s = kc; c = -ks; } else if (n == 2) { s = -ks; c = -kc; } else { s = -kc; c = ks; }
+}
+
+namespace artic {
+static inline double dot3(const double* a, const double* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline void cross3(const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+static inline void mat3mul(const double* A, const double* B, double* C) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[3*i+j] = (A[3*i] * B[j] + A[3*i+1] * B[3+j]) + A[3*i+2] * B[6+j];
+}
+static inline void mat3vec(const double* A, const double* v, double* y) { for (int i = 0; i < 3; i++) y[i] = (A[3*i] * v[0] + A[3*i+1] * v[1]) + A[3*i+2] * v[2]; }
+static inline double dot6(const double* a, const double* b) { double acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + a[k] * b[k]; return acc; }
+static inline void mat6vec(const double* A, const double* v, double* y) { for (int r = 0; r < 6; r++) { double acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + A[6*r+k] * v[k]; y[r] = acc; } }
+// spatial cross products, [angular; linear]
+static inline void crm(const double* v, const double* m, double* o) {
+  double a[3], b[3], c[3];
+  cross3(v, m, a); cross3(v, m + 3, b); cross3(v + 3, m, c);
+  for (int k = 0; k < 3; k++) { o[k] = a[k]; o[3+k] = b[k] + c[k]; }
+}
+static inline void crf(const double* v, const double* f, double* o) {
+  double a[3], b[3], c[3];
+  cross3(v, f, a); cross3(v + 3, f + 3, b); cross3(v, f + 3, c);
+  for (int k = 0; k < 3; k++) { o[k] = a[k] + b[k]; o[3+k] = c[k]; }
+}
+}  // namespace artic
+
+class Artic {
+ public:
+  static const int NJ = MH_ARTIC_MAX_JOINTS;
+  const mh_artic_model* m; double* q; double* qd; mh_world_aux* aux;
+  int nj;
+  double R[NJ][9], x[NJ][3], S[NJ][6], Is[NJ][36], Ic[NJ][36], H[NJ * NJ], C[NJ];
+  int32_t* trace = nullptr; int trace_cap = 0; int trace_len = 0;
+
+  Artic(const mh_artic_model* model, double* q_, double* qd_, mh_world_aux* a) : m(model), q(q_), qd(qd_), aux(a), nj(model->nj) {}
+
+  // link frames, motion subspaces and spatial inertias about the world origin
+  void kinematics() {
+    using namespace artic;
+    for (int i = 0; i < nj; i++) {
+      const int p = m->parent[i];
+      const double* ax = m->axis[i];
+      double Rl[9], tl[3];
+      if (m->jtype[i] == MH_JOINT_REVOLUTE) {
+        double s, c; sincos_kernel(q[i], s, c);
+        const double t = 1.0 - c;
+        const double K[9] = { 0.0, -ax[2], ax[1], ax[2], 0.0, -ax[0], -ax[1], ax[0], 0.0 };
+        double Rq[9];
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Rq[3*a+b] = (((a == b) ? c : 0.0) + (t * ax[a]) * ax[b]) + s * K[3*a+b];
+        mat3mul(m->Rrel[i], Rq, Rl);
+        for (int k = 0; k < 3; k++) tl[k] = m->trel[i][k];
+      } else {
+        for (int k = 0; k < 9; k++) Rl[k] = m->Rrel[i][k];
+        double d[3], Rd[3];
+        for (int k = 0; k < 3; k++) d[k] = ax[k] * q[i];
+        mat3vec(m->Rrel[i], d, Rd);
+        for (int k = 0; k < 3; k++) tl[k] = m->trel[i][k] + Rd[k];
+      }
+      if (p < 0) { for (int k = 0; k < 9; k++) R[i][k] = Rl[k]; for (int k = 0; k < 3; k++) x[i][k] = tl[k]; }
+      else { mat3mul(R[p], Rl, R[i]); double Rt[3]; mat3vec(R[p], tl, Rt); for (int k = 0; k < 3; k++) x[i][k] = x[p][k] + Rt[k]; }
+      double aw[3]; mat3vec(R[i], ax, aw);
+      if (m->jtype[i] == MH_JOINT_REVOLUTE) { double xa[3]; cross3(x[i], aw, xa); for (int k = 0; k < 3; k++) { S[i][k] = aw[k]; S[i][3+k] = xa[k]; } }
+      else for (int k = 0; k < 3; k++) { S[i][k] = 0.0; S[i][3+k] = aw[k]; }
+      double rc[3], r[3]; mat3vec(R[i], m->com[i], rc);
+      for (int k = 0; k < 3; k++) r[k] = x[i][k] + rc[k];
+      double T[9], Iw[9];
+      mat3mul(R[i], m->inertia[i], T);
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Iw[3*a+b] = (T[3*a] * R[i][3*b] + T[3*a+1] * R[i][3*b+1]) + T[3*a+2] * R[i][3*b+2];
+      Iw[1] = Iw[3]; Iw[2] = Iw[6]; Iw[5] = Iw[7];
+      const double mass = m->mass[i];
+      const double rr = dot3(r, r);
+      const double rx[9] = { 0.0, -r[2], r[1], r[2], 0.0, -r[0], -r[1], r[0], 0.0 };
+      double* I6 = Is[i];
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+        I6[6*a+b] = Iw[3*a+b] + mass * (((a == b) ? rr : 0.0) - r[a] * r[b]);
+        I6[6*a+3+b] = mass * rx[3*a+b];
+        I6[6*(3+a)+b] = mass * rx[3*b+a];
+        I6[6*(3+a)+3+b] = (a == b) ? mass : 0.0;
+      }
+    }
+  }
+  // composite-rigid-body algorithm: H(i, j) = S_j' Ic_i S_i for j on the path from i to the base
+  void crba() {
+    using namespace artic;
+    for (int i = 0; i < nj; i++) for (int e = 0; e < 36; e++) Ic[i][e] = Is[i][e];
+    for (int i = nj - 1; i >= 0; i--) { const int p = m->parent[i]; if (p >= 0) for (int e = 0; e < 36; e++) Ic[p][e] = Ic[p][e] + Ic[i][e]; }
+    for (int e = 0; e < nj * nj; e++) H[e] = 0.0;
+    for (int i = 0; i < nj; i++) {
+      double F[6]; mat6vec(Ic[i], S[i], F);
+      H[i * nj + i] = dot6(S[i], F);
+      for (int j = m->parent[i]; j >= 0; j = m->parent[j]) { const double h = dot6(S[j], F); H[i * nj + j] = h; H[j * nj + i] = h; }
+    }
+  }
+  // recursive Newton-Euler with qdd = 0: C(q, qd) including gravity (base acceleration -g)
+  void bias() {
+    using namespace artic;
+    double v[NJ][6], a[NJ][6], f[NJ][6];
+    for (int i = 0; i < nj; i++) {
+      const int p = m->parent[i];
+      double vj[6], cv[6];
+      for (int k = 0; k < 6; k++) vj[k] = S[i][k] * qd[i];
+      for (int k = 0; k < 6; k++) v[i][k] = (p < 0) ? vj[k] : v[p][k] + vj[k];
+      crm(v[i], vj, cv);
+      for (int k = 0; k < 6; k++) {
+        const double ap = (p < 0) ? ((k < 3) ? 0.0 : -m->gravity[k - 3]) : a[p][k];
+        a[i][k] = ap + cv[k];
+      }
+      double Ia[6], Iv[6], cf[6];
+      mat6vec(Is[i], a[i], Ia); mat6vec(Is[i], v[i], Iv); crf(v[i], Iv, cf);
+      for (int k = 0; k < 6; k++) f[i][k] = Ia[k] + cf[k];
+    }
+    for (int i = nj - 1; i >= 0; i--) {
+      C[i] = dot6(S[i], f[i]);
+      const int p = m->parent[i];
+      if (p >= 0) for (int k = 0; k < 6; k++) f[p][k] = f[p][k] + f[i][k];
+    }
+  }
+  // calc_fwd_dyn: H qdd = tau - C by Cholesky; false if H is not positive definite
+  bool fwd_dyn(const double* tau, double* qdd) {
+    kinematics(); crba(); bias();
+    std::vector<double> L(H, H + nj * nj);
+    if (!chol_factor(nj, L.data(), nj)) return false;
+    for (int i = 0; i < nj; i++) qdd[i] = (tau ? tau[i] : 0.0) - C[i];
+    chol_solve(nj, L.data(), nj, qdd);
+    return true;
+  }
+  void lcp_account(int n, unsigned pivots) { aux->lcp_solves++; aux->lcp_rows += (unsigned long long)n; aux->lcp_pivots += pivots; aux->lcp_alg_bytes += 8ull * ((unsigned long long)n * n + 2ull * n); }
+
+  // find_limit_constraints + calc_impacting_unilateral_constraint_forces for the limits of this body
+  void handle_limits() {
+    int idx[2 * NJ]; bool upper[2 * NJ]; int nl = 0;
+    for (int i = 0; i < nj; i++) {                                   // ArticulatedBody.inl:9-43 (q_tare = 0)
+      if (q[i] >= m->hilimit[i]) { idx[nl] = i; upper[nl] = true; nl++; }
+      if (q[i] <= m->lolimit[i]) { idx[nl] = i; upper[nl] = false; nl++; }
+    }
+    if (nl == 0) return;
+    bool impacting = false;                                          // CSim:313-323
+    for (int k = 0; k < nl; k++) { const double v = upper[k] ? -qd[idx[k]] : qd[idx[k]]; if (v < -A_NEAR_ZERO) impacting = true; }
+    if (!impacting) return;
+    if (nl > MH_NOSLIP_MAX) { aux->status |= MH_WORLD_UNSUPPORTED; return; }
+    // compute_X: X = inverse_SPD(H) (ICH:1607); compute_limit_components (ICH:1755-1781)
+    std::vector<double> X(H, H + nj * nj);
+    if (!inverse_spd(nj, X.data(), nj)) { aux->status |= MH_WORLD_LCP_FAILED; return; }
+    std::vector<double> MM((size_t)nl * nl), Lv(nl), l(nl);
+    for (int a = 0; a < nl; a++) for (int b = a; b < nl; b++) { const double e = X[idx[a] * nj + idx[b]]; MM[a + (size_t)nl * b] = e; MM[b + (size_t)nl * a] = e; }
+    for (int k = 0; k < nl; k++) { Lv[k] = qd[idx[k]]; if (upper[k]) Lv[k] = -Lv[k]; }
+    // apply_no_slip_model with no contacts: MM = L X L', qq = L v; lcp_fast on the persistent _v, then the Lemke ladder
+    Vec z; z.d.assign(aux->vns, aux->vns + MH_NOSLIP_MAX); z.len = (unsigned)aux->vns_size;
+    oracle_rand_t rs; std::memcpy(&rs, aux->rng, sizeof(rs));
+    LCP lcp; lcp.rng = &rs;
+    Trace tr; tr.buf = trace ? trace + trace_len : nullptr; tr.cap = trace ? ((trace_cap - trace_len > 0) ? trace_cap - trace_len : 0) : 0;
+    lcp.trace = &tr;
+    unsigned piv = 0;
+    bool ok = lcp.lcp_fast(nl, MM.data(), nl, Lv.data(), z, -1.0);
+    piv += lcp.pivots;
+    if (!ok) { ok = lcp.lcp_lemke_regularized(nl, MM.data(), nl, Lv.data(), z); piv += lcp.pivots; }
+    trace_len += tr.len;
+    std::memcpy(aux->rng, &rs, sizeof(rs));
+    lcp_account(nl, piv);
+    if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; return; }       // std::runtime_error("Unable to solve constraint LCP!")
+    for (int k = 0; k < nl; k++) aux->vns[k] = z[k];
+    aux->vns_size = nl;
+    for (int k = 0; k < nl; k++) l[k] = z[k];
+    auto apply = [&]() {                                             // update_from_stacked (ICH:298-397): dv = X_LT ls
+      std::vector<double> dv(nj, 0.0);
+      for (int k = 0; k < nl; k++) { const double ls = upper[k] ? -l[k] : l[k]; for (int r = 0; r < nj; r++) dv[r] = dv[r] + ls * X[idx[k] * nj + r]; }
+      for (int r = 0; r < nj; r++) qd[r] = qd[r] + dv[r];
+    };
+    auto update_vels = [&]() {                                       // L_v += L_X_LT l (ICH:452)
+      std::vector<double> t(nl, 0.0);
+      for (int k = 0; k < nl; k++) for (int r = 0; r < nl; r++) t[r] = t[r] + l[k] * MM[r + (size_t)nl * k];
+      for (int r = 0; r < nl; r++) Lv[r] = Lv[r] + t[r];
+    };
+    auto minv_of = [&]() { double mn = Lv[0]; for (int k = 1; k < nl; k++) mn = (Lv[k] < mn) ? Lv[k] : mn; return mn; };
+    apply(); update_vels();
+    const double minv = minv_of();
+    bool changed = false;                                            // apply_restitution(q) (ICH:497-525)
+    for (int k = 0; k < nl; k++) { l[k] = l[k] * m->limit_restitution[idx[k]]; if (!changed && l[k] > A_NEAR_ZERO) changed = true; }
+    if (changed) {
+      apply(); update_vels();
+      const double minv_plus = minv_of();
+      // ICH:284-291 would re-solve and then read the Drumwright-Shell solver's _z, which this path never sized
+      if (minv_plus < 0.0 && minv_plus < minv - A_NEAR_ZERO) aux->status |= MH_WORLD_UNSUPPORTED;
+    }
+    for (int k = 0; k < nl; k++) { const double v = upper[k] ? -qd[idx[k]] : qd[idx[k]]; if (v < -A_NEAR_ZERO) aux->status |= MH_WORLD_IMPACT_TOL; }   // ICH:157-167
+  }
+
+  // TimeSteppingSimulator::step for this world: no collision geometry => one mini-step of dt (TSS:114-222)
+  void step(double dt) {
+    for (int i = 0; i < nj; i++) { double qn = qd[i] * dt; qn = qn + q[i]; q[i] = qn; }        // positions with the OLD velocity (TSS:156-164)
+    double qdd[NJ];
+    if (!fwd_dyn(nullptr, qdd)) { aux->status |= MH_WORLD_LCP_FAILED; for (int i = 0; i < nj; i++) qdd[i] = 0.0; }
+    for (int i = 0; i < nj; i++) qd[i] = qd[i] + qdd[i] * dt;                                      // TSS:182-192
+    handle_limits();
+    aux->time += dt; aux->mini_steps++; aux->steps++;
+  }
+};
+
+}  // namespace oracle
+#endif

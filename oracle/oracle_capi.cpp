@@ -247,4 +247,39 @@ double oracle_big_step(const mh_big_scene* s, double dt, int nsteps, double* sta
   return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
 }
 
+
+} // extern "C"
+
+// ---- articulated bodies (include/moby_hip_artic.h) ----------------------------------------------------
+#include "artic.hpp"
+
+extern "C" {
+
+// B worlds x nsteps of TimeSteppingSimulator::step, sequentially on one thread; returns elapsed seconds
+double oracle_artic_step(const mh_artic_model* m, int B, double dt, int nsteps, double* q, double* qd, mh_world_aux* aux)
+{
+  timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int b = 0; b < B; b++) {
+    Artic w(m, q + (size_t)b * m->nj, qd + (size_t)b * m->nj, aux + b);
+    for (int s = 0; s < nsteps; s++) w.step(dt);
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}
+
+// qdd = H^-1 (tau - C) of one state; H (nj x nj, row-major), C (nj) and the link poses (nj x 12) optional.  Returns 1 / 0 (H not PD).
+int oracle_artic_fwd_dyn(const mh_artic_model* m, const double* q, const double* qd, const double* tau, double* qdd, double* H, double* C, double* poses)
+{
+  mh_world_aux aux; std::memset(&aux, 0, sizeof(aux));
+  std::vector<double> qq(q, q + m->nj), qv(qd, qd + m->nj);
+  Artic w(m, qq.data(), qv.data(), &aux);
+  const bool ok = w.fwd_dyn(tau, qdd);
+  if (H) for (int e = 0; e < m->nj * m->nj; e++) H[e] = w.H[e];
+  if (C) for (int i = 0; i < m->nj; i++) C[i] = w.C[i];
+  if (poses) for (int i = 0; i < m->nj; i++) { for (int k = 0; k < 9; k++) poses[12 * i + k] = w.R[i][k]; for (int k = 0; k < 3; k++) poses[12 * i + 9 + k] = w.x[i][k]; }
+  return ok ? 1 : 0;
+}
+
+void oracle_sincos(double x, double* s, double* c) { sincos_kernel(x, *s, *c); }
+
 } // extern "C"

@@ -165,3 +165,34 @@ def oracle_big_step(self, scene, state, aux, dt, nsteps=1, zlast=None, zbuf=None
 
 
 Oracle.big_step = oracle_big_step
+
+
+def oracle_artic_step(self, model, q, qd, aux, dt, nsteps=1):
+    """B worlds (q, qd: (B, nj); aux: B records) x nsteps of TimeSteppingSimulator::step, in place; returns seconds."""
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    self.lib.oracle_artic_step.restype = ctypes.c_double
+    return self.lib.oracle_artic_step(ctypes.byref(model), int(q.shape[0]), ctypes.c_double(dt), int(nsteps), P(q), P(qd), P(aux))
+
+
+def oracle_artic_fwd_dyn(self, model, q, qd, tau=None):
+    """One state -> dict(ok, qdd, H (nj, nj), C (nj), poses (nj, 12))."""
+    nj = model.nj
+    qdd = np.zeros(nj); H = np.zeros((nj, nj)); C = np.zeros(nj); poses = np.zeros((nj, 12))
+    P = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(ctypes.c_void_p)
+    q = np.ascontiguousarray(q, dtype=np.float64); qd = np.ascontiguousarray(qd, dtype=np.float64)
+    t = None if tau is None else np.ascontiguousarray(tau, dtype=np.float64)
+    ok = self.lib.oracle_artic_fwd_dyn(ctypes.byref(model), P(q), P(qd), P(t), qdd.ctypes.data_as(ctypes.c_void_p),
+                                       H.ctypes.data_as(ctypes.c_void_p), C.ctypes.data_as(ctypes.c_void_p), poses.ctypes.data_as(ctypes.c_void_p))
+    return dict(ok=bool(ok), qdd=qdd, H=H, C=C, poses=poses)
+
+
+def oracle_sincos(self, x):
+    s = ctypes.c_double(0.0); c = ctypes.c_double(0.0)
+    self.lib.oracle_sincos.restype = None
+    self.lib.oracle_sincos(ctypes.c_double(x), ctypes.byref(s), ctypes.byref(c))
+    return s.value, c.value
+
+
+Oracle.artic_step = oracle_artic_step
+Oracle.artic_fwd_dyn = oracle_artic_fwd_dyn
+Oracle.sincos = oracle_sincos

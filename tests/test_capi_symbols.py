@@ -19,7 +19,7 @@ def _declared_symbols(header="moby_hip.h"):
 def test_library_exports_every_declared_symbol():
     from moby_amd import _lib
     lib = _lib.load()
-    declared = sorted(set(_declared_symbols() + _declared_symbols("moby_hip_impact.h") + _declared_symbols("moby_hip_stack.h")))
+    declared = sorted(set(_declared_symbols() + _declared_symbols("moby_hip_impact.h") + _declared_symbols("moby_hip_stack.h") + _declared_symbols("moby_hip_artic.h")))
     assert "mh_lcp_solve_batch_dev" in declared and "mh_rand_seed" in declared and "mh_impact_batch_process" in declared
     for name in declared:
         assert hasattr(lib, name), "libmoby_hip.so does not export %s" % name
@@ -40,7 +40,7 @@ def test_headers_are_plain_c(tmp_path):
     """The boundary is a C ABI: both public headers compile as C99 (-pedantic -Werror) and as C++11."""
     import subprocess
     src = tmp_path / "hdr.c"
-    src.write_text('#include "moby_hip.h"\n#include "moby_hip_io.h"\n#include "moby_hip_impact.h"\n#include "moby_hip_stack.h"\n'
+    src.write_text('#include "moby_hip.h"\n#include "moby_hip_io.h"\n#include "moby_hip_impact.h"\n#include "moby_hip_stack.h"\n#include "moby_hip_artic.h"\n'
                    'int main(void) { mh_scene s; mh_world_aux a; mh_io_scene io; mh_contact c; (void)s; (void)a; (void)io; (void)c;\n'
                    '  return (int)sizeof(mh_lcp_opts) == 0 || sizeof(mh_contact) != 96; }\n')
     inc = os.path.join(ROOT, "include")
