@@ -643,6 +643,8 @@ int mh_impact_batch_create(int B, int nb, int nc, int nk, const double* mass, co
   if (B <= 0 || nb <= 0 || nc <= 0) return fail(MH_ERR_INVALID_ARG, "B, nb, nc must be positive");
   if (!mass || !inertia) return fail(MH_ERR_INVALID_ARG, "null mass/inertia");
   if (nk < 4 || (nk & 1)) return fail(MH_ERR_INVALID_ARG, "nk must be even and >= 4 (ContactParameters.cpp:128-135), got %d", nk);
+  if (nb > mh::imp::MAXB) return fail(MH_ERR_INVALID_ARG, "nb = %d > %d bodies per world", nb, mh::imp::MAXB);
+  if (nc > mh::imp::MAXC) return fail(MH_ERR_INVALID_ARG, "nc = %d > %d contacts per world", nc, mh::imp::MAXC);
   const long n = 6L * nc + (long)nc * (nk / 2);
   if (n > MH_LCP_MAX_N_BLOCK) return fail(MH_ERR_UNSUPPORTED_N, "impact LCP n = %ld > %d", n, MH_LCP_MAX_N_BLOCK);
   for (int i = 0; i < nb; i++) {
