@@ -21,8 +21,10 @@ ONE batch of `--worlds` split N ways (4096 / 8 = 512 worlds per GPU = 2 waves pe
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel) and
 `cpu_baseline` (the CPU oracle on the host cores; rank 0, N = 1 only).
-`config4_impact_handler` (rank 0, N = 1; informational, outside the timed region): BASELINE config 4 in the small --
-4-box stacks x1024 through the impact-handler entry (include/moby_hip_impact.h), one cold and one warm call.
+Informational legs (rank 0, N = 1, outside the timed region): `config4_impact_handler` -- 4-box stacks x1024 through the
+impact-handler entry (include/moby_hip_impact.h), one cold and one warm call; `config4_full_step` -- box stacks as full
+simulator steps (include/moby_hip_stack.h); `config5_ur10` -- the ur10 arm x8192 (include/moby_hip_artic.h);
+`long_horizon` -- the headline batch at steps 4000-4200.
 """
 import argparse
 import json
@@ -152,6 +154,67 @@ def config4_leg(torch, nboxes=4, B=1024):
         return {"error": repr(e)}
 
 
+def config4_full_step_leg(torch, nboxes, B, steps):
+    """BASELINE config 4 as FULL simulator steps (include/moby_hip_stack.h): B stacks of `nboxes` boxes, each step =
+    conservative advancement + contact generation + process_constraints over every island + stabilisation, all on the
+    device.  The first step is cold, the rest warm-started.  Informational; the stated size of this configuration is
+    16 boxes (n = 512) -- tests/test_big_gpu.py -- and is measured in profiles/ (a step there takes tens of seconds)."""
+    try:
+        from moby_amd import stack as K
+        sc = K.box_stack_scene(nboxes)
+        bb = K.BigBatch(sc, K.box_stack_state(nboxes, B))
+        res = {"workload": "box stack of %d (impact LCP n = %d) x%d worlds, full TimeSteppingSimulator::step, dt = 1e-3" % (nboxes, 32 * nboxes, B),
+               "steps": []}
+        prev = None
+        for k in range(steps):
+            t0 = time.perf_counter(); bb.step(DT, 1); torch.cuda.synchronize(); dt_s = time.perf_counter() - t0
+            _, aux = bb.download()
+            rows = float(aux["lcp_rows"].astype(np.int64).sum()) - (prev if prev is not None else 0.0)
+            prev = float(aux["lcp_rows"].astype(np.int64).sum())
+            res["steps"].append({"s": dt_s, "world_steps_per_sec": B / dt_s, "lcp_rows_per_sec": rows / dt_s})
+        res["worlds_with_errors"] = int(((aux["status"] & ~2) != 0).sum())
+        res["pivots_per_world_step"] = float(aux["lcp_pivots"].astype(np.int64).mean()) / steps
+        bb.close()
+        return res
+    except Exception as e:          # noqa: BLE001 -- informational leg
+        return {"error": repr(e)}
+
+
+def config5_leg(torch, B=8192, steps=200):
+    """BASELINE config 5: the ur10 arm (tests/scenes/ten_joint_arm.sdf = the numbers of example/ur10/model.sdf) x B random
+    states, dt = 5e-4 (ur10.xml:2), `steps` steps in one launch: CRBA + RNEA + Cholesky forward dynamics and the joint-limit
+    LCP every step.  Also times the CPU oracle (oracle/artic.hpp, one thread) on a sample of the same batch."""
+    try:
+        from moby_amd import artic as A
+        from tests.oracle_api import Oracle
+        from tests.test_artic_gpu import ur10_states
+        from moby_amd import scene as S
+        m, _, _ = A.load_sdf(os.path.join(ROOT, "tests", "scenes", "ten_joint_arm.sdf"))
+        q0, qd0 = ur10_states(m, B)
+        oracle = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+        nw = min(B, 256)
+        qo, qdo, auxo = q0[:nw].copy(), qd0[:nw].copy(), S.new_aux(nw)
+        secs = oracle.artic_step(m, qo, qdo, auxo, 5e-4, steps)
+        ab = A.ArticBatch(m, q0, qd0)
+        stream = torch.cuda.current_stream().cuda_stream
+        ab.step(5e-4, 10, stream); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _, _, a0 = ab.download()
+        e0.record(); ab.step(5e-4, steps, stream); e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        _, _, a1 = ab.download()
+        rows = float(a1["lcp_rows"].astype(np.int64).sum() - a0["lcp_rows"].astype(np.int64).sum())
+        ab.close()
+        # algorithmic bytes of one world-step: q, qd in and out once per LAUNCH (state stays in LDS between steps)
+        return {"workload": "ur10 (10 joints) x%d, dt = 5e-4, %d steps in one launch" % (B, steps), "ms": ms,
+                "world_steps_per_sec": B * steps / (ms * 1e-3), "lcp_rows_per_sec": rows / (ms * 1e-3),
+                "worlds_with_errors": int(((a1["status"] & ~2) != 0).sum()),
+                "flops_per_world_step_est": 21000, "gflops_est": 21000.0 * B * steps / (ms * 1e-3) / 1e9,
+                "cpu_oracle": {"world_steps_per_sec": nw * steps / secs, "cores": 1, "sample": "%d worlds x %d steps" % (nw, steps)}}
+    except Exception as e:          # noqa: BLE001 -- informational leg
+        return {"error": repr(e)}
+
+
 def strong_leg(torch, dist, mdist, S, WorldBatchDevice, sc, B_total, rank, world_size, dev, args):
     """Strong scaling: ONE batch of `B_total` worlds split over the ranks (rank r owns worlds [r B/N, (r+1) B/N) of the
     same batch the N = 1 run steps), W warmup + K timed steps, barrier + synchronize on both sides, MAX over ranks."""
@@ -209,6 +272,10 @@ def main():
     ap.add_argument("--worlds", type=int, default=WORLDS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config4", action="store_true")
+    ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--config4-boxes", type=int, default=8, help="box stack height of the informational full-step leg (n = 32 x boxes)")
+    ap.add_argument("--config4-worlds", type=int, default=256)
+    ap.add_argument("--config4-steps", type=int, default=2)
     ap.add_argument("--no-long-horizon", action="store_true")
     ap.add_argument("--long-horizon-start", type=int, default=4000)
     args = ap.parse_args()
@@ -325,6 +392,9 @@ def main():
         out["long_horizon"] = long_horizon_leg(torch, wb, stream, B, args)   # after the timed region; informational
     if rank == 0 and world_size == 1 and not args.no_config4:
         out["config4_impact_handler"] = config4_leg(torch)             # after the timed region; informational
+        out["config4_full_step"] = config4_full_step_leg(torch, args.config4_boxes, args.config4_worlds, args.config4_steps)
+    if rank == 0 and world_size == 1 and not args.no_config5:
+        out["config5_ur10"] = config5_leg(torch)
     if rank == 0:
         print(json.dumps(out))
     if world_size > 1:
