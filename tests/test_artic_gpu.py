@@ -112,3 +112,16 @@ def test_config5_full_size_properties():
     q2, qd2, aux2 = ab2.download()
     assert np.array_equal(q2, q[:64]) and np.array_equal(qd2, qd[:64]) and np.array_equal(aux2["lcp_pivots"], aux["lcp_pivots"][:64])
     ab.close(); ab2.close()
+
+
+def test_cpp_articulated_adapter_example():
+    """moby_amd/cpp/MobyHipArticulatedBody.h (calc_fwd_dyn / get_generalized_inertia / step) through its example program
+    on the SDF model."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    cpp = os.path.join(root, "moby_amd", "cpp")
+    exe = os.path.join(cpp, "example_articulated")
+    subprocess.check_call(["g++", "-std=c++11", os.path.join(cpp, "example_articulated.cpp"), "-L" + os.path.join(root, "moby_amd"),
+                           "-lmoby_hip", "-lmoby_hip_io", "-Wl,-rpath," + os.path.join(root, "moby_amd"), "-o", exe])
+    out = subprocess.check_output([exe, UR10]).decode()
+    assert "joints=10 world_joint..r_finger_actuator same=1" in out, out

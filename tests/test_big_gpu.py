@@ -151,3 +151,16 @@ def test_config4_stated_size_properties():
     b = st.reshape(B, N, 13)
     assert np.abs(b[:, :, 1] - 0.5 - np.arange(N)).max() < 1e-4     # nothing sank or flew
     assert np.abs(b[:, :, 7:13]).max() < 5e-2
+
+
+def test_cpp_stack_simulator_adapter_example():
+    """moby_amd/cpp/MobyHipStackSimulator.h (TimeSteppingSimulator::step and ConstraintStabilization::stabilize for
+    large worlds) through its example program."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = os.path.join(root, "moby_amd", "cpp")
+    exe = os.path.join(cpp, "example_stack")
+    subprocess.check_call(["g++", "-std=c++11", os.path.join(cpp, "example_stack.cpp"), "-L" + os.path.join(root, "moby_amd"),
+                           "-lmoby_hip", "-Wl,-rpath," + os.path.join(root, "moby_amd"), "-o", exe])
+    out = subprocess.check_output([exe]).decode()
+    assert "status=0/0" in out and "time=0.003" in out, out

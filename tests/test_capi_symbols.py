@@ -115,3 +115,20 @@ def test_cpp_adapter_compiles_and_fails_loudly_without_gpu(tmp_path):
                            "-lmoby_hip", "-Wl,-rpath," + os.path.join(ROOT, "moby_amd"), "-o", exe])
     p = subprocess.run([exe], capture_output=True, timeout=120)
     assert p.returncode == 2 and b"no HIP device" in p.stdout
+
+
+@pytest.mark.parametrize("example,libs", [("example_stack", ["-lmoby_hip"]), ("example_articulated", ["-lmoby_hip", "-lmoby_hip_io"])])
+def test_new_cpp_adapters_compile_and_fail_loudly_without_gpu(tmp_path, example, libs):
+    """MobyHipStackSimulator.h (seams B5 / B3 for large worlds) and MobyHipArticulatedBody.h (seam B4) build with plain
+    g++ against the C ABI; without a device they report the error (no fallback)."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU tests")
+    cpp = os.path.join(ROOT, "moby_amd", "cpp")
+    exe = str(tmp_path / example)
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", os.path.join(cpp, example + ".cpp"), "-L" + os.path.join(ROOT, "moby_amd")] + libs +
+                          ["-Wl,-rpath," + os.path.join(ROOT, "moby_amd"), "-o", exe])
+    args = [exe] + ([os.path.join(ROOT, "tests", "scenes", "ten_joint_arm.sdf")] if example == "example_articulated" else [])
+    p = subprocess.run(args, capture_output=True, timeout=120)
+    assert p.returncode == 1 and b"no HIP device" in p.stdout, p.stdout
