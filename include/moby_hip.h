@@ -135,6 +135,10 @@ int mh_lcp_solve_batch(int kind, int B, int n,
                                        only ever tested against the ground plane, and always (plugin :53-74) */
 #define MH_GEOM_BOX 2               /* BoxPrimitive, tested against the ground plane only (vertex-plane contacts,
                                        CCD.inl:848-886); box-box / box-sphere pairs must be disabled */
+#define MH_GEOM_PIN 3               /* a body point (geom_dim, body frame) held at the global origin by six frictionless contacts with
+                                       normals +-y, +-z, +-x: the collision plugin of example/contact-constrained-pendulum
+                                       (contact-constrained-pendulum-coldet-plugin.cpp:53-146).  Large-world stepper (moby_hip_stack.h)
+                                       and oracle only; the pair (body, static world) is always a candidate */
 #define MH_MAX_SPOKES 8
 #define MH_NOSLIP_MAX 16            /* largest no-slip LCP (contacts of one island) whose warm start is kept */
 

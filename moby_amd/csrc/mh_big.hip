@@ -82,6 +82,7 @@ struct W {
   MH_DEV P3 Vl(int b) const { return ld3(st + 13 * b + 7); }
   MH_DEV P3 Wa(int b) const { return ld3(st + 13 * b + 10); }
   MH_DEV bool is_box(int b) const { return b < d.nb && d.geom_type[b] == MH_GEOM_BOX; }
+  MH_DEV bool is_pin(int b) const { return b >= 0 && b < d.nb && d.geom_type[b] == MH_GEOM_PIN; }
   MH_DEV bool vertex_face(int p) const { return d.pair_model[p] == MH_PAIR_VERTEX_FACE; }
   MH_DEV void rot(int b, double* R) const {
     const double x = st[13*b+3], y = st[13*b+4], z = st[13*b+5], w = st[13*b+6];
@@ -103,12 +104,20 @@ struct W {
   // CCD::construct_bounding_sphere (CCD.cpp:1040-1063)
   MH_DEV double bounding_radius(int b) const {
     if (is_box(b)) return norm3(p3(d.geom_dim[3*b] / 2.0, d.geom_dim[3*b+1] / 2.0, d.geom_dim[3*b+2] / 2.0));
+    if (is_pin(b)) return 0.0;
     return d.geom_dim[3*b];
   }
   // BoxPrimitive::get_vertices order (BoxPrimitive.cpp:358-365), global frame
   MH_DEV P3 box_vertex(int b, int i) const {
     const double hx = d.geom_dim[3*b] * 0.5, hy = d.geom_dim[3*b+1] * 0.5, hz = d.geom_dim[3*b+2] * 0.5;
     const double px = (i & 4) ? -hx : hx, py = (i & 2) ? -hy : hy, pz = (i & 1) ? -hz : hz;
+    double R[9]; rot(b, R);
+    const P3 c = X(b);
+    return p3(c.x + ((R[0]*px + R[1]*py) + R[2]*pz), c.y + ((R[3]*px + R[4]*py) + R[5]*pz), c.z + ((R[6]*px + R[7]*py) + R[8]*pz));
+  }
+  // PendulumColdetPlugin: the body point geom_dim (body frame) in the global frame
+  MH_DEV P3 pin_point(int b) const {
+    const double px = d.geom_dim[3*b], py = d.geom_dim[3*b+1], pz = d.geom_dim[3*b+2];
     double R[9]; rot(b, R);
     const P3 c = X(b);
     return p3(c.x + ((R[0]*px + R[1]*py) + R[2]*pz), c.y + ((R[3]*px + R[4]*py) + R[5]*pz), c.z + ((R[6]*px + R[7]*py) + R[8]*pz));
@@ -121,6 +130,12 @@ struct W {
   // CollisionGeometry::calc_signed_dist (CollisionGeometry.cpp:236-250) and the primitives behind it
   MH_DEV PD signed_dist(int p) const {
     PD r; r.pair = p; r.a = d.pair_a[p]; r.b = d.pair_b[p];
+    if (is_pin(r.a)) {                                   // plugin :65-82: -|p|; "pA" = the body point, "pB" = the origin (:130-136)
+      const P3 g = pin_point(r.a);
+      r.dist = -norm3(g - p3(0.0, 0.0, 0.0));
+      r.pa = g; r.pb = p3(0.0, 0.0, 0.0);
+      return r;
+    }
     if (vertex_face(p)) {
       double md = INF_;
       const P3 nL = face_n(r.a);
@@ -167,6 +182,16 @@ struct W {
   // CCD::find_contacts (CCD.inl:3-83): emit(point, normal, geom1, geom2, signed_violation) per contact, in list order
   template <class F> MH_DEV void find_contacts(int p, double TOL, F emit) const {
     const int a = d.pair_a[p], b = d.pair_b[p];
+    if (is_pin(a)) {                                     // plugin :84-110: six contacts at the midpoint, violation min(0, -p[axis])
+      const P3 g = pin_point(a);
+      const P3 pt = (g + p3(0.0, 0.0, 0.0)) * 0.5;
+      for (int i = 0; i < 6; i++) {
+        const P3 n = (i == 0) ? p3(0, 1, 0) : (i == 1 ? p3(0, -1, 0) : (i == 2 ? p3(0, 0, 1) : (i == 3 ? p3(0, 0, -1) : (i == 4 ? p3(1, 0, 0) : p3(-1, 0, 0)))));
+        const double pv = (i < 2) ? g.y : ((i < 4) ? g.z : g.x);
+        emit(pt, n, a, b, (-pv < 0.0) ? -pv : 0.0);
+      }
+      return;
+    }
     if (vertex_face(p)) {
       const P3 nL = face_n(a);
       for (int i = 0; i < 8; i++) {
@@ -253,6 +278,7 @@ struct W {
   }
   // CCD::calc_next_CA_Euler_step_generic (CCD.cpp:238-405)
   MH_DEV double next_CA_generic(const PD& pd) const {
+    if (is_pin(pd.a)) return INF_;                       // PendulumColdetPlugin::calc_next_CA_Euler_step (plugin :139-142)
     int cnt = 0; bool approaching = false;
     P3 c3[3]; P3 n0 = p3(0, 0, 0);
     find_contacts(pd.pair, NEAR_ZERO_, [&](P3 p, P3 n, int g1, int g2, double) {
@@ -285,7 +311,7 @@ struct W {
   }
   // CCD::calc_CA_Euler_step_sphere (CCD.cpp:138-166)
   MH_DEV double CA_step(const PD& pd) const {
-    if (is_box(pd.a)) return CA_generic(pd);
+    if (is_box(pd.a) || is_pin(pd.a)) return CA_generic(pd);
     if (pd.dist > NEAR_ZERO_) return CA_generic(pd);
     int cnt = 0; double v0 = 0.0;
     find_contacts(pd.pair, NEAR_ZERO_, [&](P3 p, P3 n, int g1, int g2, double) { if (cnt == 0) v0 = contact_vel(g1, g2, p, n); cnt++; });
@@ -335,6 +361,7 @@ MH_DEV int broad_phase(const W& w, double dt, int* list) {
     bool ov = true;
     for (int k = 0; k < 3; k++) if (!(s_lo[3*i+k] <= s_hi[3*j+k] && s_lo[3*j+k] <= s_hi[3*i+k])) ov = false;
     keep = (ov && (w.enabled(i) || w.enabled(j))) ? 1 : 0;
+    if (w.is_pin(i) || w.is_pin(j)) keep = (w.is_pin(i) && j == d.nb) ? 1 : 0;   // the plugin's broad phase: always, and nothing else (:53-58)
   }
   int total;
   const int o = blk_excl_scan(keep, total);
@@ -714,8 +741,8 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
     return fail(MH_ERR_INVALID_ARG, "null pair table");
   if (sc->nk < 4 || (sc->nk & 1)) return fail(MH_ERR_INVALID_ARG, "nk must be even and >= 4 (ContactParameters.cpp:128-135), got %d", sc->nk);
   for (int b = 0; b < nb; b++) {
-    if (sc->geom_type[b] != MH_GEOM_SPHERE && sc->geom_type[b] != MH_GEOM_BOX) return fail(MH_ERR_INVALID_ARG, "body %d: geometry type %d is not built here (sphere, box)", b, sc->geom_type[b]);
-    if (!(sc->geom_dim[3*b] > 0.0) || !(sc->mass[b] > 0.0)) return fail(MH_ERR_INVALID_ARG, "body %d: size and mass must be > 0", b);
+    if (sc->geom_type[b] != MH_GEOM_SPHERE && sc->geom_type[b] != MH_GEOM_BOX && sc->geom_type[b] != MH_GEOM_PIN) return fail(MH_ERR_INVALID_ARG, "body %d: geometry type %d is not built here (sphere, box, pin)", b, sc->geom_type[b]);
+    if ((sc->geom_type[b] != MH_GEOM_PIN && !(sc->geom_dim[3*b] > 0.0)) || !(sc->mass[b] > 0.0)) return fail(MH_ERR_INVALID_ARG, "body %d: size and mass must be > 0", b);
     if (sc->geom_type[b] == MH_GEOM_BOX && (!(sc->geom_dim[3*b+1] > 0.0) || !(sc->geom_dim[3*b+2] > 0.0))) return fail(MH_ERR_INVALID_ARG, "body %d: box edge lengths must be > 0", b);
     for (int k = 0; k < 3; k++) if (!(sc->inertia[3*b+k] > 0.0)) return fail(MH_ERR_INVALID_ARG, "body %d: inertia must be > 0", b);
   }
@@ -725,10 +752,12 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
     if (!(0 <= a && a < bq && bq <= nb) || (bq == nb && !sc->has_ground)) return fail(MH_ERR_INVALID_ARG, "pair %d: (%d, %d) is not a < b <= nb", p, a, bq);
     if (p > 0 && !(sc->pair_a[p-1] < a || (sc->pair_a[p-1] == a && sc->pair_b[p-1] < bq))) return fail(MH_ERR_INVALID_ARG, "pair %d: the list must be sorted lexicographically, without repeats", p);
     const bool boxa = sc->geom_type[a] == MH_GEOM_BOX, boxb = bq < nb && sc->geom_type[bq] == MH_GEOM_BOX;
+    const bool pina = sc->geom_type[a] == MH_GEOM_PIN, pinb = bq < nb && sc->geom_type[bq] == MH_GEOM_PIN;
+    if ((pina && bq != nb) || pinb) return fail(MH_ERR_INVALID_ARG, "pair %d: a pin geometry only pairs with the static world body", p);
     if (sc->pair_model[p] == MH_PAIR_VERTEX_FACE) { if (!(boxa && boxb)) return fail(MH_ERR_INVALID_ARG, "pair %d: the vertex-face model needs two boxes", p); }
     else if (sc->pair_model[p] != MH_PAIR_CLOSED_FORM) return fail(MH_ERR_INVALID_ARG, "pair %d: unknown model %d", p, sc->pair_model[p]);
     else if ((boxa || boxb) && bq != nb) return fail(MH_ERR_INVALID_ARG, "pair %d: box-box / box-sphere contact is only built as MH_PAIR_VERTEX_FACE", p);
-    ncmax += (boxa || boxb) ? 4 : 1;                        // a box face rests on at most 4 vertices ... of a box in general position; 8 fit below
+    ncmax += (boxa || boxb) ? 4 : (pina ? 3 : 1);                        // a box face rests on at most 4 vertices ... of a box in general position; 8 fit below
   }
   ncmax *= 2;                                               // a box lying inside the tolerance band can put all 8 vertices in contact
   if (ncmax < 8) ncmax = 8;

@@ -22,7 +22,7 @@ MH_LCP_MAX_N_WAVE = 64
 MH_NOSLIP_MAX = 16
 MH_CSTAB_DEFAULT_MAX_ITERATIONS = 10   # include/moby_hip.h
 MH_MAX_SPOKES = 8
-MH_GEOM_SPHERE, MH_GEOM_SPOKES, MH_GEOM_BOX = 0, 1, 2
+MH_GEOM_SPHERE, MH_GEOM_SPOKES, MH_GEOM_BOX, MH_GEOM_PIN = 0, 1, 2, 3
 NEAR_ZERO = math.sqrt(np.finfo(np.float64).eps)   # include/Moby/Constants.h:21
 
 MH_WORLD_OK, MH_WORLD_LCP_FAILED, MH_WORLD_IMPACT_TOL, MH_WORLD_UNSUPPORTED, MH_WORLD_STAB_FAILED, MH_WORLD_STALLED = 0, 1, 2, 4, 8, 16

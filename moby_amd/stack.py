@@ -74,10 +74,32 @@ class BigScene:
         bound mh_big_batch_create uses when lcp_n_max is 0."""
         if self.c.lcp_n_max:
             return int(self.c.lcp_n_max)
-        per = [4 if (m == MH_PAIR_VERTEX_FACE or self.geom_type[a] == S.MH_GEOM_BOX) else 1
+        per = [4 if (m == MH_PAIR_VERTEX_FACE or self.geom_type[a] == S.MH_GEOM_BOX) else (6 if self.geom_type[a] == S.MH_GEOM_PIN else 1)
                for a, m in zip(self.pair_a, self.pair_model)]
         nc = int(sum(per))
         return min(4096, max(64, 6 * nc + nc * (self.c.nk // 2)))
+
+
+def pendulum_scene(cstab_max_iterations=25):
+    """example/contact-constrained-pendulum/contact-constrained-pendulum.xml: one free body (mass 1, the inertia of a sphere of
+    radius 1.5811) whose point (0, 1, 0) the collision plugin pins to the global origin with six frictionless contacts
+    (epsilon 0, mu 0, NK 4: a 48-row impact LCP every step), gravity (0, -9.81, 0), 25 stabilisation iterations."""
+    r = 1.5811
+    J = r * r * 1.0 * 2.0 / 5.0                                      # SpherePrimitive.cpp:149
+    return BigScene([S.MH_GEOM_PIN], [(0.0, 1.0, 0.0)], [1.0], [(J, J, J)], [(0, 1, MH_PAIR_CLOSED_FORM)], gravity=(0.0, -9.81, 0.0),
+                    nk=4, epsilon=0.0, mu_coulomb=0.0, cstab_max_iterations=cstab_max_iterations, lcp_n_max=64)
+
+
+def pendulum_state(B=1, seed0=0x4D4F4259):
+    """position 1 0 0, rpy 0 0 pi/2 (the XML's numbers), at rest; worlds > 0 start with a small seeded spin about z."""
+    st = np.zeros((B, S.MH_BODY_STATE))
+    st[:, 0] = 1.0
+    h = 1.57079632679490 / 2.0
+    st[:, 5] = np.sin(h); st[:, 6] = np.cos(h)
+    if B > 1:
+        w = np.random.default_rng(seed0).uniform(-0.5, 0.5, B - 1)
+        st[1:, 12] = w; st[1:, 8] = w * 1.0                             # v = omega x r with r = (1, 0, 0): rotation about the pin
+    return st
 
 
 def box_dims(k):

@@ -169,6 +169,10 @@ class World {
     for (int p = 0; p < sc->npairs; p++) {
         int i, j; pair_bodies(p, i, j);
         if (is_spokes(i) || is_spokes(j)) continue;   // removed from CCD's body list (coldet-plugin.cpp:58-66)
+        if (is_pin(i) || is_pin(j)) {                 // PendulumColdetPlugin::broad_phase: exactly the pair (world, l1), always (:53-58)
+          if (is_pin(i) && j == sc->nb && sc->pair_enabled[p]) pairs.push_back(p);
+          continue;
+        }
         if ((is_box(i) || is_box(j)) && j != sc->nb && !vertex_face(p)) {  // box-box (v-clip on a qhull polyhedron) / box-sphere: not built
           if (sc->pair_enabled[p]) aux->status |= MH_WORLD_UNSUPPORTED;
           continue;
@@ -189,9 +193,18 @@ class World {
   bool vertex_face(int p) const { return sc->pair_model && sc->pair_model[p] == MH_PAIR_VERTEX_FACE; }
   bool is_spokes(int b) const { return b < sc->nb && sc->geom_type[b] == MH_GEOM_SPOKES; }
   bool is_box(int b) const { return b < sc->nb && sc->geom_type[b] == MH_GEOM_BOX; }
+  bool is_pin(int b) const { return b >= 0 && b < sc->nb && sc->geom_type[b] == MH_GEOM_PIN; }
+  // PendulumColdetPlugin: the body point pl1 = geom_dim (l1 frame) in the global frame
+  V3 pin_point(int b) const {
+    const double px = sc->geom_dim[b][0], py = sc->geom_dim[b][1], pz = sc->geom_dim[b][2];
+    double R[9]; rot(b, R);
+    const V3 c = X(b);
+    return v3(c.x + ((R[0]*px + R[1]*py) + R[2]*pz), c.y + ((R[3]*px + R[4]*py) + R[5]*pz), c.z + ((R[6]*px + R[7]*py) + R[8]*pz));
+  }
   // radius of the bounding sphere CCD::construct_bounding_sphere builds (CCD.cpp:1040-1063)
   double bounding_radius(int b) const {
     if (is_box(b)) { const V3 h = v3(sc->geom_dim[b][0] / 2.0, sc->geom_dim[b][1] / 2.0, sc->geom_dim[b][2] / 2.0); return norm(h); }
+    if (is_pin(b)) return 0.0;                      // no primitive: the plugin's broad phase never looks at bounds
     return sc->geom_dim[b][0];
   }
   // BoxPrimitive::get_vertices order (BoxPrimitive.cpp:358-365), global frame
@@ -239,6 +252,15 @@ class World {
         if (pp.y < min_dist) { min_dist = pp.y; d.pb = from_plane(v3(pp.x, 0.0, pp.z)); d.pa = g; }
       }
       d.dist = min_dist; d.a = sc->nb; d.b = w;
+      return d;
+    }
+    if (is_pin(d.a)) {
+      // PendulumColdetPlugin::calc_signed_dist_l1_world (plugin :65-82): -|p|, p = the body point in the world body's frame
+      // (identity).  The pair is (world, l1) and the plugin is called with the geometries swapped (:130-136): "pA" receives the
+      // l1 point, "pB" the world origin -- only ever read by the stabiliser's separated case, which -|p| never reaches
+      const V3 g = pin_point(d.a);
+      d.dist = -norm(g - v3(0.0, 0.0, 0.0));
+      d.pa = g; d.pb = v3(0.0, 0.0, 0.0);
       return d;
     }
     if (vertex_face(p)) {
@@ -320,6 +342,21 @@ class World {
         if (!(pp.y < sc->contact_dist_thresh)) continue;
         c.p = (g + from_plane(v3(pp.x, 0.0, pp.z))) * 0.5;
         c.n = plane_n(); c.g1 = a; c.g2 = b; c.dist = pp.y;
+        orthonormal_basis(c.n, c.s, c.t);
+        fill_params(c);
+        out.push_back(c);
+      }
+      return;
+    }
+    if (is_pin(a)) {
+      // PendulumColdetPlugin::find_contacts_l1_world (plugin :84-110): six contacts at the midpoint between the body point and
+      // the origin, geom1 = l1, geom2 = world, normals +y -y +z -z +x -x, violation min(0, -p[axis]); TOL is ignored
+      const V3 g = pin_point(a);
+      const V3 pt = (g + v3(0.0, 0.0, 0.0)) * 0.5;
+      const V3 ns[6] = { v3(0, 1, 0), v3(0, -1, 0), v3(0, 0, 1), v3(0, 0, -1), v3(1, 0, 0), v3(-1, 0, 0) };
+      const double pv[6] = { g.y, g.y, g.z, g.z, g.x, g.x };
+      for (int i = 0; i < 6; i++) {
+        c.p = pt; c.n = ns[i]; c.g1 = a; c.g2 = b; c.dist = (-pv[i] < 0.0) ? -pv[i] : 0.0;   // std::min(0.0, -p[axis])
         orthonormal_basis(c.n, c.s, c.t);
         fill_params(c);
         out.push_back(c);
@@ -435,6 +472,7 @@ class World {
   // CCD::calc_next_CA_Euler_step_generic (CCD.cpp:238-405) for sphere pairs
   double next_CA_generic(const PairDist& d) const {
     if (is_spokes(d.b)) return INF;                 // BladePlanePlugin::calc_next_CA_Euler_step (coldet-plugin.cpp:205-208)
+    if (is_pin(d.a)) return INF;                    // PendulumColdetPlugin::calc_next_CA_Euler_step (plugin :139-142)
     std::vector<Contact> cs; find_contacts(d.pair, NEAR_ZERO, cs);
     if (cs.empty()) return INF;
     for (const Contact& c : cs) if (contact_vel(c, c.n) < -NEAR_ZERO) return 0.0;
@@ -463,7 +501,7 @@ class World {
   }
   // CCD::calc_CA_Euler_step_sphere (CCD.cpp:138-166)
   double CA_step(const PairDist& d) const {
-    if (is_spokes(d.b) || is_box(d.a)) return CA_generic(d);   // no SpherePrimitive in the pair (CCD.cpp:127-133)
+    if (is_spokes(d.b) || is_box(d.a) || is_pin(d.a)) return CA_generic(d);   // no SpherePrimitive in the pair (CCD.cpp:127-133)
     if (d.dist > NEAR_ZERO) return CA_generic(d);
     std::vector<Contact> cs; find_contacts(d.pair, NEAR_ZERO, cs);
     if (cs.size() == 1 && std::fabs(contact_vel(cs[0], cs[0].n)) < NEAR_ZERO * 10) return INF;

@@ -15,6 +15,11 @@ data (run in the build container, where /root/reference exists):
                         [x y z qx qy qz qw]; 10001 rows, dt = 1e-3): first 30, every 100th, last;
                         plus the CPU-seconds footer.
 
+  contact_constrained_pendulum_dat.npz
+                        ALL rows of /root/reference/regress/contact-constrained-pendulum.dat (t + the link's
+                        [x y z qx qy qz qw]; 6500 rows, dt = 1e-3, 6.5 s of a swinging pendulum): the one DYNAMIC
+                        trajectory among the reference's regression files that a scene in scope produces.
+
 Only DATA is stored (inputs / expected outputs), never reference source.
 """
 import os
@@ -47,6 +52,13 @@ def main():
     np.savez_compressed(os.path.join(HERE, "sitting_box_dat.npz"), row_index=np.array(keep), rows=data[keep], n_rows=len(data),
                         cpu_seconds=float(footer[-1]) if footer else np.nan)
     print("sitting-box.dat: %d rows -> %d kept" % (len(data), len(keep)))
+
+    lines = open(os.path.join(REF, "contact-constrained-pendulum.dat")).read().split("\n")
+    data = np.array([[float(x) for x in l.split()] for l in lines if len(l.split()) == 8])
+    footer = [l for l in lines if len(l.split()) == 1 and l.strip()]
+    np.savez_compressed(os.path.join(HERE, "contact_constrained_pendulum_dat.npz"), rows=data, n_rows=len(data),
+                        cpu_seconds=float(footer[-1]) if footer else np.nan)
+    print("contact-constrained-pendulum.dat: %d rows (all kept)" % len(data))
 
 
 if __name__ == "__main__":

@@ -164,3 +164,14 @@ def test_cpp_stack_simulator_adapter_example():
                            "-lmoby_hip", "-Wl,-rpath," + os.path.join(root, "moby_amd"), "-o", exe])
     out = subprocess.check_output([exe]).decode()
     assert "status=0/0" in out and "time=0.003" in out, out
+
+
+def test_contact_constrained_pendulum_matches_oracle(oracle):
+    """example/contact-constrained-pendulum (the plugin's six-contact pin, MH_GEOM_PIN) on the GPU: 48-row impact LCPs on
+    opposing contacts every step, the stabiliser entered and abandoned every step -- bit for bit like the oracle, which
+    tests/test_oracle_pendulum.py pins to the reference's 6.5 s recording."""
+    sc = K.pendulum_scene()
+    st0 = K.pendulum_state(4)
+    r = run_both(oracle, sc, st0, 1e-3, 40, chunks=3)
+    assert_parity(*r)
+    assert (r[1]["lcp_rows"] >= 48 * 120).all()
