@@ -46,25 +46,26 @@ std::vector<double> numbers(const std::string& s) {
 }
 bool boolean(const std::string& s) { return !(strcasecmp(s.c_str(), "false") == 0 || s == "0"); }
 
-// Rz(yaw) Ry(pitch) Rx(roll), the expression order of moby_amd/scene.py::rpy_to_R
-void rpy_to_R(double roll, double pitch, double yaw, double R[9]) {
-  const double cr = std::cos(roll), sr = std::sin(roll), cp = std::cos(pitch), sp = std::sin(pitch), cy = std::cos(yaw), sy = std::sin(yaw);
-  R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
-  R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
-  R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+// Quatd::rpy as Ravelin forms it (half-angle products, ZYX), x y z w: every rpy attribute becomes a quaternion first
+void rpy_to_quat(double roll, double pitch, double yaw, double q[4]) {
+  const double cr = std::cos(roll * 0.5), sr = std::sin(roll * 0.5), cp = std::cos(pitch * 0.5), sp = std::sin(pitch * 0.5);
+  const double cy = std::cos(yaw * 0.5), sy = std::sin(yaw * 0.5);
+  q[0] = sr * cp * cy - cr * sp * sy; q[1] = cr * sp * cy + sr * cp * sy; q[2] = cr * cp * sy - sr * sp * cy; q[3] = cr * cp * cy + sr * sp * sy;
 }
+// rotation matrix of a STATIC pose (plane / primitive poses) in the form Ravelin uses, diagonal 2 (w^2 + q_i^2) - 1: pinned by
+// the round-off fingerprint of regress/sphere-stack.dat (moby_amd/scene.py::quat_to_R, tests/test_oracle_world.py)
+void quat_to_R_static(const double q[4], double R[9]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 2 * (w*w + x*x) - 1; R[1] = 2 * (x*y - z*w); R[2] = 2 * (x*z + y*w);
+  R[3] = 2 * (x*y + z*w); R[4] = 2 * (w*w + y*y) - 1; R[5] = 2 * (y*z - x*w);
+  R[6] = 2 * (x*z - y*w); R[7] = 2 * (y*z + x*w); R[8] = 2 * (w*w + z*z) - 1;
+}
+void rpy_to_R(double roll, double pitch, double yaw, double R[9]) { double q[4]; rpy_to_quat(roll, pitch, yaw, q); quat_to_R_static(q, R); }
 void quat_to_R(const double q[4], double R[9]) {     // q = x y z w, row-major R (the kernels' / oracle's rot())
   const double x = q[0], y = q[1], z = q[2], w = q[3];
   R[0] = 1 - 2 * (y*y + z*z); R[1] = 2 * (x*y - z*w); R[2] = 2 * (x*z + y*w);
   R[3] = 2 * (x*y + z*w); R[4] = 1 - 2 * (x*x + z*z); R[5] = 2 * (y*z - x*w);
   R[6] = 2 * (x*z - y*w); R[7] = 2 * (y*z + x*w); R[8] = 1 - 2 * (x*x + y*y);
-}
-void R_to_quat(const double R[9], double q[4]) {   // xyzw; only used for bodies given with rpy
-  const double tr = R[0] + R[4] + R[8];
-  if (tr > 0) { const double s = std::sqrt(tr + 1.0) * 2; q[3] = 0.25 * s; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; }
-  else if (R[0] > R[4] && R[0] > R[8]) { const double s = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[3] = (R[7] - R[5]) / s; q[0] = 0.25 * s; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s; }
-  else if (R[4] > R[8]) { const double s = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[3] = (R[2] - R[6]) / s; q[0] = (R[1] + R[3]) / s; q[1] = 0.25 * s; q[2] = (R[5] + R[7]) / s; }
-  else { const double s = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[3] = (R[3] - R[1]) / s; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = 0.25 * s; }
 }
 
 struct Prim { int type; double dim[3]; double mass; double J[3]; bool posed; double R[9]; double o[3]; };   // type: 0 sphere, 2 box, 100 plane
@@ -305,7 +306,7 @@ int mh_io_load_xml(const char* path, mh_io_scene* out)
         b.q[0] = q[1] / nrm; b.q[1] = q[2] / nrm; b.q[2] = q[3] / nrm; b.q[3] = q[0] / nrm;
         quat_to_R(b.q, b.R);
         b.rotated = !(b.q[0] == 0.0 && b.q[1] == 0.0 && b.q[2] == 0.0); }
-      else if (a.has("rpy")) { const std::vector<double> r = numbers(a.str("rpy")); if (r.size() != 3) return fail("RigidBody %s: bad rpy", b.id.c_str()); rpy_to_R(r[0], r[1], r[2], b.R); R_to_quat(b.R, b.q); b.rotated = (r[0] != 0 || r[1] != 0 || r[2] != 0); }
+      else if (a.has("rpy")) { const std::vector<double> r = numbers(a.str("rpy")); if (r.size() != 3) return fail("RigidBody %s: bad rpy", b.id.c_str()); rpy_to_quat(r[0], r[1], r[2], b.q); quat_to_R_static(b.q, b.R); b.rotated = (r[0] != 0 || r[1] != 0 || r[2] != 0); }
       else if (a.has("aangle")) {                                    // axis x y z, angle (RigidBody.cpp:213-219)
         const std::vector<double> r = numbers(a.str("aangle")); if (r.size() != 4) return fail("RigidBody %s: bad aangle", b.id.c_str());
         const double nrm = std::sqrt(r[0]*r[0] + r[1]*r[1] + r[2]*r[2]);

@@ -71,12 +71,30 @@ AUX_DTYPE = np.dtype([
 assert AUX_DTYPE.itemsize == ctypes.sizeof(mh_world_aux), (AUX_DTYPE.itemsize, ctypes.sizeof(mh_world_aux))
 
 
+def rpy_to_quat(roll, pitch, yaw):
+    """Quatd::rpy as Ravelin forms it (half-angle products, ZYX), x y z w.  The XML readers turn every ``rpy`` attribute
+    into a quaternion first (XMLTree.cpp / RigidBody.cpp:201-210, Primitive.cpp:273-279)."""
+    cr, sr = math.cos(roll * 0.5), math.sin(roll * 0.5)
+    cp, sp = math.cos(pitch * 0.5), math.sin(pitch * 0.5)
+    cy, sy = math.cos(yaw * 0.5), math.sin(yaw * 0.5)
+    return np.array([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy])
+
+
+def quat_to_R(q):
+    """Rotation matrix of a unit quaternion (x y z w) in the form Ravelin uses: diagonal 2 (w^2 + q_i^2) - 1.
+    PINNED by regress/sphere-stack.dat: the plane of sphere-stack.xml is posed with rpy = (1.5707963267949, 0, 0), 3.4e-15 rad
+    past a right angle, and the recording's sphere 1 picks up dv_y = -1.07824e-16 per step = -(3 m g dt) n_y; of the
+    algebraically equal forms only 2 w^2 - 1 = -3.66374e-15 gives that n_y (cos(r) = -3.49148e-15, 1 - 2 x^2 = -3.55271e-15,
+    w^2 - x^2 = -3.60822e-15) -- tests/test_oracle_world.py::test_sphere_stack_roundoff_fingerprint."""
+    x, y, z, w = q
+    return np.array([[2 * (w * w + x * x) - 1, 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 2 * (w * w + y * y) - 1, 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 2 * (w * w + z * z) - 1]])
+
+
 def rpy_to_R(roll, pitch, yaw):
-    """Rotation matrix of an XML ``rpy`` attribute: Rz(yaw) Ry(pitch) Rx(roll)."""
-    cr, sr, cp, sp, cy, sy = math.cos(roll), math.sin(roll), math.cos(pitch), math.sin(pitch), math.cos(yaw), math.sin(yaw)
-    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
-                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
-                     [-sp, cp * sr, cp * cr]])
+    """Rotation matrix of an XML ``rpy`` attribute (a static pose: the plane), through the quaternion as the reference does."""
+    return quat_to_R(rpy_to_quat(roll, pitch, yaw))
 
 
 def pair_index(i, j, ntot):

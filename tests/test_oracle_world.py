@@ -107,3 +107,30 @@ def test_perturbed_worlds_stay_stacked(oracle):
         assert aux["status"][0] & ~S.MH_WORLD_IMPACT_TOL == 0
         z = st.reshape(3, 13)[:, 2]
         np.testing.assert_allclose(z, [1, 3, 5], atol=1e-5)
+
+
+def test_sphere_stack_roundoff_fingerprint(oracle):
+    """The sub-1e-14 columns of regress/sphere-stack.dat are a fingerprint of the reference's arithmetic:
+    sphere 1 accumulates dv_y = -1.07824e-16 per step from step 1 on.  Mechanism: the plane is posed with
+    rpy = (1.5707963267949, 0, 0), 3.4e-15 rad past a right angle, so its normal has n_y = -3.66374e-15 and the ground
+    contact's impulse 3 m g dt leaks into y -- with THAT value of n_y only if the quaternion -> matrix conversion uses the
+    diagonal form 2 (w^2 + q_i^2) - 1 (moby_amd/scene.py::quat_to_R; cos(r), 1 - 2 x^2 and w^2 - x^2 give 3.49, 3.55, 3.61e-15).
+    The recording comes from the older revision that integrates positions with the updated velocity, so oracle row k + 1
+    is compared with recording row k (as for the pendulum, tests/test_oracle_pendulum.py).  The leak then propagates up the
+    stack through the impact LCPs: sphere 2 moves by 1e-24, sphere 3 by 1e-30 -- matched to a few per cent, i.e. the
+    restated contact / LCP / impulse chain carries the same numbers as the reference's."""
+    g = np.load(os.path.join(GOLD, "sphere_stack_dat.npz"))
+    rows = g["rows"]; assert list(g["row_index"][:30]) == list(range(30))
+    sc = S.sphere_stack_scene()
+    assert abs(sc.plane_R[4] - (-3.66374e-15)) < 1e-20                  # n_y of the plane, the form-dependent number
+    st = S.sphere_stack_state(1)[0].copy(); aux = S.new_aux(1)
+    tr = oracle.world_step(sc, st, aux, 1e-3, 31)["traj"]
+    y1 = tr[:, 0, 1]                                                      # oracle rows 1 .. 31
+    # per-step velocity leak: second difference of y over dt, rows 3 .. 29 of the shifted sequence
+    dv_o = np.diff(np.diff(y1[1:30])) / 1e-3; dv_g = np.diff(np.diff(rows[1:30, 2])) / 1e-3
+    assert abs(dv_g[0] / -1.07824e-16 - 1.0) < 1e-4                      # the recording: -1.07824e-16 per step at the start ...
+    assert abs(dv_o[2] / -1.07824e-16 - 1.0) < 5e-4, dv_o[:4]           # ... and the oracle, once its step-1 one-off (6.6e-22) is through
+    np.testing.assert_allclose(dv_o[2:], dv_g[2:], rtol=5e-3)            # both then creep up together (to -1.083e-16 by row 30)
+    np.testing.assert_allclose(y1[1:30], rows[1:30, 2], rtol=7e-3)       # y of sphere 1 (a one-off 6.6e-22 in step 1 fades out)
+    np.testing.assert_allclose(tr[2:30, 1, 1], rows[2:30, 9], rtol=2e-2)   # sphere 2: 1e-24 .. 1e-21
+    np.testing.assert_allclose(tr[3:30, 2, 1], rows[3:30, 16], rtol=5e-2)  # sphere 3: 1e-30 .. 1e-26
