@@ -15,10 +15,11 @@
  * pairs the many-worlds stepper does not cover (box-box, box-sphere: v-clip on a qhull polyhedron)
  * stays with the caller.  This is the path of BASELINE config 4 (box stacks: nc ~ 200-256, n ~ 2048).
  *
- * Scope of this build: free rigid bodies; contacts only (no joint limits, no bilateral rows); every
- * world's contacts must form ONE island after UnilateralConstraint::determine_connected_constraints
- * (src/UnilateralConstraint.cpp:940-1194) and use the Drumwright-Shell model (not all mu >= 100); other
- * worlds are left untouched and flagged MH_WORLD_UNSUPPORTED -- never approximated.
+ * Scope of this build: free rigid bodies; contacts only (no joint limits, no bilateral rows).  A world's contacts may
+ * form any number of islands (UnilateralConstraint::determine_connected_constraints, src/UnilateralConstraint.cpp:940-1194);
+ * they are processed one after the other as ImpactConstraintHandler.cpp:105-151 does, each with the Drumwright-Shell model
+ * or -- when every contact of the island has mu >= 100 -- the no-slip model (ImpactConstraintHandler.cpp:134-135, 236-295,
+ * 1009-1417; islands of up to MH_NOSLIP_MAX contacts, larger ones are flagged MH_WORLD_UNSUPPORTED -- never approximated).
  */
 #ifndef MOBY_HIP_IMPACT_H
 #define MOBY_HIP_IMPACT_H

@@ -841,6 +841,10 @@ int mh_big_batch_upload(mh_big_batch* bb, const double* state, const mh_world_au
     MH_HIP(hipMemcpy(bb->d.mini_steps, minis.data(), B * 8, hipMemcpyHostToDevice));
     MH_HIP(hipMemcpy(bb->d.stab_iters, stabs.data(), B * 8, hipMemcpyHostToDevice));
     MH_HIP(hipMemcpy(bb->core.cnt, cnt.data(), B * 32, hipMemcpyHostToDevice));
+    std::vector<int> vsz(B); std::vector<double> vns(B * MH_NOSLIP_MAX);
+    for (size_t b = 0; b < B; b++) { vsz[b] = aux[b].vns_size; std::memcpy(&vns[b * MH_NOSLIP_MAX], aux[b].vns, MH_NOSLIP_MAX * 8); }
+    MH_HIP(hipMemcpy(bb->core.vns_size, vsz.data(), B * 4, hipMemcpyHostToDevice));
+    MH_HIP(hipMemcpy(bb->core.vns, vns.data(), B * MH_NOSLIP_MAX * 8, hipMemcpyHostToDevice));
   }
   return MH_OK;
 }
@@ -864,12 +868,16 @@ int mh_big_batch_download(mh_big_batch* bb, double* state, mh_world_aux* aux)
     MH_HIP(hipMemcpy(zl.data(), bb->core.zlast_size, B * 4, hipMemcpyDeviceToHost));
     MH_HIP(hipMemcpy(zs.data(), bb->core.zbuf_size, B * 4, hipMemcpyDeviceToHost));
     MH_HIP(hipMemcpy(zc.data(), bb->core.zbuf_cap, B * 4, hipMemcpyDeviceToHost));
+    std::vector<int> vsz(B); std::vector<double> vns(B * MH_NOSLIP_MAX);
+    MH_HIP(hipMemcpy(vsz.data(), bb->core.vns_size, B * 4, hipMemcpyDeviceToHost));
+    MH_HIP(hipMemcpy(vns.data(), bb->core.vns, B * MH_NOSLIP_MAX * 8, hipMemcpyDeviceToHost));
     for (size_t b = 0; b < B; b++) {
       std::memset(&aux[b], 0, sizeof(mh_world_aux));
       std::memcpy(aux[b].rng, &rng[b * MH_RAND_WORDS], MH_RAND_WORDS * 4);
       aux[b].time = tm[b]; aux[b].status = st[b]; aux[b].steps = steps[b]; aux[b].mini_steps = minis[b]; aux[b].stab_iters = stabs[b];
       aux[b].lcp_solves = cnt[4*b]; aux[b].lcp_rows = cnt[4*b+1]; aux[b].lcp_pivots = cnt[4*b+2]; aux[b].lcp_alg_bytes = cnt[4*b+3];
       aux[b].zlast_size = zl[b]; aux[b].zbuf_size = zs[b]; aux[b].zbuf_cap = zc[b];      // the vectors themselves: save_solver_state
+      aux[b].vns_size = vsz[b]; std::memcpy(aux[b].vns, &vns[b * MH_NOSLIP_MAX], MH_NOSLIP_MAX * 8);   // _v of the no-slip model
     }
   }
   return MH_OK;

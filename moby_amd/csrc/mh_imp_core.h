@@ -22,11 +22,12 @@ struct mh_imp_core {
   int* status;                                      // B, MH_WORLD_* bits (sticky)
   // island tables and per-contact problem data, in island order
   int* order; int* cbody; double* cpar; double* W; double* XJ; double* Cv; double* xinv;
-  int* nisl; int* isl_start; int* isl_len; int* maxisl;      // maxisl: one int, max over worlds of nisl
+  int* nisl; int* isl_start; int* isl_len; int* isl_model; int* maxisl;   // isl_model: 0 Drumwright-Shell, 1 no-slip (ICH:123-135); maxisl: max over worlds of nisl
   // the LCP of the current round
   double* G; double* MM; double* qq; double* z; int* zsz; int* ncur;
   // what the handler object keeps between solves: _zlast and the storage of _z (ICH-QP:158-162, 233)
   double* zlast; double* zbuf; int* zlast_size; int* zbuf_size; int* zbuf_cap;
+  double* vns; int* vns_size;                       // ImpactConstraintHandler::_v, the no-slip LCP's z (ICH:1239): B x MH_NOSLIP_MAX, B
   int* run; int* need2; int* again; int* lst1; int* lst2; unsigned* piv1; unsigned* piv2;
   double* imp;                                      // B x ncmax x 3 accumulated (cn, cs, ct), caller order
   unsigned long long* cnt;                          // B x 4: LCPs solved, rows, pivots, LCP-entry bytes 8 (n^2 + 2n)

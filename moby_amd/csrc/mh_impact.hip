@@ -29,6 +29,7 @@
 #include "mh_host.h"
 #include "mh_imp_core.h"
 #include "mh_imp_dev.h"
+#include "mh_lcp_wave.h"
 
 namespace mh { namespace imp {
 
@@ -111,11 +112,12 @@ void k_prep(Dev d, int mode)
         bool keep = true;
         if (mode == MH_CORE_IMPACT) {
           if (!active) keep = false;                                               // remove_inactive_groups (UC:1197-1225)
-          else if (all_inf) { keep = false; d.status[b] |= MH_WORLD_UNSUPPORTED; } // the no-slip model (ICH:134-135): not built here
         }
         if (keep && nisl >= d.islmax) { keep = false; d.status[b] |= MH_WORLD_UNSUPPORTED; }
         if (!keep) { cnt = begin; continue; }
-        d.isl_start[(size_t)b * d.islmax + nisl] = begin; d.isl_len[(size_t)b * d.islmax + nisl] = cnt - begin; nisl++;
+        d.isl_start[(size_t)b * d.islmax + nisl] = begin; d.isl_len[(size_t)b * d.islmax + nisl] = cnt - begin;
+        d.isl_model[(size_t)b * d.islmax + nisl] = (mode == MH_CORE_IMPACT && all_inf) ? 1 : 0;   // every mu >= 100: the no-slip model (ICH:134-135)
+        nisl++;
       }
     }
     s_flag[2] = cnt; s_flag[3] = nisl;
@@ -250,6 +252,10 @@ void k_mm(Dev d, int r, int mode, int phase)
     return;
   }
   if (phase == 1 && !d.again[b]) return;
+  if (d.isl_model[(size_t)b * d.islmax + r] == 1) {   // the no-slip model builds its own (nc x nc) LCP: k_noslip
+    if (last && t == 0 && phase == 0) { d.run[b] = 0; d.ncur[b] = 0; d.again[b] = 0; }
+    return;
+  }
   const int nvars = 5 * nc;
   const int n = (mode == MH_CORE_STAB) ? nc : nvars + nc + nc * d.kh;
   if (n > d.nmax) {                                   // beyond the capacity the batch was created with
@@ -462,6 +468,198 @@ void k_stab_apply(Dev d, int r)
   }
 }
 
+// ImpactConstraintHandler::apply_no_slip_model[_to_connected_constraints] (ICH:236-295, 1009-1417), contacts only, for the
+// islands k_prep marked (every mu >= 100).  One wavefront per world: the dense algebra is tiny (at most 2 x MH_NOSLIP_MAX
+// tangent rows) and sequential by construction (greedy Cholesky tests of a growing matrix), lane 0 does it serially over
+// LDS in the operation order of oracle/world.hpp::apply_no_slip_model; the (nc x nc) LCP runs wave-wide on the persistent
+// _v (lcp_fast, then the Lemke ladder: ICH:1239, 1281), impulses / constraint velocities / restitution lane-parallel.
+constexpr int NSC = MH_NOSLIP_MAX, NSM = 2 * MH_NOSLIP_MAX;
+MH_DEV bool ns_chol_factor(int n, double* A) {                      // oracle/linalg.hpp chol_factor (dpotf2 'L')
+  for (int j = 0; j < n; j++) {
+    double ajj = A[j + n*j];
+    for (int k = 0; k < j; k++) ajj = ajj - A[j + n*k] * A[j + n*k];
+    if (!(ajj > 0.0)) return false;
+    ajj = sqrt(ajj);
+    A[j + n*j] = ajj;
+    for (int i = j+1; i < n; i++) {
+      double t = A[i + n*j];
+      for (int k = 0; k < j; k++) t = t - A[i + n*k] * A[j + n*k];
+      A[i + n*j] = t / ajj;
+    }
+  }
+  return true;
+}
+MH_DEV void ns_chol_solve(int n, const double* L, double* b) {      // oracle/linalg.hpp chol_solve
+  for (int k = 0; k < n; k++) {
+    b[k] = b[k] / L[k + n*k];
+    const double bk = b[k];
+    for (int i = k+1; i < n; i++) b[i] = b[i] - bk * L[i + n*k];
+  }
+  for (int k = n-1; k >= 0; k--) {
+    double t = b[k];
+    for (int i = k+1; i < n; i++) t = t - L[i + n*k] * b[i];
+    b[k] = t / L[k + n*k];
+  }
+}
+
+__global__ __launch_bounds__(64)
+void k_noslip(Dev d, int r, mh::Pow10Table p10)
+{
+  const int b = blockIdx.x, lane = mh::lane_id();
+  int start, nc;
+  if (!island(d, b, r, start, nc)) return;
+  if (d.isl_model[(size_t)b * d.islmax + r] != 1) return;
+  if (nc > NSC) { if (lane == 0) d.status[b] |= MH_WORLD_UNSUPPORTED; return; }    // _v's warm start is kept for up to MH_NOSLIP_MAX contacts
+  __shared__ double Y[NSM * NSM], QX[NSC * NSM], Wm[NSM * NSC], MM[NSC * NSC], Alu[NSC * NSC], art[NSC], YXv[NSM], t2[NSM], col[NSM], qq[NSC];
+  __shared__ double s_c[3][NSC], s_cv[3][NSC];
+  __shared__ int S[NSC], Tt[NSC], s_b[2][NSC], s_m[2];
+  const int nb = d.nb, ncm = d.ncmax;
+  double* st = d.state + (size_t)b * nb * 13;
+  const double* G = d.G + (size_t)b * 6 * ncm * ncm;                 // blocks nn ns nt ss st tt, nc x nc row-major each
+  const double* cpar = d.cpar + ((size_t)b * ncm + start) * 4;
+  auto g = [&](int blk, int i, int j) { return G[((size_t)blk * nc + i) * nc + j]; };
+  if (lane < nc) {
+    const size_t ck = (size_t)b * ncm + start + lane;
+    s_b[0][lane] = d.cbody[2 * ck]; s_b[1][lane] = d.cbody[2 * ck + 1];
+    for (int a = 0; a < 3; a++) s_cv[a][lane] = d.Cv[((size_t)b * 3 + a) * ncm + start + lane];
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int ns = 0, nt = 0;
+    auto build_Y = [&](bool skew) -> int {                            // ICH:1098-1111
+      const int m = ns + nt;
+      for (int a = 0; a < ns; a++) for (int c = 0; c < ns; c++) Y[a + m*c] = g(3, S[a], S[c]);
+      for (int a = 0; a < nt; a++) for (int c = 0; c < nt; c++) Y[(ns + a) + m*(ns + c)] = g(5, Tt[a], Tt[c]);
+      for (int a = 0; a < ns; a++) for (int c = 0; c < nt; c++) { const double v = g(4, S[a], Tt[c]); Y[a + m*(ns + c)] = v; Y[(ns + c) + m*a] = v; }
+      if (skew) for (int j = 0; j < m; j++) Y[j + m*j] = Y[j + m*j] - NEAR_ZERO_;
+      return m;
+    };
+    for (int i = 0; i < nc; i++) {                                    // greedy largest non-singular tangent set (ICH:1087-1145)
+      S[ns] = i; ns++;
+      int m = build_Y(true);
+      if (!ns_chol_factor(m, Y)) ns--;
+      Tt[nt] = i; nt++;
+      m = build_Y(true);
+      if (!ns_chol_factor(m, Y)) nt--;
+    }
+    const int m = build_Y(false);                                     // ICH:1166-1183
+    const bool ok = ns_chol_factor(m, Y);
+    if (ok) {
+      for (int i = 0; i < nc; i++) {                                  // Q X X' (ICH:1198-1203)
+        for (int a = 0; a < ns; a++) QX[i*m + a] = g(1, i, S[a]);
+        for (int a = 0; a < nt; a++) QX[i*m + ns + a] = g(2, i, Tt[a]);
+      }
+      for (int j = 0; j < nc; j++) {                                  // W = Y^-1 (Q X X')' (ICH:1210-1211)
+        for (int a = 0; a < m; a++) col[a] = QX[j*m + a];
+        ns_chol_solve(m, Y, col);
+        for (int a = 0; a < m; a++) Wm[a + m*j] = col[a];
+      }
+      for (int i = 0; i < nc; i++) for (int j = 0; j < nc; j++) {     // MM = Cn X Cn' - QX W (ICH:1190-1215), column-major
+        double acc = 0.0;
+        for (int a = 0; a < m; a++) acc = acc + QX[i*m + a] * Wm[a + m*j];
+        MM[i + nc*j] = g(0, i, j) - acc;
+      }
+      for (int a = 0; a < ns; a++) YXv[a] = s_cv[1][S[a]];            // Y^-1 [Cs v(S); Ct v(T)] (ICH:1222-1232)
+      for (int a = 0; a < nt; a++) YXv[ns + a] = s_cv[2][Tt[a]];
+      ns_chol_solve(m, Y, YXv);
+      for (int i = 0; i < nc; i++) {                                  // qq = Cn v - QX YXv (ICH:1217-1236)
+        double acc = 0.0;
+        for (int a = 0; a < m; a++) acc = acc + QX[i*m + a] * YXv[a];
+        qq[i] = s_cv[0][i] - acc;
+      }
+    }
+    s_m[0] = ok ? m : -1; s_m[1] = ns;
+  }
+  __syncthreads();
+  const int m = s_m[0], ns = s_m[1], nt = m - ns;
+  if (m < 0) { if (lane == 0) d.status[b] |= MH_WORLD_LCP_FAILED; return; }       // assert(success), ICH:1184-1186
+  // lcp_fast(_MM, _qq, _v), then the Lemke ladder
+  const bool valid = lane < nc;
+  double nrm0 = 0.0;
+  for (int e = lane; e < nc * nc; e += 64) { const double a = fabs(MM[e]); nrm0 = (a > nrm0) ? a : nrm0; }
+  nrm0 = mh::wave_max(nrm0);
+  const double dii = valid ? MM[lane + nc * lane] : 0.0;
+  const double qi = valid ? qq[lane] : 0.0;
+  int zsize = mh::uni(d.vns_size[b]);
+  double zi = (valid && zsize == nc) ? d.vns[(size_t)b * NSC + lane] : 0.0;
+  if (lane == 0) mh::g_lcp_prof_on = 0;
+  __syncthreads();
+  mh::WaveRand rng; rng.load(d.rng + (size_t)b * MH_RAND_WORDS);
+  mh::DenseLds Md; Md.M = MM; Md.n = nc;
+  mh::LuScratch Sc; Sc.small = Alu; Sc.ka = nc; Sc.big = Alu;
+  mh::Trace tr; tr.buf = nullptr; tr.cap = 0; tr.len = 0;
+  mh::LcpParams P; P.kind = MH_LCP_FAST; P.min_exp = -20; P.step_exp = 1u; P.max_exp = 1; P.piv_tol = -1.0; P.zero_tol = -1.0;
+  unsigned piv = 0, total = 0;
+  bool ok = mh::lcp_solve_wave(P, p10, nc, Md, Sc, art, nrm0, dii, qi, zi, zsize, rng, piv, tr);
+  total += piv;
+  if (!ok) { P.kind = MH_LCP_LEMKE_REG; ok = mh::lcp_solve_wave(P, p10, nc, Md, Sc, art, nrm0, dii, qi, zi, zsize, rng, piv, tr); total += piv; }
+  rng.store(d.rng + (size_t)b * MH_RAND_WORDS);
+  if (lane == 0) {
+    unsigned long long* c = d.cnt + (size_t)b * 4;
+    c[0] += 1ull; c[1] += (unsigned long long)nc; c[2] += (unsigned long long)total; c[3] += 8ull * ((unsigned long long)nc * nc + 2ull * nc);
+    if (!ok) d.status[b] |= MH_WORLD_LCP_FAILED;          // std::runtime_error("Unable to solve constraint LCP!")
+  }
+  if (!ok) return;
+  if (valid) { d.vns[(size_t)b * NSC + lane] = zi; s_c[0][lane] = zi; s_c[1][lane] = 0.0; s_c[2][lane] = 0.0; }
+  if (lane == 0) d.vns_size[b] = nc;
+  __syncthreads();
+  if (lane == 0) {                                                   // [cs; ct] = -(Y^-1 X v + Y^-1 (QX)' cn) (ICH:1293-1308)
+    for (int a = 0; a < m; a++) { double acc = 0.0; for (int i = 0; i < nc; i++) acc = acc + QX[i*m + a] * s_c[0][i]; t2[a] = acc; }
+    ns_chol_solve(m, Y, t2);
+    for (int a = 0; a < ns; a++) s_c[1][S[a]] = -(YXv[a] + t2[a]);
+    for (int a = 0; a < nt; a++) s_c[2][Tt[a]] = -(YXv[ns + a] + t2[ns + a]);
+  }
+  __syncthreads();
+  MMv mg; mg.G = G; mg.nc = nc;
+  // update_from_stacked (ICH:298-410) + update_constraint_velocities_from_impulses (ICH:427-464) for the impulses in s_c
+  auto apply = [&]() {
+    if (valid) { double* im = d.imp + ((size_t)b * ncm + d.order[(size_t)b * ncm + start + lane]) * 3; im[0] += s_c[0][lane]; im[1] += s_c[1][lane]; im[2] += s_c[2][lane]; }
+    for (int e = lane; e < nb * 6; e += 64) {
+      const int bb = e / 6, q = e - bb * 6;
+      double dv = 0.0;
+      bool touched = false;
+      for (int dd = 0; dd < 3; dd++) {
+        double tmp = 0.0;
+        for (int j = 0; j < nc; j++) {
+          const int sd = (s_b[0][j] == bb) ? 0 : ((s_b[1][j] == bb) ? 1 : -1);
+          if (sd < 0) continue;
+          touched = true;
+          tmp = tmp + s_c[dd][j] * d.XJ[((size_t)b * ncm + start + j) * 36 + dd * 12 + sd * 6 + q];
+        }
+        dv = (dd == 0) ? tmp : dv + tmp;
+      }
+      if (touched) st[13 * bb + 7 + q] = st[13 * bb + 7 + q] + dv;
+    }
+    double y3[3] = { 0.0, 0.0, 0.0 };
+    if (valid) for (int a = 0; a < 3; a++) {
+      double y = s_cv[a][lane];
+      for (int bb = 0; bb < 3; bb++) { double acc = 0.0; for (int j = 0; j < nc; j++) acc = acc + s_c[bb][j] * mg.gab(a, bb, lane, j); y = y + acc; }
+      y3[a] = y;
+    }
+    __syncthreads();
+    if (valid) for (int a = 0; a < 3; a++) s_cv[a][lane] = y3[a];
+    __syncthreads();
+  };
+  auto min_cn_v = [&]() -> double { double mn = s_cv[0][0]; for (int i = 1; i < nc; i++) mn = (s_cv[0][i] < mn) ? s_cv[0][i] : mn; return mn; };
+  apply();                                                            // ICH:1351-1385, :265
+  const double minv = min_cn_v();
+  // apply_restitution(q) (ICH:497-525)
+  double cn = 0.0; bool ch = false;
+  if (valid) { cn = s_c[0][lane] * cpar[4 * lane + 2]; ch = cn > NEAR_ZERO_; }
+  const bool changed = mh::ballot(ch) != 0ull;
+  __syncthreads();
+  if (valid) s_c[0][lane] = cn;
+  if (changed) {
+    if (valid) { s_c[1][lane] = 0.0; s_c[2][lane] = 0.0; }
+    __syncthreads();
+    apply();                                                          // update_from_stacked(q) (ICH:274)
+    const double minv_plus = min_cn_v();
+    // ICH:284-291 would re-solve and then read the Drumwright-Shell solver's _z, which this path never sized
+    if (minv_plus < 0.0 && minv_plus < minv - NEAR_ZERO_ && lane == 0) d.status[b] |= MH_WORLD_UNSUPPORTED;
+  }
+  if (valid) for (int a = 0; a < 3; a++) d.Cv[((size_t)b * 3 + a) * ncm + start + lane] = s_cv[a][lane];
+}
+
 // ImpactToleranceException test (ICH:157-167) over the contacts of the processed islands: any still approaching
 // faster than NEAR_ZERO
 __global__ __launch_bounds__(T)
@@ -523,6 +721,8 @@ int mh_imp_core_create(mh_imp_core* c, int B, int nb, int ncmax, int nk, int nma
   c->W = (double*)A(sB * snc * 36 * 8, true); c->XJ = (double*)A(sB * snc * 36 * 8, true);
   c->Cv = (double*)A(sB * 3 * snc * 8, true); c->xinv = (double*)A(sB * nb * 80, true);
   c->nisl = (int*)A(sB * 4, true); c->isl_start = (int*)A(sB * c->islmax * 4, true); c->isl_len = (int*)A(sB * c->islmax * 4, true);
+  c->isl_model = (int*)A(sB * c->islmax * 4, true);
+  c->vns = (double*)A(sB * MH_NOSLIP_MAX * 8, true); c->vns_size = (int*)A(sB * 4, true);
   c->maxisl = (int*)A(4, true);
   c->G = (double*)A(sB * 6 * snc * snc * 8, true);
   c->MM = (double*)A(sB * sn * sn * 8, false); c->qq = (double*)A(sB * sn * 8, true);
@@ -607,6 +807,8 @@ int mh_imp_core_process(mh_imp_core* c, void* stream, int mode)
     rc = core_solve_round(c, s, c->again, mode);
     if (rc != MH_OK) return rc;
     hipLaunchKernelGGL(im::k_post, dim3(B), dim3(im::T), 0, s, *c, r, 1);
+    static const mh::Pow10Table p10 = [] { mh::Pow10Table t; for (int i = 0; i < 64; i++) t.v[i] = std::pow(10.0, (double)(i - 32)); return t; }();   // LCP.cpp:285
+    hipLaunchKernelGGL(im::k_noslip, dim3(B), dim3(64), 0, s, *c, r, p10);      // the islands of this round that take the no-slip model
     MH_HIP(hipGetLastError());
   }
   if (mode == MH_CORE_IMPACT) { hipLaunchKernelGGL(im::k_finish, dim3(B), dim3(im::T), 0, s, *c); MH_HIP(hipGetLastError()); }
