@@ -349,7 +349,7 @@ def main():
     tot = mdist.counter_vector(aux0, aux1, (aux1["status"] & ~S.MH_WORLD_IMPACT_TOL) != 0)
     # the per-interval reduction of SURVEY 8e: one MAX + one SUM all-reduce (RCCL over xGMI)
     elapsed, tot = mdist.reduce_interval(elapsed, tot, dist if world_size > 1 else None, dev)
-    rows, solves, pivots, minis, stabs, alg_bytes_all, bad = [float(x) for x in tot]
+    rows, solves, pivots, minis, stabs, alg_bytes_all, stab_rows, bad = [float(x) for x in tot]
 
     world_steps = B * world_size * args.steps
     value = rows / elapsed
@@ -375,7 +375,8 @@ def main():
                    "worlds_per_gpu": B, "dt": DT, "parallelism": "worlds sharded x%d, no data-path collective" % world_size},
         "world_steps_per_sec": world_steps / elapsed,
         "batch_steps_per_sec": args.steps / elapsed,
-        "lcp_solves": solves, "lcp_rows": rows, "lcp_pivots": pivots, "mini_steps": minis, "stab_iters": stabs,
+        "lcp_solves": solves, "lcp_rows": rows, "lcp_rows_impact": rows - stab_rows, "lcp_rows_stabilisation": stab_rows,
+        "lcp_pivots": pivots, "mini_steps": minis, "stab_iters": stabs,
         "worlds_with_errors": bad,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(B, args.steps),

@@ -204,6 +204,7 @@ typedef struct mh_world_aux {
   unsigned long long lcp_pivots;
   unsigned long long stab_iters;
   unsigned long long lcp_alg_bytes;/* sum of 8 (n^2 + 2n): bytes the same solves move through the LCP entry */
+  unsigned long long stab_rows;    /* the part of lcp_rows that ConstraintStabilization::determine_dq solved (impact rows = lcp_rows - stab_rows) */
 } mh_world_aux;
 
 /* test hooks: key 1 = edge of the LDS-resident LU block of the world kernel (0..64, clamped to what the

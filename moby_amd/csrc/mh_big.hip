@@ -828,11 +828,11 @@ int mh_big_batch_upload(mh_big_batch* bb, const double* state, const mh_world_au
   if (state) MH_HIP(hipMemcpy(bb->d.state, state, B * bb->nb * 13 * 8, hipMemcpyHostToDevice));
   if (aux) {
     std::vector<uint32_t> rng(B * MH_RAND_WORDS); std::vector<double> tm(B); std::vector<int> st(B), zs(3 * B);
-    std::vector<unsigned long long> steps(B), minis(B), stabs(B), cnt(4 * B);
+    std::vector<unsigned long long> steps(B), minis(B), stabs(B), cnt(5 * B);
     for (size_t b = 0; b < B; b++) {
       std::memcpy(&rng[b * MH_RAND_WORDS], aux[b].rng, MH_RAND_WORDS * 4);
       tm[b] = aux[b].time; st[b] = aux[b].status; steps[b] = aux[b].steps; minis[b] = aux[b].mini_steps; stabs[b] = aux[b].stab_iters;
-      cnt[4*b] = aux[b].lcp_solves; cnt[4*b+1] = aux[b].lcp_rows; cnt[4*b+2] = aux[b].lcp_pivots; cnt[4*b+3] = aux[b].lcp_alg_bytes;
+      cnt[5*b] = aux[b].lcp_solves; cnt[5*b+1] = aux[b].lcp_rows; cnt[5*b+2] = aux[b].lcp_pivots; cnt[5*b+3] = aux[b].lcp_alg_bytes; cnt[5*b+4] = aux[b].stab_rows;
     }
     MH_HIP(hipMemcpy(bb->d_rng, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
     MH_HIP(hipMemcpy(bb->d.time, tm.data(), B * 8, hipMemcpyHostToDevice));
@@ -840,7 +840,7 @@ int mh_big_batch_upload(mh_big_batch* bb, const double* state, const mh_world_au
     MH_HIP(hipMemcpy(bb->d.steps, steps.data(), B * 8, hipMemcpyHostToDevice));
     MH_HIP(hipMemcpy(bb->d.mini_steps, minis.data(), B * 8, hipMemcpyHostToDevice));
     MH_HIP(hipMemcpy(bb->d.stab_iters, stabs.data(), B * 8, hipMemcpyHostToDevice));
-    MH_HIP(hipMemcpy(bb->core.cnt, cnt.data(), B * 32, hipMemcpyHostToDevice));
+    MH_HIP(hipMemcpy(bb->core.cnt, cnt.data(), B * 40, hipMemcpyHostToDevice));
     std::vector<int> vsz(B); std::vector<double> vns(B * MH_NOSLIP_MAX);
     for (size_t b = 0; b < B; b++) { vsz[b] = aux[b].vns_size; std::memcpy(&vns[b * MH_NOSLIP_MAX], aux[b].vns, MH_NOSLIP_MAX * 8); }
     MH_HIP(hipMemcpy(bb->core.vns_size, vsz.data(), B * 4, hipMemcpyHostToDevice));
@@ -857,14 +857,14 @@ int mh_big_batch_download(mh_big_batch* bb, double* state, mh_world_aux* aux)
   if (state) MH_HIP(hipMemcpy(state, bb->d.state, B * bb->nb * 13 * 8, hipMemcpyDeviceToHost));
   if (aux) {
     std::vector<uint32_t> rng(B * MH_RAND_WORDS); std::vector<double> tm(B); std::vector<int> st(B), zl(B), zs(B), zc(B);
-    std::vector<unsigned long long> steps(B), minis(B), stabs(B), cnt(4 * B);
+    std::vector<unsigned long long> steps(B), minis(B), stabs(B), cnt(5 * B);
     MH_HIP(hipMemcpy(rng.data(), bb->d_rng, rng.size() * 4, hipMemcpyDeviceToHost));
     MH_HIP(hipMemcpy(tm.data(), bb->d.time, B * 8, hipMemcpyDeviceToHost));
     MH_HIP(hipMemcpy(st.data(), bb->d.status, B * 4, hipMemcpyDeviceToHost));
     MH_HIP(hipMemcpy(steps.data(), bb->d.steps, B * 8, hipMemcpyDeviceToHost));
     MH_HIP(hipMemcpy(minis.data(), bb->d.mini_steps, B * 8, hipMemcpyDeviceToHost));
     MH_HIP(hipMemcpy(stabs.data(), bb->d.stab_iters, B * 8, hipMemcpyDeviceToHost));
-    MH_HIP(hipMemcpy(cnt.data(), bb->core.cnt, B * 32, hipMemcpyDeviceToHost));
+    MH_HIP(hipMemcpy(cnt.data(), bb->core.cnt, B * 40, hipMemcpyDeviceToHost));
     MH_HIP(hipMemcpy(zl.data(), bb->core.zlast_size, B * 4, hipMemcpyDeviceToHost));
     MH_HIP(hipMemcpy(zs.data(), bb->core.zbuf_size, B * 4, hipMemcpyDeviceToHost));
     MH_HIP(hipMemcpy(zc.data(), bb->core.zbuf_cap, B * 4, hipMemcpyDeviceToHost));
@@ -875,7 +875,7 @@ int mh_big_batch_download(mh_big_batch* bb, double* state, mh_world_aux* aux)
       std::memset(&aux[b], 0, sizeof(mh_world_aux));
       std::memcpy(aux[b].rng, &rng[b * MH_RAND_WORDS], MH_RAND_WORDS * 4);
       aux[b].time = tm[b]; aux[b].status = st[b]; aux[b].steps = steps[b]; aux[b].mini_steps = minis[b]; aux[b].stab_iters = stabs[b];
-      aux[b].lcp_solves = cnt[4*b]; aux[b].lcp_rows = cnt[4*b+1]; aux[b].lcp_pivots = cnt[4*b+2]; aux[b].lcp_alg_bytes = cnt[4*b+3];
+      aux[b].lcp_solves = cnt[5*b]; aux[b].lcp_rows = cnt[5*b+1]; aux[b].lcp_pivots = cnt[5*b+2]; aux[b].lcp_alg_bytes = cnt[5*b+3]; aux[b].stab_rows = cnt[5*b+4];
       aux[b].zlast_size = zl[b]; aux[b].zbuf_size = zs[b]; aux[b].zbuf_cap = zc[b];      // the vectors themselves: save_solver_state
       aux[b].vns_size = vsz[b]; std::memcpy(aux[b].vns, &vns[b * MH_NOSLIP_MAX], MH_NOSLIP_MAX * 8);   // _v of the no-slip model
     }

@@ -30,7 +30,7 @@ struct mh_imp_core {
   double* vns; int* vns_size;                       // ImpactConstraintHandler::_v, the no-slip LCP's z (ICH:1239): B x MH_NOSLIP_MAX, B
   int* run; int* need2; int* again; int* lst1; int* lst2; unsigned* piv1; unsigned* piv2;
   double* imp;                                      // B x ncmax x 3 accumulated (cn, cs, ct), caller order
-  unsigned long long* cnt;                          // B x 4: LCPs solved, rows, pivots, LCP-entry bytes 8 (n^2 + 2n)
+  unsigned long long* cnt;                          // B x 5: LCPs solved, rows, pivots, LCP-entry bytes 8 (n^2 + 2n), stabilisation rows
   const double* fcos; const double* fsin;           // kh each (host libm)
   double* ws_d; int* ws_i;                          // block-solver workspace (nmax > 64)
   int* hmax;                                        // pinned host copy of maxisl

@@ -318,7 +318,7 @@ void k_lemke_prep(Dev d, const int* __restrict__ run_if, int mode)
 }
 
 MH_DEV void account(const Dev& d, int b, int n) {      // World::lcp_account
-  unsigned long long* c = d.cnt + (size_t)b * 4;
+  unsigned long long* c = d.cnt + (size_t)b * 5;
   c[0] += 1ull; c[1] += (unsigned long long)n; c[2] += (unsigned long long)(d.piv1[b] + (d.lst1[b] == 0 ? d.piv2[b] : 0u));
   c[3] += 8ull * ((unsigned long long)n * n + 2ull * n);
 }
@@ -445,7 +445,7 @@ void k_stab_apply(Dev d, int r)
   __shared__ int s_b[2][MAXC];
   double* st = d.state + (size_t)b * nb * 13;
   const double* z = d.z + (size_t)b * d.nmax;
-  if (t == 0) account(d, b, nc);
+  if (t == 0) { account(d, b, nc); d.cnt[(size_t)b * 5 + 4] += (unsigned long long)nc; }
   // cn = z, whatever z holds (even after a failed solve)
   for (int i = t; i < nc; i += T) {
     const size_t ck = (size_t)b * ncm + start + i;
@@ -595,7 +595,7 @@ void k_noslip(Dev d, int r, mh::Pow10Table p10)
   if (!ok) { P.kind = MH_LCP_LEMKE_REG; ok = mh::lcp_solve_wave(P, p10, nc, Md, Sc, art, nrm0, dii, qi, zi, zsize, rng, piv, tr); total += piv; }
   rng.store(d.rng + (size_t)b * MH_RAND_WORDS);
   if (lane == 0) {
-    unsigned long long* c = d.cnt + (size_t)b * 4;
+    unsigned long long* c = d.cnt + (size_t)b * 5;
     c[0] += 1ull; c[1] += (unsigned long long)nc; c[2] += (unsigned long long)total; c[3] += 8ull * ((unsigned long long)nc * nc + 2ull * nc);
     if (!ok) d.status[b] |= MH_WORLD_LCP_FAILED;          // std::runtime_error("Unable to solve constraint LCP!")
   }
@@ -733,7 +733,7 @@ int mh_imp_core_create(mh_imp_core* c, int B, int nb, int ncmax, int nk, int nma
   c->lst1 = (int*)A(sB * 4, true); c->lst2 = (int*)A(sB * 4, true);
   c->piv1 = (unsigned*)A(sB * 4, true); c->piv2 = (unsigned*)A(sB * 4, true);
   c->imp = (double*)A(sB * snc * 3 * 8, true);
-  c->cnt = (unsigned long long*)A(sB * 4 * 8, true);
+  c->cnt = (unsigned long long*)A(sB * 5 * 8, true);
   double* dcos = (double*)A(c->kh * 8, false); double* dsin = (double*)A(c->kh * 8, false);
   if (nmax > MH_LCP_MAX_N_WAVE) {
     c->ws_d = (double*)A(sB * (sn * sn + 5 * sn) * 8, false);
@@ -903,7 +903,7 @@ int mh_impact_batch_upload(mh_impact_batch* ib, const double* state, const mh_co
 int mh_impact_batch_process(mh_impact_batch* ib, void* stream)
 {
   if (!ib) return fail(MH_ERR_INVALID_ARG, "null batch");
-  MH_HIP(hipMemsetAsync(ib->c.cnt, 0, (size_t)ib->B * 4 * 8, (hipStream_t)stream));     // pivots / solves are per call
+  MH_HIP(hipMemsetAsync(ib->c.cnt, 0, (size_t)ib->B * 5 * 8, (hipStream_t)stream));     // pivots / solves are per call
   return mh_imp_core_process(&ib->c, stream, MH_CORE_IMPACT);
 }
 
@@ -916,9 +916,9 @@ int mh_impact_batch_download(mh_impact_batch* ib, double* state, double* impulse
   if (impulses) MH_HIP(hipMemcpy(impulses, ib->c.imp, B * ib->nc * 3 * 8, hipMemcpyDeviceToHost));
   if (status) MH_HIP(hipMemcpy(status, ib->d_status, B * 4, hipMemcpyDeviceToHost));
   if (pivots || solves) {
-    std::vector<unsigned long long> cnt(B * 4);
-    MH_HIP(hipMemcpy(cnt.data(), ib->c.cnt, B * 4 * 8, hipMemcpyDeviceToHost));
-    for (size_t b = 0; b < B; b++) { if (solves) solves[b] = (int)cnt[4 * b]; if (pivots) pivots[b] = (unsigned)cnt[4 * b + 2]; }
+    std::vector<unsigned long long> cnt(B * 5);
+    MH_HIP(hipMemcpy(cnt.data(), ib->c.cnt, B * 5 * 8, hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < B; b++) { if (solves) solves[b] = (int)cnt[5 * b]; if (pivots) pivots[b] = (unsigned)cnt[5 * b + 2]; }
   }
   return MH_OK;
 }

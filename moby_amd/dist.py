@@ -3,7 +3,7 @@ an N-rank job owns the contiguous world range [r*B, (r+1)*B) (weak scaling) and 
 communication is one small all-reduce of counters per reporting interval."""
 import numpy as np
 
-COUNTER_FIELDS = ("lcp_rows", "lcp_solves", "lcp_pivots", "mini_steps", "stab_iters", "lcp_alg_bytes")
+COUNTER_FIELDS = ("lcp_rows", "lcp_solves", "lcp_pivots", "mini_steps", "stab_iters", "lcp_alg_bytes", "stab_rows")
 
 
 def shard_range(rank, worlds_per_rank):

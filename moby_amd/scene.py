@@ -56,7 +56,7 @@ class mh_world_aux(ctypes.Structure):
         ("vns", ctypes.c_double * MH_NOSLIP_MAX), ("vns_size", ctypes.c_int), ("pad0", ctypes.c_int),
         ("steps", ctypes.c_ulonglong), ("mini_steps", ctypes.c_ulonglong), ("lcp_solves", ctypes.c_ulonglong),
         ("lcp_rows", ctypes.c_ulonglong), ("lcp_pivots", ctypes.c_ulonglong), ("stab_iters", ctypes.c_ulonglong),
-        ("lcp_alg_bytes", ctypes.c_ulonglong),
+        ("lcp_alg_bytes", ctypes.c_ulonglong), ("stab_rows", ctypes.c_ulonglong),
     ]
 
 
@@ -67,7 +67,7 @@ AUX_DTYPE = np.dtype([
     ("vns", np.float64, MH_NOSLIP_MAX), ("vns_size", np.int32), ("pad0", np.int32),
     ("steps", np.uint64), ("mini_steps", np.uint64), ("lcp_solves", np.uint64),
     ("lcp_rows", np.uint64), ("lcp_pivots", np.uint64), ("stab_iters", np.uint64),
-    ("lcp_alg_bytes", np.uint64)], align=True)
+    ("lcp_alg_bytes", np.uint64), ("stab_rows", np.uint64)], align=True)
 assert AUX_DTYPE.itemsize == ctypes.sizeof(mh_world_aux), (AUX_DTYPE.itemsize, ctypes.sizeof(mh_world_aux))
 
 

@@ -1189,7 +1189,7 @@ class World {
         if (!ok) { ok = lcp.lcp_lemke_regularized(nc, MM.data(), nc, pd.Cv[0].data(), z); piv += lcp.pivots; }
         trace_len += tr.len;
         std::memcpy(aux->rng, &rs, sizeof(rs));
-        lcp_account(nc, piv);
+        lcp_account(nc, piv); aux->stab_rows += (unsigned long long)nc;
         // update_from_stacked(pd, z): cn = z (whatever z holds, even after a failed solve)
         for (int i = 0; i < nc; i++) pd.cn[i] = (i < (int)z.size()) ? z[i] : 0.0;
         pd.XJ[1].clear(); pd.XJ[2].clear();

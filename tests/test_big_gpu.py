@@ -11,7 +11,7 @@ from tests.test_oracle_big import big_from_small
 
 pytestmark = pytest.mark.gpu
 
-FIELDS = ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "stab_iters", "lcp_alg_bytes",
+FIELDS = ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "stab_iters", "lcp_alg_bytes", "stab_rows",
           "zlast_size", "zbuf_size", "zbuf_cap")
 
 

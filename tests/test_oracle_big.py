@@ -25,7 +25,7 @@ def big_from_small(sc, pairs=None):
 
 def assert_same_world(st_a, aux_a, st_b, aux_b):
     assert np.array_equal(st_a, st_b)
-    for f in ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "stab_iters", "lcp_alg_bytes"):
+    for f in ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "stab_iters", "lcp_alg_bytes", "stab_rows"):
         assert np.array_equal(aux_a[f], aux_b[f]), f
 
 

@@ -10,7 +10,7 @@ from moby_amd.world import WorldBatch
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-COUNTERS = ["time", "zlast_size", "zbuf_size", "zbuf_cap", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "stab_iters", "lcp_alg_bytes"]
+COUNTERS = ["time", "zlast_size", "zbuf_size", "zbuf_cap", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "stab_iters", "lcp_alg_bytes", "stab_rows"]
 
 
 def oracle_run(oracle, sc, states, nsteps, dt):
