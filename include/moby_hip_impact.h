@@ -69,6 +69,14 @@ int mh_impact_batch_debug_lcp(mh_impact_batch* ib, double* MM, double* qq);
 int mh_impact_batch_save_solver_state(mh_impact_batch* ib, double* zlast, int* zlast_size, uint32_t* rng, int* status);
 int mh_impact_batch_load_solver_state(mh_impact_batch* ib, const double* zlast, const int* zlast_size, const uint32_t* rng,
                                       const int* status);
+/* Which model the islands with finite friction take (src/ImpactConstraintHandler.cpp:139-146): the reference chooses at
+ * BUILD time -- Drumwright-Shell (apply_model_to_connected_constraints, the default) or, with -DUSE_AP (CMakeLists.txt:19,
+ * 77-79), Anitescu-Potra (src/ImpactConstraintHandlerLCP.cpp:36-370: LCP [UL UR; LL 0] of 5 nc + NK_DIRS rows,
+ * lcp_lemke_regularized(-20, 1, -2) on a fresh z, impulses applied through the contacts' accumulated wrenches).  Here it
+ * is a property of the batch; islands whose contacts all have mu >= 100 take the no-slip model either way. */
+#define MH_IMPACT_MODEL_DS 0
+#define MH_IMPACT_MODEL_AP 1
+int mh_impact_batch_set_model(mh_impact_batch* ib, int model);
 /* raw device pointers for zero-copy interop.  Contacts written straight to contacts_dev skip upload()'s host
  * checks; the device repeats them (nk of the batch, unit normal, two distinct bodies with at least one dynamic) and
  * flags a world with a malformed contact MH_WORLD_UNSUPPORTED instead of processing it.  The restitution round

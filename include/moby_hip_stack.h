@@ -28,6 +28,7 @@
 #ifndef MOBY_HIP_STACK_H
 #define MOBY_HIP_STACK_H
 #include "moby_hip.h"
+#include "moby_hip_impact.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -62,6 +63,8 @@ typedef struct mh_big_scene {
   unsigned cstab_max_iterations;
   int    lcp_n_max;             /* capacity of the handlers' LCPs (0 = as large as the pair list allows, <= MH_LCP_MAX_N_BLOCK);
                                    an island that needs more flags its world MH_WORLD_UNSUPPORTED */
+  int    impact_model;          /* MH_IMPACT_MODEL_DS (0, the reference's default build) or MH_IMPACT_MODEL_AP (its -DUSE_AP build):
+                                   moby_hip_impact.h */
 } mh_big_scene;
 
 /* B worlds resident on the GPU.  mh_world_aux carries the rand() stream, time, status bits and counters; the

@@ -64,6 +64,7 @@ SYMBOLS = {
     "mh_impact_batch_process": (_i, [_vp, _vp]),
     "mh_impact_batch_download": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mh_impact_batch_lcp_size": (_i, [_vp]),
+    "mh_impact_batch_set_model": (_i, [_vp, _i]),
     "mh_impact_batch_debug_lcp": (_i, [_vp, _vp, _vp]),
     "mh_impact_batch_save_solver_state": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mh_impact_batch_load_solver_state": (_i, [_vp, _vp, _vp, _vp, _vp]),

@@ -36,6 +36,9 @@ class BatchedImpactHandler {
     if (mh_impact_batch_download(_ib, state, _imp.data(), _status.data(), _pivots.data(), _solves.data()) != MH_OK)
       throw std::runtime_error(mh_last_error());
   }
+  // what the reference fixes at build time with -DUSE_AP (CMakeLists.txt:19, ImpactConstraintHandler.cpp:139-146):
+  // MH_IMPACT_MODEL_DS (Drumwright-Shell, default) or MH_IMPACT_MODEL_AP (Anitescu-Potra) for islands with finite friction
+  void set_model(int model) { if (mh_impact_batch_set_model(_ib, model) != MH_OK) throw std::runtime_error(mh_last_error()); }
   int lcp_size() const { return mh_impact_batch_lcp_size(_ib); }
   int status(int w) const { return _status[(size_t)w]; }
   unsigned pivots(int w) const { return _pivots[(size_t)w]; }

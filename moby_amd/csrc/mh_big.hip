@@ -49,7 +49,6 @@ struct Dev {
   int* status; int* anyflag;
 };
 
-MH_DEV P3 operator*(P3 a, double s) { return p3(a.x * s, a.y * s, a.z * s); }
 MH_DEV double norm3(P3 a) { return sqrt(dot3(a, a)); }
 MH_DEV double comp3(P3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
@@ -771,6 +770,11 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
   std::memset(&bb->d, 0, sizeof(bb->d)); std::memset(&bb->core, 0, sizeof(bb->core));
   int rc = mh_imp_core_create(&bb->core, B, nb, ncmax, sc->nk, (int)cap);
   if (rc != MH_OK) { delete bb; return rc; }
+  if (sc->impact_model != MH_IMPACT_MODEL_DS && sc->impact_model != MH_IMPACT_MODEL_AP) {
+    mh_imp_core_destroy(&bb->core); delete bb;
+    return fail(MH_ERR_INVALID_ARG, "impact_model %d (MH_IMPACT_MODEL_DS / _AP)", sc->impact_model);
+  }
+  bb->core.ap = (sc->impact_model == MH_IMPACT_MODEL_AP) ? 1 : 0;
   bool okall = true;
   auto A = [&](size_t bytes, bool zero) -> void* {
     void* p = nullptr;

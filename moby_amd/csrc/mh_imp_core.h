@@ -32,6 +32,10 @@ struct mh_imp_core {
   double* imp;                                      // B x ncmax x 3 accumulated (cn, cs, ct), caller order
   unsigned long long* cnt;                          // B x 5: LCPs solved, rows, pivots, LCP-entry bytes 8 (n^2 + 2n), stabilisation rows
   const double* fcos; const double* fsin;           // kh each (host libm)
+  // Anitescu-Potra model (ImpactConstraintHandlerLCP.cpp; the reference's -DUSE_AP build): ap != 0 sends every island with
+  // finite friction through it.  nk4 = NK_DIRS rows per contact, apcos / apsin their polygon directions (host libm),
+  // apw = the contacts' accumulated impulse wrenches in the global frame (B x ncmax x 6, island order)
+  int ap, nk4; const double* apcos; const double* apsin; double* apw;
   double* ws_d; int* ws_i;                          // block-solver workspace (nmax > 64)
   int* hmax;                                        // pinned host copy of maxisl
   void* allocs[48]; int nallocs;

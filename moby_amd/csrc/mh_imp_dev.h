@@ -14,6 +14,7 @@ MH_DEV P3 p3(double x, double y, double z) { P3 r; r.x = x; r.y = y; r.z = z; re
 MH_DEV P3 operator+(P3 a, P3 b) { return p3(a.x + b.x, a.y + b.y, a.z + b.z); }
 MH_DEV P3 operator-(P3 a, P3 b) { return p3(a.x - b.x, a.y - b.y, a.z - b.z); }
 MH_DEV P3 operator-(P3 a) { return p3(-a.x, -a.y, -a.z); }
+MH_DEV P3 operator*(P3 a, double s) { return p3(a.x * s, a.y * s, a.z * s); }
 MH_DEV P3 operator/(P3 a, double s) { return p3(a.x / s, a.y / s, a.z / s); }
 MH_DEV double dot3(P3 a, P3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 MH_DEV P3 cross3(P3 a, P3 b) { return p3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }

@@ -23,6 +23,8 @@
 // update_constraint_vels), which restates the reference's SparseJacobian products.
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "../../include/moby_hip_impact.h"
@@ -116,7 +118,8 @@ void k_prep(Dev d, int mode)
         if (keep && nisl >= d.islmax) { keep = false; d.status[b] |= MH_WORLD_UNSUPPORTED; }
         if (!keep) { cnt = begin; continue; }
         d.isl_start[(size_t)b * d.islmax + nisl] = begin; d.isl_len[(size_t)b * d.islmax + nisl] = cnt - begin;
-        d.isl_model[(size_t)b * d.islmax + nisl] = (mode == MH_CORE_IMPACT && all_inf) ? 1 : 0;   // every mu >= 100: the no-slip model (ICH:134-135)
+        // every mu >= 100: the no-slip model (ICH:134-135); otherwise Drumwright-Shell, or Anitescu-Potra in a USE_AP batch (ICH:139-146)
+        d.isl_model[(size_t)b * d.islmax + nisl] = (mode != MH_CORE_IMPACT) ? 0 : (all_inf ? 1 : (d.ap ? 2 : 0));
         nisl++;
       }
     }
@@ -239,6 +242,31 @@ struct MMv {
 };
 
 
+// apply_ap_model's _MM = [UL UR; LL 0] (ICH-AP:120-303) over z = [cn, cs+, cs-, ct+, ct-, friction rows]
+struct APv {
+  MMv g; const double* apcos; const double* apsin; int nc, nk4, nvars;
+  MH_DEV double at(int r, int c) const {
+    if (r < nvars && c < nvars) {
+      const int a = r / nc, i = r - a * nc, bb = c / nc, j = c - bb * nc;
+      double v = g.gab((a + 1) >> 1, (bb + 1) >> 1, i, j);            // directions n, s, s, t, t
+      if ((a == 2 || a == 4) != (bb == 2 || bb == 4)) v = -v;
+      return v;
+    }
+    if (r >= nvars && c < nvars) {                                      // LL: mu, -cos, -cos, -sin, -sin
+      const int fr = r - nvars, i = fr / nk4, k = fr - i * nk4, bc = c / nc, ci = c - bc * nc;
+      if (ci != i) return 0.0;
+      if (bc == 0) return g.cpar[4 * i];
+      return (bc <= 2) ? -apcos[k] : -apsin[k];
+    }
+    if (r < nvars) {                                                    // UR: the friction part of -LL^T
+      const int fc = c - nvars, i = fc / nk4, k = fc - i * nk4, a = r / nc, ri = r - a * nc;
+      if (ri != i || a == 0) return 0.0;
+      return (a <= 2) ? apcos[k] : apsin[k];
+    }
+    return 0.0;
+  }
+};
+
 // _MM (column c = blockIdx.x < n, leading dimension n) and, in the LAST workgroup of a world, _qq, the start z and the
 // round's mask.  phase 1 (the second solve of ICH:591-600: same _MM, new _qq) launches only that last workgroup.
 __global__ __launch_bounds__(T)
@@ -257,7 +285,8 @@ void k_mm(Dev d, int r, int mode, int phase)
     return;
   }
   const int nvars = 5 * nc;
-  const int n = (mode == MH_CORE_STAB) ? nc : nvars + nc + nc * d.kh;
+  const bool apm = d.isl_model[(size_t)b * d.islmax + r] == 2;
+  const int n = (mode == MH_CORE_STAB) ? nc : (apm ? nvars + nc * d.nk4 : nvars + nc + nc * d.kh);
   if (n > d.nmax) {                                   // beyond the capacity the batch was created with
     if (last && t == 0) { d.status[b] |= MH_WORLD_UNSUPPORTED; d.run[b] = 0; d.ncur[b] = 0; }
     return;
@@ -270,6 +299,11 @@ void k_mm(Dev d, int r, int mode, int phase)
     double* col = d.MM + (size_t)b * d.nmax * d.nmax + (size_t)c * n;
     if (mode == MH_CORE_STAB) { for (int rr = t; rr < n; rr += T) col[rr] = G[(size_t)rr * nc + c]; return; }   // MM = Cn X Cn^T (CStab:940)
     MMv m; m.G = G; m.cpar = cpar; m.fcos = d.fcos; m.fsin = d.fsin; m.nc = nc; m.kh = d.kh; m.nvars = nvars;
+    if (apm) {
+      APv a; a.g = m; a.apcos = d.apcos; a.apsin = d.apsin; a.nc = nc; a.nk4 = d.nk4; a.nvars = nvars;
+      for (int rr = t; rr < n; rr += T) col[rr] = a.at(rr, c);
+      return;
+    }
     for (int rr = t; rr < n; rr += T) col[rr] = m.at(rr, c);
     return;
   }
@@ -280,6 +314,18 @@ void k_mm(Dev d, int r, int mode, int phase)
   if (mode == MH_CORE_STAB) {
     for (int rr = t; rr < n; rr += T) { q[rr] = Cv[rr]; z[rr] = 0.0; }
     if (t == 0) { d.zsz[b] = 0; d.ncur[b] = n; d.run[b] = 1; }      // VectorNd z: fresh, size 0 => cold start (CStab:934)
+    return;
+  }
+  if (apm) {                                            // ICH-AP:186-187, 305-311; VectorNd z: fresh (ICH-AP:331)
+    for (int rr = t; rr < n; rr += T) {
+      double v = 0.0;
+      if (rr < nvars) {
+        const int a = rr / nc, i = rr - a * nc;
+        v = (a == 0) ? Cv[i] : (a == 1 ? Cv[ncm + i] : (a == 2 ? -Cv[ncm + i] : (a == 3 ? Cv[2 * ncm + i] : -Cv[2 * ncm + i])));
+      }
+      q[rr] = v; z[rr] = 0.0;
+    }
+    if (t == 0) { d.zsz[b] = 0; d.ncur[b] = n; d.run[b] = 1; }
     return;
   }
   for (int rr = t; rr < n; rr += T) {
@@ -332,10 +378,11 @@ void k_post(Dev d, int r, int phase)
   if (!island(d, b, r, start, nc)) return;
   if (!d.run[b]) return;
   if (phase == 1 && !d.again[b]) return;
+  if (d.isl_model[(size_t)b * d.islmax + r] != 0) return;
   const int nb = d.nb, n = d.ncur[b], ncm = d.ncmax;
   __shared__ double s_c[3][MAXC], s_cv[3][MAXC];
   __shared__ int s_b[2][MAXC];
-  __shared__ double s_red[T];
+  __shared__ double s_red[1];
   __shared__ int s_any;
   double* st = d.state + (size_t)b * nb * 13;
   const double* z = d.z + (size_t)b * d.nmax;
@@ -405,12 +452,9 @@ void k_post(Dev d, int r, int phase)
     }
     __syncthreads();
   };
-  auto min_cn_v = [&]() -> double {
-    double mn = 1.7976931348623157e308;
-    for (int i = t; i < nc; i += T) mn = (s_cv[0][i] < mn) ? s_cv[0][i] : mn;
-    s_red[t] = mn;
+  auto min_cn_v = [&]() -> double {                     // one thread, at most MAXC LDS reads (a tree reduction with barriers in
+    if (t == 0) { double mn = s_cv[0][0]; for (int i = 1; i < nc; i++) mn = (s_cv[0][i] < mn) ? s_cv[0][i] : mn; s_red[0] = mn; }   // its loop made k_post_ap miscompile)
     __syncthreads();
-    for (int w = T / 2; w > 0; w >>= 1) { if (t < w) s_red[t] = (s_red[t + w] < s_red[t]) ? s_red[t + w] : s_red[t]; __syncthreads(); }
     const double rr = s_red[0];
     __syncthreads();
     return rr;
@@ -430,6 +474,157 @@ void k_post(Dev d, int r, int phase)
   for (int i = t; i < nc; i += T) for (int a = 0; a < 3; a++) d.Cv[((size_t)b * 3 + a) * ncm + start + i] = s_cv[a][i];
   if (t == 0 && phase == 0) d.again[b] = second ? 1 : 0;
   }   // ok
+}
+
+// apply_ap_model_to_connected_constraints around its LCPs (ICH-AP:36-92, 336-350) for the islands of model 2, in two
+// small kernels (a single one needed spilled SGPRs, and came out of the compiler with a wrong execution mask after its
+// min-reduction: tools/ap_case.py found it).
+// k_post_ap, phase 0: after the first solve -- impulses from z, propagate_impulse_data, constraint velocities,
+// restitution, the second-solve test; phase 1: after the second solve.  It leaves need2[b] = 1 when the island's wrenches
+// are final; k_apply_ap then does apply_impulses (ICH:676-745) and clears the flag.
+__global__ __launch_bounds__(T)
+void k_post_ap(Dev d, int r, int phase)
+{
+  const int b = blockIdx.x, t = threadIdx.x;
+  int start, nc;
+  if (!island(d, b, r, start, nc)) return;
+  if (!d.run[b]) return;
+  if (phase == 1 && !d.again[b]) return;
+  if (d.isl_model[(size_t)b * d.islmax + r] != 2) return;
+  const int ncm = d.ncmax;
+  __shared__ double s_c[3][MAXC], s_cv[3][MAXC];
+  __shared__ double s_min;
+  __shared__ int s_any;
+  const double* z = d.z + (size_t)b * d.nmax;
+  const bool ok = d.lst1[b] != 0;
+  if (t == 0) {
+    const int n = d.ncur[b];
+    unsigned long long* c = d.cnt + (size_t)b * 5;
+    c[0] += 1ull; c[1] += (unsigned long long)n; c[2] += (unsigned long long)d.piv1[b]; c[3] += 8ull * ((unsigned long long)n * n + 2ull * n);
+    if (!ok) d.status[b] |= MH_WORLD_LCP_FAILED;        // throw std::exception() (ICH-AP:334): nothing is applied
+    if (phase == 0) d.again[b] = 0;
+    d.need2[b] = 0;
+    s_any = 0;
+  }
+  if (!ok) return;
+  const double* cpar = d.cpar + ((size_t)b * ncm + start) * 4;
+  double* apw = d.apw + ((size_t)b * ncm + start) * 6;
+  MMv m; m.G = d.G + (size_t)b * 6 * ncm * ncm; m.nc = nc;
+  for (int i = t; i < nc; i += T) {
+    s_cv[0][i] = d.Cv[((size_t)b * 3 + 0) * ncm + start + i];
+    s_cv[1][i] = d.Cv[((size_t)b * 3 + 1) * ncm + start + i];
+    s_cv[2][i] = d.Cv[((size_t)b * 3 + 2) * ncm + start + i];
+    if (phase == 0) { double* w = apw + 6 * i; w[0] = 0.0; w[1] = 0.0; w[2] = 0.0; w[3] = 0.0; w[4] = 0.0; w[5] = 0.0; }   // ICH-AP:52-55
+    s_c[0][i] = z[i];                                                         // ICH-AP:336-342
+    s_c[1][i] = z[nc + i] - z[2 * nc + i];
+    s_c[2][i] = z[3 * nc + i] - z[4 * nc + i];
+  }
+  __syncthreads();
+  auto propagate = [&]() {                              // propagate_impulse_data (ICH:643-673)
+    const mh_contact* C = d.contacts + (size_t)b * ncm;
+    for (int i = t; i < nc; i += T) {
+      const int ci = d.order[(size_t)b * ncm + start + i];
+      const P3 p = ld3(C[ci].point), nn = ld3(C[ci].normal);
+      P3 s, tt; basis(nn, s, tt);
+      P3 j = nn * s_c[0][i]; j = j + s * s_c[1][i]; j = j + tt * s_c[2][i];
+      const P3 a = cross3(p, j);
+      double* w = apw + 6 * i;
+      w[0] = w[0] + j.x; w[1] = w[1] + j.y; w[2] = w[2] + j.z; w[3] = w[3] + a.x; w[4] = w[4] + a.y; w[5] = w[5] + a.z;
+      double* im = d.imp + ((size_t)b * ncm + ci) * 3;
+      im[0] += s_c[0][i]; im[1] += s_c[1][i]; im[2] += s_c[2][i];
+    }
+    __syncthreads();
+  };
+  auto row_update = [&](int a, int i) -> double {       // C_a v(i) + sum_b (C_a X C_b^T c_b)(i), each product from 0 over ascending j
+    double y = s_cv[a][i];
+    for (int bb = 0; bb < 3; bb++) {
+      double acc = 0.0;
+      for (int j = 0; j < nc; j++) acc = acc + s_c[bb][j] * m.gab(a, bb, i, j);
+      y = y + acc;
+    }
+    return y;
+  };
+  auto update_cv = [&]() {                              // update_constraint_velocities_from_impulses (ICH:427-464)
+    for (int i = t; i < nc; i += T) {
+      const double y0 = row_update(0, i), y1 = row_update(1, i), y2 = row_update(2, i);
+      s_cv[0][i] = y0; s_cv[1][i] = y1; s_cv[2][i] = y2;
+    }
+    __syncthreads();
+  };
+  auto min_cn_v = [&]() -> double {                     // calc_min_constraint_velocity (ICH:413-424): one thread, at most MAXC reads
+    if (t == 0) { double mn = s_cv[0][0]; for (int i = 1; i < nc; i++) mn = (s_cv[0][i] < mn) ? s_cv[0][i] : mn; s_min = mn; }
+    __syncthreads();
+    const double rr = s_min;
+    __syncthreads();
+    return rr;
+  };
+  propagate();
+  bool second = false;
+  if (phase == 0) {
+    update_cv();                                                                // ICH-AP:61
+    const double minv = min_cn_v();
+    for (int i = t; i < nc; i += T) { const double e = s_c[0][i] * cpar[4 * i + 2]; s_c[0][i] = e; if (e > NEAR_ZERO_) s_any = 1; }   // apply_restitution(q) (ICH:497-525)
+    __syncthreads();
+    if (s_any) {
+      for (int i = t; i < nc; i += T) { s_c[1][i] = 0.0; s_c[2][i] = 0.0; }
+      __syncthreads();
+      update_cv();
+      const double minv_plus = min_cn_v();
+      second = (minv_plus < 0.0 && minv_plus < minv - NEAR_ZERO_);              // ICH-AP:78
+      if (!second) propagate();                                                 // ICH-AP:84 (on the other branch the restitution impulses are never propagated)
+    }
+    for (int i = t; i < nc; i += T) {
+      d.Cv[((size_t)b * 3 + 0) * ncm + start + i] = s_cv[0][i];
+      d.Cv[((size_t)b * 3 + 1) * ncm + start + i] = s_cv[1][i];
+      d.Cv[((size_t)b * 3 + 2) * ncm + start + i] = s_cv[2][i];
+    }
+  }
+  if (t == 0) { if (phase == 0) d.again[b] = second ? 1 : 0; d.need2[b] = second ? 0 : 1; }
+}
+
+// apply_impulses (ICH:676-745) for the A-P islands k_post_ap has finished: the accumulated wrench w of every contact on
+// geom1's body, -w on geom2's, as generalized forces about the body centre, summed in contact order; v += M^-1 gj
+__global__ __launch_bounds__(T)
+void k_apply_ap(Dev d, int r)
+{
+  const int b = blockIdx.x, t = threadIdx.x;
+  int start, nc;
+  if (!island(d, b, r, start, nc)) return;
+  if (d.isl_model[(size_t)b * d.islmax + r] != 2 || !d.run[b] || !d.need2[b]) return;
+  const int nb = d.nb, ncm = d.ncmax;
+  __shared__ int s_b[2][MAXC];
+  for (int i = t; i < nc; i += T) {
+    const size_t ck = (size_t)b * ncm + start + i;
+    s_b[0][i] = d.cbody[2 * ck]; s_b[1][i] = d.cbody[2 * ck + 1];
+  }
+  __syncthreads();
+  if (t == 0) d.need2[b] = 0;
+  double* st = d.state + (size_t)b * nb * 13;
+  const double* apw = d.apw + ((size_t)b * ncm + start) * 6;
+  const double* xinv = d.xinv + (size_t)b * nb * 10;
+  for (int bb = t; bb < nb; bb += T) {
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0, g4 = 0.0, g5 = 0.0;
+    bool seen = false;
+    const P3 x = ld3(st + 13 * bb);
+    for (int j = 0; j < nc; j++) {
+      const int sd = (s_b[0][j] == bb) ? 0 : ((s_b[1][j] == bb) ? 1 : -1);
+      if (sd < 0) continue;
+      const double sg = (sd == 0) ? 1.0 : -1.0;
+      const double* w = apw + 6 * j;
+      P3 f; f.x = sg * w[0]; f.y = sg * w[1]; f.z = sg * w[2];
+      P3 tq; tq.x = sg * w[3]; tq.y = sg * w[4]; tq.z = sg * w[5];
+      tq = tq - cross3(x, f);
+      if (!seen) { g0 = f.x; g1 = f.y; g2 = f.z; g3 = tq.x; g4 = tq.y; g5 = tq.z; seen = true; }
+      else { g0 = g0 + f.x; g1 = g1 + f.y; g2 = g2 + f.z; g3 = g3 + tq.x; g4 = g4 + tq.y; g5 = g5 + tq.z; }
+    }
+    if (!seen) continue;
+    const double* X = xinv + 10 * bb;
+    double* v = st + 13 * bb + 7;
+    v[0] = v[0] + X[0] * g0; v[1] = v[1] + X[0] * g1; v[2] = v[2] + X[0] * g2;
+    v[3] = v[3] + ((X[1] * g3 + X[2] * g4) + X[3] * g5);
+    v[4] = v[4] + ((X[4] * g3 + X[5] * g4) + X[6] * g5);
+    v[5] = v[5] + ((X[7] * g3 + X[8] * g4) + X[9] * g5);
+  }
 }
 
 // determine_dq's tail (CStab:958-969): update_from_stacked with cn = z -- the bodies' velocities become X Cn^T z
@@ -735,6 +930,9 @@ int mh_imp_core_create(mh_imp_core* c, int B, int nb, int ncmax, int nk, int nma
   c->imp = (double*)A(sB * snc * 3 * 8, true);
   c->cnt = (unsigned long long*)A(sB * 5 * 8, true);
   double* dcos = (double*)A(c->kh * 8, false); double* dsin = (double*)A(c->kh * 8, false);
+  c->nk4 = (nk > 4) ? (nk + 4) / 4 : 1;                                     // ICH-AP:113-118
+  double* acos_ = (double*)A(c->nk4 * 8, false); double* asin_ = (double*)A(c->nk4 * 8, false);
+  c->apw = (double*)A(sB * snc * 6 * 8, true);
   if (nmax > MH_LCP_MAX_N_WAVE) {
     c->ws_d = (double*)A(sB * (sn * sn + 5 * sn) * 8, false);
     c->ws_i = (int*)A(sB * 4 * sn * 4, false);
@@ -748,7 +946,12 @@ int mh_imp_core_create(mh_imp_core* c, int B, int nb, int ncmax, int nk, int nma
   // friction polygon directions (ICH-QP:452-470) with the host libm, like the world kernel's table
   std::vector<double> hc(c->kh), hs(c->kh);
   for (int j = 0; j < c->kh; j++) { const double theta = (double)j / (c->kh - 1) * M_PI_2; hc[j] = std::cos(theta); hs[j] = std::sin(theta); }
-  if (hipMemcpy(dcos, hc.data(), c->kh * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dsin, hs.data(), c->kh * 8, hipMemcpyHostToDevice) != hipSuccess) {
+  // Anitescu-Potra polygon rows (ICH-AP:250-295): cos / sin(pi k / (2 nk4)); one row of ones for a 4-edge cone
+  std::vector<double> ac(c->nk4), as(c->nk4);
+  for (int k = 0; k < c->nk4; k++) { ac[k] = (nk > 4) ? std::cos((M_PI * k) / (2.0 * c->nk4)) : 1.0; as[k] = (nk > 4) ? std::sin((M_PI * k) / (2.0 * c->nk4)) : 1.0; }
+  c->apcos = acos_; c->apsin = asin_;
+  if (hipMemcpy(acos_, ac.data(), c->nk4 * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(asin_, as.data(), c->nk4 * 8, hipMemcpyHostToDevice) != hipSuccess
+      || hipMemcpy(dcos, hc.data(), c->kh * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dsin, hs.data(), c->kh * 8, hipMemcpyHostToDevice) != hipSuccess) {
     mh_imp_core_destroy(c);
     return fail(MH_ERR_HIP, "upload of the friction table failed");
   }
@@ -761,6 +964,12 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   namespace im = mh::imp;
   const int B = c->B, n = c->nmax;
   int rc;
+  if (mode == MH_CORE_IMPACT && c->ap) {
+    // every island the mask selects takes the Anitescu-Potra model: lcp_lemke_regularized(_MM, _qq, z, -20, 1, -2) alone (ICH-AP:333)
+    mh_lcp_opts oa; oa.min_exp = -20; oa.step_exp = 1u; oa.max_exp = -2; oa.piv_tol = -1.0; oa.zero_tol = -1.0;
+    return mh_lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, c->lst1, c->piv1,
+                                   nullptr, 0, nullptr, &oa, run_if, c->ws_d, c->ws_i, c->ncur);
+  }
   if (mode == MH_CORE_IMPACT) {
     mh_lcp_opts o1; o1.min_exp = -20; o1.step_exp = 4u; o1.max_exp = -8; o1.piv_tol = -1.0; o1.zero_tol = -1.0;   // ICH-QP:219
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, nullptr, c->rng, c->lst1, c->piv1,
@@ -787,26 +996,37 @@ int mh_imp_core_process(mh_imp_core* c, void* stream, int mode)
   MH_HIP(hipMemcpyAsync(c->hmax, c->maxisl, sizeof(int), hipMemcpyDeviceToHost, s));
   MH_HIP(hipStreamSynchronize(s));
   const int rounds = *c->hmax;
+  // MH_IMP_TRACE=1: synchronise after every stage and name it on stderr (locates a faulting kernel)
+  static const bool trace_stages = std::getenv("MH_IMP_TRACE") != nullptr;
+  auto stage = [&](const char* what, int r) { if (trace_stages) { hipError_t e = hipStreamSynchronize(s); std::fprintf(stderr, "[mh_imp] round %d %s: %s\n", r, what, hipGetErrorString(e)); std::fflush(stderr); } };
   for (int r = 0; r < rounds; r++) {
     hipLaunchKernelGGL(im::k_gram, dim3((ncm * ncm + im::T - 1) / im::T, B), dim3(im::T), 0, s, *c, r, mode);
     hipLaunchKernelGGL(im::k_mm, dim3(c->nmax + 1, B), dim3(im::T), 0, s, *c, r, mode, 0);
     MH_HIP(hipGetLastError());
+    stage("gram + mm", r);
     int rc = core_solve_round(c, s, c->run, mode);
     if (rc != MH_OK) return rc;
+    stage("first solve", r);
     if (mode == MH_CORE_STAB) {
       hipLaunchKernelGGL(im::k_stab_apply, dim3(B), dim3(im::T), 0, s, *c, r);
       MH_HIP(hipGetLastError());
       continue;
     }
-    hipLaunchKernelGGL(im::k_post, dim3(B), dim3(im::T), 0, s, *c, r, 0);
+    hipLaunchKernelGGL(c->ap ? im::k_post_ap : im::k_post, dim3(B), dim3(im::T), 0, s, *c, r, 0);
+    if (c->ap) hipLaunchKernelGGL(im::k_apply_ap, dim3(B), dim3(im::T), 0, s, *c, r);
+    stage("post 0", r);
     // second solve for the worlds whose restitution impulses left a contact approaching (ICH:591-600): same _MM, new _qq.
     // The mask `again` is computed on the device (k_post, phase 0) and the round is always enqueued -- masked
     // workgroups exit at once -- so contacts written through device_ptrs() get it too (no host-side epsilon scan).
     hipLaunchKernelGGL(im::k_mm, dim3(1, B), dim3(im::T), 0, s, *c, r, mode, 1);
     MH_HIP(hipGetLastError());
+    stage("mm 1", r);
     rc = core_solve_round(c, s, c->again, mode);
     if (rc != MH_OK) return rc;
-    hipLaunchKernelGGL(im::k_post, dim3(B), dim3(im::T), 0, s, *c, r, 1);
+    stage("second solve", r);
+    hipLaunchKernelGGL(c->ap ? im::k_post_ap : im::k_post, dim3(B), dim3(im::T), 0, s, *c, r, 1);
+    if (c->ap) hipLaunchKernelGGL(im::k_apply_ap, dim3(B), dim3(im::T), 0, s, *c, r);
+    stage("post 1", r);
     static const mh::Pow10Table p10 = [] { mh::Pow10Table t; for (int i = 0; i < 64; i++) t.v[i] = std::pow(10.0, (double)(i - 32)); return t; }();   // LCP.cpp:285
     hipLaunchKernelGGL(im::k_noslip, dim3(B), dim3(64), 0, s, *c, r, p10);      // the islands of this round that take the no-slip model
     MH_HIP(hipGetLastError());
@@ -881,6 +1101,14 @@ int mh_impact_batch_create(int B, int nb, int nc, int nk, const double* mass, co
 }
 
 int mh_impact_batch_lcp_size(const mh_impact_batch* ib) { return ib ? ib->n : 0; }
+
+int mh_impact_batch_set_model(mh_impact_batch* ib, int model)
+{
+  if (!ib) return fail(MH_ERR_INVALID_ARG, "null batch");
+  if (model != MH_IMPACT_MODEL_DS && model != MH_IMPACT_MODEL_AP) return fail(MH_ERR_INVALID_ARG, "impact model %d (MH_IMPACT_MODEL_DS / _AP)", model);
+  ib->c.ap = (model == MH_IMPACT_MODEL_AP) ? 1 : 0;
+  return MH_OK;
+}
 
 int mh_impact_batch_upload(mh_impact_batch* ib, const double* state, const mh_contact* contacts)
 {

@@ -18,6 +18,14 @@ CONTACT_DTYPE = np.dtype([("point", np.float64, 3), ("normal", np.float64, 3), (
 assert CONTACT_DTYPE.itemsize == 96
 
 
+MH_IMPACT_MODEL_DS, MH_IMPACT_MODEL_AP = 0, 1      # moby_hip_impact.h: the reference's default build / its -DUSE_AP build
+
+
+def ap_lcp_size(nc, nk):
+    """Anitescu-Potra LCP: 5 NC variables + NK_DIRS friction rows (ImpactConstraintHandlerLCP.cpp:105-118)."""
+    return 5 * nc + nc * ((nk + 4) // 4 if nk > 4 else 1)
+
+
 def lcp_size(nc, nk):
     """n_imp = 6 NC + NC NK/2 (5 NC variables + NC normal rows + NK/2 friction-polygon rows per contact)."""
     return 6 * nc + nc * (nk // 2)
@@ -55,7 +63,7 @@ def box_stack(nboxes, B=1, dt=1e-3, mu=1e-4, epsilon=0.0, nk=4, perturb=True, se
 class ImpactBatch:
     """B worlds x (nb bodies, nc contacts) behind an ``mh_impact_batch`` handle (persistent handler state)."""
 
-    def __init__(self, B, nb, nc, nk, mass, inertia):
+    def __init__(self, B, nb, nc, nk, mass, inertia, model=MH_IMPACT_MODEL_DS):
         lib = _lib.load()
         self.B, self.nb, self.nc, self.nk = int(B), int(nb), int(nc), int(nk)
         m = np.ascontiguousarray(mass, dtype=np.float64); J = np.ascontiguousarray(inertia, dtype=np.float64)
@@ -63,6 +71,8 @@ class ImpactBatch:
         self.handle = ctypes.c_void_p()
         _lib.check(lib.mh_impact_batch_create(self.B, self.nb, self.nc, self.nk, m.ctypes.data, J.ctypes.data, ctypes.byref(self.handle)))
         self.n = lib.mh_impact_batch_lcp_size(self.handle)
+        if model != MH_IMPACT_MODEL_DS:
+            _lib.check(lib.mh_impact_batch_set_model(self.handle, int(model)))
 
     def upload(self, state, contacts):
         st = np.ascontiguousarray(state, dtype=np.float64); cs = np.ascontiguousarray(contacts)

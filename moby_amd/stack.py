@@ -26,7 +26,7 @@ class mh_big_scene(ctypes.Structure):
         ("cp_epsilon", _dp), ("cp_mu_coulomb", _dp), ("cp_mu_viscous", _dp), ("cp_compliance", _dp),
         ("nk", ctypes.c_int),
         ("min_step_size", ctypes.c_double), ("contact_dist_thresh", ctypes.c_double), ("cstab_eps", ctypes.c_double),
-        ("cstab_max_iterations", ctypes.c_uint), ("lcp_n_max", ctypes.c_int),
+        ("cstab_max_iterations", ctypes.c_uint), ("lcp_n_max", ctypes.c_int), ("impact_model", ctypes.c_int),
     ]
 
 
@@ -35,7 +35,7 @@ class BigScene:
 
     def __init__(self, geom_type, geom_dim, mass, inertia, pairs, gravity, plane_R=None, plane_o=(0.0, 0.0, 0.0), has_ground=True,
                  nk=4, epsilon=0.0, mu_coulomb=0.0, mu_viscous=0.0, compliance=0.0,
-                 cstab_max_iterations=S.MH_CSTAB_DEFAULT_MAX_ITERATIONS, lcp_n_max=0):
+                 cstab_max_iterations=S.MH_CSTAB_DEFAULT_MAX_ITERATIONS, lcp_n_max=0, impact_model=0):
         self.geom_type = np.ascontiguousarray(geom_type, dtype=np.int32)
         self.nb = len(self.geom_type)
         self.geom_dim = np.ascontiguousarray(geom_dim, dtype=np.float64).reshape(self.nb, 3)
@@ -63,6 +63,7 @@ class BigScene:
             c.plane_o[k] = plane_o[k]; c.gravity[k] = gravity[k]
         c.min_step_size = S.NEAR_ZERO; c.contact_dist_thresh = 1e-6; c.cstab_eps = S.NEAR_ZERO
         c.cstab_max_iterations = int(cstab_max_iterations); c.lcp_n_max = int(lcp_n_max)
+        c.impact_model = int(impact_model)                     # MH_IMPACT_MODEL_DS / _AP (moby_hip_impact.h)
         self.c = c
 
     @property
@@ -108,7 +109,8 @@ def box_dims(k):
     return s, 1.0, s
 
 
-def box_stack_scene(nboxes, mu=1e-4, epsilon=0.0, nk=4, cstab_max_iterations=S.MH_CSTAB_DEFAULT_MAX_ITERATIONS, lcp_n_max=None):
+def box_stack_scene(nboxes, mu=1e-4, epsilon=0.0, nk=4, cstab_max_iterations=S.MH_CSTAB_DEFAULT_MAX_ITERATIONS, lcp_n_max=None,
+                    impact_model=0):
     """nboxes boxes, density 10, centre y = 0.5 + k, on the plane y = 0, gravity (0, -9.81, 0).  Candidate pairs: the
     ground with every box (its DummyBV is infinite, CCD.cpp:1091-1094) and each box with the one above it (the only
     box pairs whose bounding spheres of radius ~0.87 can overlap at a centre distance of 1), as vertex-face pairs."""
@@ -123,7 +125,7 @@ def box_stack_scene(nboxes, mu=1e-4, epsilon=0.0, nk=4, cstab_max_iterations=S.M
         lcp_n_max = max(64, nboxes * 4 * (6 + nk // 2))
     pairs = [(k, nboxes, MH_PAIR_CLOSED_FORM) for k in range(nboxes)] + [(k, k + 1, MH_PAIR_VERTEX_FACE) for k in range(nboxes - 1)]
     return BigScene(gt, dims, mass, inertia, pairs, gravity=(0.0, -9.81, 0.0), nk=nk, epsilon=epsilon, mu_coulomb=mu,
-                    cstab_max_iterations=cstab_max_iterations, lcp_n_max=lcp_n_max)
+                    cstab_max_iterations=cstab_max_iterations, lcp_n_max=lcp_n_max, impact_model=impact_model)
 
 
 def box_stack_state(nboxes, B=1, perturb=True, seed0=0x4D4F4259):

@@ -29,6 +29,7 @@ namespace oracle {
 // its LU factors, b by the solution.  Returns LAPACK `info`: 0 = ok,
 // j>0 = U(j,j) is exactly zero (Ravelin throws SingularException; the
 // solution is then NOT computed, b is left untouched).
+static unsigned long long g_lu_nan_pivots = 0;   // diagnostic: columns whose diagonal entry was NaN at its pivot search
 inline int lu_solve(int n, double* A, int ld, double* b, int* ipiv_out = nullptr)
 {
   std::vector<int> ipiv_local;
@@ -39,6 +40,7 @@ inline int lu_solve(int n, double* A, int ld, double* b, int* ipiv_out = nullptr
   for (int j = 0; j < n; j++) {
     // idamax: first index of max |A(i,j)|, i>=j
     int jp = j; double amax = std::fabs(A[j + ld*j]);
+    if (amax != amax) g_lu_nan_pivots++;     // idamax keeps index j then: no |a| compares greater than NaN
     for (int i = j+1; i < n; i++) {
       double v = std::fabs(A[i + ld*j]);
       if (v > amax) { amax = v; jp = i; }

@@ -157,12 +157,18 @@ int oracle_world_impact_lcp(const mh_scene* sc, double* state, mh_world_aux* aux
   std::vector<World::Island> isl; w.find_islands(cs, isl);
   if (isl.empty()) return 0;
   World::ProblemData p; w.compute_problem_data(cs, isl[0], p, false);
-  std::vector<double> M, q; int n; w.build_impact_lcp(p, M, q, n);
+  std::vector<double> M, q; int n;
+  if (w.impact_model == MH_IMPACT_MODEL_AP) w.build_ap_lcp(p, M, q, n); else w.build_impact_lcp(p, M, q, n);
   if (n > cap) return -n;
   std::memcpy(MM, M.data(), sizeof(double) * (size_t)n * n);
   std::memcpy(qq, q.data(), sizeof(double) * n);
   return n;
 }
+
+unsigned long long oracle_lu_nan_pivots() { return g_lu_nan_pivots; }
+
+// the impact model of every World built from now on (MH_IMPACT_MODEL_DS / _AP: the reference's USE_AP build option)
+void oracle_set_impact_model(int model) { g_impact_model = model; }
 
 // ImpactConstraintHandler::process_constraints (ICH:75-168) on an explicit contact list: the checker of
 // mh_impact_batch_process (include/moby_hip_impact.h).  Bodies / buffers of any size; aux carries the rand()
@@ -209,7 +215,8 @@ int oracle_impact_lcp(int nb, int nc, const double* mass, const double* inertia,
   std::vector<World::Island> isl; w.find_islands(cs, isl);
   if (isl.empty()) return 0;
   World::ProblemData p; w.compute_problem_data(cs, isl[0], p, false);
-  std::vector<double> M, q; int n; w.build_impact_lcp(p, M, q, n);
+  std::vector<double> M, q; int n;
+  if (w.impact_model == MH_IMPACT_MODEL_AP) w.build_ap_lcp(p, M, q, n); else w.build_impact_lcp(p, M, q, n);
   if (n > cap) return -n;
   std::memcpy(MM, M.data(), sizeof(double) * (size_t)n * n);
   std::memcpy(qq, q.data(), sizeof(double) * n);
@@ -238,6 +245,7 @@ double oracle_big_step(const mh_big_scene* s, double dt, int nsteps, double* sta
   SceneView v = view_of(s, en);
   v.cp_nk = nk.data();
   World w(v, state, aux, zlast, zbuf, lcp_cap);
+  w.impact_model = s->impact_model;
   if (mode == 1) {
     w.broad_phase(0.0, w.pairs_to_check);              // the simulator's pair list of the step that just ended
     w.calc_pairwise_distances(w.pairs_to_check, w.pairwise);

@@ -67,6 +67,8 @@ struct Contact {            // UnilateralConstraint (eContact)
 
 struct PairDist { int pair, a, b; double dist; V3 pa, pb; };  // PairwiseDistInfo (global points)
 
+static int g_impact_model = MH_IMPACT_MODEL_DS;   // what the next World is built with: the reference's USE_AP build option
+static inline int oracle_impact_model() { return g_impact_model; }
 static unsigned long long g_ca_iters = 0;   // diagnostic: conservative-advancement sub-steps taken
 
 // What the stepper reads of a scene: the members of mh_scene under the same names, as pointers, so that scenes of any
@@ -89,6 +91,7 @@ class World {
   double* st;               // nb * 13
   mh_world_aux* aux;
   int32_t* trace = nullptr; int trace_cap = 0; int trace_len = 0;  // concatenated LCP traces (tests)
+  int impact_model = oracle_impact_model();                        // the reference's build option USE_AP (CMakeLists.txt:19)
 
   // body table and handler storage: the scene's / the aux record's by default; the impact-handler entry
   // (oracle_impact_process) and the big-scene stepper point them at caller arrays of any size instead
@@ -949,6 +952,131 @@ class World {
     }
   }
 
+  // ---- Anitescu-Potra model (ImpactConstraintHandlerLCP.cpp; the reference builds it with -DUSE_AP_MODEL) ------------
+  // NK_DIRS rows of one contact (ICH-AP:113-118)
+  static int ap_rows(int nk) { return (nk > 4) ? (nk + 4) / 4 : 1; }
+  // apply_ap_model's LCP (ICH-AP:94-330), contacts only: _MM = [UL UR; LL 0] over z = [cn, cs+, cs-, ct+, ct-, friction rows],
+  // UL block (a, b) = +/- C_a X C_b^T, LL = [mu, -cos, -cos, -sin, -sin], UR = friction part of -LL^T; column-major
+  void build_ap_lcp(const ProblemData& pd, std::vector<double>& MM, std::vector<double>& qq, int& n) const {
+    const int nc = pd.nc, nvars = 5 * nc;
+    int nkdirs = 0;
+    for (int i = 0; i < nc; i++) nkdirs += ap_rows(pd.c[i]->nk);
+    n = nvars + nkdirs;
+    MM.assign((size_t)n * n, 0.0); qq.assign(n, 0.0);
+    auto at = [&](int r, int c) -> double& { return MM[(size_t)r + (size_t)n * c]; };
+    const int dirs[5] = { 0, 1, 1, 2, 2 }; const double sgn[5] = { 1, 1, -1, 1, -1 };
+    for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++)
+      for (int i = 0; i < nc; i++) for (int j = 0; j < nc; j++) {
+        double g = Gab(pd, dirs[a], dirs[b], i, j);
+        if (sgn[a] * sgn[b] < 0) g = -g;
+        at(a * nc + i, b * nc + j) = g;
+      }
+    int r = nvars;
+    for (int i = 0; i < nc; i++) {
+      const int rows = ap_rows(pd.c[i]->nk);
+      for (int k = 0; k < rows; k++) {
+        // ICH-AP:250-295: polygon directions cos / sin(pi k / (2 nk4)); a 4-edge cone is the single row of ones
+        const double ck = (pd.c[i]->nk > 4) ? std::cos((M_PI * k) / (2.0 * rows)) : 1.0;
+        const double sk = (pd.c[i]->nk > 4) ? std::sin((M_PI * k) / (2.0 * rows)) : 1.0;
+        at(r + k, i) = pd.c[i]->mu;
+        at(r + k, nc + i) = -ck; at(r + k, 2*nc + i) = -ck; at(r + k, 3*nc + i) = -sk; at(r + k, 4*nc + i) = -sk;
+        at(nc + i, r + k) = ck;  at(2*nc + i, r + k) = ck;  at(3*nc + i, r + k) = sk;  at(4*nc + i, r + k) = sk;
+      }
+      r += rows;
+    }
+    for (int i = 0; i < nc; i++) {                               // ICH-AP:186-187, 305-311
+      qq[i] = pd.Cv[0][i]; qq[nc + i] = pd.Cv[1][i]; qq[2*nc + i] = -pd.Cv[1][i];
+      qq[3*nc + i] = pd.Cv[2][i]; qq[4*nc + i] = -pd.Cv[2][i];
+    }
+  }
+  // propagate_impulse_data (ICH:643-673): contact_impulse += the wrench of j = n cn + s cs + t ct at the contact point,
+  // moved to the global frame (angular part p x j)
+  void ap_propagate(const ProblemData& pd, std::vector<double>& wrench) const {
+    for (int i = 0; i < pd.nc; i++) {
+      const Contact& c = *pd.c[i];
+      V3 j = c.n * pd.cn[i]; j = j + c.s * pd.cs[i]; j = j + c.t * pd.ct[i];
+      const V3 a = cross(c.p, j);
+      double* w = &wrench[6 * (size_t)i];
+      w[0] = w[0] + j.x; w[1] = w[1] + j.y; w[2] = w[2] + j.z; w[3] = w[3] + a.x; w[4] = w[4] + a.y; w[5] = w[5] + a.z;
+      c.imp[0] += pd.cn[i]; c.imp[1] += pd.cs[i]; c.imp[2] += pd.ct[i];
+    }
+  }
+  bool apply_ap_model(ProblemData& pd, std::vector<double>& wrench) {
+    std::vector<double> MM, qq; int n;
+    build_ap_lcp(pd, MM, qq, n);
+    if (n > lcp_cap_) { aux->status |= MH_WORLD_UNSUPPORTED; return false; }
+    Vec z;                                                         // a fresh VectorNd (ICH-AP:331)
+    oracle_rand_t rs; std::memcpy(&rs, aux->rng, sizeof(rs));
+    LCP lcp; lcp.rng = &rs;
+    Trace tr; tr.buf = trace ? trace + trace_len : nullptr; tr.cap = trace ? std::max(0, trace_cap - trace_len) : 0;
+    lcp.trace = &tr;
+    const bool ok = lcp.lcp_lemke_regularized(n, MM.data(), n, qq.data(), z, -20, 1, -2);   // ICH-AP:333
+    trace_len += tr.len;
+    std::memcpy(aux->rng, &rs, sizeof(rs));
+    lcp_account(n, lcp.pivots);
+    if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; return false; }   // throw std::exception()
+    const int nc = pd.nc;
+    for (int i = 0; i < nc; i++) {                                   // ICH-AP:336-342
+      pd.cn[i] = z[i];
+      pd.cs[i] = z[nc + i] - z[2*nc + i];
+      pd.ct[i] = z[3*nc + i] - z[4*nc + i];
+    }
+    ap_propagate(pd, wrench);                                        // ICH-AP:350
+    return true;
+  }
+  // apply_impulses (ICH:676-745) for free bodies: every contact's accumulated wrench w on geom1's body, -w on geom2's,
+  // as generalized forces about the body's centre (convert_to_generalized_force), summed per body in contact order;
+  // then apply_generalized_impulse: v += M^-1 gj.  (Ravelin arithmetic, unpinned: the order here is the build's.)
+  void ap_apply_impulses(const ProblemData& pd, const std::vector<double>& wrench) {
+    const size_t nbod = pd.bodies.size();
+    std::vector<double> gj(6 * nbod, 0.0); std::vector<char> seen(nbod, 0);
+    for (int i = 0; i < pd.nc; i++) {
+      const Contact& c = *pd.c[i];
+      const int bodies2[2] = { c.g1, c.g2 };
+      for (int k = 0; k < 2; k++) {
+        const int b = bodies2[k];
+        if (!enabled(b)) continue;
+        const double sg = (k == 0) ? 1.0 : -1.0;
+        const V3 f = v3(sg * wrench[6*(size_t)i], sg * wrench[6*(size_t)i+1], sg * wrench[6*(size_t)i+2]);
+        const V3 tq = v3(sg * wrench[6*(size_t)i+3], sg * wrench[6*(size_t)i+4], sg * wrench[6*(size_t)i+5]) - cross(X(b), f);
+        const int o = gc_of(pd, b); const size_t bi = (size_t)o / 6;
+        const double g[6] = { f.x, f.y, f.z, tq.x, tq.y, tq.z };
+        if (!seen[bi]) { for (int q = 0; q < 6; q++) gj[o + q] = g[q]; seen[bi] = 1; }
+        else for (int q = 0; q < 6; q++) gj[o + q] = gj[o + q] + g[q];
+      }
+    }
+    for (size_t bi = 0; bi < nbod; bi++) {
+      if (!seen[bi]) continue;
+      const int b = pd.bodies[bi];
+      double im, Ji[9]; inv_inertia(b, im, Ji);
+      const double* g = &gj[6 * bi];
+      const V3 dv = v3(im * g[0], im * g[1], im * g[2]);
+      const V3 dw = v3((Ji[0] * g[3] + Ji[1] * g[4]) + Ji[2] * g[5], (Ji[3] * g[3] + Ji[4] * g[4]) + Ji[5] * g[5], (Ji[6] * g[3] + Ji[7] * g[4]) + Ji[8] * g[5]);
+      setV(b, Vl(b) + dv); setW(b, Wa(b) + dw);
+    }
+  }
+  // apply_ap_model_to_connected_constraints (ICH-AP:36-92)
+  void apply_ap_model_to_island(const std::vector<Contact>& all, const Island& isl) {
+    ProblemData pd; compute_problem_data(all, isl, pd, false);
+    const int nc = pd.nc;
+    for (int i = 0; i < nc; i++) { pd.c[i]->imp[0] = 0.0; pd.c[i]->imp[1] = 0.0; pd.c[i]->imp[2] = 0.0; }   // ICH-AP:52-55
+    std::vector<double> wrench(6 * (size_t)nc, 0.0);
+    if (!apply_ap_model(pd, wrench)) return;
+    update_constraint_vels(pd);                                      // ICH-AP:61
+    const double minv = *std::min_element(pd.Cv[0].begin(), pd.Cv[0].end());
+    bool changed = false;                                            // apply_restitution(q) (ICH:497-525)
+    for (int i = 0; i < nc; i++) { pd.cn[i] = pd.cn[i] * pd.c[i]->eps; if (!changed && pd.cn[i] > NEAR_ZERO) changed = true; }
+    if (changed) {
+      for (int i = 0; i < nc; i++) { pd.cs[i] = 0.0; pd.ct[i] = 0.0; }
+      update_constraint_vels(pd);
+      const double minv_plus = *std::min_element(pd.Cv[0].begin(), pd.Cv[0].end());
+      if (minv_plus < 0.0 && minv_plus < minv - NEAR_ZERO) {        // ICH-AP:78-82: the restitution impulses are never
+        if (!apply_ap_model(pd, wrench)) return;                    // propagated on this branch (the reference's behaviour)
+      } else ap_propagate(pd, wrench);
+    }
+    ap_apply_impulses(pd, wrench);                                   // ICH-AP:88
+  }
+
   // apply_model_to_connected_constraints (ICH:530-626), Drumwright-Shell path
   void apply_model(const std::vector<Contact>& all, const Island& isl) {
     ProblemData pd; compute_problem_data(all, isl, pd, false);
@@ -1004,6 +1132,7 @@ class World {
       bool all_inf = true;
       for (int ci : isl.contacts) if (cs[ci].mu < 1e2) all_inf = false;
       if (all_inf) apply_no_slip_model_to_island(cs, isl);              // ICH:134-135
+      else if (impact_model == MH_IMPACT_MODEL_AP) apply_ap_model_to_island(cs, isl);   // ICH:139-142
       else apply_model(cs, isl);
     }
     for (const Island& isl : active)

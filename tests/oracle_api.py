@@ -147,6 +147,13 @@ def oracle_impact_lcp(self, nb, mass, inertia, state, contacts, cap):
     return n, MM[:n * n].reshape(n, n).T.copy(), qq[:n].copy()
 
 
+def oracle_set_impact_model(self, model):
+    """MH_IMPACT_MODEL_DS / _AP for every world built from now on (the reference's USE_AP build option)."""
+    self.lib.oracle_set_impact_model.restype = None
+    self.lib.oracle_set_impact_model(int(model))
+
+
+Oracle.set_impact_model = oracle_set_impact_model
 Oracle.impact_process = oracle_impact_process
 Oracle.impact_lcp = oracle_impact_lcp
 

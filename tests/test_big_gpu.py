@@ -175,3 +175,18 @@ def test_contact_constrained_pendulum_matches_oracle(oracle):
     r = run_both(oracle, sc, st0, 1e-3, 40, chunks=3)
     assert_parity(*r)
     assert (r[1]["lcp_rows"] >= 48 * 120).all()
+
+
+def test_box_stacks_step_with_the_anitescu_potra_model(oracle):
+    """The same full steps with the scene in the reference's -DUSE_AP configuration (impact LCPs [UL UR; LL 0] through the
+    Lemke ladder, impulses through the contact wrenches); stabilisation is untouched by the model."""
+    nboxes, B = 3, 4
+    sc = K.box_stack_scene(nboxes, mu=0.3, impact_model=1)
+    st0 = K.box_stack_state(nboxes, B)
+    r = run_both(oracle, sc, st0, 1e-3, 5)
+    assert_parity(*r)
+    assert (r[1]["lcp_rows"] > 0).all() and (r[1]["zlast_size"] == 0).all()
+    sc_ds = K.box_stack_scene(nboxes, mu=0.3)
+    r_ds = run_both(oracle, sc_ds, st0, 1e-3, 5)
+    assert (r_ds[1]["zlast_size"] > 0).all()
+    assert np.abs(r[0] - r_ds[0]).max() < 1e-3             # two models of the same resting stack

@@ -296,3 +296,77 @@ def test_solver_state_checkpoint_resumes_bit_exact():
     bad = dict(ss); bad["zlast_size"] = ss["zlast_size"] + 1
     with pytest.raises(_lib.MobyHipError):
         b.load_solver_state(bad)
+
+
+# ---- Anitescu-Potra model (a batch in the reference's -DUSE_AP configuration) ------------------------------------------
+@pytest.fixture
+def ap_oracle(oracle):
+    oracle.set_impact_model(I.MH_IMPACT_MODEL_AP)
+    yield oracle
+    oracle.set_impact_model(I.MH_IMPACT_MODEL_DS)
+
+
+@pytest.mark.parametrize("nbx,B,eps,mu,nk", [(1, 4, 0.0, 0.3, 4), (2, 4, 0.0, 1e-4, 4), (3, 4, 0.4, 0.5, 4), (2, 4, 0.0, 0.3, 8),
+                                             (4, 3, 0.3, 0.5, 6), (3, 3, 0.0, 0.2, 16)])
+def test_ap_box_stacks_match_oracle(ap_oracle, nbx, B, eps, mu, nk):
+    """apply_ap_model (ICH-AP:94-370) on box stacks: n = 5 nc + nc NK_DIRS rows (wave solver up to 64, block solver above),
+    the Lemke ladder (-20, 1, -2) on a fresh z, restitution with and without the second solve, velocities through the
+    contacts' accumulated wrenches -- states, impulses, pivot counts and rand() streams bit for bit, three calls."""
+    mass, J, st, cs = I.box_stack(nbx, B=B, epsilon=eps, mu=mu, nk=nk)
+    nc = 4 * nbx; n = I.lcp_size(nc, nk)
+    ib = I.ImpactBatch(B, nbx, nc, nk, mass, J, model=I.MH_IMPACT_MODEL_AP)
+    aux = S.new_aux(B); zl = np.zeros((B, n)); zb = np.zeros((B, n))
+    st_g = st.copy(); st_o = st.copy()
+    for call in range(3):
+        r = ib.process(st_g, cs)
+        if call == 0:
+            MMg, qqg = ib.debug_lcp()
+            na = I.ap_lcp_size(nc, nk)
+            for w in range(min(B, 2)):
+                nn, MMo, qqo = ap_oracle.impact_lcp(nbx, mass, J, st[w].copy(), cs[w], n)
+                assert nn == na
+                if eps == 0.0:         # (with restitution the device's _qq is the second solve's)
+                    Mw = MMg[w].T.reshape(-1)[:na * na].reshape(na, na).T
+                    assert np.array_equal(MMo, Mw) and np.array_equal(qqo, qqg[w][:na])
+        imp_o, piv_o, sol_o = oracle_batch(ap_oracle, nbx, mass, J, st_o, cs, n, aux, zl, zb)
+        assert_same(r, st_o, imp_o, piv_o, sol_o, aux)
+        assert (aux["lcp_rows"] > 0).all()
+        st_g = r["state"].copy()
+        for a in (st_g, st_o):
+            a.reshape(B, nbx, 13)[:, :, 8] += -9.81e-3
+    assert (aux["zlast_size"] == 0).all()                  # the A-P path never touches the QP solver's _zlast
+    ib.close()
+
+
+@pytest.mark.parametrize("seed,nb,nc,nk", [(20, 4, 6, 4), (21, 6, 9, 8), (22, 7, 12, 4), (23, 3, 10, 12)])
+def test_ap_random_multi_island_graphs_match_oracle(ap_oracle, seed, nb, nc, nk):
+    """Random multi-island contact lists (mixed friction, restitution, static sides, rotated bodies) through the A-P model."""
+    rng = np.random.default_rng(seed)
+    B = 4
+    n = I.lcp_size(nc, nk)
+    mass = rng.uniform(0.5, 3.0, nb); J = rng.uniform(0.2, 2.0, (nb, 3))
+    cs = np.stack([random_forest(rng, nb, nc) for _ in range(B)]); cs["nk"] = nk
+    st = np.zeros((B, nb, 13)); st[:, :, 0:3] = rng.standard_normal((B, nb, 3))
+    q = rng.standard_normal((B, nb, 4)); st[:, :, 3:7] = q / np.linalg.norm(q, axis=2)[:, :, None]
+    st[:, :, 7:13] = rng.standard_normal((B, nb, 6))
+    st = st.reshape(B, -1)
+    ib = I.ImpactBatch(B, nb, nc, nk, mass, J, model=I.MH_IMPACT_MODEL_AP)
+    aux = S.new_aux(B); zl = np.zeros((B, n)); zb = np.zeros((B, n))
+    st_o = st.copy(); st_g = st.copy()
+    for call in range(2):
+        r = ib.process(st_g, cs)
+        imp_o, piv_o, sol_o = oracle_batch(ap_oracle, nb, mass, J, st_o, cs, n, aux, zl, zb)
+        assert_same(r, st_o, imp_o, piv_o, sol_o, aux)
+        st_g = r["state"].copy()
+        st_g.reshape(B, nb, 13)[:, :, 7:13] += 0.1 * rng.standard_normal((B, nb, 6)); st_o[:] = st_g
+    assert (r["solves"] >= 1).any()
+    ib.close()
+
+
+def test_ap_model_argument_check():
+    mass, J, st, cs = I.box_stack(1, B=1)
+    ib = I.ImpactBatch(1, 1, 4, 4, mass, J)
+    lib = _lib.load()
+    assert lib.mh_impact_batch_set_model(ib.handle, 7) == _lib.MH_ERR_INVALID_ARG
+    assert lib.mh_impact_batch_set_model(ib.handle, I.MH_IMPACT_MODEL_AP) == 0
+    ib.close()
