@@ -55,6 +55,18 @@ def pmc_traffic(B, steps):
     return per_world_step * B * steps
 
 
+def pmc_issue():
+    """Issue-slot figures of the same kernel from the committed SQ_* counter passes (profiles/pmc_issue.json): the share of
+    SIMD cycles with the vector ALU occupied, the wave-cycle breakdown, instructions per world-step.  The kernel is
+    issue / LDS-latency bound, so this -- not the HBM fraction -- is how far it is from its own roofline."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_issue.json")))
+        return {"valu_busy_frac": t["valu_busy_frac"], "wave_cycles": t["wave_cycles"], "per_world_step": t["per_world_step"],
+                "source": "profiles/pmc_issue.json"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def _cpu_worker(arg):
     """One process of the all-cores CPU baseline: `passes` x (nw worlds x ns steps) of the oracle."""
     first, nw, ns, passes = arg
@@ -381,7 +393,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(B, args.steps),
                      "kernel": "mh_k_world_step", "kernel_avg_us": kern_s * 1e6, "launches": 1,
-                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "algorithmic_bytes_per_launch": alg_bytes, "issue": pmc_issue(),
                      "model": "LCP-entry bytes 8(n^2+2n) per solved LCP (SURVEY 8d); the fused kernel itself only moves %d B of state per launch" % int(fused_bytes)},
     }
 

@@ -36,6 +36,12 @@ extern "C" {
 #define MH_PAIR_CLOSED_FORM 0   /* sphere-sphere, sphere-plane, box-plane */
 #define MH_PAIR_VERTEX_FACE 1   /* box (higher id) on the +Y face of a box (lower id) */
 
+#define MH_IJOINT_SPHERICAL 0     /* 3 equations (Ravelin::SphericalJointd)                              */
+#define MH_IJOINT_REVOLUTE  1    /* 5: the axis a_0 = a_1 (inboard) stays orthogonal to b_0, b_1 (outboard) */
+#define MH_IJOINT_FIXED     2     /* 6: a_k . b_k = 0 for three pairs of orthogonal axes                  */
+#define MH_IJOINT_MAX_BODIES 16   /* bodies of one jointed island (forward-dynamics KKT system of up to 96 coordinates) */
+#define MH_IJOINT_MAX_EQNS   96   /* constraint equations of one jointed island                            */
+
 #define MH_BIG_MAX_BODIES 128
 #define MH_BIG_MAX_PAIRS  256
 #define MH_BIG_MAX_CONTACTS 512   /* per world, impact or stabilisation list */
@@ -65,6 +71,20 @@ typedef struct mh_big_scene {
                                    an island that needs more flags its world MH_WORLD_UNSUPPORTED */
   int    impact_model;          /* MH_IMPACT_MODEL_DS (0, the reference's default build) or MH_IMPACT_MODEL_AP (its -DUSE_AP build):
                                    moby_hip_impact.h */
+  /* Implicit (bilateral) joints between free bodies, or between a body and the static world (id nb): the simulator's
+   * <ImplicitConstraint> list (ConstraintSimulator.cpp, Simulator::implicit_joints).  Forward dynamics of a jointed island
+   * is the KKT solve of Simulator::solve (src/Simulator.cpp:608-805) and joints connect constraint islands
+   * (src/UnilateralConstraint.cpp:993-1008).  A joint is 3 position rows (the joint point of both bodies coincides, global
+   * axes) plus 0 / 2 / 3 orientation rows "a_k . b_k = 0" with a_k fixed in the inboard and b_k in the outboard frame.
+   * Stabilisation of bilateral constraints is not built: a scene with joints must set cstab_max_iterations = 0. */
+  int njoints;
+  const int*    joint_type;       /* njoints: MH_IJOINT_*                                                          */
+  const int*    joint_inboard;    /* body id, or nb for the static world                                           */
+  const int*    joint_outboard;
+  const double* joint_anchor_in;  /* njoints x 3: the joint point in the inboard body's frame (global if the world)  */
+  const double* joint_anchor_out; /* njoints x 3                                                                    */
+  const double* joint_vec_in;     /* njoints x 9: a_0, a_1, a_2 in the inboard frame                                */
+  const double* joint_vec_out;    /* njoints x 9: b_0, b_1, b_2 in the outboard frame                               */
 } mh_big_scene;
 
 /* B worlds resident on the GPU.  mh_world_aux carries the rand() stream, time, status bits and counters; the

@@ -13,6 +13,8 @@ from . import _lib
 from . import scene as S
 
 MH_PAIR_CLOSED_FORM, MH_PAIR_VERTEX_FACE = 0, 1
+MH_IJOINT_SPHERICAL, MH_IJOINT_REVOLUTE, MH_IJOINT_FIXED = 0, 1, 2        # moby_hip_stack.h
+IJOINT_ROWS = {MH_IJOINT_SPHERICAL: 3, MH_IJOINT_REVOLUTE: 5, MH_IJOINT_FIXED: 6}
 _dp, _ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
 
 
@@ -27,6 +29,8 @@ class mh_big_scene(ctypes.Structure):
         ("nk", ctypes.c_int),
         ("min_step_size", ctypes.c_double), ("contact_dist_thresh", ctypes.c_double), ("cstab_eps", ctypes.c_double),
         ("cstab_max_iterations", ctypes.c_uint), ("lcp_n_max", ctypes.c_int), ("impact_model", ctypes.c_int),
+        ("njoints", ctypes.c_int), ("joint_type", _ip), ("joint_inboard", _ip), ("joint_outboard", _ip),
+        ("joint_anchor_in", _dp), ("joint_anchor_out", _dp), ("joint_vec_in", _dp), ("joint_vec_out", _dp),
     ]
 
 
@@ -35,7 +39,7 @@ class BigScene:
 
     def __init__(self, geom_type, geom_dim, mass, inertia, pairs, gravity, plane_R=None, plane_o=(0.0, 0.0, 0.0), has_ground=True,
                  nk=4, epsilon=0.0, mu_coulomb=0.0, mu_viscous=0.0, compliance=0.0,
-                 cstab_max_iterations=S.MH_CSTAB_DEFAULT_MAX_ITERATIONS, lcp_n_max=0, impact_model=0):
+                 cstab_max_iterations=S.MH_CSTAB_DEFAULT_MAX_ITERATIONS, lcp_n_max=0, impact_model=0, joints=()):
         self.geom_type = np.ascontiguousarray(geom_type, dtype=np.int32)
         self.nb = len(self.geom_type)
         self.geom_dim = np.ascontiguousarray(geom_dim, dtype=np.float64).reshape(self.nb, 3)
@@ -64,6 +68,18 @@ class BigScene:
         c.min_step_size = S.NEAR_ZERO; c.contact_dist_thresh = 1e-6; c.cstab_eps = S.NEAR_ZERO
         c.cstab_max_iterations = int(cstab_max_iterations); c.lcp_n_max = int(lcp_n_max)
         c.impact_model = int(impact_model)                     # MH_IMPACT_MODEL_DS / _AP (moby_hip_impact.h)
+        # implicit joints: records of make_joint() (the simulator's <ImplicitConstraint> list, in that order)
+        nj = len(joints)
+        self.joint_type = np.array([j["type"] for j in joints], dtype=np.int32)
+        self.joint_inboard = np.array([j["inboard"] for j in joints], dtype=np.int32)
+        self.joint_outboard = np.array([j["outboard"] for j in joints], dtype=np.int32)
+        arr = lambda key, w: np.ascontiguousarray(np.array([j[key] for j in joints], dtype=np.float64).reshape(nj, w))
+        self.joint_anchor_in, self.joint_anchor_out = arr("anchor_in", 3), arr("anchor_out", 3)
+        self.joint_vec_in, self.joint_vec_out = arr("vec_in", 9), arr("vec_out", 9)
+        c.njoints = nj
+        c.joint_type, c.joint_inboard, c.joint_outboard = P(self.joint_type, _ip), P(self.joint_inboard, _ip), P(self.joint_outboard, _ip)
+        c.joint_anchor_in, c.joint_anchor_out = P(self.joint_anchor_in, _dp), P(self.joint_anchor_out, _dp)
+        c.joint_vec_in, c.joint_vec_out = P(self.joint_vec_in, _dp), P(self.joint_vec_out, _dp)
         self.c = c
 
     @property
@@ -79,6 +95,36 @@ class BigScene:
                for a, m in zip(self.pair_a, self.pair_model)]
         nc = int(sum(per))
         return min(4096, max(64, 6 * nc + nc * (self.c.nk // 2)))
+
+
+def make_joint(kind, inboard, outboard, location, state, nb, axis=(0.0, 0.0, 1.0)):
+    """An implicit joint as the XML states it (<RevoluteJoint location= axis= inboard-link-id= outboard-link-id=>: global
+    location and axis at the bodies' reference poses) turned into the body-frame data of mh_big_scene.  ``state``: the
+    reference poses (nb x 13); a link id of nb (or -1) is the static world."""
+    st = np.asarray(state, dtype=np.float64).reshape(nb, S.MH_BODY_STATE)
+
+    def frame(b):
+        if b < 0 or b >= nb:
+            return np.eye(3), np.zeros(3)
+        x, y, z, w = st[b, 3:7]
+        return S.quat_to_R((x, y, z, w)), st[b, 0:3]
+    inboard = nb if inboard < 0 else inboard
+    outboard = nb if outboard < 0 else outboard
+    Ri, xi = frame(inboard); Ro, xo = frame(outboard)
+    p = np.asarray(location, dtype=np.float64)
+    a = np.asarray(axis, dtype=np.float64); a = a / np.linalg.norm(a)
+    vin = np.zeros((3, 3)); vout = np.zeros((3, 3))
+    if kind == MH_IJOINT_REVOLUTE:
+        from .synth import orthonormal_basis
+        v1, v2 = orthonormal_basis(a)                               # two directions orthogonal to the axis
+        vin[0] = Ri.T @ a; vin[1] = Ri.T @ a
+        vout[0] = Ro.T @ np.asarray(v1); vout[1] = Ro.T @ np.asarray(v2)
+    elif kind == MH_IJOINT_FIXED:
+        e = np.eye(3)
+        for k in range(3):                                          # e_k (inboard) stays orthogonal to e_{k+1} (outboard)
+            vin[k] = Ri.T @ e[k]; vout[k] = Ro.T @ e[(k + 1) % 3]
+    return dict(type=int(kind), inboard=int(inboard), outboard=int(outboard), anchor_in=Ri.T @ (p - xi), anchor_out=Ro.T @ (p - xo),
+                vec_in=vin.reshape(9), vec_out=vout.reshape(9))
 
 
 def pendulum_scene(cstab_max_iterations=25):

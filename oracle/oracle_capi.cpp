@@ -231,7 +231,26 @@ static SceneView view_of(const mh_big_scene* s, const std::vector<int>& enabled_
                     reinterpret_cast<const double (*)[3]>(s->inertia), s->plane_R, s->plane_o, s->gravity,
                     s->npairs, s->pair_a, s->pair_b, s->pair_model, enabled_all.data(),
                     s->cp_epsilon, s->cp_mu_coulomb, s->cp_mu_viscous, s->cp_compliance, nullptr,
-                    s->min_step_size, s->contact_dist_thresh, s->cstab_eps, s->cstab_max_iterations };
+                    s->min_step_size, s->contact_dist_thresh, s->cstab_eps, s->cstab_max_iterations,
+                    s->njoints, s->joint_type, s->joint_inboard, s->joint_outboard,
+                    reinterpret_cast<const double (*)[3]>(s->joint_anchor_in), reinterpret_cast<const double (*)[3]>(s->joint_anchor_out),
+                    reinterpret_cast<const double (*)[9]>(s->joint_vec_in), reinterpret_cast<const double (*)[9]>(s->joint_vec_out) };
+}
+
+// implicit joint j of a big scene at `state`: its constraint values C (6) and the two Jacobian blocks (6 x 6 each, row-major,
+// inboard then outboard) -- the tests differentiate one against the other
+void oracle_joint_eval(const mh_big_scene* s, double* state, int j, double* C, double* Cq_in, double* Cq_out)
+{
+  std::vector<int> en((size_t)s->npairs, 1);
+  SceneView v = view_of(s, en);
+  mh_world_aux aux; std::memset(&aux, 0, sizeof(aux));
+  World w(v, state, &aux, nullptr, nullptr, 0);
+  for (int k = 0; k < 6; k++) C[k] = 0.0;
+  w.joint_eval(j, C);
+  double A[6][6], B[6][6];
+  std::memset(A, 0, sizeof(A)); std::memset(B, 0, sizeof(B));
+  w.joint_jac(j, true, A); w.joint_jac(j, false, B);
+  std::memcpy(Cq_in, A, sizeof(A)); std::memcpy(Cq_out, B, sizeof(B));
 }
 
 // nsteps x TimeSteppingSimulator::step (mode 0) or one ConstraintStabilization::stabilize (mode 1) of ONE big world.

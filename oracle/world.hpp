@@ -82,6 +82,9 @@ struct SceneView {
   const int* pair_enabled; const double* cp_epsilon; const double* cp_mu_coulomb; const double* cp_mu_viscous;
   const double* cp_compliance; const int* cp_nk;
   double min_step_size, contact_dist_thresh, cstab_eps; unsigned cstab_max_iterations;
+  // implicit joints (mh_big_scene's fields, under the same names); absent in small scenes
+  int njoints; const int* joint_type; const int* joint_inboard; const int* joint_outboard;
+  const double (*joint_anchor_in)[3]; const double (*joint_anchor_out)[3]; const double (*joint_vec_in)[9]; const double (*joint_vec_out)[9];
 };
 
 class World {
@@ -104,7 +107,8 @@ class World {
     view_ = SceneView{ s->nb, s->has_ground, s->geom_type, s->geom_dim, s->mass, s->inertia, s->plane_R, s->plane_o, s->gravity,
                        ntot * (ntot - 1) / 2, nullptr, nullptr, nullptr,
                        s->pair_enabled, s->cp_epsilon, s->cp_mu_coulomb, s->cp_mu_viscous, s->cp_compliance, s->cp_nk,
-                       s->min_step_size, s->contact_dist_thresh, s->cstab_eps, s->cstab_max_iterations };
+                       s->min_step_size, s->contact_dist_thresh, s->cstab_eps, s->cstab_max_iterations,
+                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
   }
   World(int nb, const double* mass, const double (*inertia)[3], double* state, mh_world_aux* a, double* zlast, double* zbuf, int lcp_cap)
     : sc(nullptr), st(state), aux(a), nb_(nb), mass_(mass), inertia_(inertia), zlast_(zlast), zbuf_(zbuf), lcp_cap_(lcp_cap) {}
@@ -563,6 +567,188 @@ class World {
     for (int i = 3; i < 7; i++) st[13*b+i] = q[i] / nrm;
   }
 
+  // ---- implicit joints and the KKT forward dynamics (Simulator::solve, Sim:608-805) ---------------------------
+  // Joint::num_constraint_eqns / evaluate_constraints / calc_constraint_jacobian are Ravelin's (source not in the tree:
+  // parity unpinned).  Restated as the standard forms: 3 position rows C = p_in - p_out along the global axes, Jacobian
+  // rows [e_k, r x e_k] (inboard, + ; outboard, -) exactly like a contact row (ICH:1847-1895); orientation rows
+  // C = a . b with a fixed in the inboard and b in the outboard frame, Jacobian rows [0, a x b] (+ / -).
+  int njoints() const { return sc ? sc->njoints : 0; }
+  static int joint_rows(int type) { return type == MH_IJOINT_SPHERICAL ? 3 : (type == MH_IJOINT_REVOLUTE ? 5 : 6); }
+  V3 body_vec(int b, const double* u) const {           // R u for a dynamic body, u for the static world
+    if (!enabled(b)) return v3(u[0], u[1], u[2]);
+    double R[9]; rot(b, R);
+    return v3((R[0]*u[0] + R[1]*u[1]) + R[2]*u[2], (R[3]*u[0] + R[4]*u[1]) + R[5]*u[2], (R[6]*u[0] + R[7]*u[1]) + R[8]*u[2]);
+  }
+  void joint_eval(int j, double C[6]) const {
+    const int bi = sc->joint_inboard[j], bo = sc->joint_outboard[j];
+    const V3 ri = body_vec(bi, sc->joint_anchor_in[j]), ro = body_vec(bo, sc->joint_anchor_out[j]);
+    const V3 pi = enabled(bi) ? X(bi) + ri : ri, po = enabled(bo) ? X(bo) + ro : ro;
+    const V3 d = pi - po;
+    C[0] = d.x; C[1] = d.y; C[2] = d.z;
+    const int nori = joint_rows(sc->joint_type[j]) - 3;
+    for (int k = 0; k < nori; k++) C[3 + k] = dot(body_vec(bi, sc->joint_vec_in[j] + 3 * k), body_vec(bo, sc->joint_vec_out[j] + 3 * k));
+  }
+  void joint_jac(int j, bool inboard, double Cq[6][6]) const {
+    const int bi = sc->joint_inboard[j], bo = sc->joint_outboard[j];
+    const V3 r = inboard ? body_vec(bi, sc->joint_anchor_in[j]) : body_vec(bo, sc->joint_anchor_out[j]);
+    const double sg = inboard ? 1.0 : -1.0;
+    for (int k = 0; k < 3; k++) {
+      const V3 e = v3(k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0);
+      const V3 rxe = cross(r, e);
+      Cq[k][0] = e.x; Cq[k][1] = e.y; Cq[k][2] = e.z; Cq[k][3] = rxe.x; Cq[k][4] = rxe.y; Cq[k][5] = rxe.z;
+    }
+    const int nori = joint_rows(sc->joint_type[j]) - 3;
+    for (int k = 0; k < nori; k++) {
+      V3 axb = cross(body_vec(bi, sc->joint_vec_in[j] + 3 * k), body_vec(bo, sc->joint_vec_out[j] + 3 * k));
+      if (!inboard) axb = -axb;
+      Cq[3 + k][0] = 0.0; Cq[3 + k][1] = 0.0; Cq[3 + k][2] = 0.0; Cq[3 + k][3] = axb.x; Cq[3 + k][4] = axb.y; Cq[3 + k][5] = axb.z;
+    }
+  }
+  // Simulator::find_islands (Sim:956-1045): bodies connected by implicit joints whose two links are both enabled; islands
+  // from the lowest body id, then sorted (Sim:501) -- body ids stand for the reference's pointer order
+  void find_body_islands(std::vector<std::vector<int> >& islands) const {
+    const int nb = nb_;
+    std::vector<std::vector<int> > adj(nb);
+    for (int j = 0; j < njoints(); j++) {
+      const int a = sc->joint_inboard[j], b = sc->joint_outboard[j];
+      if (enabled(a) && enabled(b)) { adj[a].push_back(b); adj[b].push_back(a); }
+    }
+    std::vector<char> seen(nb, 0);
+    islands.clear();
+    for (int s = 0; s < nb; s++) {
+      if (seen[s]) continue;
+      std::vector<int> q; q.push_back(s); seen[s] = 1;
+      for (size_t qi = 0; qi < q.size(); qi++) for (int nbr : adj[q[qi]]) if (!seen[nbr]) { seen[nbr] = 1; q.push_back(nbr); }
+      std::sort(q.begin(), q.end());
+      islands.push_back(q);
+    }
+  }
+  // generalized force of a free body (gravity + the gyroscopic term), as fwd_dyn uses them
+  void gen_force(int b, double f[6]) const {
+    const double m = sc->mass[b];
+    f[0] = sc->gravity[0] * m; f[1] = sc->gravity[1] * m; f[2] = sc->gravity[2] * m;
+    double Jw[9]; inertia_world(b, Jw);
+    const V3 w = Wa(b);
+    const V3 Jww = v3((Jw[0]*w.x + Jw[1]*w.y) + Jw[2]*w.z, (Jw[3]*w.x + Jw[4]*w.y) + Jw[5]*w.z, (Jw[6]*w.x + Jw[7]*w.y) + Jw[8]*w.z);
+    const V3 tau = -cross(w, Jww);
+    f[3] = tau.x; f[4] = tau.y; f[5] = tau.z;
+  }
+  // Simulator::solve (Sim:608-805): accelerations a (6 per island body) of one island with implicit joints.
+  //   (J iM J') lambda = J v + J iM f dt on the largest leading full-rank row set (greedy Cholesky), a = (iM f dt - iM J' lambda) / dt
+  // Dense products accumulate from 0 over ascending indices.  Returns false when the island is beyond the built sizes.
+  bool solve_kkt(const std::vector<int>& island, const std::vector<int>& joints, double dt, std::vector<double>& a) const {
+    const int nbod = (int)island.size(), ngc = 6 * nbod;
+    int m = 0;
+    for (int j : joints) m += joint_rows(sc->joint_type[j]);
+    if (nbod > MH_IJOINT_MAX_BODIES || m > MH_IJOINT_MAX_EQNS) return false;
+    auto gc_of_body = [&](int b) { for (int i = 0; i < nbod; i++) if (island[i] == b) return 6 * i; return -1; };
+    std::vector<double> iM((size_t)nbod * 36, 0.0), f(ngc), v(ngc), iMf(ngc);
+    for (int i = 0; i < nbod; i++) {
+      const int b = island[i];
+      double im, Ji[9]; inv_inertia(b, im, Ji);
+      double* B = &iM[(size_t)i * 36];                                   // row-major 6 x 6, blockdiag(im I, Ji)
+      for (int k = 0; k < 3; k++) B[7 * k] = im;
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) B[6 * (3 + r) + 3 + c] = Ji[3 * r + c];
+      gen_force(b, &f[6 * i]);
+      const V3 vl = Vl(b), wa = Wa(b);
+      double* vv = &v[6 * i]; vv[0] = vl.x; vv[1] = vl.y; vv[2] = vl.z; vv[3] = wa.x; vv[4] = wa.y; vv[5] = wa.z;
+      for (int r = 0; r < 6; r++) { double acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + B[6 * r + k] * f[6 * i + k]; iMf[6 * i + r] = acc; }
+    }
+    for (int g = 0; g < ngc; g++) iMf[g] = iMf[g] * dt;
+    // Jacobian blocks: per joint the inboard block (if enabled) then the outboard block (Sim:679-706)
+    struct Blk { int row, off, rows; double w[6][6]; };
+    std::vector<Blk> blocks;
+    int eq = 0;
+    for (int j : joints) {
+      const int rows = joint_rows(sc->joint_type[j]);
+      const int sides[2] = { sc->joint_inboard[j], sc->joint_outboard[j] };
+      for (int sd = 0; sd < 2; sd++) {
+        if (!enabled(sides[sd])) continue;
+        Blk k; k.row = eq; k.off = gc_of_body(sides[sd]); k.rows = rows;
+        joint_jac(j, sd == 0, k.w);
+        blocks.push_back(k);
+      }
+      eq += rows;
+    }
+    // JiM = J iM (m x ngc), iMJT its transpose
+    std::vector<double> JiM((size_t)m * ngc, 0.0);
+    for (const Blk& k : blocks) {
+      const double* B = &iM[(size_t)(k.off / 6) * 36];
+      for (int r = 0; r < k.rows; r++) for (int c = 0; c < 6; c++) {
+        double acc = 0.0;
+        for (int q = 0; q < 6; q++) acc = acc + k.w[r][q] * B[6 * q + c];
+        JiM[(size_t)(k.row + r) * ngc + k.off + c] = acc;
+      }
+    }
+    // JiMJT (m x m) = J (JiM)', JiMf = JiM f dt, Jv = J v
+    std::vector<double> JiMJT((size_t)m * m, 0.0), JiMf(m, 0.0), Jv(m, 0.0);
+    for (const Blk& k : blocks) for (int r = 0; r < k.rows; r++) {
+      for (int c = 0; c < m; c++) {
+        double acc = 0.0;
+        for (int q = 0; q < 6; q++) acc = acc + k.w[r][q] * JiM[(size_t)c * ngc + k.off + q];
+        JiMJT[(size_t)(k.row + r) * m + c] = JiMJT[(size_t)(k.row + r) * m + c] + acc;
+      }
+      double acc = 0.0;
+      for (int q = 0; q < 6; q++) acc = acc + k.w[r][q] * v[k.off + q];
+      Jv[k.row + r] = Jv[k.row + r] + acc;
+    }
+    for (int r = 0; r < m; r++) { double acc = 0.0; for (int g = 0; g < ngc; g++) acc = acc + JiM[(size_t)r * ngc + g] * f[g]; JiMf[r] = acc * dt; }
+    // the biggest full-rank leading set (Sim:728-755): Cholesky of the selected square, row by row
+    std::vector<int> act;
+    std::vector<double> L;
+    for (int i = 0; i < m; i++) {
+      if ((int)act.size() == ngc) break;
+      act.push_back(i);
+      const int k = (int)act.size();
+      L.assign((size_t)k * k, 0.0);
+      for (int r = 0; r < k; r++) for (int c = 0; c < k; c++) L[r + (size_t)k * c] = JiMJT[(size_t)act[r] * m + act[c]];
+      if (!chol_factor(k, L.data(), k)) act.pop_back();
+    }
+    const int k = (int)act.size();
+    L.assign((size_t)k * k, 0.0);
+    for (int r = 0; r < k; r++) for (int c = 0; c < k; c++) L[r + (size_t)k * c] = JiMJT[(size_t)act[r] * m + act[c]];
+    if (k > 0) chol_factor(k, L.data(), k);
+    std::vector<double> lam(k);
+    for (int r = 0; r < k; r++) lam[r] = JiMf[act[r]] + Jv[act[r]];       // JiMf_frr += Jv_frr (Sim:769)
+    if (k > 0) chol_solve(k, L.data(), k, lam.data());
+    a.assign(ngc, 0.0);
+    for (int g = 0; g < ngc; g++) {
+      double acc = 0.0;
+      for (int r = 0; r < k; r++) acc = acc + JiM[(size_t)act[r] * ngc + g] * lam[r];   // iMJT_frr lambda (Sim:795)
+      a[g] = ((-acc) + iMf[g]) / dt;
+    }
+    return true;
+  }
+  // Simulator::calc_fwd_dyn (Sim:482-602) + the velocity integration of do_mini_step (TSS:181-192)
+  void fwd_dyn_and_integrate(double h) {
+    const int nb = sc->nb;
+    if (njoints() == 0) {
+      for (int b = 0; b < nb; b++) { V3 xdd, wd; fwd_dyn(b, xdd, wd); setV(b, Vl(b) + xdd * h); setW(b, Wa(b) + wd * h); }
+      return;
+    }
+    std::vector<std::vector<int> > islands; find_body_islands(islands);
+    std::vector<double> acc(6 * (size_t)nb, 0.0);
+    for (const std::vector<int>& isl : islands) {
+      std::vector<int> ij;                                           // the island's implicit joints (Sim:506-520)
+      for (int j = 0; j < njoints(); j++) {
+        const int a = sc->joint_inboard[j], b = sc->joint_outboard[j];
+        if ((enabled(a) && std::binary_search(isl.begin(), isl.end(), a)) || (enabled(b) && std::binary_search(isl.begin(), isl.end(), b))) ij.push_back(j);
+      }
+      if (ij.empty()) {
+        for (int b : isl) { V3 xdd, wd; fwd_dyn(b, xdd, wd); double* o = &acc[6 * (size_t)b]; o[0] = xdd.x; o[1] = xdd.y; o[2] = xdd.z; o[3] = wd.x; o[4] = wd.y; o[5] = wd.z; }
+        continue;
+      }
+      std::vector<double> a;
+      if (!solve_kkt(isl, ij, h, a)) { aux->status |= MH_WORLD_UNSUPPORTED; continue; }
+      for (size_t i = 0; i < isl.size(); i++) for (int k = 0; k < 6; k++) acc[6 * (size_t)isl[i] + k] = a[6 * i + k];
+    }
+    for (int b = 0; b < nb; b++) {
+      const double* o = &acc[6 * (size_t)b];
+      setV(b, Vl(b) + v3(o[0], o[1], o[2]) * h);
+      setW(b, Wa(b) + v3(o[3], o[4], o[5]) * h);
+    }
+  }
+
   // ---- impact handling ------------------------------------------------------
   struct Island { std::vector<int> contacts; std::vector<int> bodies; };
 
@@ -574,6 +760,12 @@ class World {
     std::vector<std::vector<int> > adj(nb);           // multimap in insertion order
     for (size_t i = 0; i < cs.size(); i++) {
       const int a = cs[i].g1, b = cs[i].g2;
+      if (enabled(a)) node[a] = 1;
+      if (enabled(b)) node[b] = 1;
+      if (enabled(a) && enabled(b)) { adj[a].push_back(b); adj[b].push_back(a); }
+    }
+    for (int j = 0; j < njoints(); j++) {                 // the implicit joints' links are nodes too, joined by an edge (UC:993-1008)
+      const int a = sc->joint_inboard[j], b = sc->joint_outboard[j];
       if (enabled(a)) node[a] = 1;
       if (enabled(b)) node[b] = 1;
       if (enabled(a) && enabled(b)) { adj[a].push_back(b); adj[b].push_back(a); }
@@ -1178,11 +1370,7 @@ class World {
       h += tc;
     }
     // forward dynamics + velocity integration by h (TSS:173-192)
-    for (int b = 0; b < nb; b++) {
-      V3 xdd, wd; fwd_dyn(b, xdd, wd);
-      setV(b, Vl(b) + xdd * h);
-      setW(b, Wa(b) + wd * h);
-    }
+    fwd_dyn_and_integrate(h);
     calc_pairwise_distances(pairs_to_check, pairwise);             // TSS:206
     std::vector<Contact> cs;                                       // find_unilateral_constraints (CSim:488-537)
     for (const PairDist& d : pairwise) if (d.dist < sc->contact_dist_thresh) find_contacts(d.pair, sc->contact_dist_thresh, cs);
@@ -1270,6 +1458,7 @@ class World {
   // ConstraintStabilization::stabilize (CStab:167-254)
   void stabilize() {
     if (sc->cstab_max_iterations == 0) return;
+    if (njoints() > 0) { aux->status |= MH_WORLD_UNSUPPORTED; return; }   // bilateral stabilisation (CStab:133-160, 531-700, 1132-1145) is not built
     const int nb = sc->nb;
     std::vector<double> vsave_v(6 * (size_t)nb);
     double (*vsave)[6] = reinterpret_cast<double (*)[6]>(vsave_v.data());

@@ -171,7 +171,18 @@ def oracle_big_step(self, scene, state, aux, dt, nsteps=1, zlast=None, zbuf=None
     return dict(seconds=secs, zlast=zlast, zbuf=zbuf)
 
 
+def oracle_joint_eval(self, scene, state, j):
+    """(C (6,), Cq_inboard (6, 6), Cq_outboard (6, 6)) of implicit joint j at ``state`` (nb*13,)."""
+    C = np.zeros(6); A = np.zeros((6, 6)); B = np.zeros((6, 6))
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    st = np.ascontiguousarray(state, dtype=np.float64)
+    self.lib.oracle_joint_eval.restype = None
+    self.lib.oracle_joint_eval(ctypes.byref(scene.c), P(st), int(j), P(C), P(A), P(B))
+    return C, A, B
+
+
 Oracle.big_step = oracle_big_step
+Oracle.joint_eval = oracle_joint_eval
 
 
 def oracle_artic_step(self, model, q, qd, aux, dt, nsteps=1):
