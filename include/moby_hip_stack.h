@@ -40,7 +40,8 @@ extern "C" {
 #define MH_IJOINT_REVOLUTE  1    /* 5: the axis a_0 = a_1 (inboard) stays orthogonal to b_0, b_1 (outboard) */
 #define MH_IJOINT_FIXED     2     /* 6: a_k . b_k = 0 for three pairs of orthogonal axes                  */
 #define MH_IJOINT_MAX_BODIES 16   /* bodies of one jointed island (forward-dynamics KKT system of up to 96 coordinates) */
-#define MH_IJOINT_MAX_EQNS   96   /* constraint equations of one jointed island                            */
+#define MH_IJOINT_MAX_JOINTS 16   /* joints of one jointed island                                           */
+#define MH_IJOINT_MAX_EQNS   48   /* constraint equations of one jointed island (J iM J' and its factor live in LDS) */
 
 #define MH_BIG_MAX_BODIES 128
 #define MH_BIG_MAX_PAIRS  256

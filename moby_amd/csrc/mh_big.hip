@@ -16,6 +16,7 @@
 // whether any world goes on (one int read back).  Arithmetic order follows oracle/world.hpp statement by statement.
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 #include "../../include/moby_hip_stack.h"
@@ -45,6 +46,13 @@ struct Dev {
   mh_contact* contacts; int* ncount; double* cdist;
   double* hdone; double* hmini; int* mini_active; unsigned* guard;
   int* stab_active; unsigned* stab_iter;
+  // implicit joints (scene tables) and the jointed islands of Simulator::find_islands, fixed per scene (host, create):
+  // island i holds kk_nbod[i] bodies (kk_body + i * MH_IJOINT_MAX_BODIES, ascending ids) and kk_nj[i] joints
+  // (kk_joint + i * KKJ, scene order) with kk_m[i] equations; jointed[b] marks the bodies k_mini_pre leaves to k_kkt_fwd
+  int nj, kk_nisl, kk_mmax;
+  const int* jtype; const int* jin; const int* jout; const double* janchor_in; const double* janchor_out; const double* jvec_in; const double* jvec_out;
+  const int* kk_nbod; const int* kk_body; const int* kk_nj; const int* kk_joint; const int* kk_m; const unsigned char* jointed;
+  double* kk_JiM;                            // B x kk_nisl x (kk_mmax x 6 MH_IJOINT_MAX_BODIES) scratch
   double* time; unsigned long long* steps; unsigned long long* mini_steps; unsigned long long* stab_iters;
   int* status; int* anyflag;
 };
@@ -411,6 +419,7 @@ void k_mini_pre(Dev d, double dt_step)
   __syncthreads();
   // forward dynamics + velocity integration by h (TSS:173-192): xdd = (g m) / m ; wd = Jw^-1 (0 - w x (Jw w))
   for (int bb = t; bb < nb; bb += T) {
+    if (d.jointed && d.jointed[bb]) continue;            // an island with implicit joints: Simulator::solve (k_kkt_fwd)
     const double m = d.mass[bb];
     const P3 f = p3(d.gravity[0] * m, d.gravity[1] * m, d.gravity[2] * m);
     const P3 xdd = f / m;
@@ -447,6 +456,170 @@ void k_mini_pre(Dev d, double dt_step)
     });
   }
   if (t == 0) { d.ncount[b] = total; d.nptc[b] = np; d.hmini[b] = h; if (s_stall) d.status[b] |= MH_WORLD_STALLED; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Simulator::calc_fwd_dyn for the islands with implicit joints (Sim:482-602): Simulator::solve (Sim:608-805) and the
+// velocity integration of do_mini_step (TSS:181-192).  One 64-thread workgroup per (island, world); the operation order
+// is oracle/world.hpp::solve_kkt's (dense products from 0 over ascending indices; the greedy full-rank selection is ONE
+// incremental Cholesky: a row appended at the end leaves the leading factor unchanged, so re-factorising from scratch
+// for every candidate, as the reference does, gives the same numbers).
+constexpr int KKB = MH_IJOINT_MAX_BODIES, KKM = MH_IJOINT_MAX_EQNS, KKJ = MH_IJOINT_MAX_JOINTS, KKT_T = 64;
+MH_DEV P3 body_vec(const W& w, int b, const double* u) {      // R u for a dynamic body, u for the static world
+  if (!w.enabled(b)) return p3(u[0], u[1], u[2]);
+  double R[9]; w.rot(b, R);
+  return p3((R[0]*u[0] + R[1]*u[1]) + R[2]*u[2], (R[3]*u[0] + R[4]*u[1]) + R[5]*u[2], (R[6]*u[0] + R[7]*u[1]) + R[8]*u[2]);
+}
+MH_DEV int joint_rows(int type) { return type == MH_IJOINT_SPHERICAL ? 3 : (type == MH_IJOINT_REVOLUTE ? 5 : 6); }
+// calc_constraint_jacobian (oracle World::joint_jac): rows x 6, row-major, into Cq[36]
+MH_DEV void joint_jac(const W& w, int j, bool inboard, double* Cq) {
+  const Dev& d = w.d;
+  const int bi = d.jin[j], bo = d.jout[j];
+  const P3 r = inboard ? body_vec(w, bi, d.janchor_in + 3 * j) : body_vec(w, bo, d.janchor_out + 3 * j);
+  const double sg = inboard ? 1.0 : -1.0;
+  for (int k = 0; k < 3; k++) {
+    const P3 e = p3(k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0);
+    const P3 rxe = cross3(r, e);
+    Cq[6*k] = e.x; Cq[6*k+1] = e.y; Cq[6*k+2] = e.z; Cq[6*k+3] = rxe.x; Cq[6*k+4] = rxe.y; Cq[6*k+5] = rxe.z;
+  }
+  const int nori = joint_rows(d.jtype[j]) - 3;
+  for (int k = 0; k < nori; k++) {
+    P3 axb = cross3(body_vec(w, bi, d.jvec_in + 9 * j + 3 * k), body_vec(w, bo, d.jvec_out + 9 * j + 3 * k));
+    if (!inboard) axb = -axb;
+    Cq[6*(3+k)] = 0.0; Cq[6*(3+k)+1] = 0.0; Cq[6*(3+k)+2] = 0.0; Cq[6*(3+k)+3] = axb.x; Cq[6*(3+k)+4] = axb.y; Cq[6*(3+k)+5] = axb.z;
+  }
+}
+
+__global__ __launch_bounds__(KKT_T)
+void k_kkt_fwd(Dev d)
+{
+  const int isl = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  if (!d.mini_active[b]) return;
+  W w(d, d.state + (size_t)b * d.nb * 13);
+  const double dt = d.hmini[b];                          // calc_fwd_dyn(h), then v += a h (TSS:179-192)
+  const int nbod = d.kk_nbod[isl], njl = d.kk_nj[isl], m = d.kk_m[isl], ngc = 6 * nbod;
+  const int* bodies = d.kk_body + isl * KKB;
+  const int* joints = d.kk_joint + isl * KKJ;
+  __shared__ double s_iM[KKB * 36], s_f[6 * KKB], s_v[6 * KKB], s_iMf[6 * KKB];
+  __shared__ double s_w[2 * KKJ * 36];                   // Jacobian blocks: joint jl, side sd at (2 jl + sd) * 36
+  __shared__ int s_brow[2 * KKJ], s_boff[2 * KKJ], s_brows[2 * KKJ];   // first row, gc offset (-1: static side), rows
+  __shared__ double s_A[KKM * KKM], s_L[KKM * KKM];      // J iM J' (row-major, ld m) and its Cholesky factor (ld m)
+  __shared__ double s_JiMf[KKM], s_Jv[KKM], s_lam[KKM];
+  __shared__ int s_act[KKM], s_nact;
+  double* JiM = d.kk_JiM + ((size_t)b * d.kk_nisl + isl) * ((size_t)d.kk_mmax * 6 * KKB);    // m x ngc, row-major
+  for (int i = t; i < nbod; i += KKT_T) {
+    const int bb = bodies[i];
+    double xi[10], Jw[9];
+    inv_inertia(w.st + 13 * bb, d.inertia + 3 * bb, d.mass[bb], xi, Jw);
+    double* Bm = s_iM + 36 * i;
+    for (int k = 0; k < 36; k++) Bm[k] = 0.0;
+    for (int k = 0; k < 3; k++) Bm[7 * k] = xi[0];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Bm[6 * (3 + r) + 3 + c] = xi[1 + 3 * r + c];
+    const double mm = d.mass[bb];
+    double* f = s_f + 6 * i;
+    f[0] = d.gravity[0] * mm; f[1] = d.gravity[1] * mm; f[2] = d.gravity[2] * mm;
+    const P3 om = w.Wa(bb);
+    const P3 Jww = p3((Jw[0]*om.x + Jw[1]*om.y) + Jw[2]*om.z, (Jw[3]*om.x + Jw[4]*om.y) + Jw[5]*om.z, (Jw[6]*om.x + Jw[7]*om.y) + Jw[8]*om.z);
+    const P3 tau = -cross3(om, Jww);
+    f[3] = tau.x; f[4] = tau.y; f[5] = tau.z;
+    for (int k = 0; k < 6; k++) s_v[6 * i + k] = w.st[13 * bb + 7 + k];
+    for (int r = 0; r < 6; r++) { double acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + Bm[6 * r + k] * f[k]; s_iMf[6 * i + r] = acc * dt; }
+  }
+  if (t == 0) {                                          // block table: rows of each joint side
+    int eq = 0;
+    for (int jl = 0; jl < njl; jl++) {
+      const int j = joints[jl], rows = joint_rows(d.jtype[j]);
+      const int sides[2] = { d.jin[j], d.jout[j] };
+      for (int sd = 0; sd < 2; sd++) {
+        int off = -1;
+        if (w.enabled(sides[sd])) for (int i = 0; i < nbod; i++) if (bodies[i] == sides[sd]) off = 6 * i;
+        s_brow[2 * jl + sd] = eq; s_boff[2 * jl + sd] = off; s_brows[2 * jl + sd] = rows;
+      }
+      eq += rows;
+    }
+  }
+  __syncthreads();
+  for (int k = t; k < 2 * njl; k += KKT_T) if (s_boff[k] >= 0) joint_jac(w, joints[k >> 1], (k & 1) == 0, s_w + 36 * k);
+  for (int e = t; e < m * ngc; e += KKT_T) JiM[e] = 0.0;
+  __syncthreads();
+  // JiM = J iM: block k covers rows s_brow .. + rows, columns s_boff .. + 6
+  for (int k = 0; k < 2 * njl; k++) {
+    if (s_boff[k] < 0) continue;
+    const double* Bm = s_iM + 36 * (s_boff[k] / 6);
+    for (int e = t; e < s_brows[k] * 6; e += KKT_T) {
+      const int r = e / 6, c = e - 6 * r;
+      double acc = 0.0;
+      for (int q = 0; q < 6; q++) acc = acc + s_w[36 * k + 6 * r + q] * Bm[6 * q + c];
+      JiM[(size_t)(s_brow[k] + r) * ngc + s_boff[k] + c] = acc;
+    }
+  }
+  __syncthreads();
+  // J iM J' (row, c): the row's blocks in order (inboard, outboard), each a 6-term product; J v and J iM f dt likewise
+  for (int e = t; e < m * m; e += KKT_T) {
+    const int row = e / m, c = e - row * m;
+    double tot = 0.0;
+    for (int k = 0; k < 2 * njl; k++) {
+      if (s_boff[k] < 0 || row < s_brow[k] || row >= s_brow[k] + s_brows[k]) continue;
+      const int r = row - s_brow[k];
+      double acc = 0.0;
+      for (int q = 0; q < 6; q++) acc = acc + s_w[36 * k + 6 * r + q] * JiM[(size_t)c * ngc + s_boff[k] + q];
+      tot = tot + acc;
+    }
+    s_A[row * m + c] = tot;
+  }
+  for (int row = t; row < m; row += KKT_T) {
+    double tot = 0.0;
+    for (int k = 0; k < 2 * njl; k++) {
+      if (s_boff[k] < 0 || row < s_brow[k] || row >= s_brow[k] + s_brows[k]) continue;
+      const int r = row - s_brow[k];
+      double acc = 0.0;
+      for (int q = 0; q < 6; q++) acc = acc + s_w[36 * k + 6 * r + q] * s_v[s_boff[k] + q];
+      tot = tot + acc;
+    }
+    s_Jv[row] = tot;
+    double acc = 0.0;
+    for (int g = 0; g < ngc; g++) acc = acc + JiM[(size_t)row * ngc + g] * s_f[g];
+    s_JiMf[row] = acc * dt;
+  }
+  __syncthreads();
+  if (t == 0) {
+    // the biggest full-rank leading set (Sim:728-755), dpotf2 'L' arithmetic row by row; then lambda (Sim:769-789)
+    int k = 0;
+    for (int i = 0; i < m; i++) {
+      if (k == ngc) break;
+      bool ok = true;
+      for (int j = 0; j < k; j++) {
+        double tv = s_A[i * m + s_act[j]];
+        for (int p = 0; p < j; p++) tv = tv - s_L[k * m + p] * s_L[j * m + p];
+        s_L[k * m + j] = tv / s_L[j * m + j];
+      }
+      double ajj = s_A[i * m + i];
+      for (int p = 0; p < k; p++) ajj = ajj - s_L[k * m + p] * s_L[k * m + p];
+      if (!(ajj > 0.0)) ok = false;
+      if (ok) { s_L[k * m + k] = sqrt(ajj); s_act[k] = i; k++; }
+    }
+    for (int r = 0; r < k; r++) s_lam[r] = s_JiMf[s_act[r]] + s_Jv[s_act[r]];
+    for (int c = 0; c < k; c++) {                        // chol_solve: L y = b, L' x = y
+      s_lam[c] = s_lam[c] / s_L[c * m + c];
+      const double bk = s_lam[c];
+      for (int i = c + 1; i < k; i++) s_lam[i] = s_lam[i] - bk * s_L[i * m + c];
+    }
+    for (int c = k - 1; c >= 0; c--) {
+      double tv = s_lam[c];
+      for (int i = c + 1; i < k; i++) tv = tv - s_L[i * m + c] * s_lam[i];
+      s_lam[c] = tv / s_L[c * m + c];
+    }
+    s_nact = k;
+  }
+  __syncthreads();
+  const int k = s_nact;
+  for (int g = t; g < ngc; g += KKT_T) {
+    double acc = 0.0;
+    for (int r = 0; r < k; r++) acc = acc + JiM[(size_t)s_act[r] * ngc + g] * s_lam[r];
+    const double a = ((-acc) + s_iMf[g]) / dt;
+    const int bb = bodies[g / 6], q = g - 6 * (g / 6);
+    w.st[13 * bb + 7 + q] = w.st[13 * bb + 7 + q] + a * dt;
+  }
 }
 
 // the tail of do_mini_step (TSS:215) and of the loop in step_si_Euler (TSS:433-455)
@@ -758,6 +931,51 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
     else if ((boxa || boxb) && bq != nb) return fail(MH_ERR_INVALID_ARG, "pair %d: box-box / box-sphere contact is only built as MH_PAIR_VERTEX_FACE", p);
     ncmax += (boxa || boxb) ? 4 : (pina ? 3 : 1);                        // a box face rests on at most 4 vertices ... of a box in general position; 8 fit below
   }
+  // implicit joints: tables, then the islands of Simulator::find_islands (Sim:956-1045) that contain a joint -- bodies
+  // connected by joints whose two links are dynamic, from the lowest id, sorted (Sim:501); a joint belongs to the island
+  // of either of its dynamic links (Sim:506-520)
+  const int nj = sc->njoints;
+  std::vector<int> kk_nbod, kk_body, kk_nj, kk_joint, kk_m;
+  std::vector<unsigned char> jointed((size_t)nb, 0);
+  int kk_mmax = 0;
+  if (nj < 0) return fail(MH_ERR_INVALID_ARG, "njoints = %d", nj);
+  if (nj > 0) {
+    if (!sc->joint_type || !sc->joint_inboard || !sc->joint_outboard || !sc->joint_anchor_in || !sc->joint_anchor_out || !sc->joint_vec_in || !sc->joint_vec_out)
+      return fail(MH_ERR_INVALID_ARG, "null joint table");
+    if (sc->cstab_max_iterations != 0)
+      return fail(MH_ERR_INVALID_ARG, "a scene with implicit joints needs cstab_max_iterations = 0: stabilisation of bilateral constraints "
+                                      "(ConstraintStabilization.cpp:133-160, 531-700, 1132-1145) is not built");
+    std::vector<std::vector<int> > adj((size_t)nb);
+    for (int j = 0; j < nj; j++) {
+      const int a = sc->joint_inboard[j], bq = sc->joint_outboard[j], ty = sc->joint_type[j];
+      if (ty != MH_IJOINT_SPHERICAL && ty != MH_IJOINT_REVOLUTE && ty != MH_IJOINT_FIXED) return fail(MH_ERR_INVALID_ARG, "joint %d: type %d (MH_IJOINT_*)", j, ty);
+      if (a < 0 || a > nb || bq < 0 || bq > nb || a == bq) return fail(MH_ERR_INVALID_ARG, "joint %d: links (%d, %d) must be two different ids in [0, nb]", j, a, bq);
+      if (a < nb && bq < nb) { adj[a].push_back(bq); adj[bq].push_back(a); }
+    }
+    std::vector<char> seen((size_t)nb, 0);
+    for (int s0 = 0; s0 < nb; s0++) {
+      if (seen[s0]) continue;
+      std::vector<int> q; q.push_back(s0); seen[s0] = 1;
+      for (size_t qi = 0; qi < q.size(); qi++) for (int nbr : adj[q[qi]]) if (!seen[nbr]) { seen[nbr] = 1; q.push_back(nbr); }
+      std::sort(q.begin(), q.end());
+      std::vector<int> ij; int m = 0;
+      for (int j = 0; j < nj; j++) {
+        const int a = sc->joint_inboard[j], bq = sc->joint_outboard[j];
+        if ((a < nb && std::binary_search(q.begin(), q.end(), a)) || (bq < nb && std::binary_search(q.begin(), q.end(), bq))) {
+          ij.push_back(j); m += (sc->joint_type[j] == MH_IJOINT_SPHERICAL) ? 3 : (sc->joint_type[j] == MH_IJOINT_REVOLUTE ? 5 : 6);
+        }
+      }
+      if (ij.empty()) continue;
+      if ((int)q.size() > MH_IJOINT_MAX_BODIES || (int)ij.size() > MH_IJOINT_MAX_JOINTS || m > MH_IJOINT_MAX_EQNS)
+        return fail(MH_ERR_UNSUPPORTED_N, "jointed island of %d bodies, %d joints, %d equations (limits %d, %d, %d)", (int)q.size(), (int)ij.size(), m,
+                    MH_IJOINT_MAX_BODIES, MH_IJOINT_MAX_JOINTS, MH_IJOINT_MAX_EQNS);
+      kk_nbod.push_back((int)q.size()); kk_nj.push_back((int)ij.size()); kk_m.push_back(m);
+      q.resize(MH_IJOINT_MAX_BODIES, 0); ij.resize(MH_IJOINT_MAX_JOINTS, 0);
+      kk_body.insert(kk_body.end(), q.begin(), q.end()); kk_joint.insert(kk_joint.end(), ij.begin(), ij.end());
+      for (int i = 0; i < kk_nbod.back(); i++) jointed[(size_t)q[i]] = 1;
+      if (m > kk_mmax) kk_mmax = m;
+    }
+  }
   ncmax *= 2;                                               // a box lying inside the tolerance band can put all 8 vertices in contact
   if (ncmax < 8) ncmax = 8;
   if (ncmax > MH_BIG_MAX_CONTACTS) ncmax = MH_BIG_MAX_CONTACTS;
@@ -798,6 +1016,20 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
   d.cp_eps = (const double*)U(sc->cp_epsilon, np * 8); d.cp_mu = (const double*)U(sc->cp_mu_coulomb, np * 8);
   d.cp_muv = (const double*)U(sc->cp_mu_viscous, np * 8); d.cp_comp = (const double*)U(sc->cp_compliance, np * 8);
   d.min_step = sc->min_step_size; d.thresh = sc->contact_dist_thresh; d.cstab_eps = sc->cstab_eps; d.cstab_maxit = sc->cstab_max_iterations;
+  d.nj = nj; d.kk_nisl = (int)kk_nbod.size(); d.kk_mmax = kk_mmax;
+  if (nj > 0) {
+    d.jtype = (const int*)U(sc->joint_type, nj * 4); d.jin = (const int*)U(sc->joint_inboard, nj * 4); d.jout = (const int*)U(sc->joint_outboard, nj * 4);
+    d.janchor_in = (const double*)U(sc->joint_anchor_in, nj * 24); d.janchor_out = (const double*)U(sc->joint_anchor_out, nj * 24);
+    d.jvec_in = (const double*)U(sc->joint_vec_in, nj * 72); d.jvec_out = (const double*)U(sc->joint_vec_out, nj * 72);
+    d.jointed = (const unsigned char*)U(jointed.data(), nb);
+    if (d.kk_nisl > 0) {
+      d.kk_nbod = (const int*)U(kk_nbod.data(), kk_nbod.size() * 4); d.kk_body = (const int*)U(kk_body.data(), kk_body.size() * 4);
+      d.kk_nj = (const int*)U(kk_nj.data(), kk_nj.size() * 4); d.kk_joint = (const int*)U(kk_joint.data(), kk_joint.size() * 4);
+      d.kk_m = (const int*)U(kk_m.data(), kk_m.size() * 4);
+      d.kk_JiM = (double*)A((size_t)B * d.kk_nisl * kk_mmax * 6 * MH_IJOINT_MAX_BODIES * 8, true);
+    }
+    bb->core.nj = nj; bb->core.jin = d.jin; bb->core.jout = d.jout;     // joint edges of the constraint islands (UC:993-1008)
+  }
   const size_t sB = (size_t)B;
   d.state = (double*)A(sB * nb * 13 * 8, true); d.qsave = (double*)A(sB * nb * 7 * 8, true); d.vsave = (double*)A(sB * nb * 6 * 8, true);
   d.qstab = (double*)A(sB * nb * 7 * 8, true); d.dq = (double*)A(sB * nb * 7 * 8, true);
@@ -901,6 +1133,7 @@ int mh_big_batch_step(mh_big_batch* bb, void* stream, double dt, int nsteps)
     while (any) {                                           // step_si_Euler: while (h < dt) h += do_mini_step(dt - h)
       MH_HIP(hipMemsetAsync(bb->d.anyflag, 0, sizeof(int), s));
       hipLaunchKernelGGL(bg::k_mini_pre, dim3(B), dim3(bg::T), 0, s, bb->d, dt);
+      if (bb->d.kk_nisl > 0) hipLaunchKernelGGL(bg::k_kkt_fwd, dim3(bb->d.kk_nisl, B), dim3(bg::KKT_T), 0, s, bb->d);
       MH_HIP(hipGetLastError());
       int rc = mh_imp_core_process(&bb->core, s, MH_CORE_IMPACT);
       if (rc != MH_OK) return rc;

@@ -36,6 +36,9 @@ struct mh_imp_core {
   // finite friction through it.  nk4 = NK_DIRS rows per contact, apcos / apsin their polygon directions (host libm),
   // apw = the contacts' accumulated impulse wrenches in the global frame (B x ncmax x 6, island order)
   int ap, nk4; const double* apcos; const double* apsin; double* apw;
+  // implicit joints of the scene (0 / NULL without): their dynamic links are nodes of the island search and an edge
+  // joins the two (UC:993-1008); the handler itself never sees their rows (island_ijoints stays empty in ICH)
+  int nj; const int* jin; const int* jout;
   double* ws_d; int* ws_i;                          // block-solver workspace (nmax > 64)
   int* hmax;                                        // pinned host copy of maxisl
   void* allocs[48]; int nallocs;

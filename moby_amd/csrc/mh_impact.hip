@@ -78,6 +78,11 @@ void k_prep(Dev d, int mode)
     if ((mode == MH_CORE_IMPACT && C[i].nk != d.nk) || !(nn > 0.25 && nn < 4.0) || g1 == g2) s_flag[1] = 1;
   }
   for (int i = t; i < nb; i += T) inv_inertia(st + 13 * i, d.inertia + 3 * i, d.mass[i], xinv + 10 * i);
+  for (int j = t; j < d.nj; j += T) {                    // the joints' dynamic links are nodes as well (UC:993-1008)
+    const int a = d.jin[j], c = d.jout[j];
+    if (a >= 0 && a < nb) s_node[a] = 1;
+    if (c >= 0 && c < nb) s_node[c] = 1;
+  }
   __syncthreads();
   if (t == 0) {
     int cnt = 0, nisl = 0;
@@ -101,6 +106,12 @@ void k_prep(Dev d, int mode)
             if (g1 < 0 || g2 < 0) continue;
             int other = -1;
             if (g1 == nd) other = g2; else if (g2 == nd) other = g1;
+            if (other >= 0 && !s_queued[other]) { s_queued[other] = 1; s_queue[qlen++] = other; }
+          }
+          for (int j = 0; j < d.nj; j++) {               // joint edges come after the contact edges in the multimap
+            const int a = d.jin[j], c = d.jout[j];
+            if (a < 0 || a >= nb || c < 0 || c >= nb) continue;
+            const int other = (a == nd) ? c : ((c == nd) ? a : -1);
             if (other >= 0 && !s_queued[other]) { s_queued[other] = 1; s_queue[qlen++] = other; }
           }
           for (int i = 0; i < nc; i++)

@@ -640,7 +640,7 @@ class World {
     const int nbod = (int)island.size(), ngc = 6 * nbod;
     int m = 0;
     for (int j : joints) m += joint_rows(sc->joint_type[j]);
-    if (nbod > MH_IJOINT_MAX_BODIES || m > MH_IJOINT_MAX_EQNS) return false;
+    if (nbod > MH_IJOINT_MAX_BODIES || (int)joints.size() > MH_IJOINT_MAX_JOINTS || m > MH_IJOINT_MAX_EQNS) return false;
     auto gc_of_body = [&](int b) { for (int i = 0; i < nbod; i++) if (island[i] == b) return 6 * i; return -1; };
     std::vector<double> iM((size_t)nbod * 36, 0.0), f(ngc), v(ngc), iMf(ngc);
     for (int i = 0; i < nbod; i++) {

@@ -1,0 +1,105 @@
+"""GPU parity of the implicit-joint path of the large-world stepper (include/moby_hip_stack.h: mh_big_scene.njoints ...)
+against the oracle: Simulator::solve's KKT forward dynamics (src/Simulator.cpp:608-805) for every jointed island, joint
+edges in the constraint islands (src/UnilateralConstraint.cpp:993-1008) -- states, counters and rand() streams bit for bit."""
+import numpy as np
+import pytest
+
+from moby_amd import scene as S, stack as K
+from tests.test_oracle_joints import free_scene, rest_state
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "stab_iters", "lcp_alg_bytes", "stab_rows",
+          "zlast_size", "zbuf_size", "zbuf_cap")
+
+
+def run_both(oracle, sc, st0, dt, nsteps, chunks=1):
+    B = st0.shape[0]
+    bb = K.BigBatch(sc, st0)
+    cap = bb.cap
+    st_o = st0.copy(); aux_o = S.new_aux(B); zl = np.zeros((B, cap)); zb = np.zeros((B, cap))
+    for _ in range(chunks):
+        bb.step(dt, nsteps)
+        for w in range(B):
+            oracle.big_step(sc, st_o[w], aux_o[w:w + 1], dt, nsteps, zlast=zl[w], zbuf=zb[w], cap=cap)
+    st_g, aux_g = bb.download()
+    bb.close()
+    for f in FIELDS:
+        assert np.array_equal(aux_g[f], aux_o[f]), "%s: gpu %r oracle %r" % (f, aux_g[f], aux_o[f])
+    assert np.array_equal(st_g, st_o), "max |diff| = %.3e" % np.abs(st_g - st_o).max()
+    return st_g, aux_g
+
+
+def perturbed(st, B, seed, vel=0.3):
+    rng = np.random.default_rng(seed)
+    out = np.repeat(st.reshape(1, -1, 13), B, axis=0).copy()
+    out[1:, :, 7:13] += vel * rng.standard_normal((B - 1, st.shape[0], 6))
+    return out.reshape(B, -1)
+
+
+def test_revolute_pendulums_match_oracle(oracle):
+    th0 = 0.4
+    st = rest_state([[np.sin(th0), -np.cos(th0), 0.0]])
+    st[0, 3:7] = (0.0, 0.0, np.sin(th0 / 2), np.cos(th0 / 2))
+    sc = free_scene(1, [K.make_joint(K.MH_IJOINT_REVOLUTE, 1, 0, (0.0, 0.0, 0.0), st, 1, axis=(0, 0, 1))])
+    st_g, aux = run_both(oracle, sc, perturbed(st, 6, 1), 1e-3, 100, chunks=2)
+    assert (aux["status"] == 0).all() and (aux["lcp_solves"] == 0).all()
+    assert np.abs(st_g[0].reshape(1, 13)[0, [2, 9, 10, 11]]).max() < 1e-12
+
+
+def test_chains_of_spherical_joints_and_a_weld_match_oracle(oracle):
+    """World - s0 - s1 - s2 (spherical joints) with s3 welded to s2, plus a free body: one jointed island of four bodies
+    (3 + 3 + 3 + 6 equations), one island without joints that keeps the free-body forward dynamics."""
+    nb = 5
+    st = rest_state([[0.5, 0.0, 0.0], [1.5, 0.0, 0.0], [2.5, 0.0, 0.0], [2.5, 0.6, 0.0], [0.0, 3.0, 0.0]])
+    joints = [K.make_joint(K.MH_IJOINT_SPHERICAL, nb, 0, (0.0, 0.0, 0.0), st, nb),
+              K.make_joint(K.MH_IJOINT_SPHERICAL, 0, 1, (1.0, 0.0, 0.0), st, nb),
+              K.make_joint(K.MH_IJOINT_SPHERICAL, 2, 1, (2.0, 0.0, 0.0), st, nb),      # inboard / outboard swapped on purpose
+              K.make_joint(K.MH_IJOINT_FIXED, 2, 3, (2.5, 0.3, 0.0), st, nb)]
+    sc = free_scene(nb, joints, mass=[1.0, 2.0, 0.5, 1.5, 1.0])
+    st_g, aux = run_both(oracle, sc, perturbed(st, 5, 2), 1e-3, 60, chunks=2)
+    assert (aux["status"] == 0).all()
+    b = st_g.reshape(5, nb, 13)
+    assert abs(b[0, 4, 8] + 9.81 * 0.12) < 1e-12                    # the free body just falls: v = g t
+
+
+def test_redundant_and_closed_loop_joints_match_oracle(oracle):
+    """A closed loop (world - a - b - world) and a doubled joint: J iM J' is rank deficient, the greedy Cholesky of
+    Simulator::solve (Sim:728-755) drops the dependent rows -- identically on both sides."""
+    nb = 2
+    st = rest_state([[0.5, 0.0, 0.0], [1.5, 0.0, 0.0]])
+    j1 = K.make_joint(K.MH_IJOINT_REVOLUTE, nb, 0, (0.0, 0.0, 0.0), st, nb, axis=(0, 0, 1))
+    j2 = K.make_joint(K.MH_IJOINT_REVOLUTE, 0, 1, (1.0, 0.0, 0.0), st, nb, axis=(0, 0, 1))
+    j3 = K.make_joint(K.MH_IJOINT_REVOLUTE, 1, nb, (2.0, 0.0, 0.0), st, nb, axis=(0, 0, 1))
+    sc = free_scene(nb, [j1, j2, j3, j2])
+    st_g, aux = run_both(oracle, sc, perturbed(st, 4, 3, vel=0.1), 1e-3, 40)
+    assert (aux["status"] == 0).all()
+
+
+def test_joints_merge_contact_islands_and_step_with_impacts(oracle):
+    """Spheres dropped on the plane, two of them tied by a spherical joint, a third welded on top of the second: the joint
+    edges merge constraint islands (one impact LCP for the tied spheres), the impact handler ignores the joint rows (as the
+    reference's does), forward dynamics of the jointed island is the KKT solve.  (The run ends before anything comes to
+    rest: with stabilisation off a resting contact sinks, conservative advancement then returns 0 and Simulator::solve
+    divides by that h -- in the reference as in the oracle.)"""
+    r = 0.2
+    nb = 4
+    h0 = 0.03
+    st = rest_state([[0.0, r + h0, 0.0], [1.0, r + h0, 0.0], [1.0, r + h0 + 0.5, 0.0], [3.0, r + 0.3, 0.0]])
+    joints = [K.make_joint(K.MH_IJOINT_SPHERICAL, 0, 1, (0.5, r + h0, 0.0), st, nb),
+              K.make_joint(K.MH_IJOINT_FIXED, 1, 2, (1.0, r + h0 + 0.25, 0.0), st, nb)]
+    sc = K.BigScene([S.MH_GEOM_SPHERE] * nb, [(r, 0, 0)] * nb, [1.0, 1.0, 0.5, 1.0], [[0.016] * 3] * 2 + [[0.008] * 3] + [[0.016] * 3],
+                    [(k, nb, 0) for k in range(nb)], gravity=(0.0, -9.81, 0.0), cstab_max_iterations=0, joints=joints, lcp_n_max=64,
+                    mu_coulomb=0.3, epsilon=0.8)
+    st_g, aux = run_both(oracle, sc, perturbed(st, 6, 4, vel=0.05), 1e-3, 60, chunks=2)
+    assert np.isfinite(st_g).all()
+    assert ((aux["status"] & ~S.MH_WORLD_IMPACT_TOL) == 0).all() and (aux["lcp_solves"] > 0).all()
+    assert (aux["mini_steps"] > aux["steps"]).any()                # conservative-advancement sub-steps before the impact
+
+
+def test_scene_checks_for_joints():
+    st = rest_state([[0.5, 0.0, 0.0]])
+    j = K.make_joint(K.MH_IJOINT_SPHERICAL, 1, 0, (0.0, 0.0, 0.0), st, 1)
+    sc = K.BigScene([S.MH_GEOM_SPHERE], [(0.2, 0, 0)], [1.0], [[0.016] * 3], [], gravity=(0, -9.81, 0), joints=[j], cstab_max_iterations=5)
+    with pytest.raises(Exception, match="cstab_max_iterations"):
+        K.BigBatch(sc, st.reshape(1, -1))
