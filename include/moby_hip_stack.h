@@ -43,6 +43,9 @@ extern "C" {
 #define MH_IJOINT_MAX_JOINTS 16   /* joints of one jointed island                                           */
 #define MH_IJOINT_MAX_EQNS   48   /* constraint equations of one jointed island (J iM J' and its factor live in LDS) */
 
+#define MH_BIG_MAX_JOINTS 64      /* implicit joints per scene                                               */
+#define MH_BIG_MAX_JOINT_ROWS (6 * MH_BIG_MAX_JOINTS)
+
 #define MH_BIG_MAX_BODIES 128
 #define MH_BIG_MAX_PAIRS  256
 #define MH_BIG_MAX_CONTACTS 512   /* per world, impact or stabilisation list */
@@ -77,7 +80,9 @@ typedef struct mh_big_scene {
    * is the KKT solve of Simulator::solve (src/Simulator.cpp:608-805) and joints connect constraint islands
    * (src/UnilateralConstraint.cpp:993-1008).  A joint is 3 position rows (the joint point of both bodies coincides, global
    * axes) plus 0 / 2 / 3 orientation rows "a_k . b_k = 0" with a_k fixed in the inboard and b_k in the outboard frame.
-   * Stabilisation of bilateral constraints is not built: a scene with joints must set cstab_max_iterations = 0. */
+   * ConstraintStabilization closes the joints of islands no contact touches (CStab:133-160, 462-486, 531-700, 1132-1192); a
+ * jointed island touched by the stabiliser's contact list would need compute_X's general case (ICH:1590-1695): not built,
+ * such a world is flagged MH_WORLD_UNSUPPORTED (run those scenes with cstab_max_iterations = 0, as ur10.xml does). */
   int njoints;
   const int*    joint_type;       /* njoints: MH_IJOINT_*                                                          */
   const int*    joint_inboard;    /* body id, or nb for the static world                                           */

@@ -33,6 +33,7 @@ constexpr int NBMAX = MH_BIG_MAX_BODIES;
 constexpr int NPMAX = MH_BIG_MAX_PAIRS;
 constexpr double NEAR_ZERO_ = 1.4901161193847656e-08;   // Constants.h:21
 constexpr double INF_ = 1.7976931348623157e308;         // std::numeric_limits<double>::max()
+constexpr double BILATERAL_EPS_ = 1e-6;                 // ConstraintStabilization::bilateral_eps (CStab:62)
 
 struct Dev {
   int B, nb, has_ground, npairs, ncmax, nk;
@@ -49,7 +50,8 @@ struct Dev {
   // implicit joints (scene tables) and the jointed islands of Simulator::find_islands, fixed per scene (host, create):
   // island i holds kk_nbod[i] bodies (kk_body + i * MH_IJOINT_MAX_BODIES, ascending ids) and kk_nj[i] joints
   // (kk_joint + i * KKJ, scene order) with kk_m[i] equations; jointed[b] marks the bodies k_mini_pre leaves to k_kkt_fwd
-  int nj, kk_nisl, kk_mmax;
+  int nj, kk_nisl, kk_mmax, jrows;           // jrows: equations of all joints (scene-wide C vector, joint order)
+  const int* jrow0;                          // first row of each joint in that vector
   const int* jtype; const int* jin; const int* jout; const double* janchor_in; const double* janchor_out; const double* jvec_in; const double* jvec_out;
   const int* kk_nbod; const int* kk_body; const int* kk_nj; const int* kk_joint; const int* kk_m; const unsigned char* jointed;
   double* kk_JiM;                            // B x kk_nisl x (kk_mmax x 6 MH_IJOINT_MAX_BODIES) scratch
@@ -490,6 +492,30 @@ MH_DEV void joint_jac(const W& w, int j, bool inboard, double* Cq) {
   }
 }
 
+// evaluate_constraints (oracle World::joint_eval)
+MH_DEV void joint_eval(const W& w, int j, double* C) {
+  const Dev& d = w.d;
+  const int bi = d.jin[j], bo = d.jout[j];
+  const P3 ri = body_vec(w, bi, d.janchor_in + 3 * j), ro = body_vec(w, bo, d.janchor_out + 3 * j);
+  const P3 pi = w.enabled(bi) ? w.X(bi) + ri : ri, po = w.enabled(bo) ? w.X(bo) + ro : ro;
+  const P3 dd = pi - po;
+  C[0] = dd.x; C[1] = dd.y; C[2] = dd.z;
+  const int nori = joint_rows(d.jtype[j]) - 3;
+  for (int k = 0; k < nori; k++) C[3 + k] = dot3(body_vec(w, bi, d.jvec_in + 9 * j + 3 * k), body_vec(w, bo, d.jvec_out + 9 * j + 3 * k));
+}
+constexpr int JROWS = MH_BIG_MAX_JOINT_ROWS;
+// evaluate_bilateral_constraints (CStab:133-160): C of every joint -> s_c[0 .. jrows), returns max |C| (uniform)
+MH_DEV double eval_bilateral(const W& w, double* s_c) {
+  const Dev& d = w.d; const int t = threadIdx.x;
+  double mx = 0.0;
+  for (int j = t; j < d.nj; j += T) {
+    double c6[6]; joint_eval(w, j, c6);
+    const int rows = joint_rows(d.jtype[j]);
+    for (int k = 0; k < rows; k++) { s_c[d.jrow0[j] + k] = c6[k]; const double a = fabs(c6[k]); mx = (a > mx) ? a : mx; }
+  }
+  return -blk_min(-mx);
+}
+
 __global__ __launch_bounds__(KKT_T)
 void k_kkt_fwd(Dev d)
 {
@@ -673,7 +699,9 @@ void k_stab_begin(Dev d)
   for (int i = t; i < nb * 6; i += T) d.vsave[(size_t)b * nb * 6 + i] = w.st[13 * (i / 6) + 7 + (i % 6)];
   for (int i = t; i < nb * 7; i += T) d.qstab[(size_t)b * nb * 7 + i] = w.st[13 * (i / 7) + (i % 7)];
   const double mu = eval_unilateral(w, d.ptc + (size_t)b * d.npairs, d.nptc[b], s_uc);
-  if (t == 0) { d.stab_iter[b] = 0u; const int act = (mu < d.cstab_eps) ? 1 : 0; d.stab_active[b] = act; if (act) atomicOr(d.anyflag, 1); }
+  __shared__ double s_c[JROWS];
+  const double mb = (d.nj > 0) ? eval_bilateral(w, s_c) : 0.0;
+  if (t == 0) { d.stab_iter[b] = 0u; const int act = (mu < d.cstab_eps || mb > BILATERAL_EPS_) ? 1 : 0; d.stab_active[b] = act; if (act) atomicOr(d.anyflag, 1); }
 }
 
 // top of the loop + compute_problem_data's contact list (CStab:197-221, 306-343, 364-378)
@@ -726,6 +754,167 @@ void k_stab_prep(Dev d)
   if (t == 0) d.ncount[b] = total;
 }
 
+// The islands tied by implicit joints and touched by no contact of the stabiliser's list ("remaining islands", UC:1158-1191;
+// the jointed islands are fixed per scene): set_bilateral_only_constraint_data (CStab:531-700) -- Jfull, the greedy
+// full-rank set on J J' - sqrt(eps) I (ICH:1698-1739), J iM and J iM J' on the active rows (ICH:1657-1660), Jx_v = C
+// (CStab:475-486) -- then update_from_stacked's bilateral step (ICH:356-374): (J iM J') lambda = C, v = 0 + (0 - iM J' lambda).
+// A jointed island that a contact touches needs compute_X's general case: not built, the world is flagged (and k_prep drops
+// the contact island).  Operation order: oracle World::bilateral_only_dq.
+__global__ __launch_bounds__(KKT_T)
+void k_stab_bilat(Dev d)
+{
+  const int isl = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  if (!d.stab_active[b]) return;
+  W w(d, d.state + (size_t)b * d.nb * 13);
+  const int nbod = d.kk_nbod[isl], njl = d.kk_nj[isl], m = d.kk_m[isl], ngc = 6 * nbod;
+  const int* bodies = d.kk_body + isl * KKB;
+  const int* joints = d.kk_joint + isl * KKJ;
+  __shared__ double s_iM[KKB * 36];
+  __shared__ double s_w[2 * KKJ * 36];
+  __shared__ int s_brow[2 * KKJ], s_boff[2 * KKJ], s_brows[2 * KKJ];
+  __shared__ double s_A[KKM * KKM], s_L[KKM * KKM];      // J J', then J iM J' on the active rows; the Cholesky factor
+  __shared__ double s_C[KKM], s_lam[KKM];
+  __shared__ int s_act[KKM], s_nact, s_touched, s_fail;
+  double* JiM = d.kk_JiM + ((size_t)b * d.kk_nisl + isl) * ((size_t)d.kk_mmax * 6 * KKB);
+  if (t == 0) { s_touched = 0; s_fail = 0; }
+  __syncthreads();
+  {
+    const mh_contact* C = d.contacts + (size_t)b * d.ncmax;
+    const int ncnt = d.ncount[b];
+    for (int i = t; i < ncnt; i += KKT_T) {
+      const int g1 = C[i].body1, g2 = C[i].body2;
+      for (int k = 0; k < nbod; k++) if (bodies[k] == g1 || bodies[k] == g2) s_touched = 1;
+    }
+  }
+  __syncthreads();
+  if (s_touched) { if (t == 0) d.status[b] |= MH_WORLD_UNSUPPORTED; return; }
+  for (int i = t; i < nbod; i += KKT_T) {
+    const int bb = bodies[i];
+    double xi[10];
+    inv_inertia(w.st + 13 * bb, d.inertia + 3 * bb, d.mass[bb], xi);
+    double* Bm = s_iM + 36 * i;
+    for (int k = 0; k < 36; k++) Bm[k] = 0.0;
+    for (int k = 0; k < 3; k++) Bm[7 * k] = xi[0];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Bm[6 * (3 + r) + 3 + c] = xi[1 + 3 * r + c];
+  }
+  if (t == 0) {
+    int eq = 0;
+    for (int jl = 0; jl < njl; jl++) {
+      const int j = joints[jl], rows = joint_rows(d.jtype[j]);
+      const int sides[2] = { d.jin[j], d.jout[j] };
+      for (int sd = 0; sd < 2; sd++) {
+        int off = -1;
+        if (w.enabled(sides[sd])) for (int i = 0; i < nbod; i++) if (bodies[i] == sides[sd]) off = 6 * i;
+        s_brow[2 * jl + sd] = eq; s_boff[2 * jl + sd] = off; s_brows[2 * jl + sd] = rows;
+      }
+      eq += rows;
+    }
+  }
+  for (int jl = t; jl < njl; jl += KKT_T) {               // Jx_v: the island's rows of C (joint order)
+    double c6[6]; joint_eval(w, joints[jl], c6);
+    int eq = 0;
+    for (int k = 0; k < jl; k++) eq += joint_rows(d.jtype[joints[k]]);
+    for (int k = 0; k < joint_rows(d.jtype[joints[jl]]); k++) s_C[eq + k] = c6[k];
+  }
+  __syncthreads();
+  for (int k = t; k < 2 * njl; k += KKT_T) if (s_boff[k] >= 0) joint_jac(w, joints[k >> 1], (k & 1) == 0, s_w + 36 * k);
+  for (int e = t; e < m * ngc; e += KKT_T) JiM[e] = 0.0;
+  __syncthreads();
+  // J J' (r, c): block pairs on the same body, in block order
+  for (int e = t; e < m * m; e += KKT_T) {
+    const int row = e / m, c = e - row * m;
+    double tot = 0.0;
+    for (int k = 0; k < 2 * njl; k++) {
+      if (s_boff[k] < 0 || row < s_brow[k] || row >= s_brow[k] + s_brows[k]) continue;
+      for (int k2 = 0; k2 < 2 * njl; k2++) {
+        if (s_boff[k2] != s_boff[k] || c < s_brow[k2] || c >= s_brow[k2] + s_brows[k2]) continue;
+        double acc = 0.0;
+        for (int q = 0; q < 6; q++) acc = acc + s_w[36 * k + 6 * (row - s_brow[k]) + q] * s_w[36 * k2 + 6 * (c - s_brow[k2]) + q];
+        tot = tot + acc;
+      }
+    }
+    s_A[row * m + c] = tot;
+  }
+  for (int k = 0; k < 2 * njl; k++) {                     // J iM
+    if (s_boff[k] < 0) continue;
+    const double* Bm = s_iM + 36 * (s_boff[k] / 6);
+    for (int e = t; e < s_brows[k] * 6; e += KKT_T) {
+      const int r = e / 6, c = e - 6 * r;
+      double acc = 0.0;
+      for (int q = 0; q < 6; q++) acc = acc + s_w[36 * k + 6 * r + q] * Bm[6 * q + c];
+      JiM[(size_t)(s_brow[k] + r) * ngc + s_boff[k] + c] = acc;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {                                          // get_full_rank_implicit_constraints: incremental Cholesky of J J' - sqrt(eps) I
+    int k = 0;
+    for (int i = 0; i < m; i++) {
+      if (k == ngc) break;
+      for (int j = 0; j < k; j++) {
+        double tv = s_A[i * m + s_act[j]];
+        for (int p = 0; p < j; p++) tv = tv - s_L[k * m + p] * s_L[j * m + p];
+        s_L[k * m + j] = tv / s_L[j * m + j];
+      }
+      double ajj = s_A[i * m + i] - NEAR_ZERO_;
+      for (int p = 0; p < k; p++) ajj = ajj - s_L[k * m + p] * s_L[k * m + p];
+      if (ajj > 0.0) { s_L[k * m + k] = sqrt(ajj); s_act[k] = i; k++; }
+    }
+    s_nact = k;
+  }
+  __syncthreads();
+  const int k = s_nact;
+  // J iM J' on the active rows -> s_A (k x k, ld m)
+  for (int e = t; e < k * k; e += KKT_T) {
+    const int r = e / k, c = e - r * k, row = s_act[r];
+    double tot = 0.0;
+    for (int kb = 0; kb < 2 * njl; kb++) {
+      if (s_boff[kb] < 0 || row < s_brow[kb] || row >= s_brow[kb] + s_brows[kb]) continue;
+      double acc = 0.0;
+      for (int q = 0; q < 6; q++) acc = acc + s_w[36 * kb + 6 * (row - s_brow[kb]) + q] * JiM[(size_t)s_act[c] * ngc + s_boff[kb] + q];
+      tot = tot + acc;
+    }
+    s_L[r * m + c] = tot;                                  // (the greedy factor is not needed any more)
+  }
+  __syncthreads();
+  if (t == 0) {                                          // factor_chol + solve_chol_fast (ICH:365-367): dpotf2 'L', then L y = C, L' x = y
+    bool ok = true;
+    for (int j = 0; j < k && ok; j++) {
+      double ajj = s_L[j * m + j];
+      for (int p = 0; p < j; p++) ajj = ajj - s_L[j * m + p] * s_L[j * m + p];
+      if (!(ajj > 0.0)) { ok = false; break; }
+      ajj = sqrt(ajj);
+      s_L[j * m + j] = ajj;
+      for (int i = j + 1; i < k; i++) {
+        double tv = s_L[i * m + j];
+        for (int p = 0; p < j; p++) tv = tv - s_L[i * m + p] * s_L[j * m + p];
+        s_L[i * m + j] = tv / ajj;
+      }
+    }
+    if (!ok) { s_fail = 1; d.status[b] |= MH_WORLD_STAB_FAILED; }
+    else {
+      for (int r = 0; r < k; r++) s_lam[r] = s_C[s_act[r]];
+      for (int c = 0; c < k; c++) {
+        s_lam[c] = s_lam[c] / s_L[c * m + c];
+        const double bk = s_lam[c];
+        for (int i = c + 1; i < k; i++) s_lam[i] = s_lam[i] - bk * s_L[i * m + c];
+      }
+      for (int c = k - 1; c >= 0; c--) {
+        double tv = s_lam[c];
+        for (int i = c + 1; i < k; i++) tv = tv - s_L[i * m + c] * s_lam[i];
+        s_lam[c] = tv / s_L[c * m + c];
+      }
+    }
+  }
+  __syncthreads();
+  if (s_fail) return;
+  for (int g = t; g < ngc; g += KKT_T) {
+    double acc = 0.0;
+    for (int r = 0; r < k; r++) acc = acc + JiM[(size_t)s_act[r] * ngc + g] * s_lam[r];
+    const int bb = bodies[g / 6], q = g - 6 * (g / 6);
+    w.st[13 * bb + 7 + q] = 0.0 + (0.0 - acc);
+  }
+}
+
 // determine_dq's read-back, update_q, the loop's tail (CStab:962-969, 1056-1216, 230-242)
 __global__ __launch_bounds__(T)
 void k_stab_update(Dev d)
@@ -739,15 +928,27 @@ void k_stab_update(Dev d)
   double* dq = d.dq + (size_t)b * nb * 7;
   __shared__ double s_uc[NPMAX], s_old[NPMAX], s_full[NPMAX];
   __shared__ unsigned char s_br[NPMAX];
-  // the bodies' velocities are X Cn^T z now: dq = their eEuler form (bodies outside every island stay at 0)
+  __shared__ double s_c[JROWS], s_cold[JROWS], s_cfull[JROWS], s_cvio;
+  const int jrows = d.jrows;
+  // the bodies' velocities are X Cn^T z (- iM J' lambda) now: dq = their eEuler form (bodies outside every island stay at 0)
   for (int bb = t; bb < nb; bb += T) { double qd[7]; w.euler_vel(bb, qd); for (int k = 0; k < 7; k++) dq[7 * bb + k] = qd[k]; }
   __syncthreads();
-  // ---- update_q (CStab:1056-1216), unilateral part ----
+  auto cvio_of = [&](const double* c) -> double {           // sqrt(sum C^2), summed in row order (CStab:1068-1071, 1182-1185)
+    if (t == 0) { double a = 0.0; for (int i = 0; i < jrows; i++) a = a + c[i] * c[i]; s_cvio = sqrt(a); }
+    __syncthreads();
+    const double r = s_cvio;
+    __syncthreads();
+    return r;
+  };
+  // ---- update_q (CStab:1056-1216) ----
   (void)eval_unilateral(w, ptc, np, s_old);
+  double old_cvio = 0.0;
+  if (d.nj > 0) { (void)eval_bilateral(w, s_cold); old_cvio = cvio_of(s_cold); }
   for (int bb = t; bb < nb; bb += T) { double qs[7]; for (int k = 0; k < 7; k++) { qs[k] = dq[7 * bb + k]; qs[k] = qs[k] + q[7 * bb + k]; } w.set_coords(bb, qs); }
   __syncthreads();
   (void)eval_unilateral(w, ptc, np, s_full);
   if (t < np) s_br[t] = ((s_old[t] < 0.0 && s_full[t] > 0.0) || (s_old[t] > 0.0 && s_full[t] < 0.0)) ? 1 : 0;
+  if (d.nj > 0) (void)eval_bilateral(w, s_cfull);
   __syncthreads();
   auto eval_at = [&](double x, int idx) -> double {          // CStab:1281-1298
     set_q_scaled(w, q, dq, x, nb);
@@ -782,31 +983,76 @@ void k_stab_update(Dev d)
     }
     return 0.0;
   };
+  auto eval_b_at = [&](double x, int idx) -> double {        // CStab:1300-1318
+    set_q_scaled(w, q, dq, x, nb);
+    (void)eval_bilateral(w, s_c);
+    const double r = s_c[idx];
+    __syncthreads();
+    return r;
+  };
+  // ridders_bilateral (CStab:1382-1439)
+  auto ridders_b = [&](double x1, double x2, double fl, double fh, int idx) -> double {
+    const double TOL = 1e-6;
+    double ans = INF_, fm, fnew, s, xh, xl, xm, xnew;
+    if ((fl > 0.0 && fh < 0.0) || (fl < 0.0 && fh > 0.0)) {
+      xl = x1; xh = x2;
+      for (unsigned j = 0; j < 25; j++) {
+        xm = 0.5 * (xl + xh);
+        fm = eval_b_at(xm, idx);
+        s = sqrt(fm * fm - fl * fh);
+        if (s == 0.0) return ans;
+        xnew = xm + (xm - xl) * ((fl >= fh ? 1.0 : -1.0) * fm / s);
+        ans = xnew;
+        fnew = eval_b_at(ans, idx);
+        if (fabs(fnew) < TOL) return ans;
+        if (sign2(fm, fnew) != fm) { xl = xm; fl = fm; xh = ans; fh = fnew; }
+        else if (sign2(fl, fnew) != fl) { xh = ans; fh = fnew; }
+        else if (sign2(fh, fnew) != fh) { xl = ans; fl = fnew; }
+      }
+    } else {
+      if (fl == 0.0) return x1;
+      if (fh == 0.0) return x2;
+    }
+    return 0.0;
+  };
   double tt = 1.0;
   for (int i = 0; i < np; i++) {
     if (!s_br[i]) continue;
     const double root = ridders(0.0, tt, s_old[i], s_full[i], i);
     if (root > 0.0 && root < 1.0) tt = (root < tt) ? root : tt;
   }
+  for (int i = 0; i < jrows; i++) {                          // CStab:1132-1145
+    const double co = s_cold[i], cf = s_cfull[i];
+    if (!((cf < 0.0 && co > 0.0) || (cf > 0.0 && co < 0.0))) continue;
+    const double root = ridders_b(0.0, tt, co, cf, i);
+    if (root > 0.0 && root < 1.0) tt = (root < tt) ? root : tt;
+  }
   set_q_scaled(w, q, dq, tt, nb);
   (void)eval_unilateral(w, ptc, np, s_uc);
+  if (d.nj > 0) (void)eval_bilateral(w, s_c);
   const double BETA = 0.6;
   bool failed = false;
   while (true) {
     const int worse = (t < np && !s_br[t] && s_uc[t] < 0.0 && s_old[t] > s_uc[t]) ? 1 : 0;
-    if (!blk_or(worse)) break;                               // no bilateral constraints: cvio 0 < bilateral_eps
+    if (!blk_or(worse)) {                                    // CStab:1180-1192 (no joints: cvio = 0 < bilateral_eps)
+      if (d.nj == 0) break;
+      const double cvio = cvio_of(s_c);
+      if (cvio < BILATERAL_EPS_ || cvio < old_cvio) break;
+    }
     tt *= BETA;
     if (tt < NEAR_ZERO_) { failed = true; break; }
     set_q_scaled(w, q, dq, tt, nb);
+    if (d.nj > 0) (void)eval_bilateral(w, s_c);
     (void)eval_unilateral(w, ptc, np, s_uc);
   }
   if (failed) { if (t == 0) { d.status[b] |= MH_WORLD_STAB_FAILED; d.stab_active[b] = 0; } return; }
   __syncthreads();
   for (int i = t; i < nb * 7; i += T) { double v = dq[i] * tt; v = v + q[i]; q[i] = v; }      // q = qstar
   const double mu = eval_unilateral(w, ptc, np, s_uc);
+  const double mb = (d.nj > 0) ? eval_bilateral(w, s_c) : 0.0;
   if (t == 0) {
     d.stab_iter[b] += 1u; d.stab_iters[b] += 1ull;
-    const int act = (mu < d.cstab_eps) ? 1 : 0;
+    const int act = (mu < d.cstab_eps || mb > BILATERAL_EPS_) ? 1 : 0;
     d.stab_active[b] = act;
     if (act) atomicOr(d.anyflag, 1);
   }
@@ -872,6 +1118,7 @@ int run_stabilize(mh_big_batch* bb, hipStream_t s, int count_step)
     MH_HIP(hipGetLastError());
     rc = mh_imp_core_process(&bb->core, s, MH_CORE_STAB);
     if (rc != MH_OK) return rc;
+    if (bb->d.kk_nisl > 0) hipLaunchKernelGGL(bg::k_stab_bilat, dim3(bb->d.kk_nisl, B), dim3(bg::KKT_T), 0, s, bb->d);
     hipLaunchKernelGGL(bg::k_stab_update, dim3(B), dim3(bg::T), 0, s, bb->d);
     MH_HIP(hipGetLastError());
     rc = read_flag(bb, s, &any);
@@ -942,9 +1189,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
   if (nj > 0) {
     if (!sc->joint_type || !sc->joint_inboard || !sc->joint_outboard || !sc->joint_anchor_in || !sc->joint_anchor_out || !sc->joint_vec_in || !sc->joint_vec_out)
       return fail(MH_ERR_INVALID_ARG, "null joint table");
-    if (sc->cstab_max_iterations != 0)
-      return fail(MH_ERR_INVALID_ARG, "a scene with implicit joints needs cstab_max_iterations = 0: stabilisation of bilateral constraints "
-                                      "(ConstraintStabilization.cpp:133-160, 531-700, 1132-1145) is not built");
+    if (nj > MH_BIG_MAX_JOINTS) return fail(MH_ERR_INVALID_ARG, "njoints = %d > %d", nj, MH_BIG_MAX_JOINTS);
     std::vector<std::vector<int> > adj((size_t)nb);
     for (int j = 0; j < nj; j++) {
       const int a = sc->joint_inboard[j], bq = sc->joint_outboard[j], ty = sc->joint_type[j];
@@ -1018,6 +1263,10 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
   d.min_step = sc->min_step_size; d.thresh = sc->contact_dist_thresh; d.cstab_eps = sc->cstab_eps; d.cstab_maxit = sc->cstab_max_iterations;
   d.nj = nj; d.kk_nisl = (int)kk_nbod.size(); d.kk_mmax = kk_mmax;
   if (nj > 0) {
+    std::vector<int> jrow0((size_t)nj); int rows = 0;
+    for (int j = 0; j < nj; j++) { jrow0[(size_t)j] = rows; rows += (sc->joint_type[j] == MH_IJOINT_SPHERICAL) ? 3 : (sc->joint_type[j] == MH_IJOINT_REVOLUTE ? 5 : 6); }
+    d.jrows = rows; d.jrow0 = (const int*)U(jrow0.data(), nj * 4);
+    bb->core.jointed = nullptr;
     d.jtype = (const int*)U(sc->joint_type, nj * 4); d.jin = (const int*)U(sc->joint_inboard, nj * 4); d.jout = (const int*)U(sc->joint_outboard, nj * 4);
     d.janchor_in = (const double*)U(sc->joint_anchor_in, nj * 24); d.janchor_out = (const double*)U(sc->joint_anchor_out, nj * 24);
     d.jvec_in = (const double*)U(sc->joint_vec_in, nj * 72); d.jvec_out = (const double*)U(sc->joint_vec_out, nj * 72);
@@ -1029,6 +1278,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
       d.kk_JiM = (double*)A((size_t)B * d.kk_nisl * kk_mmax * 6 * MH_IJOINT_MAX_BODIES * 8, true);
     }
     bb->core.nj = nj; bb->core.jin = d.jin; bb->core.jout = d.jout;     // joint edges of the constraint islands (UC:993-1008)
+    bb->core.jointed = d.jointed;
   }
   const size_t sB = (size_t)B;
   d.state = (double*)A(sB * nb * 13 * 8, true); d.qsave = (double*)A(sB * nb * 7 * 8, true); d.vsave = (double*)A(sB * nb * 6 * 8, true);

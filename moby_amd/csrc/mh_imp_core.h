@@ -39,6 +39,7 @@ struct mh_imp_core {
   // implicit joints of the scene (0 / NULL without): their dynamic links are nodes of the island search and an edge
   // joins the two (UC:993-1008); the handler itself never sees their rows (island_ijoints stays empty in ICH)
   int nj; const int* jin; const int* jout;
+  const unsigned char* jointed;                     // nb flags: body belongs to an island with a joint (MH_CORE_STAB drops contact islands that hold one)
   double* ws_d; int* ws_i;                          // block-solver workspace (nmax > 64)
   int* hmax;                                        // pinned host copy of maxisl
   void* allocs[48]; int nallocs;

@@ -95,12 +95,13 @@ void k_prep(Dev d, int mode)
       for (int start = 0; start < nb; start++) {
         if (!s_node[start]) continue;
         const int begin = cnt;
-        bool active = false, all_inf = true;
+        bool active = false, all_inf = true, has_jointed = false;
         int qlen = 0;
         s_queue[qlen++] = start; s_queued[start] = 1;
         for (int qi = 0; qi < qlen; qi++) {
           const int nd = s_queue[qi];
           s_node[nd] = 0;
+          if (d.jointed && d.jointed[nd]) has_jointed = true;
           for (int i = 0; i < nc; i++) {
             const int g1 = s_b1[i], g2 = s_b2[i];
             if (g1 < 0 || g2 < 0) continue;
@@ -126,6 +127,8 @@ void k_prep(Dev d, int mode)
         if (mode == MH_CORE_IMPACT) {
           if (!active) keep = false;                                               // remove_inactive_groups (UC:1197-1225)
         }
+        // stabilisation of a contact island that holds jointed bodies needs compute_X's general case (ICH:1590-1695): not built
+        if (keep && mode == MH_CORE_STAB && has_jointed) { keep = false; d.status[b] |= MH_WORLD_UNSUPPORTED; }
         if (keep && nisl >= d.islmax) { keep = false; d.status[b] |= MH_WORLD_UNSUPPORTED; }
         if (!keep) { cnt = begin; continue; }
         d.isl_start[(size_t)b * d.islmax + nisl] = begin; d.isl_len[(size_t)b * d.islmax + nisl] = cnt - begin;

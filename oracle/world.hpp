@@ -69,6 +69,7 @@ struct PairDist { int pair, a, b; double dist; V3 pa, pb; };  // PairwiseDistInf
 
 static int g_impact_model = MH_IMPACT_MODEL_DS;   // what the next World is built with: the reference's USE_AP build option
 static inline int oracle_impact_model() { return g_impact_model; }
+static const double BILATERAL_EPS = 1e-6;          // ConstraintStabilization::bilateral_eps (CStab:62)
 static unsigned long long g_ca_iters = 0;   // diagnostic: conservative-advancement sub-steps taken
 
 // What the stepper reads of a scene: the members of mh_scene under the same names, as pointers, so that scenes of any
@@ -1422,13 +1423,158 @@ class World {
     }
     return 0.0;
   }
-  // update_q (CStab:1056-1216), unilateral part
+  // evaluate_bilateral_constraints (CStab:133-160): every implicit joint's C, scene order; returns max |C|
+  double eval_bilateral(std::vector<double>& C) const {
+    C.clear();
+    double mx = 0.0;
+    for (int j = 0; j < njoints(); j++) {
+      double c6[6]; joint_eval(j, c6);
+      for (int k = 0; k < joint_rows(sc->joint_type[j]); k++) { C.push_back(c6[k]); const double a = std::fabs(c6[k]); mx = (a > mx) ? a : mx; }
+    }
+    return mx;
+  }
+  double eval_bilateral_at(double t, unsigned i, const std::vector<double>& dq, const std::vector<double>& q) {   // CStab:1300-1318
+    std::vector<double> qs(q.size()), C;
+    for (size_t k = 0; k < q.size(); k++) { qs[k] = dq[k] * t; qs[k] = qs[k] + q[k]; }
+    set_q(qs);
+    eval_bilateral(C);
+    return C[i];
+  }
+  double ridders_bilateral(double x1, double x2, double fl, double fh, unsigned idx, const std::vector<double>& dq, const std::vector<double>& q) {  // CStab:1382-1439
+    const double TOL = 1e-6;
+    double ans = INF, fm, fnew, s, xh, xl, xm, xnew;
+    if ((fl > 0.0 && fh < 0.0) || (fl < 0.0 && fh > 0.0)) {
+      xl = x1; xh = x2;
+      for (unsigned j = 0; j < 25; j++) {
+        xm = 0.5 * (xl + xh);
+        fm = eval_bilateral_at(xm, idx, dq, q);
+        s = std::sqrt(fm * fm - fl * fh);
+        if (s == 0.0) return ans;
+        xnew = xm + (xm - xl) * ((fl >= fh ? 1.0 : -1.0) * fm / s);
+        ans = xnew;
+        fnew = eval_bilateral_at(ans, idx, dq, q);
+        if (std::fabs(fnew) < TOL) return ans;
+        if (sign2(fm, fnew) != fm) { xl = xm; fl = fm; xh = ans; fh = fnew; }
+        else if (sign2(fl, fnew) != fl) { xh = ans; fh = fnew; }
+        else if (sign2(fh, fnew) != fh) { xl = ans; fl = fnew; }
+      }
+    } else {
+      if (fl == 0.0) return x1;
+      if (fh == 0.0) return x2;
+    }
+    return 0.0;
+  }
+  // An island of bodies tied by implicit joints and touched by no unilateral constraint ("remaining island", UC:1158-1191):
+  // set_bilateral_only_constraint_data (CStab:531-700: Jfull, get_full_rank_implicit_constraints ICH:1698-1739, the
+  // J iM, J iM J' products of compute_X ICH:1657-1660), Jx_v = C on the active rows (CStab:475-486), then determine_dq
+  // with an empty LCP (CStab:932-970) and update_from_stacked's bilateral step (ICH:356-374):
+  //   (J iM J') lambda = C ,  v = 0 + (0 - iM J' lambda) ,  dq = the bodies' eEuler velocities.
+  bool bilateral_only_dq(const std::vector<int>& island, const std::vector<int>& joints, const std::vector<double>& Call, std::vector<double>& dq) {
+    const int nbod = (int)island.size(), ngc = 6 * nbod;
+    int m = 0;
+    for (int j : joints) m += joint_rows(sc->joint_type[j]);
+    if (nbod > MH_IJOINT_MAX_BODIES || (int)joints.size() > MH_IJOINT_MAX_JOINTS || m > MH_IJOINT_MAX_EQNS) return false;
+    auto gc_of_body = [&](int b) { for (int i = 0; i < nbod; i++) if (island[i] == b) return 6 * i; return -1; };
+    struct Blk { int row, off, rows; double w[6][6]; };
+    std::vector<Blk> blocks;
+    std::vector<double> Cj(m);
+    int eq = 0;
+    for (int j : joints) {
+      const int rows = joint_rows(sc->joint_type[j]);
+      int first = 0;                                               // the joint's first row in the scene-wide C vector
+      for (int jj = 0; jj < j; jj++) first += joint_rows(sc->joint_type[jj]);
+      for (int k = 0; k < rows; k++) Cj[eq + k] = Call[first + k];
+      const int sides[2] = { sc->joint_inboard[j], sc->joint_outboard[j] };
+      for (int sd = 0; sd < 2; sd++) {
+        if (!enabled(sides[sd])) continue;
+        Blk k; k.row = eq; k.off = gc_of_body(sides[sd]); k.rows = rows;
+        joint_jac(j, sd == 0, k.w);
+        blocks.push_back(k);
+      }
+      eq += rows;
+    }
+    auto covering = [&](int row, std::vector<const Blk*>& out) { out.clear(); for (const Blk& k : blocks) if (row >= k.row && row < k.row + k.rows) out.push_back(&k); };
+    // J J' and the greedy full-rank set on J J' - sqrt(eps) I (ICH:1698-1739)
+    std::vector<double> JJT((size_t)m * m, 0.0);
+    std::vector<const Blk*> br, bc;
+    for (int r = 0; r < m; r++) { covering(r, br); for (int c = 0; c < m; c++) { covering(c, bc);
+      double tot = 0.0;
+      for (const Blk* kr : br) for (const Blk* kc : bc) {
+        if (kr->off != kc->off) continue;
+        double acc = 0.0;
+        for (int q = 0; q < 6; q++) acc = acc + kr->w[r - kr->row][q] * kc->w[c - kc->row][q];
+        tot = tot + acc;
+      }
+      JJT[(size_t)r * m + c] = tot; } }
+    std::vector<int> act; std::vector<double> L;
+    for (int i = 0; i < m; i++) {
+      if ((int)act.size() == ngc) break;
+      act.push_back(i);
+      const int k = (int)act.size();
+      L.assign((size_t)k * k, 0.0);
+      for (int r = 0; r < k; r++) for (int c = 0; c < k; c++) L[r + (size_t)k * c] = JJT[(size_t)act[r] * m + act[c]];
+      for (int r = 0; r < k; r++) L[r + (size_t)k * r] = L[r + (size_t)k * r] - NEAR_ZERO;
+      if (!chol_factor(k, L.data(), k)) act.pop_back();
+    }
+    const int k = (int)act.size();
+    // J iM (active rows matter), J iM J' on the active rows
+    std::vector<double> iM((size_t)nbod * 36, 0.0);
+    for (int i = 0; i < nbod; i++) {
+      double im, Ji[9]; inv_inertia(island[i], im, Ji);
+      double* B = &iM[(size_t)i * 36];
+      for (int q = 0; q < 3; q++) B[7 * q] = im;
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) B[6 * (3 + r) + 3 + c] = Ji[3 * r + c];
+    }
+    std::vector<double> JiM((size_t)m * ngc, 0.0);
+    for (const Blk& kb : blocks) {
+      const double* B = &iM[(size_t)(kb.off / 6) * 36];
+      for (int r = 0; r < kb.rows; r++) for (int c = 0; c < 6; c++) {
+        double acc = 0.0;
+        for (int q = 0; q < 6; q++) acc = acc + kb.w[r][q] * B[6 * q + c];
+        JiM[(size_t)(kb.row + r) * ngc + kb.off + c] = acc;
+      }
+    }
+    L.assign((size_t)k * k, 0.0);
+    for (int r = 0; r < k; r++) { covering(act[r], br); for (int c = 0; c < k; c++) {
+      double tot = 0.0;
+      for (const Blk* kr : br) {
+        double acc = 0.0;
+        for (int q = 0; q < 6; q++) acc = acc + kr->w[act[r] - kr->row][q] * JiM[(size_t)act[c] * ngc + kr->off + q];
+        tot = tot + acc;
+      }
+      L[r + (size_t)k * c] = tot; } }
+    if (k > 0 && !chol_factor(k, L.data(), k)) return false;
+    std::vector<double> lam(k);
+    for (int r = 0; r < k; r++) lam[r] = Cj[act[r]];
+    if (k > 0) chol_solve(k, L.data(), k, lam.data());
+    for (int i = 0; i < nbod; i++) {
+      double dv[6];
+      for (int q = 0; q < 6; q++) {
+        double acc = 0.0;
+        for (int r = 0; r < k; r++) acc = acc + JiM[(size_t)act[r] * ngc + 6 * i + q] * lam[r];
+        dv[q] = 0.0 + (0.0 - acc);
+      }
+      const int b = island[i];
+      setV(b, v3(dv[0], dv[1], dv[2])); setW(b, v3(dv[3], dv[4], dv[5]));
+      double qd[7]; euler_vel(b, qd);
+      for (int q = 0; q < 7; q++) dq[7 * b + q] = qd[q];
+    }
+    return true;
+  }
+  // update_q (CStab:1056-1216)
   bool update_q(const std::vector<double>& dq, std::vector<double>& q) {
-    std::vector<double> uC, uC_old, qstar(q.size());
+    std::vector<double> uC, uC_old, qstar(q.size()), C, C_old;
     eval_unilateral(uC_old);
+    eval_bilateral(C_old);
+    double old_cvio = 0.0;
+    for (double c : C_old) old_cvio = old_cvio + c * c;
+    old_cvio = std::sqrt(old_cvio);
     for (size_t k = 0; k < q.size(); k++) { qstar[k] = dq[k]; qstar[k] = qstar[k] + q[k]; }
     set_q(qstar);
     eval_unilateral(uC);
+    eval_bilateral(C);
+    std::vector<char> bbr(C.size(), 0);
+    for (size_t i = 0; i < C.size(); i++) bbr[i] = ((C[i] < 0.0 && C_old[i] > 0.0) || (C[i] > 0.0 && C_old[i] < 0.0)) ? 1 : 0;
     std::vector<char> br(uC.size(), 0);
     for (size_t i = 0; i < uC.size(); i++)
       br[i] = ((uC_old[i] < 0.0 && uC[i] > 0.0) || (uC_old[i] > 0.0 && uC[i] < 0.0)) ? 1 : 0;
@@ -1438,18 +1584,30 @@ class World {
       const double root = ridders(0, t, uC_old[i], uC[i], (unsigned)i, dq, q);
       if (root > 0.0 && root < 1.0) t = (root < t) ? root : t;
     }
+    for (size_t i = 0; i < bbr.size(); i++) {                       // CStab:1132-1145
+      if (!bbr[i]) continue;
+      const double root = ridders_bilateral(0, t, C_old[i], C[i], (unsigned)i, dq, q);
+      if (root > 0.0 && root < 1.0) t = (root < t) ? root : t;
+    }
     for (size_t k = 0; k < q.size(); k++) { qstar[k] = dq[k] * t; qstar[k] = qstar[k] + q[k]; }
     set_q(qstar);
     eval_unilateral(uC);
+    eval_bilateral(C);
     const double BETA = 0.6;
     while (true) {
       bool stop = true;
       for (size_t i = 0; i < br.size(); i++) if (!br[i] && uC[i] < 0.0 && uC_old[i] > uC[i]) { stop = false; break; }
-      if (stop) break;                                              // no bilateral constraints: cvio 0 < bilateral_eps
+      if (stop) {                                                   // CStab:1180-1192 (no joints: cvio = 0 < bilateral_eps)
+        double cvio = 0.0;
+        for (double c : C) cvio = cvio + c * c;
+        cvio = std::sqrt(cvio);
+        if (cvio < BILATERAL_EPS || cvio < old_cvio) break;
+      }
       t *= BETA;
       if (t < NEAR_ZERO) return false;
       for (size_t k = 0; k < q.size(); k++) { qstar[k] = dq[k] * t; qstar[k] = qstar[k] + q[k]; }
       set_q(qstar);
+      eval_bilateral(C);
       eval_unilateral(uC);
     }
     q = qstar;
@@ -1458,8 +1616,24 @@ class World {
   // ConstraintStabilization::stabilize (CStab:167-254)
   void stabilize() {
     if (sc->cstab_max_iterations == 0) return;
-    if (njoints() > 0) { aux->status |= MH_WORLD_UNSUPPORTED; return; }   // bilateral stabilisation (CStab:133-160, 531-700, 1132-1145) is not built
     const int nb = sc->nb;
+    // the bodies of the jointed islands (Simulator::find_islands' groups that hold a joint): static per scene
+    std::vector<std::vector<int> > jisl; std::vector<std::vector<int> > jisl_joints; std::vector<char> jointed(nb, 0);
+    if (njoints() > 0) {
+      std::vector<std::vector<int> > all; find_body_islands(all);
+      for (const std::vector<int>& isl : all) {
+        std::vector<int> ij;
+        for (int j = 0; j < njoints(); j++) {
+          const int a = sc->joint_inboard[j], b = sc->joint_outboard[j];
+          if ((enabled(a) && std::binary_search(isl.begin(), isl.end(), a)) || (enabled(b) && std::binary_search(isl.begin(), isl.end(), b))) ij.push_back(j);
+        }
+        if (ij.empty()) continue;
+        jisl.push_back(isl); jisl_joints.push_back(ij);
+        for (int b : isl) jointed[b] = 1;
+      }
+    }
+    std::vector<double> Cb;
+    double max_bvio = eval_bilateral(Cb);
     std::vector<double> vsave_v(6 * (size_t)nb);
     double (*vsave)[6] = reinterpret_cast<double (*)[6]>(vsave_v.data());
     for (int b = 0; b < nb; b++) for (int k = 0; k < 6; k++) vsave[b][k] = st[13*b + 7 + k];
@@ -1467,7 +1641,7 @@ class World {
     std::vector<double> uC;
     double max_uvio = eval_unilateral(uC);
     unsigned iterations = 0;
-    while (max_uvio < sc->cstab_eps) {
+    while (max_uvio < sc->cstab_eps || max_bvio > BILATERAL_EPS) {
       if (iterations == sc->cstab_max_iterations) break;
       // the reference's default cap is UINT_MAX: a cycling stabiliser would never return; stop and say so
       if (iterations == MH_CSTAB_HARD_CAP) { aux->status |= MH_WORLD_STALLED; break; }
@@ -1488,7 +1662,20 @@ class World {
       }
       std::vector<Island> islands; find_islands(cs, islands);
       std::vector<double> dq(q.size(), 0.0);
+      // islands tied by joints and free of unilateral constraints (UC:1158-1191): the bilateral step alone.  A jointed
+      // island that the stabiliser's contact list touches would need compute_X's general case (ICH:1590-1695): not built,
+      // the world is flagged and neither that contact island nor the jointed island moves.
+      for (size_t ji = 0; ji < jisl.size(); ji++) {
+        bool touched = false;
+        for (const Contact& c : cs) if ((enabled(c.g1) && std::binary_search(jisl[ji].begin(), jisl[ji].end(), c.g1)) ||
+                                        (enabled(c.g2) && std::binary_search(jisl[ji].begin(), jisl[ji].end(), c.g2))) { touched = true; break; }
+        if (touched) { aux->status |= MH_WORLD_UNSUPPORTED; continue; }
+        if (!bilateral_only_dq(jisl[ji], jisl_joints[ji], Cb, dq)) aux->status |= MH_WORLD_STAB_FAILED;
+      }
       for (const Island& isl : islands) {
+        bool mixed = false;
+        for (int b : isl.bodies) if (jointed[b]) mixed = true;
+        if (mixed) continue;
         ProblemData pd; compute_problem_data(cs, isl, pd, true);
         const int nc = pd.nc;
         for (int i = 0; i < nc; i++) pd.Cv[0][i] = pd.c[i]->dist - std::fabs(sc->cstab_eps) - NEAR_ZERO;   // CStab:431
@@ -1516,6 +1703,7 @@ class World {
       }
       if (!update_q(dq, q)) { aux->status |= MH_WORLD_STAB_FAILED; break; }
       max_uvio = eval_unilateral(uC);
+      max_bvio = eval_bilateral(Cb);
       iterations++;
       aux->stab_iters++;
     }

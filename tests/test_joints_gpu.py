@@ -100,6 +100,86 @@ def test_joints_merge_contact_islands_and_step_with_impacts(oracle):
 def test_scene_checks_for_joints():
     st = rest_state([[0.5, 0.0, 0.0]])
     j = K.make_joint(K.MH_IJOINT_SPHERICAL, 1, 0, (0.0, 0.0, 0.0), st, 1)
-    sc = K.BigScene([S.MH_GEOM_SPHERE], [(0.2, 0, 0)], [1.0], [[0.016] * 3], [], gravity=(0, -9.81, 0), joints=[j], cstab_max_iterations=5)
-    with pytest.raises(Exception, match="cstab_max_iterations"):
+    bad = dict(j); bad["type"] = 7
+    sc = K.BigScene([S.MH_GEOM_SPHERE], [(0.2, 0, 0)], [1.0], [[0.016] * 3], [], gravity=(0, -9.81, 0), joints=[bad], cstab_max_iterations=0)
+    with pytest.raises(Exception, match="MH_IJOINT"):
         K.BigBatch(sc, st.reshape(1, -1))
+    # an island beyond the built sizes: 10 welds = 60 equations > MH_IJOINT_MAX_EQNS
+    nb = 11
+    stn = rest_state([[float(k), 0.0, 0.0] for k in range(nb)])
+    welds = [K.make_joint(K.MH_IJOINT_FIXED, k, k + 1, (k + 0.5, 0.0, 0.0), stn, nb) for k in range(nb - 1)]
+    with pytest.raises(Exception, match="jointed island"):
+        K.BigBatch(free_scene(nb, welds), stn.reshape(1, -1))
+
+
+# ---- ConstraintStabilization with implicit joints ---------------------------------------------------------------
+def stab_scene(nb, joints, iters, pairs=(), **kw):
+    J = np.array([[0.4 * 0.2 * 0.2] * 3] * nb)
+    return K.BigScene([S.MH_GEOM_SPHERE] * nb, [(0.2, 0, 0)] * nb, np.ones(nb), J, list(pairs), gravity=(0.0, -9.81, 0.0),
+                      cstab_max_iterations=iters, joints=joints, lcp_n_max=64, **kw)
+
+
+def test_stabilised_chains_step_like_the_oracle(oracle):
+    """Full steps with the stabiliser on: every step ends with the bilateral Newton iteration of the jointed island
+    (greedy full-rank rows of J J' - sqrt(eps) I, (J iM J') lambda = C, Ridders / backtracking on |C|) -- next to a free
+    sphere bouncing on the plane whose island keeps the unilateral path."""
+    nb = 4
+    st = rest_state([[0.5, 2.0, 0.0], [1.5, 2.0, 0.0], [2.5, 2.0, 0.0], [5.0, 0.2 + 0.01, 0.0]])
+    joints = [K.make_joint(K.MH_IJOINT_SPHERICAL, nb, 0, (0.0, 2.0, 0.0), st, nb),
+              K.make_joint(K.MH_IJOINT_REVOLUTE, 0, 1, (1.0, 2.0, 0.0), st, nb, axis=(0, 0, 1)),
+              K.make_joint(K.MH_IJOINT_FIXED, 1, 2, (2.0, 2.0, 0.0), st, nb)]
+    sc = stab_scene(nb, joints, 20, pairs=[(3, nb, 0)], epsilon=0.5)
+    st_g, aux = run_both(oracle, sc, perturbed(st, 5, 7, vel=0.2), 1e-3, 50, chunks=2)
+    assert (aux["status"] == 0).all() and (aux["stab_iters"] > 0).all() and (aux["lcp_solves"] > 0).all()
+
+
+def test_standalone_stabilize_closes_open_joints_like_the_oracle(oracle):
+    """mh_big_batch_stabilize (seam B3) on joints pulled apart by up to 2e-2: same iterations, same poses."""
+    nb = 2
+    st = rest_state([[1.0, 0.0, 0.0], [2.2, 0.0, 0.0]])
+    joints = [K.make_joint(K.MH_IJOINT_REVOLUTE, nb, 0, (0.0, 0.0, 0.0), st, nb, axis=(0, 0, 1)),
+              K.make_joint(K.MH_IJOINT_REVOLUTE, 0, 1, (1.6, 0.0, 0.0), st, nb, axis=(0, 1, 0))]
+    sc = stab_scene(nb, joints, 30)
+    B = 6
+    rng = np.random.default_rng(9)
+    s = np.repeat(st.reshape(1, nb, 13), B, axis=0).copy()
+    s[:, :, 0:3] += 0.02 * rng.uniform(-1, 1, (B, nb, 3))
+    q = s[:, :, 3:7] + 0.02 * rng.uniform(-1, 1, (B, nb, 4)); s[:, :, 3:7] = q / np.linalg.norm(q, axis=2)[:, :, None]
+    s[:, :, 7:13] = 0.3
+    s = s.reshape(B, -1)
+    bb = K.BigBatch(sc, s)
+    bb.stabilize()
+    st_g, aux_g = bb.download()
+    bb.close()
+    st_o = s.copy(); aux_o = S.new_aux(B)
+    for w in range(B):
+        oracle.big_step(sc, st_o[w], aux_o[w:w + 1], 1e-3, 1, mode=1)
+    for f in FIELDS:
+        assert np.array_equal(aux_g[f], aux_o[f]), f
+    assert np.array_equal(st_g, st_o), "max |diff| = %.3e" % np.abs(st_g - st_o).max()
+    assert (aux_g["status"] == 0).all() and (aux_g["stab_iters"] >= 1).all()
+    # the line search stops at the first sign change of any row (CStab:1132-1145), so 30 iterations do not always reach 1e-6
+    # from 2e-2: every world must have come most of the way, and the unperturbed-most ones all the way
+    err = lambda states: np.array([max(np.abs(oracle.joint_eval(sc, states[w], j)[0]).max() for j in range(2)) for w in range(B)])
+    e0, e1 = err(s), err(st_g)
+    assert (e1 < 0.1 * e0).all() and e1.min() < 1e-6
+    assert np.array_equal(st_g.reshape(B, nb, 13)[:, :, 7:13], s.reshape(B, nb, 13)[:, :, 7:13])     # velocities restored
+
+
+def test_jointed_bodies_in_contact_are_flagged_on_both_sides(oracle):
+    r = 0.2
+    st = rest_state([[0.0, r - 1e-4, 0.0], [1.0, r - 1e-4, 0.0], [4.0, r - 1e-4, 0.0]])
+    j = K.make_joint(K.MH_IJOINT_SPHERICAL, 0, 1, (0.5, r, 0.0), st, 3)
+    sc = stab_scene(3, [j], 5, pairs=[(0, 3, 0), (1, 3, 0), (2, 3, 0)])
+    B = 3
+    s = np.repeat(st.reshape(1, -1), B, axis=0)
+    bb = K.BigBatch(sc, s)
+    bb.stabilize()
+    st_g, aux_g = bb.download()
+    bb.close()
+    st_o = s.copy(); aux_o = S.new_aux(B)
+    for w in range(B):
+        oracle.big_step(sc, st_o[w], aux_o[w:w + 1], 1e-3, 1, mode=1)
+    assert (aux_g["status"] & S.MH_WORLD_UNSUPPORTED).all() and np.array_equal(aux_g["status"], aux_o["status"])
+    assert np.array_equal(st_g, st_o)
+    assert (st_g.reshape(B, 3, 13)[:, 2, 1] >= r - 1e-9).all()     # the free sphere was pushed out of the plane all the same

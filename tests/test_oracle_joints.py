@@ -173,3 +173,59 @@ def test_a_joint_merges_two_contact_islands(oracle):
     assert a_free["status"][0] == 0 and a_jnt["status"][0] == 0
     assert a_free["lcp_solves"][0] == 2 * a_jnt["lcp_solves"][0] and a_free["lcp_rows"][0] == a_jnt["lcp_rows"][0]
     np.testing.assert_allclose(s_jnt[:, 0:3], s_free[:, 0:3], atol=1e-6)         # both just rest
+
+
+# ---- ConstraintStabilization with implicit joints (bilateral-only islands) ------------------------------------------
+def test_stabilisation_keeps_the_joints_closed(oracle):
+    """The spherical chain again, with the stabiliser on: after every step the bilateral violation is back under
+    bilateral_eps = 1e-6 (CStab:62, 197) where the unstabilised run has drifted to 1e-2; velocities are untouched by it."""
+    nb = 3
+    st = rest_state([[0.5 + k, 0.0, 0.0] for k in range(nb)])
+    joints = [K.make_joint(K.MH_IJOINT_SPHERICAL, nb, 0, (0.0, 0.0, 0.0), st, nb)]
+    joints += [K.make_joint(K.MH_IJOINT_SPHERICAL, k, k + 1, (1.0 + k, 0.0, 0.0), st, nb) for k in range(nb - 1)]
+    J = np.array([[0.4 * 0.2 * 0.2] * 3] * nb)
+    mk = lambda it: K.BigScene([S.MH_GEOM_SPHERE] * nb, [(0.2, 0, 0)] * nb, np.ones(nb), J, [], gravity=(0.0, -9.81, 0.0),
+                               cstab_max_iterations=it, joints=joints, lcp_n_max=64)
+    s_on, a_on = run(oracle, mk(20), st, 1e-3, 600)
+    s_off, a_off = run(oracle, mk(0), st, 1e-3, 600)
+    assert a_on["status"][0] == 0 and a_on["stab_iters"][0] > 0 and a_on["lcp_solves"][0] == 0
+    worst_on = max(np.abs(oracle.joint_eval(mk(20), s_on.reshape(-1), j)[0]).max() for j in range(nb))
+    worst_off = max(np.abs(oracle.joint_eval(mk(0), s_off.reshape(-1), j)[0]).max() for j in range(nb))
+    assert worst_on < 1e-6 < 1e-3 < worst_off
+    assert s_on[:, 1].min() < -0.3
+
+
+def test_stabilisation_closes_an_open_joint_in_a_few_iterations(oracle):
+    """A revolute joint pulled apart by 1e-2 and twisted: stabilize() alone (seam B3) brings |C| under 1e-6 -- the Newton
+    step (J iM J') lambda = C, dq = -iM J' lambda on the largest independent row set, with the Ridders / backtracking line
+    search on the constraint norm."""
+    st = rest_state([[1.0, 0.0, 0.0], [2.2, 0.0, 0.0]])
+    joints = [K.make_joint(K.MH_IJOINT_REVOLUTE, 2, 0, (0.0, 0.0, 0.0), st, 2, axis=(0, 0, 1)),
+              K.make_joint(K.MH_IJOINT_REVOLUTE, 0, 1, (1.6, 0.0, 0.0), st, 2, axis=(0, 1, 0))]
+    sc = free_scene(2, joints)
+    sc.c.cstab_max_iterations = 30
+    s = st.copy()
+    s[0, 0:3] += (0.01, -0.008, 0.004); s[1, 0:3] += (-0.006, 0.01, 0.0)
+    q = np.array([0.01, -0.02, 0.015, 1.0]); s[1, 3:7] = q / np.linalg.norm(q)
+    s[:, 7:13] = 0.3                                              # velocities are saved and restored (CStab:181, 246)
+    before = max(np.abs(oracle.joint_eval(sc, s.reshape(-1), j)[0]).max() for j in range(2))
+    aux = S.new_aux(1)
+    out = s.reshape(-1).copy()
+    oracle.big_step(sc, out, aux, 1e-3, 1, mode=1)
+    after = max(np.abs(oracle.joint_eval(sc, out, j)[0]).max() for j in range(2))
+    assert before > 5e-3 and after < 1e-6 and aux["status"][0] == 0 and 1 <= aux["stab_iters"][0] <= 10
+    np.testing.assert_array_equal(out.reshape(2, 13)[:, 7:13], s[:, 7:13])
+
+
+def test_jointed_bodies_in_contact_are_flagged_not_approximated(oracle):
+    """A jointed island that the stabiliser's contact list touches needs compute_X's general case: not built -- the world is
+    flagged MH_WORLD_UNSUPPORTED and those bodies are left where they are."""
+    r = 0.2
+    st = rest_state([[0.0, r - 1e-4, 0.0], [1.0, r - 1e-4, 0.0]])            # both penetrate the plane: stabilisation runs
+    j = K.make_joint(K.MH_IJOINT_SPHERICAL, 0, 1, (0.5, r, 0.0), st, 2)
+    sc = K.BigScene([S.MH_GEOM_SPHERE] * 2, [(r, 0, 0)] * 2, [1.0, 1.0], [[0.016] * 3] * 2, [(0, 2, 0), (1, 2, 0)],
+                    gravity=(0.0, -9.81, 0.0), cstab_max_iterations=5, joints=[j], lcp_n_max=64)
+    aux = S.new_aux(1)
+    out = st.reshape(-1).copy()
+    oracle.big_step(sc, out, aux, 1e-3, 1, mode=1)
+    assert aux["status"][0] & S.MH_WORLD_UNSUPPORTED
