@@ -813,7 +813,7 @@ class World {
     return -1;
   }
 
-  void compute_problem_data(const std::vector<Contact>& all, const Island& isl, ProblemData& pd, bool normals_only) const {
+  void compute_problem_data(const std::vector<Contact>& all, const Island& isl, ProblemData& pd, bool normals_only, const std::vector<double>* Xgen = nullptr) const {
     pd.bodies = isl.bodies;
     std::sort(pd.bodies.begin(), pd.bodies.end());
     pd.bodies.erase(std::unique(pd.bodies.begin(), pd.bodies.end()), pd.bodies.end());
@@ -823,7 +823,8 @@ class World {
     const int ngc = pd.ngc = 6 * (int)pd.bodies.size();
     // X
     pd.X.assign((size_t)ngc * ngc, 0.0);
-    for (size_t bi = 0; bi < pd.bodies.size(); bi++) {
+    if (Xgen) pd.X = *Xgen;                                  // compute_X's general case: implicit joints in the island (ICH:1590-1695)
+    else for (size_t bi = 0; bi < pd.bodies.size(); bi++) {
       double im, Ji[9]; inv_inertia(pd.bodies[bi], im, Ji);
       const int o = 6 * (int)bi;
       for (int k = 0; k < 3; k++) pd.X[(o + k) * ngc + (o + k)] = im;
@@ -1469,44 +1470,52 @@ class World {
   // J iM, J iM J' products of compute_X ICH:1657-1660), Jx_v = C on the active rows (CStab:475-486), then determine_dq
   // with an empty LCP (CStab:932-970) and update_from_stacked's bilateral step (ICH:356-374):
   //   (J iM J') lambda = C ,  v = 0 + (0 - iM J' lambda) ,  dq = the bodies' eEuler velocities.
-  bool bilateral_only_dq(const std::vector<int>& island, const std::vector<int>& joints, const std::vector<double>& Call, std::vector<double>& dq) {
+  struct JBlk { int row, off, rows; double w[6][6]; };
+  struct BilatData {                       // what compute_problem_data / compute_X keep of an island's implicit joints
+    int nbod, ngc, m, k;                   // bodies, coordinates, equations, active (full-rank) equations
+    std::vector<int> bodies, act;
+    std::vector<JBlk> blocks;
+    std::vector<double> Cj, iM, Mg, JiM, A, L, lam;   // C rows; 6x6 blocks of iM and M; J iM (m x ngc); J iM J' on the active rows (col-major k x k) and its factor
+  };
+  // Jfull, get_full_rank_implicit_constraints (ICH:1698-1739), J iM, J iM J' (ICH:1657-1660), Jx_v = C (CStab:442-453, 475-486)
+  bool build_bilateral(const std::vector<int>& island, const std::vector<int>& joints, const std::vector<double>& Call, BilatData& bd) const {
     const int nbod = (int)island.size(), ngc = 6 * nbod;
     int m = 0;
     for (int j : joints) m += joint_rows(sc->joint_type[j]);
     if (nbod > MH_IJOINT_MAX_BODIES || (int)joints.size() > MH_IJOINT_MAX_JOINTS || m > MH_IJOINT_MAX_EQNS) return false;
+    bd.nbod = nbod; bd.ngc = ngc; bd.m = m; bd.bodies = island; bd.blocks.clear(); bd.Cj.assign(m, 0.0);
     auto gc_of_body = [&](int b) { for (int i = 0; i < nbod; i++) if (island[i] == b) return 6 * i; return -1; };
-    struct Blk { int row, off, rows; double w[6][6]; };
-    std::vector<Blk> blocks;
-    std::vector<double> Cj(m);
     int eq = 0;
     for (int j : joints) {
       const int rows = joint_rows(sc->joint_type[j]);
       int first = 0;                                               // the joint's first row in the scene-wide C vector
       for (int jj = 0; jj < j; jj++) first += joint_rows(sc->joint_type[jj]);
-      for (int k = 0; k < rows; k++) Cj[eq + k] = Call[first + k];
+      for (int k = 0; k < rows; k++) bd.Cj[eq + k] = Call[first + k];
       const int sides[2] = { sc->joint_inboard[j], sc->joint_outboard[j] };
       for (int sd = 0; sd < 2; sd++) {
         if (!enabled(sides[sd])) continue;
-        Blk k; k.row = eq; k.off = gc_of_body(sides[sd]); k.rows = rows;
+        JBlk k; k.row = eq; k.off = gc_of_body(sides[sd]); k.rows = rows;
         joint_jac(j, sd == 0, k.w);
-        blocks.push_back(k);
+        bd.blocks.push_back(k);
       }
       eq += rows;
     }
-    auto covering = [&](int row, std::vector<const Blk*>& out) { out.clear(); for (const Blk& k : blocks) if (row >= k.row && row < k.row + k.rows) out.push_back(&k); };
-    // J J' and the greedy full-rank set on J J' - sqrt(eps) I (ICH:1698-1739)
+    const std::vector<JBlk>& blocks = bd.blocks;
+    auto covering = [&](int row, std::vector<const JBlk*>& out) { out.clear(); for (const JBlk& k : blocks) if (row >= k.row && row < k.row + k.rows) out.push_back(&k); };
+    // J J' and the greedy full-rank set on J J' - sqrt(eps) I
     std::vector<double> JJT((size_t)m * m, 0.0);
-    std::vector<const Blk*> br, bc;
+    std::vector<const JBlk*> br, bc;
     for (int r = 0; r < m; r++) { covering(r, br); for (int c = 0; c < m; c++) { covering(c, bc);
       double tot = 0.0;
-      for (const Blk* kr : br) for (const Blk* kc : bc) {
+      for (const JBlk* kr : br) for (const JBlk* kc : bc) {
         if (kr->off != kc->off) continue;
         double acc = 0.0;
         for (int q = 0; q < 6; q++) acc = acc + kr->w[r - kr->row][q] * kc->w[c - kc->row][q];
         tot = tot + acc;
       }
       JJT[(size_t)r * m + c] = tot; } }
-    std::vector<int> act; std::vector<double> L;
+    std::vector<int>& act = bd.act; act.clear();
+    std::vector<double> L;
     for (int i = 0; i < m; i++) {
       if ((int)act.size() == ngc) break;
       act.push_back(i);
@@ -1516,50 +1525,104 @@ class World {
       for (int r = 0; r < k; r++) L[r + (size_t)k * r] = L[r + (size_t)k * r] - NEAR_ZERO;
       if (!chol_factor(k, L.data(), k)) act.pop_back();
     }
-    const int k = (int)act.size();
-    // J iM (active rows matter), J iM J' on the active rows
-    std::vector<double> iM((size_t)nbod * 36, 0.0);
+    const int k = bd.k = (int)act.size();
+    bd.iM.assign((size_t)nbod * 36, 0.0); bd.Mg.assign((size_t)nbod * 36, 0.0);
     for (int i = 0; i < nbod; i++) {
       double im, Ji[9]; inv_inertia(island[i], im, Ji);
-      double* B = &iM[(size_t)i * 36];
-      for (int q = 0; q < 3; q++) B[7 * q] = im;
-      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) B[6 * (3 + r) + 3 + c] = Ji[3 * r + c];
+      double Jw[9]; inertia_world(island[i], Jw);
+      double* B = &bd.iM[(size_t)i * 36]; double* M = &bd.Mg[(size_t)i * 36];
+      for (int q = 0; q < 3; q++) { B[7 * q] = im; M[7 * q] = mass_[island[i]]; }
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { B[6 * (3 + r) + 3 + c] = Ji[3 * r + c]; M[6 * (3 + r) + 3 + c] = Jw[3 * r + c]; }
     }
-    std::vector<double> JiM((size_t)m * ngc, 0.0);
-    for (const Blk& kb : blocks) {
-      const double* B = &iM[(size_t)(kb.off / 6) * 36];
+    bd.JiM.assign((size_t)m * ngc, 0.0);
+    for (const JBlk& kb : blocks) {
+      const double* B = &bd.iM[(size_t)(kb.off / 6) * 36];
       for (int r = 0; r < kb.rows; r++) for (int c = 0; c < 6; c++) {
         double acc = 0.0;
         for (int q = 0; q < 6; q++) acc = acc + kb.w[r][q] * B[6 * q + c];
-        JiM[(size_t)(kb.row + r) * ngc + kb.off + c] = acc;
+        bd.JiM[(size_t)(kb.row + r) * ngc + kb.off + c] = acc;
       }
     }
-    L.assign((size_t)k * k, 0.0);
+    bd.A.assign((size_t)k * k, 0.0);
     for (int r = 0; r < k; r++) { covering(act[r], br); for (int c = 0; c < k; c++) {
       double tot = 0.0;
-      for (const Blk* kr : br) {
+      for (const JBlk* kr : br) {
         double acc = 0.0;
-        for (int q = 0; q < 6; q++) acc = acc + kr->w[act[r] - kr->row][q] * JiM[(size_t)act[c] * ngc + kr->off + q];
+        for (int q = 0; q < 6; q++) acc = acc + kr->w[act[r] - kr->row][q] * bd.JiM[(size_t)act[c] * ngc + kr->off + q];
         tot = tot + acc;
       }
-      L[r + (size_t)k * c] = tot; } }
-    if (k > 0 && !chol_factor(k, L.data(), k)) return false;
-    std::vector<double> lam(k);
-    for (int r = 0; r < k; r++) lam[r] = Cj[act[r]];
-    if (k > 0) chol_solve(k, L.data(), k, lam.data());
-    for (int i = 0; i < nbod; i++) {
+      bd.A[r + (size_t)k * c] = tot; } }
+    bd.L = bd.A;
+    if (k > 0 && !chol_factor(k, bd.L.data(), k)) return false;
+    bd.lam.assign(k, 0.0);
+    for (int r = 0; r < k; r++) bd.lam[r] = bd.Cj[act[r]];           // update_from_stacked (ICH:356-367): (J iM J') lambda = Jx_v
+    if (k > 0) chol_solve(k, bd.L.data(), k, bd.lam.data());
+    return true;
+  }
+  // iM J' lambda of coordinate g (ICH:370)
+  static double bilateral_dv(const BilatData& bd, int g) {
+    double acc = 0.0;
+    for (int r = 0; r < bd.k; r++) acc = acc + bd.JiM[(size_t)bd.act[r] * bd.ngc + g] * bd.lam[r];
+    return acc;
+  }
+  // An island of bodies tied by implicit joints and touched by no unilateral constraint ("remaining island", UC:1158-1191):
+  // set_bilateral_only_constraint_data (CStab:531-700), then determine_dq with an empty LCP (CStab:932-970) and
+  // update_from_stacked's bilateral step (ICH:356-374): v = 0 + (0 - iM J' lambda), dq = the bodies' eEuler velocities.
+  bool bilateral_only_dq(const std::vector<int>& island, const std::vector<int>& joints, const std::vector<double>& Call, std::vector<double>& dq) {
+    BilatData bd;
+    if (!build_bilateral(island, joints, Call, bd)) return false;
+    for (int i = 0; i < bd.nbod; i++) {
       double dv[6];
-      for (int q = 0; q < 6; q++) {
-        double acc = 0.0;
-        for (int r = 0; r < k; r++) acc = acc + JiM[(size_t)act[r] * ngc + 6 * i + q] * lam[r];
-        dv[q] = 0.0 + (0.0 - acc);
-      }
+      for (int q = 0; q < 6; q++) dv[q] = 0.0 + (0.0 - bilateral_dv(bd, 6 * i + q));
       const int b = island[i];
       setV(b, v3(dv[0], dv[1], dv[2])); setW(b, v3(dv[3], dv[4], dv[5]));
       double qd[7]; euler_vel(b, qd);
       for (int q = 0; q < 7; q++) dq[7 * b + q] = qd[q];
     }
     return true;
+  }
+  // ImpactConstraintHandler::compute_X (ICH:1590-1695): X = iM - 2 G + G' M G with G = iM H' J iM, H' = J' (J iM J')^-1, over the
+  // active rows -- the inverse inertia of the island projected on the joints' null space; dense ngc x ngc, row-major.
+  // Every product accumulates from 0 over ascending indices (Ravelin's gemm order is not in the tree: parity unpinned).
+  void compute_X_general(const BilatData& bd, std::vector<double>& X) const {
+    const int ngc = bd.ngc, k = bd.k, nbod = bd.nbod;
+    std::vector<double> Ainv = bd.A;
+    if (k > 0) inverse_spd(k, Ainv.data(), k);
+    // H' = J' Ainv (ngc x k): the blocks' rows in block order
+    std::vector<double> HT((size_t)ngc * k, 0.0);
+    std::vector<int> pos(bd.m, -1);
+    for (int r = 0; r < k; r++) pos[bd.act[r]] = r;
+    for (int g = 0; g < ngc; g++) for (int c = 0; c < k; c++) {
+      double acc = 0.0;
+      for (const JBlk& kb : bd.blocks) {
+        if (g < kb.off || g >= kb.off + 6) continue;
+        for (int r = 0; r < kb.rows; r++) { const int pr = pos[kb.row + r]; if (pr >= 0) acc = acc + kb.w[r][g - kb.off] * Ainv[pr + (size_t)k * c]; }
+      }
+      HT[(size_t)g * k + c] = acc;
+    }
+    std::vector<double> HTJiM((size_t)ngc * ngc), G((size_t)ngc * ngc), MG((size_t)ngc * ngc);
+    for (int g = 0; g < ngc; g++) for (int h = 0; h < ngc; h++) {
+      double acc = 0.0;
+      for (int c = 0; c < k; c++) acc = acc + HT[(size_t)g * k + c] * bd.JiM[(size_t)bd.act[c] * ngc + h];
+      HTJiM[(size_t)g * ngc + h] = acc;
+    }
+    for (int i = 0; i < nbod; i++) for (int r = 0; r < 6; r++) for (int h = 0; h < ngc; h++) {
+      double acc = 0.0;
+      for (int q = 0; q < 6; q++) acc = acc + bd.iM[(size_t)i * 36 + 6 * r + q] * HTJiM[(size_t)(6 * i + q) * ngc + h];
+      G[(size_t)(6 * i + r) * ngc + h] = acc;
+    }
+    for (int i = 0; i < nbod; i++) for (int r = 0; r < 6; r++) for (int h = 0; h < ngc; h++) {
+      double acc = 0.0;
+      for (int q = 0; q < 6; q++) acc = acc + bd.Mg[(size_t)i * 36 + 6 * r + q] * G[(size_t)(6 * i + q) * ngc + h];
+      MG[(size_t)(6 * i + r) * ngc + h] = acc;
+    }
+    X.assign((size_t)ngc * ngc, 0.0);
+    for (int i = 0; i < nbod; i++) for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) X[(size_t)(6 * i + r) * ngc + 6 * i + c] = bd.iM[(size_t)i * 36 + 6 * r + c];
+    for (int g = 0; g < ngc; g++) for (int h = 0; h < ngc; h++) {
+      double acc = 0.0;
+      for (int p2 = 0; p2 < ngc; p2++) acc = acc + G[(size_t)p2 * ngc + g] * MG[(size_t)p2 * ngc + h];
+      X[(size_t)g * ngc + h] = (X[(size_t)g * ngc + h] - 2.0 * G[(size_t)g * ngc + h]) + acc;
+    }
   }
   // update_q (CStab:1056-1216)
   bool update_q(const std::vector<double>& dq, std::vector<double>& q) {
@@ -1669,14 +1732,30 @@ class World {
         bool touched = false;
         for (const Contact& c : cs) if ((enabled(c.g1) && std::binary_search(jisl[ji].begin(), jisl[ji].end(), c.g1)) ||
                                         (enabled(c.g2) && std::binary_search(jisl[ji].begin(), jisl[ji].end(), c.g2))) { touched = true; break; }
-        if (touched) { aux->status |= MH_WORLD_UNSUPPORTED; continue; }
+        if (touched) continue;                                      // part of a contact island: below
         if (!bilateral_only_dq(jisl[ji], jisl_joints[ji], Cb, dq)) aux->status |= MH_WORLD_STAB_FAILED;
       }
       for (const Island& isl : islands) {
         bool mixed = false;
         for (int b : isl.bodies) if (jointed[b]) mixed = true;
-        if (mixed) continue;
-        ProblemData pd; compute_problem_data(cs, isl, pd, true);
+        ProblemData pd;
+        BilatData bd;
+        if (mixed) {
+          // set_unilateral_constraint_data with implicit joints (CStab:705-904): the island's joints, their full-rank rows,
+          // compute_X's general case; Jx_v = C on the active rows (CStab:442-453)
+          std::vector<int> bodies = isl.bodies;
+          std::sort(bodies.begin(), bodies.end());
+          bodies.erase(std::unique(bodies.begin(), bodies.end()), bodies.end());
+          std::vector<int> ij;
+          for (int j = 0; j < njoints(); j++) {
+            const int a = sc->joint_inboard[j], b = sc->joint_outboard[j];
+            if ((enabled(a) && std::binary_search(bodies.begin(), bodies.end(), a)) || (enabled(b) && std::binary_search(bodies.begin(), bodies.end(), b))) ij.push_back(j);
+          }
+          if (!build_bilateral(bodies, ij, Cb, bd)) { aux->status |= MH_WORLD_UNSUPPORTED; continue; }
+          std::vector<double> Xg; compute_X_general(bd, Xg);
+          compute_problem_data(cs, isl, pd, true, &Xg);
+        } else
+        compute_problem_data(cs, isl, pd, true);
         const int nc = pd.nc;
         for (int i = 0; i < nc; i++) pd.Cv[0][i] = pd.c[i]->dist - std::fabs(sc->cstab_eps) - NEAR_ZERO;   // CStab:431
         // determine_dq (CStab:932-970): MM = Cn X Cn', cold lcp_fast then Lemke ladder
@@ -1699,6 +1778,12 @@ class World {
         for (int i = 0; i < nc; i++) pd.cn[i] = (i < (int)z.size()) ? z[i] : 0.0;
         pd.XJ[1].clear(); pd.XJ[2].clear();
         apply_impulses(pd);
+        if (mixed) for (size_t bi = 0; bi < pd.bodies.size(); bi++) {    // dv -= iM J' lambda (ICH:370)
+          const int b = pd.bodies[bi];
+          double s6[6];
+          for (int q = 0; q < 6; q++) s6[q] = st[13 * b + 7 + q] - bilateral_dv(bd, 6 * (int)bi + q);
+          for (int q = 0; q < 6; q++) st[13 * b + 7 + q] = s6[q];
+        }
         for (int b : pd.bodies) { double qd[7]; euler_vel(b, qd); for (int k = 0; k < 7; k++) dq[7*b + k] = qd[k]; }
       }
       if (!update_q(dq, q)) { aux->status |= MH_WORLD_STAB_FAILED; break; }

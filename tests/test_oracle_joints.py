@@ -217,15 +217,27 @@ def test_stabilisation_closes_an_open_joint_in_a_few_iterations(oracle):
     np.testing.assert_array_equal(out.reshape(2, 13)[:, 7:13], s[:, 7:13])
 
 
-def test_jointed_bodies_in_contact_are_flagged_not_approximated(oracle):
-    """A jointed island that the stabiliser's contact list touches needs compute_X's general case: not built -- the world is
-    flagged MH_WORLD_UNSUPPORTED and those bodies are left where they are."""
+def test_jointed_bodies_in_contact_use_the_general_compute_X(oracle):
+    """A sphere sunk 1e-4 into the plane with a second sphere welded on top of it, next to a pair tied by a spherical joint
+    of which one has sunk: the stabiliser's contact islands hold implicit joints, X = iM - 2G + G'MG (ICH:1590-1695)
+    carries the contact push through the joints -- the welded sphere rises with its partner, the joints stay closed."""
     r = 0.2
-    st = rest_state([[0.0, r - 1e-4, 0.0], [1.0, r - 1e-4, 0.0]])            # both penetrate the plane: stabilisation runs
-    j = K.make_joint(K.MH_IJOINT_SPHERICAL, 0, 1, (0.5, r, 0.0), st, 2)
-    sc = K.BigScene([S.MH_GEOM_SPHERE] * 2, [(r, 0, 0)] * 2, [1.0, 1.0], [[0.016] * 3] * 2, [(0, 2, 0), (1, 2, 0)],
-                    gravity=(0.0, -9.81, 0.0), cstab_max_iterations=5, joints=[j], lcp_n_max=64)
+    nb = 4
+    st0 = rest_state([[0.0, r, 0.0], [0.0, r + 0.5, 0.0], [2.0, r, 0.0], [3.0, r + 0.3, 0.0]])
+    joints = [K.make_joint(K.MH_IJOINT_FIXED, 0, 1, (0.0, r + 0.25, 0.0), st0, nb),
+              K.make_joint(K.MH_IJOINT_SPHERICAL, 2, 3, (2.5, r + 0.15, 0.0), st0, nb)]
+    sc = K.BigScene([S.MH_GEOM_SPHERE] * nb, [(r, 0, 0)] * nb, np.ones(nb), [[0.016] * 3] * nb, [(k, nb, 0) for k in range(nb)],
+                    gravity=(0.0, -9.81, 0.0), cstab_max_iterations=20, joints=joints, lcp_n_max=64)
+    st = st0.copy()
+    st[[0, 1], 1] -= 1e-4                                           # the welded pair sinks as one
+    st[2, 1] -= 1e-4                                                # the tied sphere sinks alone: its joint opens by 1e-4 as well
     aux = S.new_aux(1)
     out = st.reshape(-1).copy()
     oracle.big_step(sc, out, aux, 1e-3, 1, mode=1)
-    assert aux["status"][0] & S.MH_WORLD_UNSUPPORTED
+    o = out.reshape(nb, 13)
+    assert aux["status"][0] == 0 and aux["stab_iters"][0] >= 1 and aux["lcp_solves"][0] >= 1
+    assert (o[[0, 2], 1] >= r - 1e-9).all()                         # out of the plane
+    assert abs((o[1, 1] - o[0, 1]) - 0.5) < 1e-6                    # the weld held: the upper sphere rose with the lower
+    for j in range(2):
+        assert np.abs(oracle.joint_eval(sc, out, j)[0]).max() < 1e-6
+    assert abs(o[1, 1] - (r + 0.5)) < 2e-5 and np.abs(o[:, [0, 2]] - st0[:, [0, 2]]).max() < 1e-4
