@@ -11,7 +11,10 @@
  *   ImpactConstraintHandler::process_constraints with its island loop       src/ImpactConstraintHandler.cpp:75-168, 530-626
  *   ConstraintStabilization::stabilize (+ compute_problem_data, determine_dq, update_q, ridders_unilateral)
  *                                                                           src/ConstraintStabilization.cpp:167-254, 347-492, 932-970, 1056-1379
- *   Simulator::calc_fwd_dyn for free bodies                                 src/Simulator.cpp:482-602
+ *   Simulator::calc_fwd_dyn for free bodies, and for islands of bodies tied by implicit joints the KKT solve of
+ *     Simulator::solve with Simulator::find_islands                         src/Simulator.cpp:482-602, 608-805, 956-1045
+ *   ImpactConstraintHandler::compute_X / get_full_rank_implicit_constraints (used by the stabiliser)
+ *                                                                           src/ImpactConstraintHandler.cpp:1590-1739
  * Every world is stepped by its own workgroup (geometry, islands, problem data, impulse application, Ridders line
  * search) and its LCPs go through the LCP entry of moby_hip.h with per-island sizes; nothing runs on the host but
  * the loop that asks "does any world have another mini-step / island / stabilisation iteration".
@@ -80,9 +83,10 @@ typedef struct mh_big_scene {
    * is the KKT solve of Simulator::solve (src/Simulator.cpp:608-805) and joints connect constraint islands
    * (src/UnilateralConstraint.cpp:993-1008).  A joint is 3 position rows (the joint point of both bodies coincides, global
    * axes) plus 0 / 2 / 3 orientation rows "a_k . b_k = 0" with a_k fixed in the inboard and b_k in the outboard frame.
-   * ConstraintStabilization closes the joints of islands no contact touches (CStab:133-160, 462-486, 531-700, 1132-1192); a
- * jointed island touched by the stabiliser's contact list would need compute_X's general case (ICH:1590-1695): not built,
- * such a world is flagged MH_WORLD_UNSUPPORTED (run those scenes with cstab_max_iterations = 0, as ur10.xml does). */
+   * ConstraintStabilization closes the joints too (CStab:133-160, 197, 1132-1192): islands no contact touches take the
+ * bilateral step alone (CStab:462-486, 531-700), contact islands that hold jointed bodies get the general
+ * ImpactConstraintHandler::compute_X (X = iM - 2G + G'MG over the full-rank joint rows, ICH:1590-1739).  The impact handler
+ * itself never sees joint rows -- the reference leaves island_ijoints empty there.  Sizes: MH_IJOINT_MAX_* per island. */
   int njoints;
   const int*    joint_type;       /* njoints: MH_IJOINT_*                                                          */
   const int*    joint_inboard;    /* body id, or nb for the static world                                           */

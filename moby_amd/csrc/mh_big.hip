@@ -758,8 +758,8 @@ void k_stab_prep(Dev d)
 // the jointed islands are fixed per scene): set_bilateral_only_constraint_data (CStab:531-700) -- Jfull, the greedy
 // full-rank set on J J' - sqrt(eps) I (ICH:1698-1739), J iM and J iM J' on the active rows (ICH:1657-1660), Jx_v = C
 // (CStab:475-486) -- then update_from_stacked's bilateral step (ICH:356-374): (J iM J') lambda = C, v = 0 + (0 - iM J' lambda).
-// A jointed island that a contact touches needs compute_X's general case: not built, the world is flagged (and k_prep drops
-// the contact island).  Operation order: oracle World::bilateral_only_dq.
+// A jointed island that a contact touches belongs to a contact island: mh_impact.hip's k_bilat_X (compute_X's general case).
+// Operation order: oracle World::build_bilateral / bilateral_only_dq.
 __global__ __launch_bounds__(KKT_T)
 void k_stab_bilat(Dev d)
 {
@@ -787,7 +787,7 @@ void k_stab_bilat(Dev d)
     }
   }
   __syncthreads();
-  if (s_touched) { if (t == 0) d.status[b] |= MH_WORLD_UNSUPPORTED; return; }
+  if (s_touched) return;                                 // part of a contact island: the island pipeline's k_bilat_X (general compute_X)
   for (int i = t; i < nbod; i += KKT_T) {
     const int bb = bodies[i];
     double xi[10];
@@ -1266,7 +1266,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
     std::vector<int> jrow0((size_t)nj); int rows = 0;
     for (int j = 0; j < nj; j++) { jrow0[(size_t)j] = rows; rows += (sc->joint_type[j] == MH_IJOINT_SPHERICAL) ? 3 : (sc->joint_type[j] == MH_IJOINT_REVOLUTE ? 5 : 6); }
     d.jrows = rows; d.jrow0 = (const int*)U(jrow0.data(), nj * 4);
-    bb->core.jointed = nullptr;
+
     d.jtype = (const int*)U(sc->joint_type, nj * 4); d.jin = (const int*)U(sc->joint_inboard, nj * 4); d.jout = (const int*)U(sc->joint_outboard, nj * 4);
     d.janchor_in = (const double*)U(sc->joint_anchor_in, nj * 24); d.janchor_out = (const double*)U(sc->joint_anchor_out, nj * 24);
     d.jvec_in = (const double*)U(sc->joint_vec_in, nj * 72); d.jvec_out = (const double*)U(sc->joint_vec_out, nj * 72);
@@ -1277,8 +1277,11 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
       d.kk_m = (const int*)U(kk_m.data(), kk_m.size() * 4);
       d.kk_JiM = (double*)A((size_t)B * d.kk_nisl * kk_mmax * 6 * MH_IJOINT_MAX_BODIES * 8, true);
     }
-    bb->core.nj = nj; bb->core.jin = d.jin; bb->core.jout = d.jout;     // joint edges of the constraint islands (UC:993-1008)
-    bb->core.jointed = d.jointed;
+    // joint edges of the constraint islands (UC:993-1008) and the stabiliser's general compute_X
+    if (okall) {
+      rc = mh_imp_core_enable_joints(&bb->core, nj, d.jtype, d.jin, d.jout, d.janchor_in, d.janchor_out, d.jvec_in, d.jvec_out, d.jointed);
+      if (rc != MH_OK) okall = false;
+    }
   }
   const size_t sB = (size_t)B;
   d.state = (double*)A(sB * nb * 13 * 8, true); d.qsave = (double*)A(sB * nb * 7 * 8, true); d.vsave = (double*)A(sB * nb * 6 * 8, true);

@@ -39,10 +39,18 @@ struct mh_imp_core {
   // implicit joints of the scene (0 / NULL without): their dynamic links are nodes of the island search and an edge
   // joins the two (UC:993-1008); the handler itself never sees their rows (island_ijoints stays empty in ICH)
   int nj; const int* jin; const int* jout;
-  const unsigned char* jointed;                     // nb flags: body belongs to an island with a joint (MH_CORE_STAB drops contact islands that hold one)
+  const unsigned char* jointed;                     // nb flags: body belongs to an island with a joint
+  // MH_CORE_STAB, contact islands that hold jointed bodies (isl_model 3): set_unilateral_constraint_data with implicit joints
+  // (CStab:705-904) and compute_X's general case (ICH:1590-1695).  Joint tables (scene), the island's sorted bodies, and per
+  // world (one such island per round): dense X and its factors' scratch (ngc <= 96), X Cn' rows, the bilateral step's data
+  const int* jtype; const double* janchor_in; const double* janchor_out; const double* jvec_in; const double* jvec_out;
+  int* isl_nbod; int* isl_bod;                      // B x islmax, B x islmax x MH_IJOINT_MAX_BODIES
+  double* bT1; double* bT2; double* bT3; double* bT4;   // B x 96 x 96 each: H'J iM then X; G; M G; H'
+  double* bXCn;                                     // B x ncmax x 96
+  double* bJiM; double* blam; int* bact; int* bk;   // B x 48 x 96, B x 48, B x 48, B
   double* ws_d; int* ws_i;                          // block-solver workspace (nmax > 64)
   int* hmax;                                        // pinned host copy of maxisl
-  void* allocs[48]; int nallocs;
+  void* allocs[64]; int nallocs;
 };
 
 extern "C" {
@@ -50,6 +58,10 @@ extern "C" {
 // status, which the caller points at its own memory) and uploads the friction-polygon table
 MH_HIDDEN int mh_imp_core_create(mh_imp_core* c, int B, int nb, int ncmax, int nk, int nmax);
 MH_HIDDEN void mh_imp_core_destroy(mh_imp_core* c);
+// after create, for scenes with implicit joints: the joint tables (device pointers, the caller's) and the scratch of the
+// stabiliser's general compute_X
+MH_HIDDEN int mh_imp_core_enable_joints(mh_imp_core* c, int nj, const int* jtype, const int* jin, const int* jout, const double* janchor_in,
+                                        const double* janchor_out, const double* jvec_in, const double* jvec_out, const unsigned char* jointed);
 // prep (islands, rows, X C^T, C v) + one round per island (gram, LCP matrix, solver chain, impulse application,
 // restitution / second solve) + the impact-tolerance check.  Synchronises `stream` once, after the island search, to
 // learn how many rounds the batch needs.

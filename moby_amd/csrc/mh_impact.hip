@@ -28,6 +28,7 @@
 #include <cstring>
 #include <vector>
 #include "../../include/moby_hip_impact.h"
+#include "../../include/moby_hip_stack.h"
 #include "mh_host.h"
 #include "mh_imp_core.h"
 #include "mh_imp_dev.h"
@@ -127,13 +128,19 @@ void k_prep(Dev d, int mode)
         if (mode == MH_CORE_IMPACT) {
           if (!active) keep = false;                                               // remove_inactive_groups (UC:1197-1225)
         }
-        // stabilisation of a contact island that holds jointed bodies needs compute_X's general case (ICH:1590-1695): not built
-        if (keep && mode == MH_CORE_STAB && has_jointed) { keep = false; d.status[b] |= MH_WORLD_UNSUPPORTED; }
+        // stabilisation of a contact island that holds jointed bodies: compute_X's general case (k_bilat_X), on islands of the built size
+        const bool bilat = keep && mode == MH_CORE_STAB && has_jointed;
+        if (bilat && (qlen > MH_IJOINT_MAX_BODIES || !d.bT1)) { keep = false; d.status[b] |= MH_WORLD_UNSUPPORTED; }
         if (keep && nisl >= d.islmax) { keep = false; d.status[b] |= MH_WORLD_UNSUPPORTED; }
         if (!keep) { cnt = begin; continue; }
         d.isl_start[(size_t)b * d.islmax + nisl] = begin; d.isl_len[(size_t)b * d.islmax + nisl] = cnt - begin;
         // every mu >= 100: the no-slip model (ICH:134-135); otherwise Drumwright-Shell, or Anitescu-Potra in a USE_AP batch (ICH:139-146)
-        d.isl_model[(size_t)b * d.islmax + nisl] = (mode != MH_CORE_IMPACT) ? 0 : (all_inf ? 1 : (d.ap ? 2 : 0));
+        d.isl_model[(size_t)b * d.islmax + nisl] = (mode != MH_CORE_IMPACT) ? (bilat ? 3 : 0) : (all_inf ? 1 : (d.ap ? 2 : 0));
+        if (bilat) {                                        // the island's super bodies, sorted (CStab:718-722)
+          int* ib = d.isl_bod + ((size_t)b * d.islmax + nisl) * MH_IJOINT_MAX_BODIES;
+          for (int i = 0; i < qlen; i++) { int v = s_queue[i], k = i; while (k > 0 && ib[k - 1] > v) { ib[k] = ib[k - 1]; k--; } ib[k] = v; }
+          d.isl_nbod[(size_t)b * d.islmax + nisl] = qlen;
+        }
         nisl++;
       }
     }
@@ -294,7 +301,7 @@ void k_mm(Dev d, int r, int mode, int phase)
     return;
   }
   if (phase == 1 && !d.again[b]) return;
-  if (d.isl_model[(size_t)b * d.islmax + r] == 1) {   // the no-slip model builds its own (nc x nc) LCP: k_noslip
+  if (d.isl_model[(size_t)b * d.islmax + r] == 1 || d.isl_model[(size_t)b * d.islmax + r] == 4) {   // the no-slip model builds its own (nc x nc) LCP: k_noslip; 4: dropped by k_bilat_X
     if (last && t == 0 && phase == 0) { d.run[b] = 0; d.ncur[b] = 0; d.again[b] = 0; }
     return;
   }
@@ -641,6 +648,249 @@ void k_apply_ap(Dev d, int r)
   }
 }
 
+// MH_CORE_STAB, islands of model 3 (contacts over bodies tied by implicit joints): set_unilateral_constraint_data's joint part
+// (CStab:725-745, 826-880: the island's joints, Jfull, get_full_rank_implicit_constraints ICH:1698-1739) and
+// ImpactConstraintHandler::compute_X (ICH:1590-1695): X = iM - 2G + G'MG, G = iM H' J iM, H' = J'(J iM J')^-1 -- then the rows
+// X Cn' of the island's contacts and Cn X Cn' over them, replacing what k_prep / k_gram computed with the block-diagonal X.
+// One workgroup per world; operation order: oracle World::build_bilateral / compute_X_general / compute_problem_data.
+constexpr int KB = MH_IJOINT_MAX_BODIES, KM = MH_IJOINT_MAX_EQNS, KJ = MH_IJOINT_MAX_JOINTS, KG = 6 * MH_IJOINT_MAX_BODIES;
+__global__ __launch_bounds__(T)
+void k_bilat_X(Dev d, int r)
+{
+  const int b = blockIdx.x, t = threadIdx.x;
+  int start, nc;
+  if (!island(d, b, r, start, nc)) return;
+  if (d.isl_model[(size_t)b * d.islmax + r] != 3) return;
+  const int nb = d.nb, ncm = d.ncmax;
+  const double* st = d.state + (size_t)b * nb * 13;
+  const int nbod = d.isl_nbod[(size_t)b * d.islmax + r], ngc = 6 * nbod;
+  const int* bodies = d.isl_bod + ((size_t)b * d.islmax + r) * KB;
+  JointTab jt; jt.nj = d.nj; jt.type = d.jtype; jt.in = d.jin; jt.out = d.jout; jt.anchor_in = d.janchor_in; jt.anchor_out = d.janchor_out;
+  jt.vec_in = d.jvec_in; jt.vec_out = d.jvec_out;
+  __shared__ double s_iM[KB * 36], s_Mg[KB * 36], s_w[2 * KJ * 36];
+  __shared__ int s_jl[KJ], s_brow[2 * KJ], s_boff[2 * KJ], s_brows[2 * KJ], s_pos[KM], s_act[KM];
+  __shared__ double s_A[KM * KM], s_L[KM * KM], s_C[KM], s_lam[KM];
+  __shared__ int s_n[4];                                  // njl, m, k, drop
+  double* T1 = d.bT1 + (size_t)b * KG * KG; double* T2 = d.bT2 + (size_t)b * KG * KG; double* T3 = d.bT3 + (size_t)b * KG * KG;
+  double* T4 = d.bT4 + (size_t)b * KG * KG;
+  double* JiM = d.bJiM + (size_t)b * KM * KG;
+  double* XCn = d.bXCn + (size_t)b * ncm * KG;
+  auto gc_of = [&](int body) { for (int i = 0; i < nbod; i++) if (bodies[i] == body) return 6 * i; return -1; };
+  if (t == 0) {
+    int njl = 0, m = 0, drop = 0;
+    for (int j = 0; j < d.nj; j++) {
+      const int a = d.jin[j], c = d.jout[j];
+      const bool inisl = (a >= 0 && a < nb && gc_of(a) >= 0) || (c >= 0 && c < nb && gc_of(c) >= 0);
+      if (!inisl) continue;
+      const int rows = jt_rows(d.jtype[j]);
+      if (njl == KJ || m + rows > KM) { drop = 1; break; }
+      const int sides[2] = { a, c };
+      for (int sd = 0; sd < 2; sd++) { s_brow[2 * njl + sd] = m; s_boff[2 * njl + sd] = (sides[sd] >= 0 && sides[sd] < nb) ? gc_of(sides[sd]) : -1; s_brows[2 * njl + sd] = rows; }
+      s_jl[njl++] = j; m += rows;
+    }
+    s_n[0] = njl; s_n[1] = m; s_n[3] = drop;
+    if (drop) { d.status[b] |= MH_WORLD_UNSUPPORTED; d.isl_model[(size_t)b * d.islmax + r] = 4; }
+  }
+  __syncthreads();
+  if (s_n[3]) return;
+  const int njl = s_n[0], m = s_n[1];
+  for (int i = t; i < nbod; i += T) {
+    const int bb = bodies[i];
+    double xi[10], Jw[9];
+    inv_inertia(st + 13 * bb, d.inertia + 3 * bb, d.mass[bb], xi, Jw);
+    double* Bm = s_iM + 36 * i; double* Mm = s_Mg + 36 * i;
+    for (int k = 0; k < 36; k++) { Bm[k] = 0.0; Mm[k] = 0.0; }
+    for (int k = 0; k < 3; k++) { Bm[7 * k] = xi[0]; Mm[7 * k] = d.mass[bb]; }
+    for (int rr = 0; rr < 3; rr++) for (int c = 0; c < 3; c++) { Bm[6 * (3 + rr) + 3 + c] = xi[1 + 3 * rr + c]; Mm[6 * (3 + rr) + 3 + c] = Jw[3 * rr + c]; }
+  }
+  for (int jl = t; jl < njl; jl += T) {
+    double c6[6]; jt_eval(jt, st, nb, s_jl[jl], c6);
+    for (int k = 0; k < s_brows[2 * jl]; k++) s_C[s_brow[2 * jl] + k] = c6[k];
+  }
+  for (int k = t; k < 2 * njl; k += T) if (s_boff[k] >= 0) jt_jac(jt, st, nb, s_jl[k >> 1], (k & 1) == 0, s_w + 36 * k);
+  for (int e = t; e < m * ngc; e += T) JiM[e] = 0.0;
+  __syncthreads();
+  for (int e = t; e < m * m; e += T) {                    // J J'
+    const int row = e / m, c = e - row * m;
+    double tot = 0.0;
+    for (int k = 0; k < 2 * njl; k++) {
+      if (s_boff[k] < 0 || row < s_brow[k] || row >= s_brow[k] + s_brows[k]) continue;
+      for (int k2 = 0; k2 < 2 * njl; k2++) {
+        if (s_boff[k2] != s_boff[k] || c < s_brow[k2] || c >= s_brow[k2] + s_brows[k2]) continue;
+        double acc = 0.0;
+        for (int q = 0; q < 6; q++) acc = acc + s_w[36 * k + 6 * (row - s_brow[k]) + q] * s_w[36 * k2 + 6 * (c - s_brow[k2]) + q];
+        tot = tot + acc;
+      }
+    }
+    s_A[row * m + c] = tot;
+  }
+  for (int k = 0; k < 2 * njl; k++) {                     // J iM
+    if (s_boff[k] < 0) continue;
+    const double* Bm = s_iM + 36 * (s_boff[k] / 6);
+    for (int e = t; e < s_brows[k] * 6; e += T) {
+      const int rr = e / 6, c = e - 6 * rr;
+      double acc = 0.0;
+      for (int q = 0; q < 6; q++) acc = acc + s_w[36 * k + 6 * rr + q] * Bm[6 * q + c];
+      JiM[(size_t)(s_brow[k] + rr) * ngc + s_boff[k] + c] = acc;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {                                          // greedy full-rank rows: incremental Cholesky of J J' - sqrt(eps) I
+    int k = 0;
+    for (int i = 0; i < m; i++) s_pos[i] = -1;
+    for (int i = 0; i < m; i++) {
+      if (k == ngc) break;
+      for (int j = 0; j < k; j++) {
+        double tv = s_A[i * m + s_act[j]];
+        for (int p = 0; p < j; p++) tv = tv - s_L[k * m + p] * s_L[j * m + p];
+        s_L[k * m + j] = tv / s_L[j * m + j];
+      }
+      double ajj = s_A[i * m + i] - NEAR_ZERO_;
+      for (int p = 0; p < k; p++) ajj = ajj - s_L[k * m + p] * s_L[k * m + p];
+      if (ajj > 0.0) { s_L[k * m + k] = sqrt(ajj); s_act[k] = i; s_pos[i] = k; k++; }
+    }
+    s_n[2] = k;
+  }
+  __syncthreads();
+  const int k = s_n[2];
+  for (int e = t; e < k * k; e += T) {                    // J iM J' on the active rows -> s_L (row r, column c at r * m + c)
+    const int rr = e / k, c = e - rr * k, row = s_act[rr];
+    double tot = 0.0;
+    for (int kb = 0; kb < 2 * njl; kb++) {
+      if (s_boff[kb] < 0 || row < s_brow[kb] || row >= s_brow[kb] + s_brows[kb]) continue;
+      double acc = 0.0;
+      for (int q = 0; q < 6; q++) acc = acc + s_w[36 * kb + 6 * (row - s_brow[kb]) + q] * JiM[(size_t)s_act[c] * ngc + s_boff[kb] + q];
+      tot = tot + acc;
+    }
+    s_L[rr * m + c] = tot;
+  }
+  __syncthreads();
+  if (t == 0) {                                          // dpotf2 'L'; lambda = (J iM J')^-1 C
+    bool ok = true;
+    for (int j = 0; j < k && ok; j++) {
+      double ajj = s_L[j * m + j];
+      for (int p = 0; p < j; p++) ajj = ajj - s_L[j * m + p] * s_L[j * m + p];
+      if (!(ajj > 0.0)) { ok = false; break; }
+      ajj = sqrt(ajj);
+      s_L[j * m + j] = ajj;
+      for (int i = j + 1; i < k; i++) {
+        double tv = s_L[i * m + j];
+        for (int p = 0; p < j; p++) tv = tv - s_L[i * m + p] * s_L[j * m + p];
+        s_L[i * m + j] = tv / ajj;
+      }
+    }
+    if (!ok) { s_n[3] = 1; d.status[b] |= MH_WORLD_UNSUPPORTED; d.isl_model[(size_t)b * d.islmax + r] = 4; }
+    else {
+      for (int rr = 0; rr < k; rr++) s_lam[rr] = s_C[s_act[rr]];
+      for (int c = 0; c < k; c++) {
+        s_lam[c] = s_lam[c] / s_L[c * m + c];
+        const double bk = s_lam[c];
+        for (int i = c + 1; i < k; i++) s_lam[i] = s_lam[i] - bk * s_L[i * m + c];
+      }
+      for (int c = k - 1; c >= 0; c--) {
+        double tv = s_lam[c];
+        for (int i = c + 1; i < k; i++) tv = tv - s_L[i * m + c] * s_lam[i];
+        s_lam[c] = tv / s_L[c * m + c];
+      }
+    }
+  }
+  __syncthreads();
+  if (s_n[3]) return;
+  for (int i = t; i < k; i += T) { d.bact[(size_t)b * KM + i] = s_act[i]; d.blam[(size_t)b * KM + i] = s_lam[i]; }
+  if (t == 0) d.bk[b] = k;
+  // inverse_SPD(J iM J') (ICH:1664-1665): column c = the solve of L L' x = e_c, then the lower triangle mirrored -> s_A (i + m c)
+  for (int c = t; c < k; c += T) {
+    double* e = s_A + (size_t)m * c;
+    for (int i = 0; i < k; i++) e[i] = (i == c) ? 1.0 : 0.0;
+    for (int kk = 0; kk < k; kk++) {
+      e[kk] = e[kk] / s_L[kk * m + kk];
+      const double bk = e[kk];
+      for (int i = kk + 1; i < k; i++) e[i] = e[i] - bk * s_L[i * m + kk];
+    }
+    for (int kk = k - 1; kk >= 0; kk--) {
+      double tv = e[kk];
+      for (int i = kk + 1; i < k; i++) tv = tv - s_L[i * m + kk] * e[i];
+      e[kk] = tv / s_L[kk * m + kk];
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < k * k; e += T) { const int c = e / k, i = e - c * k; if (i > c) s_A[c + m * i] = s_A[i + m * c]; }
+  __syncthreads();
+  // H' = J' Ainv (ngc x k) -> T4
+  for (int e = t; e < ngc * k; e += T) {
+    const int g = e / k, c = e - g * k;
+    double acc = 0.0;
+    for (int kb = 0; kb < 2 * njl; kb++) {
+      if (s_boff[kb] < 0 || g < s_boff[kb] || g >= s_boff[kb] + 6) continue;
+      for (int rr = 0; rr < s_brows[kb]; rr++) { const int pr = s_pos[s_brow[kb] + rr]; if (pr >= 0) acc = acc + s_w[36 * kb + 6 * rr + (g - s_boff[kb])] * s_A[pr + m * c]; }
+    }
+    T4[(size_t)g * k + c] = acc;
+  }
+  __syncthreads();
+  for (int e = t; e < ngc * ngc; e += T) {                // H' J iM -> T1
+    const int g = e / ngc, h = e - g * ngc;
+    double acc = 0.0;
+    for (int c = 0; c < k; c++) acc = acc + T4[(size_t)g * k + c] * JiM[(size_t)s_act[c] * ngc + h];
+    T1[(size_t)g * ngc + h] = acc;
+  }
+  __syncthreads();
+  for (int e = t; e < ngc * ngc; e += T) {                // G = iM (H' J iM) -> T2
+    const int g = e / ngc, h = e - g * ngc, i = g / 6, rr = g - 6 * i;
+    double acc = 0.0;
+    for (int q = 0; q < 6; q++) acc = acc + s_iM[36 * i + 6 * rr + q] * T1[(size_t)(6 * i + q) * ngc + h];
+    T2[(size_t)g * ngc + h] = acc;
+  }
+  __syncthreads();
+  for (int e = t; e < ngc * ngc; e += T) {                // M G -> T3
+    const int g = e / ngc, h = e - g * ngc, i = g / 6, rr = g - 6 * i;
+    double acc = 0.0;
+    for (int q = 0; q < 6; q++) acc = acc + s_Mg[36 * i + 6 * rr + q] * T2[(size_t)(6 * i + q) * ngc + h];
+    T3[(size_t)g * ngc + h] = acc;
+  }
+  __syncthreads();
+  for (int e = t; e < ngc * ngc; e += T) {                // X = (iM - 2 G) + G' M G -> T1
+    const int g = e / ngc, h = e - g * ngc;
+    double acc = 0.0;
+    for (int p = 0; p < ngc; p++) acc = acc + T2[(size_t)p * ngc + g] * T3[(size_t)p * ngc + h];
+    const double x0 = (g / 6 == h / 6) ? s_iM[36 * (g / 6) + 6 * (g - 6 * (g / 6)) + (h - 6 * (h / 6))] : 0.0;
+    T1[(size_t)g * ngc + h] = (x0 - 2.0 * T2[(size_t)g * ngc + h]) + acc;
+  }
+  __syncthreads();
+  // X Cn' of the island's contacts (compute_problem_data: sum over the row's blocks of 6-term products), then Cn X Cn'
+  for (int e = t; e < nc * ngc; e += T) {
+    const int i = e / ngc, g = e - i * ngc;
+    const size_t ck = (size_t)b * ncm + start + i;
+    double res = 0.0;
+    for (int sd = 0; sd < 2; sd++) {
+      const int body = d.cbody[2 * ck + sd];
+      if (body < 0) continue;
+      const int off = gc_of(body);
+      const double* w = d.W + ck * 36 + sd * 6;
+      double tmp = 0.0;
+      for (int q = 0; q < 6; q++) tmp = tmp + w[q] * T1[(size_t)(off + q) * ngc + g];
+      res = res + tmp;
+    }
+    XCn[(size_t)i * KG + g] = res;
+  }
+  __syncthreads();
+  double* G = d.G + (size_t)b * 6 * ncm * ncm;
+  for (int e = t; e < nc * nc; e += T) {
+    const int i = e / nc, j = e - i * nc;
+    const size_t ck = (size_t)b * ncm + start + i;
+    double res = 0.0;
+    for (int sd = 0; sd < 2; sd++) {
+      const int body = d.cbody[2 * ck + sd];
+      if (body < 0) continue;
+      const int off = gc_of(body);
+      const double* w = d.W + ck * 36 + sd * 6;
+      double tmp = 0.0;
+      for (int q = 0; q < 6; q++) tmp = tmp + w[q] * XCn[(size_t)j * KG + off + q];
+      res = res + tmp;
+    }
+    G[(size_t)i * nc + j] = res;
+  }
+}
+
 // determine_dq's tail (CStab:958-969): update_from_stacked with cn = z -- the bodies' velocities become X Cn^T z
 __global__ __launch_bounds__(T)
 void k_stab_apply(Dev d, int r)
@@ -663,6 +913,24 @@ void k_stab_apply(Dev d, int r)
     d.imp[((size_t)b * ncm + d.order[ck]) * 3] += z[i];
   }
   __syncthreads();
+  if (d.isl_model[(size_t)b * d.islmax + r] == 3) {
+    // implicit joints in the island: dv = X Cn' cn with the general X, then dv -= iM J' lambda (ICH:343-374)
+    const int nbod = d.isl_nbod[(size_t)b * d.islmax + r], ngc = 6 * nbod, k = d.bk[b];
+    const int* bodies = d.isl_bod + ((size_t)b * d.islmax + r) * MH_IJOINT_MAX_BODIES;
+    const double* XCn = d.bXCn + (size_t)b * ncm * 96;
+    const double* JiM = d.bJiM + (size_t)b * 48 * 96;
+    for (int g = t; g < ngc; g += T) {
+      double tmp = 0.0;
+      for (int j = 0; j < nc; j++) tmp = tmp + s_c[j] * XCn[(size_t)j * 96 + g];
+      double acc = 0.0;
+      for (int rr = 0; rr < k; rr++) acc = acc + JiM[(size_t)d.bact[(size_t)b * 48 + rr] * ngc + g] * d.blam[(size_t)b * 48 + rr];
+      double* v = st + 13 * bodies[g / 6] + 7 + (g - 6 * (g / 6));
+      double x = *v + tmp;
+      x = x - acc;
+      *v = x;
+    }
+    return;
+  }
   for (int e = t; e < nb * 6; e += T) {
     const int bb = e / 6, q = e - bb * 6;
     double tmp = 0.0;
@@ -972,6 +1240,29 @@ int mh_imp_core_create(mh_imp_core* c, int B, int nb, int ncmax, int nk, int nma
   return MH_OK;
 }
 
+int mh_imp_core_enable_joints(mh_imp_core* c, int nj, const int* jtype, const int* jin, const int* jout, const double* janchor_in,
+                              const double* janchor_out, const double* jvec_in, const double* jvec_out, const unsigned char* jointed)
+{
+  c->nj = nj; c->jtype = jtype; c->jin = jin; c->jout = jout; c->janchor_in = janchor_in; c->janchor_out = janchor_out;
+  c->jvec_in = jvec_in; c->jvec_out = jvec_out; c->jointed = jointed;
+  bool okall = true;
+  auto A = [&](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (!okall) return nullptr;
+    if (c->nallocs >= (int)(sizeof(c->allocs) / sizeof(c->allocs[0])) || hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { okall = false; return nullptr; }
+    c->allocs[c->nallocs++] = p;
+    if (hipMemset(p, 0, bytes) != hipSuccess) okall = false;
+    return p;
+  };
+  const size_t sB = (size_t)c->B, KG = 6 * MH_IJOINT_MAX_BODIES, KM = MH_IJOINT_MAX_EQNS;
+  c->isl_nbod = (int*)A(sB * c->islmax * 4); c->isl_bod = (int*)A(sB * c->islmax * MH_IJOINT_MAX_BODIES * 4);
+  c->bT1 = (double*)A(sB * KG * KG * 8); c->bT2 = (double*)A(sB * KG * KG * 8); c->bT3 = (double*)A(sB * KG * KG * 8); c->bT4 = (double*)A(sB * KG * KG * 8);
+  c->bXCn = (double*)A(sB * c->ncmax * KG * 8);
+  c->bJiM = (double*)A(sB * KM * KG * 8); c->blam = (double*)A(sB * KM * 8); c->bact = (int*)A(sB * KM * 4); c->bk = (int*)A(sB * 4);
+  if (!okall) { c->bT1 = nullptr; return fail(MH_ERR_HIP, "device allocation of the joint scratch failed (B = %d)", c->B); }
+  return MH_OK;
+}
+
 // the solver chain of one round over the worlds with run_if set
 static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, int mode)
 {
@@ -1015,6 +1306,7 @@ int mh_imp_core_process(mh_imp_core* c, void* stream, int mode)
   auto stage = [&](const char* what, int r) { if (trace_stages) { hipError_t e = hipStreamSynchronize(s); std::fprintf(stderr, "[mh_imp] round %d %s: %s\n", r, what, hipGetErrorString(e)); std::fflush(stderr); } };
   for (int r = 0; r < rounds; r++) {
     hipLaunchKernelGGL(im::k_gram, dim3((ncm * ncm + im::T - 1) / im::T, B), dim3(im::T), 0, s, *c, r, mode);
+    if (mode == MH_CORE_STAB && c->bT1) hipLaunchKernelGGL(im::k_bilat_X, dim3(B), dim3(im::T), 0, s, *c, r);
     hipLaunchKernelGGL(im::k_mm, dim3(c->nmax + 1, B), dim3(im::T), 0, s, *c, r, mode, 0);
     MH_HIP(hipGetLastError());
     stage("gram + mm", r);

@@ -166,13 +166,23 @@ def test_standalone_stabilize_closes_open_joints_like_the_oracle(oracle):
     assert np.array_equal(st_g.reshape(B, nb, 13)[:, :, 7:13], s.reshape(B, nb, 13)[:, :, 7:13])     # velocities restored
 
 
-def test_jointed_bodies_in_contact_are_flagged_on_both_sides(oracle):
+def test_jointed_bodies_in_contact_stabilise_like_the_oracle(oracle):
+    """The stabiliser's contact islands hold implicit joints: compute_X's general case (X = iM - 2G + G'MG, ICH:1590-1695) on
+    the device -- a welded pair and a pair tied by a spherical joint sunk into the plane by different amounts per world,
+    next to a free sphere; standalone stabilize() and full steps."""
     r = 0.2
-    st = rest_state([[0.0, r - 1e-4, 0.0], [1.0, r - 1e-4, 0.0], [4.0, r - 1e-4, 0.0]])
-    j = K.make_joint(K.MH_IJOINT_SPHERICAL, 0, 1, (0.5, r, 0.0), st, 3)
-    sc = stab_scene(3, [j], 5, pairs=[(0, 3, 0), (1, 3, 0), (2, 3, 0)])
-    B = 3
-    s = np.repeat(st.reshape(1, -1), B, axis=0)
+    nb = 5
+    st0 = rest_state([[0.0, r, 0.0], [0.0, r + 0.5, 0.0], [2.0, r, 0.0], [3.0, r + 0.3, 0.0], [6.0, r, 0.0]])
+    joints = [K.make_joint(K.MH_IJOINT_FIXED, 0, 1, (0.0, r + 0.25, 0.0), st0, nb),
+              K.make_joint(K.MH_IJOINT_SPHERICAL, 2, 3, (2.5, r + 0.15, 0.0), st0, nb)]
+    sc = stab_scene(nb, joints, 20, pairs=[(k, nb, 0) for k in range(nb)])
+    B = 5
+    rng = np.random.default_rng(12)
+    s = np.repeat(st0.reshape(1, nb, 13), B, axis=0).copy()
+    sink = rng.uniform(2e-5, 2e-4, (B, 3))
+    s[:, 0, 1] -= sink[:, 0]; s[:, 1, 1] -= sink[:, 0]; s[:, 2, 1] -= sink[:, 1]; s[:, 4, 1] -= sink[:, 2]
+    s[1:, :, 0] += 1e-3 * rng.uniform(-1, 1, (B - 1, nb))
+    s = s.reshape(B, -1)
     bb = K.BigBatch(sc, s)
     bb.stabilize()
     st_g, aux_g = bb.download()
@@ -180,6 +190,14 @@ def test_jointed_bodies_in_contact_are_flagged_on_both_sides(oracle):
     st_o = s.copy(); aux_o = S.new_aux(B)
     for w in range(B):
         oracle.big_step(sc, st_o[w], aux_o[w:w + 1], 1e-3, 1, mode=1)
-    assert (aux_g["status"] & S.MH_WORLD_UNSUPPORTED).all() and np.array_equal(aux_g["status"], aux_o["status"])
-    assert np.array_equal(st_g, st_o)
-    assert (st_g.reshape(B, 3, 13)[:, 2, 1] >= r - 1e-9).all()     # the free sphere was pushed out of the plane all the same
+    for f in FIELDS:
+        assert np.array_equal(aux_g[f], aux_o[f]), "%s: gpu %r oracle %r" % (f, aux_g[f], aux_o[f])
+    assert np.array_equal(st_g, st_o), "max |diff| = %.3e" % np.abs(st_g - st_o).max()
+    # worlds whose joints were also pulled sideways may end in the reference's "failed to effectively finish" state (update_q's
+    # backtracking gives up, CStab:1196-1198: MH_WORLD_STAB_FAILED) -- identically on both sides; the others are stabilised
+    good = aux_g["status"] == 0
+    assert good[0] and (aux_g["status"][~good] == S.MH_WORLD_STAB_FAILED).all() and (aux_g["lcp_solves"] >= 2).all()
+    o = st_g.reshape(B, nb, 13)[good]
+    assert (o[:, [0, 2, 4], 1] >= r - 1e-9).all() and np.abs((o[:, 1, 1] - o[:, 0, 1]) - 0.5).max() < 1e-6
+    # and as full steps (gravity pulls everything back into the plane every step)
+    run_both(oracle, sc, s, 1e-3, 15)
