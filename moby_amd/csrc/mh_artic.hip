@@ -8,12 +8,13 @@
 //   constraint order, ArticulatedBody.inl:9-43)  ->  X = H^-1 (lane = column), the limit LCP  L X L' l + L v >= 0  through
 //   the wave solver of mh_lcp_wave.h (lcp_fast on the persistent _v, then the Lemke ladder: ICH:1239-1283)  ->  impulses,
 //   restitution (ICH:298-525).
-// H, its factor, H^-1, the LCP and all link quantities live in LDS (dynamic, sized by the joint count: 13 KB at
-// 10 joints => 12 worlds per CU); HBM sees q, qd and the aux record once per launch.
+// H, its factor, H^-1, the LCP and all link quantities live in LDS (dynamic, sized by the joint count; the link quantities
+// and the limit LCP share one region: 10 KB at 10 joints => 16 worlds per CU); HBM sees q, qd and the aux record once per launch.
 // The dynamics algorithm is Featherstone's (Ravelin's source is not in the reference tree: SURVEY F2); operation
 // order = oracle/artic.hpp, checked bit for bit.  sin / cos: the same explicit kernel as the oracle (no libm call).
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "../../include/moby_hip_artic.h"
@@ -69,20 +70,27 @@ MH_DEV double crf_c(const double* v, const double* f, int k) { return (k < 3) ? 
 struct Lay {
   int nj;
   int q, qd, qdd, C, R, x, Rl, tl, S, I6, v, a, f, F, Iv, H, L, X, MM, A, art, Lv, l, idx, total;
+  // q, qd, qdd, C and H, L, X live for the whole step; the link quantities of dynamics() (R .. Iv) and the limit LCP's
+  // storage (MM .. idx) are never alive together -- handle_limits reads q, qd, L, X only and the next dynamics() call
+  // rebuilds everything from q, qd -- so they share one region: 10 KB per world at 10 joints = 16 worlds per CU
   MH_DEV Lay(int n) : nj(n) {
     int o = 0;
     q = o; o += n; qd = o; o += n; qdd = o; o += n; C = o; o += n;
+    H = o; o += n * n; L = o; o += n * n; X = o; o += n * n;
+    const int u = o;
     R = o; o += 9 * n; x = o; o += 3 * n; Rl = o; o += 9 * n; tl = o; o += 3 * n;
     S = o; o += 6 * n; I6 = o; o += 36 * n; v = o; o += 6 * n; a = o; o += 6 * n; f = o; o += 6 * n; F = o; o += 6 * n; Iv = o; o += 12;
-    H = o; o += n * n; L = o; o += n * n; X = o; o += n * n;
+    const int end_dyn = o;
+    o = u;
     MM = o; o += NLMAX * NLMAX; A = o; o += NLMAX * NLMAX; art = o; o += NLMAX; Lv = o; o += NLMAX; l = o; o += NLMAX;
     idx = o; o += NLMAX;           // ints stored as doubles' slots (one int each, low half)
-    total = o;
+    total = (o > end_dyn) ? o : end_dyn;
   }
 };
 static size_t lds_bytes(int nj) {
   const int n = nj;
-  return sizeof(double) * (size_t)(4 * n + 9 * n + 3 * n + 9 * n + 3 * n + 6 * n + 36 * n + 24 * n + 12 + 3 * n * n + 2 * NLMAX * NLMAX + 4 * NLMAX);
+  const int dyn = 90 * n + 12, lim = 2 * NLMAX * NLMAX + 4 * NLMAX;
+  return sizeof(double) * (size_t)(4 * n + 3 * n * n + (dyn > lim ? dyn : lim));
 }
 
 // kinematics + spatial inertias + bias + H + Cholesky + qdd for the q / qd in LDS.  Returns false if H is not PD.
@@ -370,9 +378,8 @@ MH_DEV void handle_limits(const Model& M, const Lay& Y, double* g, mh_world_aux*
   if (ballot(valid && ((myup ? -qd2 : qd2) < -NEAR_ZERO_)) != 0ull) status |= MH_WORLD_IMPACT_TOL;   // ICH:157-167
 }
 
-__global__ __launch_bounds__(64)
-void k_artic_step(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
-                  mh_world_aux* __restrict__ auxg)
+MH_DEV void artic_step_body(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
+                            mh_world_aux* __restrict__ auxg)
 {
   extern __shared__ double g[];
   const int b = blockIdx.x;
@@ -407,6 +414,20 @@ void k_artic_step(const Model* __restrict__ Mg, int B, double dt, int nsteps, do
     aux->lcp_solves += solves; aux->lcp_rows += rows; aux->lcp_pivots += pivs; aux->lcp_alg_bytes += bytes;
   }
 }
+
+// The same step at three register budgets: 128 VGPRs (4 waves per SIMD = the 16 worlds per CU the 10 KB LDS image allows; 95 spilled
+// VGPRs), 168 (3 per SIMD, 14 spilled) and 193 (2 per SIMD, none).  The kernel waits on ~250 LDS round trips per step, so
+// resident waves win over spills: ur10 x 8192, 200 steps: 25.6 / 31.2 / 39.0 ms (profiles/r02_c_artic_occupancy.jsonl).
+// Default 4; MH_ARTIC_WAVES=2|3 selects the others (experiments).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_artic_step_w3(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
+                     mh_world_aux* __restrict__ auxg) { artic_step_body(Mg, B, dt, nsteps, qg, qdg, auxg); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_artic_step_w4(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
+                     mh_world_aux* __restrict__ auxg) { artic_step_body(Mg, B, dt, nsteps, qg, qdg, auxg); }
+__global__ __launch_bounds__(64)
+void k_artic_step_w2(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
+                     mh_world_aux* __restrict__ auxg) { artic_step_body(Mg, B, dt, nsteps, qg, qdg, auxg); }
 
 // seam B4: qdd = H^-1 (tau - C), H, link poses of the resident states
 __global__ __launch_bounds__(64)
@@ -513,7 +534,8 @@ int mh_artic_batch_step(mh_artic_batch* ab, void* stream, double dt, int nsteps)
   if (nsteps < 0) return fail(MH_ERR_INVALID_ARG, "negative step count");
   if (nsteps == 0) return MH_OK;
   if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
-  hipLaunchKernelGGL(ar::k_artic_step, dim3(ab->B), dim3(64), ar::lds_bytes(ab->nj), (hipStream_t)stream,
+  static const int waves = [] { const char* e = std::getenv("MH_ARTIC_WAVES"); const int w = e ? std::atoi(e) : 4; return (w == 2 || w == 3) ? w : 4; }();
+  hipLaunchKernelGGL(waves == 4 ? ar::k_artic_step_w4 : (waves == 2 ? ar::k_artic_step_w2 : ar::k_artic_step_w3), dim3(ab->B), dim3(64), ar::lds_bytes(ab->nj), (hipStream_t)stream,
                      (const ar::Model*)ab->d_model, ab->B, dt, nsteps, ab->d_q, ab->d_qd, ab->d_aux);
   MH_HIP(hipGetLastError());
   return MH_OK;

@@ -1,5 +1,5 @@
 """Fuzz of the impact-handler entry against the oracle: random single-island contact multigraphs, random poses /
-velocities / parameters, two calls each (cold + warm).  python tools/fuzz_impact.py [seed0] [cases]"""
+velocities / parameters, two calls each (cold + warm).  python tools/fuzz_impact.py [seed0] [cases] [ds|ap]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +11,8 @@ from tests.test_impact_gpu import random_island, oracle_batch
 o = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+model = I.MH_IMPACT_MODEL_AP if (len(sys.argv) > 3 and sys.argv[3] == "ap") else I.MH_IMPACT_MODEL_DS
+o.set_impact_model(model)
 bad = 0
 for case in range(cases):
     rng = np.random.default_rng(seed0 + case)
@@ -26,7 +28,7 @@ for case in range(cases):
     q = rng.standard_normal((B, nb, 4)); st[:, :, 3:7] = q / np.linalg.norm(q, axis=2)[:, :, None]
     st[:, :, 7:13] = rng.standard_normal((B, nb, 6)) * rng.choice([0.01, 1.0, 10.0])
     st = st.reshape(B, -1)
-    ib = I.ImpactBatch(B, nb, nc, nk, mass, J)
+    ib = I.ImpactBatch(B, nb, nc, nk, mass, J, model=model)
     aux = S.new_aux(B); zl = np.zeros((B, n)); zb = np.zeros((B, n))
     st_o = st.copy(); st_g = st.copy(); okc = True
     for call in range(2):
@@ -38,4 +40,5 @@ for case in range(cases):
     ib.close()
     bad += (not okc)
     print("%s seed %d nb %d nc %d nk %d n %d  solves %s status %s pivots max %d" % ("ok  " if okc else "FAIL", seed0 + case, nb, nc, nk, n, r["solves"], r["status"], r["pivots"].max()), flush=True)
-print("mismatches:", bad)
+print("fuzz_impact (%s model): %d cases from seed %d, mismatches: %d" % ("A-P" if model else "D-S", cases, seed0, bad))
+sys.exit(1 if bad else 0)

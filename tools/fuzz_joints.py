@@ -1,0 +1,63 @@
+"""Fuzz of the implicit-joint path of the large-world stepper against the oracle: random trees / loops of spheres tied by
+spherical, revolute and fixed joints (some to the world, some doubled), random poses and velocities, with and without
+ground contact pairs and stabilisation, a few steps each -- states and counters bit for bit.
+python tools/fuzz_joints.py [seed0] [cases]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from moby_amd import scene as S, stack as K
+from tests.oracle_api import Oracle
+
+FIELDS = ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "stab_iters", "lcp_alg_bytes", "stab_rows",
+          "zlast_size", "zbuf_size", "zbuf_cap")
+o = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+bad = 0; flagged = 0; stab_total = 0; solves_total = 0
+for case in range(cases):
+    rng = np.random.default_rng(seed0 + case)
+    nb = int(rng.integers(2, 8)); r = 0.2
+    ground = bool(rng.integers(0, 2)); stab = int(rng.choice([0, 0, 8, 20]))
+    pos = np.zeros((nb, 3)); pos[:, 0] = 0.7 * np.arange(nb); pos[:, 1] = (r + rng.uniform(0.0, 0.4, nb)) if ground else rng.uniform(-1, 1, nb)
+    pos[:, 2] = rng.uniform(-0.3, 0.3, nb)
+    st = np.zeros((nb, 13)); st[:, 0:3] = pos
+    q = rng.standard_normal((nb, 4)); st[:, 3:7] = q / np.linalg.norm(q, axis=1)[:, None]
+    joints = []
+    for b in range(1, nb):                                          # a random tree (some bodies stay free)
+        if rng.random() < 0.25: continue
+        a = int(rng.integers(0, b))
+        kind = int(rng.choice([K.MH_IJOINT_SPHERICAL, K.MH_IJOINT_REVOLUTE, K.MH_IJOINT_FIXED], p=[0.45, 0.35, 0.2]))
+        pair = (a, b) if rng.random() < 0.5 else (b, a)
+        joints.append(K.make_joint(kind, pair[0], pair[1], 0.5 * (pos[a] + pos[b]), st, nb, axis=rng.standard_normal(3)))
+    if rng.random() < 0.4:
+        joints.append(K.make_joint(int(rng.choice([0, 1])), nb, int(rng.integers(0, nb)), pos[0] + (0, 0.5, 0), st, nb, axis=rng.standard_normal(3)))
+    if joints and rng.random() < 0.2: joints.append(dict(joints[int(rng.integers(0, len(joints)))]))     # a redundant copy
+    if not joints: joints.append(K.make_joint(K.MH_IJOINT_SPHERICAL, 0, 1, 0.5 * (pos[0] + pos[1]), st, nb))
+    pairs = [(k, nb, 0) for k in range(nb) if rng.random() < 0.7] if ground else []
+    mass = rng.uniform(0.5, 2.0, nb); J = np.array([[0.4 * m * r * r] * 3 for m in mass])
+    try:
+        sc = K.BigScene([S.MH_GEOM_SPHERE] * nb, [(r, 0, 0)] * nb, mass, J, pairs, gravity=(float(rng.uniform(-1, 1)), -9.81, 0.0),
+                        cstab_max_iterations=stab, joints=joints, lcp_n_max=96, mu_coulomb=float(rng.uniform(0, 0.8)), epsilon=float(rng.choice([0.0, 0.5])))
+        B = 3
+        s0 = np.repeat(st.reshape(1, nb, 13), B, axis=0).copy()
+        s0[:, :, 7:13] = 0.3 * rng.standard_normal((B, nb, 6))
+        if stab: s0[1:, :, 0:3] += 1e-3 * rng.uniform(-1, 1, (B - 1, nb, 3))      # joints start slightly open
+        s0 = s0.reshape(B, -1)
+        bb = K.BigBatch(sc, s0)
+    except Exception as e:                                          # e.g. an island beyond the built sizes
+        print("case %d: scene rejected (%s)" % (case, str(e)[:80])); continue
+    nsteps = int(rng.integers(3, 25))
+    bb.step(1e-3, nsteps)
+    st_g, aux_g = bb.download(); bb.close()
+    st_o = s0.copy(); aux_o = S.new_aux(B); cap = sc.lcp_capacity()
+    for w in range(B):
+        o.big_step(sc, st_o[w], aux_o[w:w + 1], 1e-3, nsteps, zlast=np.zeros(cap), zbuf=np.zeros(cap), cap=cap)
+    same = all(np.array_equal(aux_g[f], aux_o[f]) for f in FIELDS) and np.array_equal(st_g, st_o, equal_nan=True)
+    flagged += int((aux_g["status"] != 0).sum()); stab_total += int(aux_g["stab_iters"].sum()); solves_total += int(aux_g["lcp_solves"].sum())
+    if not same:
+        bad += 1
+        print("MISMATCH case %d (seed %d): nb %d joints %d ground %s stab %d steps %d; max |dstate| %.3e; status gpu %r oracle %r" % (
+            case, seed0 + case, nb, len(joints), ground, stab, nsteps, np.nanmax(np.abs(st_g - st_o)), aux_g["status"], aux_o["status"]))
+print("fuzz_joints: %d cases from seed %d, %d mismatches; %d flagged world-runs, %d stabilisation iterations, %d LCP solves" % (cases, seed0, bad, flagged, stab_total, solves_total))
+sys.exit(1 if bad else 0)
