@@ -42,6 +42,9 @@ extern "C" {
 #define MH_IJOINT_SPHERICAL 0     /* 3 equations (Ravelin::SphericalJointd)                              */
 #define MH_IJOINT_REVOLUTE  1    /* 5: the axis a_0 = a_1 (inboard) stays orthogonal to b_0, b_1 (outboard) */
 #define MH_IJOINT_FIXED     2     /* 6: a_k . b_k = 0 for three pairs of orthogonal axes                  */
+#define MH_IJOINT_PLANAR    3     /* 3 (Ravelin::PlanarJointd): ONE position row along the plane normal a_2 (inboard frame),
+                                     then a_0 . b_0 = 0, a_1 . b_1 = 0 with a_0, a_1 the in-plane directions (inboard) and
+                                     b_0 = b_1 the normal in the outboard frame: the body slides on the plane and turns about its normal */
 #define MH_IJOINT_MAX_BODIES 16   /* bodies of one jointed island (forward-dynamics KKT system of up to 96 coordinates) */
 #define MH_IJOINT_MAX_JOINTS 16   /* joints of one jointed island                                           */
 #define MH_IJOINT_MAX_EQNS   48   /* constraint equations of one jointed island (J iM J' and its factor live in LDS) */
@@ -82,7 +85,7 @@ typedef struct mh_big_scene {
    * <ImplicitConstraint> list (ConstraintSimulator.cpp, Simulator::implicit_joints).  Forward dynamics of a jointed island
    * is the KKT solve of Simulator::solve (src/Simulator.cpp:608-805) and joints connect constraint islands
    * (src/UnilateralConstraint.cpp:993-1008).  A joint is 3 position rows (the joint point of both bodies coincides, global
-   * axes) plus 0 / 2 / 3 orientation rows "a_k . b_k = 0" with a_k fixed in the inboard and b_k in the outboard frame.
+   * axes; the planar joint: one row along its normal) plus 0 / 2 / 3 orientation rows "a_k . b_k = 0" with a_k fixed in the inboard and b_k in the outboard frame.
    * ConstraintStabilization closes the joints too (CStab:133-160, 197, 1132-1192): islands no contact touches take the
  * bilateral step alone (CStab:462-486, 531-700), contact islands that hold jointed bodies get the general
  * ImpactConstraintHandler::compute_X (X = iM - 2G + G'MG over the full-rank joint rows, ICH:1590-1739).  The impact handler

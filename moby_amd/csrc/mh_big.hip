@@ -472,23 +472,33 @@ MH_DEV P3 body_vec(const W& w, int b, const double* u) {      // R u for a dynam
   double R[9]; w.rot(b, R);
   return p3((R[0]*u[0] + R[1]*u[1]) + R[2]*u[2], (R[3]*u[0] + R[4]*u[1]) + R[5]*u[2], (R[6]*u[0] + R[7]*u[1]) + R[8]*u[2]);
 }
-MH_DEV int joint_rows(int type) { return type == MH_IJOINT_SPHERICAL ? 3 : (type == MH_IJOINT_REVOLUTE ? 5 : 6); }
+MH_DEV int joint_rows(int type) { return (type == MH_IJOINT_SPHERICAL || type == MH_IJOINT_PLANAR) ? 3 : (type == MH_IJOINT_REVOLUTE ? 5 : 6); }
+MH_DEV int joint_pos_rows(int type) { return type == MH_IJOINT_PLANAR ? 1 : 3; }
 // calc_constraint_jacobian (oracle World::joint_jac): rows x 6, row-major, into Cq[36]
 MH_DEV void joint_jac(const W& w, int j, bool inboard, double* Cq) {
   const Dev& d = w.d;
   const int bi = d.jin[j], bo = d.jout[j];
   const P3 r = inboard ? body_vec(w, bi, d.janchor_in + 3 * j) : body_vec(w, bo, d.janchor_out + 3 * j);
   const double sg = inboard ? 1.0 : -1.0;
-  for (int k = 0; k < 3; k++) {
+  const int np = joint_pos_rows(d.jtype[j]);
+  if (np == 1) {                                            // planar: one row along the inboard-fixed normal a_2
+    const P3 u = body_vec(w, bi, d.jvec_in + 9 * j + 6);
+    const P3 ri = body_vec(w, bi, d.janchor_in + 3 * j), ro = body_vec(w, bo, d.janchor_out + 3 * j);
+    const P3 pi = w.enabled(bi) ? w.X(bi) + ri : ri, po = w.enabled(bo) ? w.X(bo) + ro : ro;
+    const P3 e = u * sg;
+    P3 ang = cross3(r, e);
+    if (inboard) ang = ang + cross3(u, pi - po);
+    Cq[0] = e.x; Cq[1] = e.y; Cq[2] = e.z; Cq[3] = ang.x; Cq[4] = ang.y; Cq[5] = ang.z;
+  } else for (int k = 0; k < 3; k++) {
     const P3 e = p3(k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0);
     const P3 rxe = cross3(r, e);
     Cq[6*k] = e.x; Cq[6*k+1] = e.y; Cq[6*k+2] = e.z; Cq[6*k+3] = rxe.x; Cq[6*k+4] = rxe.y; Cq[6*k+5] = rxe.z;
   }
-  const int nori = joint_rows(d.jtype[j]) - 3;
+  const int nori = joint_rows(d.jtype[j]) - np;
   for (int k = 0; k < nori; k++) {
     P3 axb = cross3(body_vec(w, bi, d.jvec_in + 9 * j + 3 * k), body_vec(w, bo, d.jvec_out + 9 * j + 3 * k));
     if (!inboard) axb = -axb;
-    Cq[6*(3+k)] = 0.0; Cq[6*(3+k)+1] = 0.0; Cq[6*(3+k)+2] = 0.0; Cq[6*(3+k)+3] = axb.x; Cq[6*(3+k)+4] = axb.y; Cq[6*(3+k)+5] = axb.z;
+    Cq[6*(np+k)] = 0.0; Cq[6*(np+k)+1] = 0.0; Cq[6*(np+k)+2] = 0.0; Cq[6*(np+k)+3] = axb.x; Cq[6*(np+k)+4] = axb.y; Cq[6*(np+k)+5] = axb.z;
   }
 }
 
@@ -499,9 +509,11 @@ MH_DEV void joint_eval(const W& w, int j, double* C) {
   const P3 ri = body_vec(w, bi, d.janchor_in + 3 * j), ro = body_vec(w, bo, d.janchor_out + 3 * j);
   const P3 pi = w.enabled(bi) ? w.X(bi) + ri : ri, po = w.enabled(bo) ? w.X(bo) + ro : ro;
   const P3 dd = pi - po;
-  C[0] = dd.x; C[1] = dd.y; C[2] = dd.z;
-  const int nori = joint_rows(d.jtype[j]) - 3;
-  for (int k = 0; k < nori; k++) C[3 + k] = dot3(body_vec(w, bi, d.jvec_in + 9 * j + 3 * k), body_vec(w, bo, d.jvec_out + 9 * j + 3 * k));
+  const int np = joint_pos_rows(d.jtype[j]);
+  if (np == 1) C[0] = dot3(body_vec(w, bi, d.jvec_in + 9 * j + 6), dd);
+  else { C[0] = dd.x; C[1] = dd.y; C[2] = dd.z; }
+  const int nori = joint_rows(d.jtype[j]) - np;
+  for (int k = 0; k < nori; k++) C[np + k] = dot3(body_vec(w, bi, d.jvec_in + 9 * j + 3 * k), body_vec(w, bo, d.jvec_out + 9 * j + 3 * k));
 }
 constexpr int JROWS = MH_BIG_MAX_JOINT_ROWS;
 // evaluate_bilateral_constraints (CStab:133-160): C of every joint -> s_c[0 .. jrows), returns max |C| (uniform)
@@ -523,6 +535,7 @@ void k_kkt_fwd(Dev d)
   if (!d.mini_active[b]) return;
   W w(d, d.state + (size_t)b * d.nb * 13);
   const double dt = d.hmini[b];                          // calc_fwd_dyn(h), then v += a h (TSS:179-192)
+  if (!(dt > 0.0)) return;                               // h = 0 (conservative advancement at a resting contact): a * 0, the island keeps its velocities (deviation 9)
   const int nbod = d.kk_nbod[isl], njl = d.kk_nj[isl], m = d.kk_m[isl], ngc = 6 * nbod;
   const int* bodies = d.kk_body + isl * KKB;
   const int* joints = d.kk_joint + isl * KKJ;
@@ -1193,7 +1206,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
     std::vector<std::vector<int> > adj((size_t)nb);
     for (int j = 0; j < nj; j++) {
       const int a = sc->joint_inboard[j], bq = sc->joint_outboard[j], ty = sc->joint_type[j];
-      if (ty != MH_IJOINT_SPHERICAL && ty != MH_IJOINT_REVOLUTE && ty != MH_IJOINT_FIXED) return fail(MH_ERR_INVALID_ARG, "joint %d: type %d (MH_IJOINT_*)", j, ty);
+      if (ty != MH_IJOINT_SPHERICAL && ty != MH_IJOINT_REVOLUTE && ty != MH_IJOINT_FIXED && ty != MH_IJOINT_PLANAR) return fail(MH_ERR_INVALID_ARG, "joint %d: type %d (MH_IJOINT_*)", j, ty);
       if (a < 0 || a > nb || bq < 0 || bq > nb || a == bq) return fail(MH_ERR_INVALID_ARG, "joint %d: links (%d, %d) must be two different ids in [0, nb]", j, a, bq);
       if (a < nb && bq < nb) { adj[a].push_back(bq); adj[bq].push_back(a); }
     }
@@ -1207,7 +1220,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
       for (int j = 0; j < nj; j++) {
         const int a = sc->joint_inboard[j], bq = sc->joint_outboard[j];
         if ((a < nb && std::binary_search(q.begin(), q.end(), a)) || (bq < nb && std::binary_search(q.begin(), q.end(), bq))) {
-          ij.push_back(j); m += (sc->joint_type[j] == MH_IJOINT_SPHERICAL) ? 3 : (sc->joint_type[j] == MH_IJOINT_REVOLUTE ? 5 : 6);
+          ij.push_back(j); m += (sc->joint_type[j] == MH_IJOINT_SPHERICAL || sc->joint_type[j] == MH_IJOINT_PLANAR) ? 3 : (sc->joint_type[j] == MH_IJOINT_REVOLUTE ? 5 : 6);
         }
       }
       if (ij.empty()) continue;
@@ -1264,7 +1277,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
   d.nj = nj; d.kk_nisl = (int)kk_nbod.size(); d.kk_mmax = kk_mmax;
   if (nj > 0) {
     std::vector<int> jrow0((size_t)nj); int rows = 0;
-    for (int j = 0; j < nj; j++) { jrow0[(size_t)j] = rows; rows += (sc->joint_type[j] == MH_IJOINT_SPHERICAL) ? 3 : (sc->joint_type[j] == MH_IJOINT_REVOLUTE ? 5 : 6); }
+    for (int j = 0; j < nj; j++) { jrow0[(size_t)j] = rows; rows += (sc->joint_type[j] == MH_IJOINT_SPHERICAL || sc->joint_type[j] == MH_IJOINT_PLANAR) ? 3 : (sc->joint_type[j] == MH_IJOINT_REVOLUTE ? 5 : 6); }
     d.jrows = rows; d.jrow0 = (const int*)U(jrow0.data(), nj * 4);
 
     d.jtype = (const int*)U(sc->joint_type, nj * 4); d.jin = (const int*)U(sc->joint_inboard, nj * 4); d.jout = (const int*)U(sc->joint_outboard, nj * 4);

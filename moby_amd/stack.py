@@ -13,8 +13,8 @@ from . import _lib
 from . import scene as S
 
 MH_PAIR_CLOSED_FORM, MH_PAIR_VERTEX_FACE = 0, 1
-MH_IJOINT_SPHERICAL, MH_IJOINT_REVOLUTE, MH_IJOINT_FIXED = 0, 1, 2        # moby_hip_stack.h
-IJOINT_ROWS = {MH_IJOINT_SPHERICAL: 3, MH_IJOINT_REVOLUTE: 5, MH_IJOINT_FIXED: 6}
+MH_IJOINT_SPHERICAL, MH_IJOINT_REVOLUTE, MH_IJOINT_FIXED, MH_IJOINT_PLANAR = 0, 1, 2, 3        # moby_hip_stack.h
+IJOINT_ROWS = {MH_IJOINT_SPHERICAL: 3, MH_IJOINT_REVOLUTE: 5, MH_IJOINT_FIXED: 6, MH_IJOINT_PLANAR: 3}
 _dp, _ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
 
 
@@ -119,6 +119,11 @@ def make_joint(kind, inboard, outboard, location, state, nb, axis=(0.0, 0.0, 1.0
         v1, v2 = orthonormal_basis(a)                               # two directions orthogonal to the axis
         vin[0] = Ri.T @ a; vin[1] = Ri.T @ a
         vout[0] = Ro.T @ np.asarray(v1); vout[1] = Ro.T @ np.asarray(v2)
+    elif kind == MH_IJOINT_PLANAR:                                  # axis = the plane's normal (<PlanarJoint normal=...>)
+        from .synth import orthonormal_basis
+        t1, t2 = orthonormal_basis(a)
+        vin[0] = Ri.T @ np.asarray(t1); vin[1] = Ri.T @ np.asarray(t2); vin[2] = Ri.T @ a
+        vout[0] = Ro.T @ a; vout[1] = Ro.T @ a
     elif kind == MH_IJOINT_FIXED:
         e = np.eye(3)
         for k in range(3):                                          # e_k (inboard) stays orthogonal to e_{k+1} (outboard)

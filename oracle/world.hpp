@@ -574,7 +574,8 @@ class World {
   // rows [e_k, r x e_k] (inboard, + ; outboard, -) exactly like a contact row (ICH:1847-1895); orientation rows
   // C = a . b with a fixed in the inboard and b in the outboard frame, Jacobian rows [0, a x b] (+ / -).
   int njoints() const { return sc ? sc->njoints : 0; }
-  static int joint_rows(int type) { return type == MH_IJOINT_SPHERICAL ? 3 : (type == MH_IJOINT_REVOLUTE ? 5 : 6); }
+  static int joint_rows(int type) { return (type == MH_IJOINT_SPHERICAL || type == MH_IJOINT_PLANAR) ? 3 : (type == MH_IJOINT_REVOLUTE ? 5 : 6); }
+  static int joint_pos_rows(int type) { return type == MH_IJOINT_PLANAR ? 1 : 3; }
   V3 body_vec(int b, const double* u) const {           // R u for a dynamic body, u for the static world
     if (!enabled(b)) return v3(u[0], u[1], u[2]);
     double R[9]; rot(b, R);
@@ -585,24 +586,36 @@ class World {
     const V3 ri = body_vec(bi, sc->joint_anchor_in[j]), ro = body_vec(bo, sc->joint_anchor_out[j]);
     const V3 pi = enabled(bi) ? X(bi) + ri : ri, po = enabled(bo) ? X(bo) + ro : ro;
     const V3 d = pi - po;
-    C[0] = d.x; C[1] = d.y; C[2] = d.z;
-    const int nori = joint_rows(sc->joint_type[j]) - 3;
-    for (int k = 0; k < nori; k++) C[3 + k] = dot(body_vec(bi, sc->joint_vec_in[j] + 3 * k), body_vec(bo, sc->joint_vec_out[j] + 3 * k));
+    const int np = joint_pos_rows(sc->joint_type[j]);
+    if (np == 1) C[0] = dot(body_vec(bi, sc->joint_vec_in[j] + 6), d);          // planar: the distance along the normal a_2
+    else { C[0] = d.x; C[1] = d.y; C[2] = d.z; }
+    const int nori = joint_rows(sc->joint_type[j]) - np;
+    for (int k = 0; k < nori; k++) C[np + k] = dot(body_vec(bi, sc->joint_vec_in[j] + 3 * k), body_vec(bo, sc->joint_vec_out[j] + 3 * k));
   }
   void joint_jac(int j, bool inboard, double Cq[6][6]) const {
     const int bi = sc->joint_inboard[j], bo = sc->joint_outboard[j];
     const V3 r = inboard ? body_vec(bi, sc->joint_anchor_in[j]) : body_vec(bo, sc->joint_anchor_out[j]);
     const double sg = inboard ? 1.0 : -1.0;
-    for (int k = 0; k < 3; k++) {
+    const int np = joint_pos_rows(sc->joint_type[j]);
+    if (np == 1) {
+      // C = u . (p_in - p_out), u fixed in the inboard frame: dC/dt = u . (v_pin - v_pout) + (w_in x u) . d
+      const V3 u = body_vec(bi, sc->joint_vec_in[j] + 6);
+      const V3 ri = body_vec(bi, sc->joint_anchor_in[j]), ro = body_vec(bo, sc->joint_anchor_out[j]);
+      const V3 pi = enabled(bi) ? X(bi) + ri : ri, po = enabled(bo) ? X(bo) + ro : ro;
+      const V3 e = u * sg;
+      V3 ang = cross(r, e);
+      if (inboard) ang = ang + cross(u, pi - po);
+      Cq[0][0] = e.x; Cq[0][1] = e.y; Cq[0][2] = e.z; Cq[0][3] = ang.x; Cq[0][4] = ang.y; Cq[0][5] = ang.z;
+    } else for (int k = 0; k < 3; k++) {
       const V3 e = v3(k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0);
       const V3 rxe = cross(r, e);
       Cq[k][0] = e.x; Cq[k][1] = e.y; Cq[k][2] = e.z; Cq[k][3] = rxe.x; Cq[k][4] = rxe.y; Cq[k][5] = rxe.z;
     }
-    const int nori = joint_rows(sc->joint_type[j]) - 3;
+    const int nori = joint_rows(sc->joint_type[j]) - np;
     for (int k = 0; k < nori; k++) {
       V3 axb = cross(body_vec(bi, sc->joint_vec_in[j] + 3 * k), body_vec(bo, sc->joint_vec_out[j] + 3 * k));
       if (!inboard) axb = -axb;
-      Cq[3 + k][0] = 0.0; Cq[3 + k][1] = 0.0; Cq[3 + k][2] = 0.0; Cq[3 + k][3] = axb.x; Cq[3 + k][4] = axb.y; Cq[3 + k][5] = axb.z;
+      Cq[np + k][0] = 0.0; Cq[np + k][1] = 0.0; Cq[np + k][2] = 0.0; Cq[np + k][3] = axb.x; Cq[np + k][4] = axb.y; Cq[np + k][5] = axb.z;
     }
   }
   // Simulator::find_islands (Sim:956-1045): bodies connected by implicit joints whose two links are both enabled; islands
@@ -739,6 +752,10 @@ class World {
         for (int b : isl) { V3 xdd, wd; fwd_dyn(b, xdd, wd); double* o = &acc[6 * (size_t)b]; o[0] = xdd.x; o[1] = xdd.y; o[2] = xdd.z; o[3] = wd.x; o[4] = wd.y; o[5] = wd.z; }
         continue;
       }
+      // DEVIATION (deviation 9): a mini-step that conservative advancement cut to h = 0 (a resting contact) makes
+      // Simulator::solve divide by dt = 0 -- NaN accelerations, then NaN * 0 velocities in the reference.  The velocity change
+      // of such a mini-step is a * 0: the island keeps its velocities.
+      if (!(h > 0.0)) continue;
       std::vector<double> a;
       if (!solve_kkt(isl, ij, h, a)) { aux->status |= MH_WORLD_UNSUPPORTED; continue; }
       for (size_t i = 0; i < isl.size(); i++) for (int k = 0; k < 6; k++) acc[6 * (size_t)isl[i] + k] = a[6 * i + k];

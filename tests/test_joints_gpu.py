@@ -201,3 +201,19 @@ def test_jointed_bodies_in_contact_stabilise_like_the_oracle(oracle):
     assert (o[:, [0, 2, 4], 1] >= r - 1e-9).all() and np.abs((o[:, 1, 1] - o[:, 0, 1]) - 0.5).max() < 1e-6
     # and as full steps (gravity pulls everything back into the plane every step)
     run_both(oracle, sc, s, 1e-3, 15)
+
+
+def test_planar_joint_example_matches_oracle(oracle):
+    """The scene after example/planar-joint/constrained.xml (tests/test_oracle_joints.py::planar_box_scene): a joint to the static
+    world with a position row along a direction -- KKT forward dynamics with a single body (the first step removes the forbidden
+    spin after positions were integrated with it: the stabiliser then turns the box back), bilateral stabilisation."""
+    from tests.test_oracle_joints import planar_box_scene
+    sc, st = planar_box_scene()
+    B = 4
+    s0 = np.repeat(st.reshape(1, -1), B, axis=0).copy()
+    rng = np.random.default_rng(21)
+    s0.reshape(B, 1, 13)[1:, 0, 10:13] += rng.uniform(-2, 2, (B - 1, 3))
+    s0.reshape(B, 1, 13)[1:, 0, 7:10] += rng.uniform(-0.2, 0.2, (B - 1, 3))
+    st_g, aux = run_both(oracle, sc, s0, 1e-3, 40, chunks=2)
+    assert np.isfinite(st_g).all() and (aux["status"] == 0).all() and (aux["stab_iters"] > 0).all()
+    assert np.abs(st_g.reshape(B, 13)[:, [10, 12]]).max() < 1e-5 and np.abs(st_g.reshape(B, 13)[:, 1] - 0.5).max() < 1e-6

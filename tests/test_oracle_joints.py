@@ -35,7 +35,7 @@ def advance(st, v, eps):
     return out
 
 
-@pytest.mark.parametrize("kind", [K.MH_IJOINT_SPHERICAL, K.MH_IJOINT_REVOLUTE, K.MH_IJOINT_FIXED])
+@pytest.mark.parametrize("kind", [K.MH_IJOINT_SPHERICAL, K.MH_IJOINT_REVOLUTE, K.MH_IJOINT_FIXED, K.MH_IJOINT_PLANAR])
 def test_jacobian_is_the_derivative_of_the_constraint_function(oracle, kind):
     rng = np.random.default_rng(3 + kind)
     nb = 2
@@ -241,3 +241,29 @@ def test_jointed_bodies_in_contact_use_the_general_compute_X(oracle):
     for j in range(2):
         assert np.abs(oracle.joint_eval(sc, out, j)[0]).max() < 1e-6
     assert abs(o[1, 1] - (r + 0.5)) < 2e-5 and np.abs(o[:, [0, 2]] - st0[:, [0, 2]]).max() < 1e-4
+
+
+def planar_box_scene(iters=10):
+    """After example/planar-joint/constrained.xml: a unit box (density 1) on the plane y = 0, tied to the ground by a planar
+    joint with normal +y -- it may slide and turn about y only --, spun about x and y, gravity (1, -9.81, 1).  The joint alone
+    carries the box here: the file also lists the box-plane contact pair, but with the joint's plane ON the contact plane the
+    stabiliser's normal row has no mobility left (Cn X Cn' = 0 with the general X) and its LCP is unsolvable, and the box
+    starts exactly on the plane, where conservative advancement returns h = 0 (deviation 9)."""
+    st = rest_state([[0.0, 0.5, 0.0]])
+    j = K.make_joint(K.MH_IJOINT_PLANAR, 1, 0, (0.0, 0.0, 0.0), st, 1, axis=(0.0, 1.0, 0.0))
+    sc = K.BigScene([S.MH_GEOM_BOX], [(1.0, 1.0, 1.0)], [1.0], [[1.0 / 6.0] * 3], [], gravity=(1.0, -9.81, 1.0),
+                    cstab_max_iterations=iters, joints=[j], lcp_n_max=64)
+    st[0, 10:13] = (10.0, 2.0, 0.0)                               # spin about x (the joint forbids it) and about y (allowed)
+    return sc, st
+
+
+def test_planar_joint_example_slides_and_turns_about_the_normal_only(oracle):
+    sc, st = planar_box_scene()
+    s, aux = run(oracle, sc, st, 1e-3, 200)
+    assert aux["status"][0] == 0 and aux["stab_iters"][0] > 0
+    assert abs(s[0, 1] - 0.5) < 1e-6                              # stays on the plane (gravity's normal part is carried by the joint)
+    assert abs(s[0, 10]) < 1e-6 and abs(s[0, 12]) < 1e-6           # the forbidden spin is gone after the first step ...
+    assert abs(s[0, 11] - 2.0) < 1e-3                              # ... the spin about the normal is untouched
+    np.testing.assert_allclose(s[0, [7, 9]], [0.2, 0.2], atol=1e-3)     # g_x = g_z = 1 for 0.2 s
+    C, _, _ = oracle.joint_eval(sc, s.reshape(-1), 0)
+    assert np.abs(C).max() < 1e-6
