@@ -217,3 +217,45 @@ def test_planar_joint_example_matches_oracle(oracle):
     st_g, aux = run_both(oracle, sc, s0, 1e-3, 40, chunks=2)
     assert np.isfinite(st_g).all() and (aux["status"] == 0).all() and (aux["stab_iters"] > 0).all()
     assert np.abs(st_g.reshape(B, 13)[:, [10, 12]]).max() < 1e-5 and np.abs(st_g.reshape(B, 13)[:, 1] - 0.5).max() < 1e-6
+
+
+def test_thousand_jointed_chains_properties():
+    """1024 worlds of a four-link chain hung from the world (revolute, spherical, fixed, spherical), random initial spins, 100 steps
+    with the stabiliser on: no world fails, every joint stays closed to bilateral_eps, identical worlds give identical results
+    wherever they sit in the batch, and the chains really swing."""
+    nb, B = 4, 1024
+    st = rest_state([[0.5 + k, 0.0, 0.0] for k in range(nb)])
+    joints = [K.make_joint(K.MH_IJOINT_REVOLUTE, nb, 0, (0.0, 0.0, 0.0), st, nb, axis=(0, 0, 1)),
+              K.make_joint(K.MH_IJOINT_SPHERICAL, 0, 1, (1.0, 0.0, 0.0), st, nb),
+              K.make_joint(K.MH_IJOINT_FIXED, 1, 2, (2.0, 0.0, 0.0), st, nb),
+              K.make_joint(K.MH_IJOINT_SPHERICAL, 2, 3, (3.0, 0.0, 0.0), st, nb)]
+    sc = stab_scene(nb, joints, 20)
+    rng = np.random.default_rng(33)
+    s0 = np.repeat(st.reshape(1, nb, 13), B, axis=0).copy()
+    w = rng.uniform(-1, 1, (B // 2, 3))                           # a rigid rotation about the pivot: consistent with every joint
+    for k in range(nb):
+        s0[:B // 2, k, 10:13] = w * np.array([0.0, 0.0, 1.0]); s0[:B // 2, k, 7:10] = np.cross(s0[:B // 2, k, 10:13], s0[:B // 2, k, 0:3])
+    s0[B // 2:] = s0[:B // 2]                                     # second half = copy of the first
+    s0 = s0.reshape(B, -1)
+    bb = K.BigBatch(sc, s0)
+    bb.step(1e-3, 100)
+    st_g, aux = bb.download()
+    bb.close()
+    assert (aux["status"] == 0).all() and (aux["steps"] == 100).all() and (aux["stab_iters"] > 0).all()
+    assert np.array_equal(st_g[B // 2:], st_g[:B // 2]) and np.array_equal(aux["stab_iters"][B // 2:], aux["stab_iters"][:B // 2])
+    b = st_g.reshape(B, nb, 13)
+    # joint closure, computed from the poses: anchors coincide
+    def R(q):
+        x, y, z, ww = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+        return np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * ww), 2 * (x * z + y * ww)], -1),
+                         np.stack([2 * (x * y + z * ww), 1 - 2 * (x * x + z * z), 2 * (y * z - x * ww)], -1),
+                         np.stack([2 * (x * z - y * ww), 2 * (y * z + x * ww), 1 - 2 * (x * x + y * y)], -1)], -2)
+    worst = 0.0
+    for j in joints:
+        def pt(body, anchor):
+            if body >= nb:
+                return np.broadcast_to(np.asarray(anchor), (B, 3))
+            return b[:, body, 0:3] + np.einsum("bij,j->bi", R(b[:, body, 3:7]), np.asarray(anchor))
+        worst = max(worst, np.abs(pt(j["inboard"], j["anchor_in"]) - pt(j["outboard"], j["anchor_out"])).max())
+    assert worst < 1e-6
+    assert b[:, 3, 1].min() < -0.05 and np.abs(b[:, :, 2]).max() < 1e-6        # they fell, in the plane of the hinge
