@@ -69,6 +69,10 @@ int mh_impact_batch_debug_lcp(mh_impact_batch* ib, double* MM, double* qq);
 int mh_impact_batch_save_solver_state(mh_impact_batch* ib, double* zlast, int* zlast_size, uint32_t* rng, int* status);
 int mh_impact_batch_load_solver_state(mh_impact_batch* ib, const double* zlast, const int* zlast_size, const uint32_t* rng,
                                       const int* status);
+/* ... and the no-slip model's warm start ImpactConstraintHandler::_v (src/ImpactConstraintHandler.cpp:1239): v is
+ * B x MH_NOSLIP_MAX doubles, v_size B ints.  A batch whose islands never take the no-slip model keeps size 0. */
+int mh_impact_batch_save_noslip_state(mh_impact_batch* ib, double* v, int* v_size);
+int mh_impact_batch_load_noslip_state(mh_impact_batch* ib, const double* v, const int* v_size);
 /* Which model the islands with finite friction take (src/ImpactConstraintHandler.cpp:139-146): the reference chooses at
  * BUILD time -- Drumwright-Shell (apply_model_to_connected_constraints, the default) or, with -DUSE_AP (CMakeLists.txt:19,
  * 77-79), Anitescu-Potra (src/ImpactConstraintHandlerLCP.cpp:36-370: LCP [UL UR; LL 0] of 5 nc + NK_DIRS rows,

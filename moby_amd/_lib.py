@@ -68,6 +68,8 @@ SYMBOLS = {
     "mh_impact_batch_debug_lcp": (_i, [_vp, _vp, _vp]),
     "mh_impact_batch_save_solver_state": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mh_impact_batch_load_solver_state": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mh_impact_batch_save_noslip_state": (_i, [_vp, _vp, _vp]),
+    "mh_impact_batch_load_noslip_state": (_i, [_vp, _vp, _vp]),
     "mh_impact_batch_device_ptrs": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "mh_impact_process_batch": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     # include/moby_hip_stack.h

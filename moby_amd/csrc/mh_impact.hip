@@ -1498,6 +1498,26 @@ int mh_impact_batch_load_solver_state(mh_impact_batch* ib, const double* zlast, 
   return MH_OK;
 }
 
+int mh_impact_batch_save_noslip_state(mh_impact_batch* ib, double* v, int* v_size)
+{
+  if (!ib || !v || !v_size) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  MH_HIP(hipDeviceSynchronize());
+  MH_HIP(hipMemcpy(v, ib->c.vns, (size_t)ib->B * MH_NOSLIP_MAX * 8, hipMemcpyDeviceToHost));
+  MH_HIP(hipMemcpy(v_size, ib->c.vns_size, (size_t)ib->B * 4, hipMemcpyDeviceToHost));
+  return MH_OK;
+}
+
+int mh_impact_batch_load_noslip_state(mh_impact_batch* ib, const double* v, const int* v_size)
+{
+  if (!ib || !v || !v_size) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  for (int b = 0; b < ib->B; b++)
+    if (v_size[b] < 0 || v_size[b] > MH_NOSLIP_MAX) return fail(MH_ERR_INVALID_ARG, "world %d: _v of size %d (0 .. %d)", b, v_size[b], MH_NOSLIP_MAX);
+  MH_HIP(hipDeviceSynchronize());
+  MH_HIP(hipMemcpy(ib->c.vns, v, (size_t)ib->B * MH_NOSLIP_MAX * 8, hipMemcpyHostToDevice));
+  MH_HIP(hipMemcpy(ib->c.vns_size, v_size, (size_t)ib->B * 4, hipMemcpyHostToDevice));
+  return MH_OK;
+}
+
 int mh_impact_batch_device_ptrs(mh_impact_batch* ib, double** state_dev, mh_contact** contacts_dev)
 {
   if (!ib) return fail(MH_ERR_INVALID_ARG, "null batch");

@@ -104,13 +104,19 @@ class ImpactBatch:
         zl = np.zeros((self.B, self.n)); zs = np.zeros(self.B, dtype=np.int32)
         rng = np.zeros((self.B, S.MH_RAND_WORDS), dtype=np.uint32); status = np.zeros(self.B, dtype=np.int32)
         _lib.check(_lib.load().mh_impact_batch_save_solver_state(self.handle, zl.ctypes.data, zs.ctypes.data, rng.ctypes.data, status.ctypes.data))
-        return dict(zlast=zl, zlast_size=zs, rng=rng, status=status)
+        v = np.zeros((self.B, S.MH_NOSLIP_MAX)); vs = np.zeros(self.B, dtype=np.int32)
+        _lib.check(_lib.load().mh_impact_batch_save_noslip_state(self.handle, v.ctypes.data, vs.ctypes.data))
+        return dict(zlast=zl, zlast_size=zs, rng=rng, status=status, v=v, v_size=vs)
 
     def load_solver_state(self, ss):
         zl = np.ascontiguousarray(ss["zlast"], dtype=np.float64); zs = np.ascontiguousarray(ss["zlast_size"], dtype=np.int32)
         rng = np.ascontiguousarray(ss["rng"], dtype=np.uint32); status = np.ascontiguousarray(ss["status"], dtype=np.int32)
         assert zl.shape == (self.B, self.n) and rng.shape == (self.B, S.MH_RAND_WORDS)
         _lib.check(_lib.load().mh_impact_batch_load_solver_state(self.handle, zl.ctypes.data, zs.ctypes.data, rng.ctypes.data, status.ctypes.data))
+        if "v" in ss:
+            v = np.ascontiguousarray(ss["v"], dtype=np.float64); vs = np.ascontiguousarray(ss["v_size"], dtype=np.int32)
+            assert v.shape == (self.B, S.MH_NOSLIP_MAX)
+            _lib.check(_lib.load().mh_impact_batch_load_noslip_state(self.handle, v.ctypes.data, vs.ctypes.data))
 
     def close(self):
         if self.handle:

@@ -298,6 +298,28 @@ def test_solver_state_checkpoint_resumes_bit_exact():
         b.load_solver_state(bad)
 
 
+def test_noslip_state_checkpoint_resumes_bit_exact():
+    """The no-slip model's warm start _v (ICH:1239) travels with the checkpoint: a handler restored from it makes the same
+    second call (pivots included) as the uninterrupted one; without _v the restored handler starts lcp_fast cold."""
+    nbx, B = 3, 4
+    mass, J, st, cs = I.box_stack(nbx, B=B, mu=200.0)              # every mu >= 100: the no-slip model
+    a = I.ImpactBatch(B, nbx, 12, 4, mass, J)
+    r1 = a.process(st, cs)
+    s2 = r1["state"].copy(); s2.reshape(B, nbx, 13)[:, :, 8] += -9.81e-3
+    ss = a.solver_state()
+    assert (ss["v_size"] == 12).all()
+    r2 = a.process(s2, cs)
+    b = I.ImpactBatch(B, nbx, 12, 4, mass, J); b.load_solver_state(ss)
+    r2b = b.process(s2, cs)
+    assert np.array_equal(r2b["state"], r2["state"]) and np.array_equal(r2b["pivots"], r2["pivots"]) and np.array_equal(r2b["impulses"], r2["impulses"])
+    without = {k: v for k, v in ss.items() if k not in ("v", "v_size")}
+    c = I.ImpactBatch(B, nbx, 12, 4, mass, J); c.load_solver_state(without)
+    r2c = c.process(s2, cs)
+    assert not np.array_equal(r2c["pivots"], r2["pivots"])
+    for h in (a, b, c):
+        h.close()
+
+
 # ---- Anitescu-Potra model (a batch in the reference's -DUSE_AP configuration) ------------------------------------------
 @pytest.fixture
 def ap_oracle(oracle):
