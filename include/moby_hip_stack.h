@@ -45,6 +45,8 @@ extern "C" {
 #define MH_IJOINT_PLANAR    3     /* 3 (Ravelin::PlanarJointd): ONE position row along the plane normal a_2 (inboard frame),
                                      then a_0 . b_0 = 0, a_1 . b_1 = 0 with a_0, a_1 the in-plane directions (inboard) and
                                      b_0 = b_1 the normal in the outboard frame: the body slides on the plane and turns about its normal */
+#define MH_IJOINT_UNIVERSAL 4     /* 4 (Ravelin::UniversalJointd): the joint point + a_0 . b_0 = 0 for the two axes of the cross,
+                                     a_0 fixed in the inboard frame, b_0 in the outboard frame */
 #define MH_IJOINT_MAX_BODIES 16   /* bodies of one jointed island (forward-dynamics KKT system of up to 96 coordinates) */
 #define MH_IJOINT_MAX_JOINTS 16   /* joints of one jointed island                                           */
 #define MH_IJOINT_MAX_EQNS   48   /* constraint equations of one jointed island (J iM J' and its factor live in LDS) */

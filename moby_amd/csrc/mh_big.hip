@@ -472,7 +472,7 @@ MH_DEV P3 body_vec(const W& w, int b, const double* u) {      // R u for a dynam
   double R[9]; w.rot(b, R);
   return p3((R[0]*u[0] + R[1]*u[1]) + R[2]*u[2], (R[3]*u[0] + R[4]*u[1]) + R[5]*u[2], (R[6]*u[0] + R[7]*u[1]) + R[8]*u[2]);
 }
-MH_DEV int joint_rows(int type) { return (type == MH_IJOINT_SPHERICAL || type == MH_IJOINT_PLANAR) ? 3 : (type == MH_IJOINT_REVOLUTE ? 5 : 6); }
+MH_DEV int joint_rows(int type) { return (type == MH_IJOINT_SPHERICAL || type == MH_IJOINT_PLANAR) ? 3 : (type == MH_IJOINT_UNIVERSAL ? 4 : (type == MH_IJOINT_REVOLUTE ? 5 : 6)); }
 MH_DEV int joint_pos_rows(int type) { return type == MH_IJOINT_PLANAR ? 1 : 3; }
 // calc_constraint_jacobian (oracle World::joint_jac): rows x 6, row-major, into Cq[36]
 MH_DEV void joint_jac(const W& w, int j, bool inboard, double* Cq) {
@@ -1206,7 +1206,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
     std::vector<std::vector<int> > adj((size_t)nb);
     for (int j = 0; j < nj; j++) {
       const int a = sc->joint_inboard[j], bq = sc->joint_outboard[j], ty = sc->joint_type[j];
-      if (ty != MH_IJOINT_SPHERICAL && ty != MH_IJOINT_REVOLUTE && ty != MH_IJOINT_FIXED && ty != MH_IJOINT_PLANAR) return fail(MH_ERR_INVALID_ARG, "joint %d: type %d (MH_IJOINT_*)", j, ty);
+      if (ty != MH_IJOINT_SPHERICAL && ty != MH_IJOINT_REVOLUTE && ty != MH_IJOINT_FIXED && ty != MH_IJOINT_PLANAR && ty != MH_IJOINT_UNIVERSAL) return fail(MH_ERR_INVALID_ARG, "joint %d: type %d (MH_IJOINT_*)", j, ty);
       if (a < 0 || a > nb || bq < 0 || bq > nb || a == bq) return fail(MH_ERR_INVALID_ARG, "joint %d: links (%d, %d) must be two different ids in [0, nb]", j, a, bq);
       if (a < nb && bq < nb) { adj[a].push_back(bq); adj[bq].push_back(a); }
     }
@@ -1220,7 +1220,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
       for (int j = 0; j < nj; j++) {
         const int a = sc->joint_inboard[j], bq = sc->joint_outboard[j];
         if ((a < nb && std::binary_search(q.begin(), q.end(), a)) || (bq < nb && std::binary_search(q.begin(), q.end(), bq))) {
-          ij.push_back(j); m += (sc->joint_type[j] == MH_IJOINT_SPHERICAL || sc->joint_type[j] == MH_IJOINT_PLANAR) ? 3 : (sc->joint_type[j] == MH_IJOINT_REVOLUTE ? 5 : 6);
+          ij.push_back(j); m += (sc->joint_type[j] == MH_IJOINT_SPHERICAL || sc->joint_type[j] == MH_IJOINT_PLANAR) ? 3 : (sc->joint_type[j] == MH_IJOINT_UNIVERSAL ? 4 : (sc->joint_type[j] == MH_IJOINT_REVOLUTE ? 5 : 6));
         }
       }
       if (ij.empty()) continue;
@@ -1277,7 +1277,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
   d.nj = nj; d.kk_nisl = (int)kk_nbod.size(); d.kk_mmax = kk_mmax;
   if (nj > 0) {
     std::vector<int> jrow0((size_t)nj); int rows = 0;
-    for (int j = 0; j < nj; j++) { jrow0[(size_t)j] = rows; rows += (sc->joint_type[j] == MH_IJOINT_SPHERICAL || sc->joint_type[j] == MH_IJOINT_PLANAR) ? 3 : (sc->joint_type[j] == MH_IJOINT_REVOLUTE ? 5 : 6); }
+    for (int j = 0; j < nj; j++) { jrow0[(size_t)j] = rows; rows += (sc->joint_type[j] == MH_IJOINT_SPHERICAL || sc->joint_type[j] == MH_IJOINT_PLANAR) ? 3 : (sc->joint_type[j] == MH_IJOINT_UNIVERSAL ? 4 : (sc->joint_type[j] == MH_IJOINT_REVOLUTE ? 5 : 6)); }
     d.jrows = rows; d.jrow0 = (const int*)U(jrow0.data(), nj * 4);
 
     d.jtype = (const int*)U(sc->joint_type, nj * 4); d.jin = (const int*)U(sc->joint_inboard, nj * 4); d.jout = (const int*)U(sc->joint_outboard, nj * 4);

@@ -79,7 +79,7 @@ MH_DEV P3 jt_body_vec(const double* st, int nb, int b, const double* u) {      /
   R[6] = 2.0 * (x*z - y*w);       R[7] = 2.0 * (y*z + x*w);       R[8] = 1.0 - 2.0 * (x*x + y*y);
   return p3((R[0]*u[0] + R[1]*u[1]) + R[2]*u[2], (R[3]*u[0] + R[4]*u[1]) + R[5]*u[2], (R[6]*u[0] + R[7]*u[1]) + R[8]*u[2]);
 }
-MH_DEV int jt_rows(int type) { return (type == 0 || type == 3) ? 3 : (type == 1 ? 5 : 6); }   // MH_IJOINT_SPHERICAL / _REVOLUTE / _FIXED / _PLANAR
+MH_DEV int jt_rows(int type) { return (type == 0 || type == 3) ? 3 : (type == 4 ? 4 : (type == 1 ? 5 : 6)); }   // MH_IJOINT_SPHERICAL / _REVOLUTE / _FIXED / _PLANAR / _UNIVERSAL
 MH_DEV int jt_pos_rows(int type) { return type == 3 ? 1 : 3; }
 MH_DEV void jt_eval(const JointTab& jt, const double* st, int nb, int j, double* C) {
   const int bi = jt.in[j], bo = jt.out[j];

@@ -13,8 +13,8 @@ from . import _lib
 from . import scene as S
 
 MH_PAIR_CLOSED_FORM, MH_PAIR_VERTEX_FACE = 0, 1
-MH_IJOINT_SPHERICAL, MH_IJOINT_REVOLUTE, MH_IJOINT_FIXED, MH_IJOINT_PLANAR = 0, 1, 2, 3        # moby_hip_stack.h
-IJOINT_ROWS = {MH_IJOINT_SPHERICAL: 3, MH_IJOINT_REVOLUTE: 5, MH_IJOINT_FIXED: 6, MH_IJOINT_PLANAR: 3}
+MH_IJOINT_SPHERICAL, MH_IJOINT_REVOLUTE, MH_IJOINT_FIXED, MH_IJOINT_PLANAR, MH_IJOINT_UNIVERSAL = 0, 1, 2, 3, 4        # moby_hip_stack.h
+IJOINT_ROWS = {MH_IJOINT_SPHERICAL: 3, MH_IJOINT_REVOLUTE: 5, MH_IJOINT_FIXED: 6, MH_IJOINT_PLANAR: 3, MH_IJOINT_UNIVERSAL: 4}
 _dp, _ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
 
 
@@ -97,7 +97,7 @@ class BigScene:
         return min(4096, max(64, 6 * nc + nc * (self.c.nk // 2)))
 
 
-def make_joint(kind, inboard, outboard, location, state, nb, axis=(0.0, 0.0, 1.0)):
+def make_joint(kind, inboard, outboard, location, state, nb, axis=(0.0, 0.0, 1.0), axis2=None):
     """An implicit joint as the XML states it (<RevoluteJoint location= axis= inboard-link-id= outboard-link-id=>: global
     location and axis at the bodies' reference poses) turned into the body-frame data of mh_big_scene.  ``state``: the
     reference poses (nb x 13); a link id of nb (or -1) is the static world."""
@@ -119,6 +119,11 @@ def make_joint(kind, inboard, outboard, location, state, nb, axis=(0.0, 0.0, 1.0
         v1, v2 = orthonormal_basis(a)                               # two directions orthogonal to the axis
         vin[0] = Ri.T @ a; vin[1] = Ri.T @ a
         vout[0] = Ro.T @ np.asarray(v1); vout[1] = Ro.T @ np.asarray(v2)
+    elif kind == MH_IJOINT_UNIVERSAL:                               # axis (inboard) and axis2 (outboard) stay orthogonal
+        from .synth import orthonormal_basis
+        a2 = np.asarray(orthonormal_basis(a)[0] if axis2 is None else axis2, dtype=np.float64)
+        a2 = a2 - a * (a @ a2); a2 = a2 / np.linalg.norm(a2)
+        vin[0] = Ri.T @ a; vout[0] = Ro.T @ a2
     elif kind == MH_IJOINT_PLANAR:                                  # axis = the plane's normal (<PlanarJoint normal=...>)
         from .synth import orthonormal_basis
         t1, t2 = orthonormal_basis(a)

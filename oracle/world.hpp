@@ -574,7 +574,7 @@ class World {
   // rows [e_k, r x e_k] (inboard, + ; outboard, -) exactly like a contact row (ICH:1847-1895); orientation rows
   // C = a . b with a fixed in the inboard and b in the outboard frame, Jacobian rows [0, a x b] (+ / -).
   int njoints() const { return sc ? sc->njoints : 0; }
-  static int joint_rows(int type) { return (type == MH_IJOINT_SPHERICAL || type == MH_IJOINT_PLANAR) ? 3 : (type == MH_IJOINT_REVOLUTE ? 5 : 6); }
+  static int joint_rows(int type) { return (type == MH_IJOINT_SPHERICAL || type == MH_IJOINT_PLANAR) ? 3 : (type == MH_IJOINT_UNIVERSAL ? 4 : (type == MH_IJOINT_REVOLUTE ? 5 : 6)); }
   static int joint_pos_rows(int type) { return type == MH_IJOINT_PLANAR ? 1 : 3; }
   V3 body_vec(int b, const double* u) const {           // R u for a dynamic body, u for the static world
     if (!enabled(b)) return v3(u[0], u[1], u[2]);
