@@ -38,7 +38,8 @@ for case in range(cases):
     mass = rng.uniform(0.5, 2.0, nb); J = np.array([[0.4 * m * r * r] * 3 for m in mass])
     try:
         sc = K.BigScene([S.MH_GEOM_SPHERE] * nb, [(r, 0, 0)] * nb, mass, J, pairs, gravity=(float(rng.uniform(-1, 1)), -9.81, 0.0),
-                        cstab_max_iterations=stab, joints=joints, lcp_n_max=96, mu_coulomb=float(rng.uniform(0, 0.8)), epsilon=float(rng.choice([0.0, 0.5])))
+                        cstab_max_iterations=stab, joints=joints, lcp_n_max=96, mu_coulomb=float(rng.uniform(0, 0.8)), epsilon=float(rng.choice([0.0, 0.5])),
+                        impact_model=int(rng.random() < 0.3))          # now and then the scene of a -DUSE_AP build
         B = 3
         s0 = np.repeat(st.reshape(1, nb, 13), B, axis=0).copy()
         s0[:, :, 7:13] = 0.3 * rng.standard_normal((B, nb, 6))
