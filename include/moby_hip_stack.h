@@ -47,6 +47,9 @@ extern "C" {
                                      b_0 = b_1 the normal in the outboard frame: the body slides on the plane and turns about its normal */
 #define MH_IJOINT_UNIVERSAL 4     /* 4 (Ravelin::UniversalJointd): the joint point + a_0 . b_0 = 0 for the two axes of the cross,
                                      a_0 fixed in the inboard frame, b_0 in the outboard frame */
+#define MH_IJOINT_PRISMATIC 5     /* 5 (Ravelin::PrismaticJointd): TWO position rows along a_0, a_1 (inboard frame, orthogonal to
+                                     the sliding axis a_2), then a_k . b_k = 0, k = 0, 1, 2 (b = the outboard images of a_1, a_2, a_0):
+                                     the outboard link slides along the axis without turning */
 #define MH_IJOINT_MAX_BODIES 16   /* bodies of one jointed island (forward-dynamics KKT system of up to 96 coordinates) */
 #define MH_IJOINT_MAX_JOINTS 16   /* joints of one jointed island                                           */
 #define MH_IJOINT_MAX_EQNS   48   /* constraint equations of one jointed island (J iM J' and its factor live in LDS) */

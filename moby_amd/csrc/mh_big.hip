@@ -472,8 +472,9 @@ MH_DEV P3 body_vec(const W& w, int b, const double* u) {      // R u for a dynam
   double R[9]; w.rot(b, R);
   return p3((R[0]*u[0] + R[1]*u[1]) + R[2]*u[2], (R[3]*u[0] + R[4]*u[1]) + R[5]*u[2], (R[6]*u[0] + R[7]*u[1]) + R[8]*u[2]);
 }
-MH_DEV int joint_rows(int type) { return (type == MH_IJOINT_SPHERICAL || type == MH_IJOINT_PLANAR) ? 3 : (type == MH_IJOINT_UNIVERSAL ? 4 : (type == MH_IJOINT_REVOLUTE ? 5 : 6)); }
-MH_DEV int joint_pos_rows(int type) { return type == MH_IJOINT_PLANAR ? 1 : 3; }
+MH_DEV int joint_rows(int type) { return (type == MH_IJOINT_SPHERICAL || type == MH_IJOINT_PLANAR) ? 3 : (type == MH_IJOINT_UNIVERSAL ? 4 : ((type == MH_IJOINT_REVOLUTE || type == MH_IJOINT_PRISMATIC) ? 5 : 6)); }
+MH_DEV int joint_pos_rows(int type) { return type == MH_IJOINT_PLANAR ? 1 : (type == MH_IJOINT_PRISMATIC ? 2 : 3); }
+MH_DEV int joint_dir_slot(int type, int k) { return type == MH_IJOINT_PLANAR ? 2 : k; }
 // calc_constraint_jacobian (oracle World::joint_jac): rows x 6, row-major, into Cq[36]
 MH_DEV void joint_jac(const W& w, int j, bool inboard, double* Cq) {
   const Dev& d = w.d;
@@ -481,14 +482,14 @@ MH_DEV void joint_jac(const W& w, int j, bool inboard, double* Cq) {
   const P3 r = inboard ? body_vec(w, bi, d.janchor_in + 3 * j) : body_vec(w, bo, d.janchor_out + 3 * j);
   const double sg = inboard ? 1.0 : -1.0;
   const int np = joint_pos_rows(d.jtype[j]);
-  if (np == 1) {                                            // planar: one row along the inboard-fixed normal a_2
-    const P3 u = body_vec(w, bi, d.jvec_in + 9 * j + 6);
+  if (np != 3) for (int k = 0; k < np; k++) {             // planar / prismatic: rows along inboard-fixed directions
+    const P3 u = body_vec(w, bi, d.jvec_in + 9 * j + 3 * joint_dir_slot(d.jtype[j], k));
     const P3 ri = body_vec(w, bi, d.janchor_in + 3 * j), ro = body_vec(w, bo, d.janchor_out + 3 * j);
     const P3 pi = w.enabled(bi) ? w.X(bi) + ri : ri, po = w.enabled(bo) ? w.X(bo) + ro : ro;
     const P3 e = u * sg;
     P3 ang = cross3(r, e);
     if (inboard) ang = ang + cross3(u, pi - po);
-    Cq[0] = e.x; Cq[1] = e.y; Cq[2] = e.z; Cq[3] = ang.x; Cq[4] = ang.y; Cq[5] = ang.z;
+    Cq[6*k] = e.x; Cq[6*k+1] = e.y; Cq[6*k+2] = e.z; Cq[6*k+3] = ang.x; Cq[6*k+4] = ang.y; Cq[6*k+5] = ang.z;
   } else for (int k = 0; k < 3; k++) {
     const P3 e = p3(k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0);
     const P3 rxe = cross3(r, e);
@@ -510,7 +511,7 @@ MH_DEV void joint_eval(const W& w, int j, double* C) {
   const P3 pi = w.enabled(bi) ? w.X(bi) + ri : ri, po = w.enabled(bo) ? w.X(bo) + ro : ro;
   const P3 dd = pi - po;
   const int np = joint_pos_rows(d.jtype[j]);
-  if (np == 1) C[0] = dot3(body_vec(w, bi, d.jvec_in + 9 * j + 6), dd);
+  if (np != 3) for (int k = 0; k < np; k++) C[k] = dot3(body_vec(w, bi, d.jvec_in + 9 * j + 3 * joint_dir_slot(d.jtype[j], k)), dd);
   else { C[0] = dd.x; C[1] = dd.y; C[2] = dd.z; }
   const int nori = joint_rows(d.jtype[j]) - np;
   for (int k = 0; k < nori; k++) C[np + k] = dot3(body_vec(w, bi, d.jvec_in + 9 * j + 3 * k), body_vec(w, bo, d.jvec_out + 9 * j + 3 * k));
@@ -1206,7 +1207,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
     std::vector<std::vector<int> > adj((size_t)nb);
     for (int j = 0; j < nj; j++) {
       const int a = sc->joint_inboard[j], bq = sc->joint_outboard[j], ty = sc->joint_type[j];
-      if (ty != MH_IJOINT_SPHERICAL && ty != MH_IJOINT_REVOLUTE && ty != MH_IJOINT_FIXED && ty != MH_IJOINT_PLANAR && ty != MH_IJOINT_UNIVERSAL) return fail(MH_ERR_INVALID_ARG, "joint %d: type %d (MH_IJOINT_*)", j, ty);
+      if (ty != MH_IJOINT_SPHERICAL && ty != MH_IJOINT_REVOLUTE && ty != MH_IJOINT_FIXED && ty != MH_IJOINT_PLANAR && ty != MH_IJOINT_UNIVERSAL && ty != MH_IJOINT_PRISMATIC) return fail(MH_ERR_INVALID_ARG, "joint %d: type %d (MH_IJOINT_*)", j, ty);
       if (a < 0 || a > nb || bq < 0 || bq > nb || a == bq) return fail(MH_ERR_INVALID_ARG, "joint %d: links (%d, %d) must be two different ids in [0, nb]", j, a, bq);
       if (a < nb && bq < nb) { adj[a].push_back(bq); adj[bq].push_back(a); }
     }
@@ -1220,7 +1221,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
       for (int j = 0; j < nj; j++) {
         const int a = sc->joint_inboard[j], bq = sc->joint_outboard[j];
         if ((a < nb && std::binary_search(q.begin(), q.end(), a)) || (bq < nb && std::binary_search(q.begin(), q.end(), bq))) {
-          ij.push_back(j); m += (sc->joint_type[j] == MH_IJOINT_SPHERICAL || sc->joint_type[j] == MH_IJOINT_PLANAR) ? 3 : (sc->joint_type[j] == MH_IJOINT_UNIVERSAL ? 4 : (sc->joint_type[j] == MH_IJOINT_REVOLUTE ? 5 : 6));
+          ij.push_back(j); m += (sc->joint_type[j] == MH_IJOINT_SPHERICAL || sc->joint_type[j] == MH_IJOINT_PLANAR) ? 3 : (sc->joint_type[j] == MH_IJOINT_UNIVERSAL ? 4 : ((sc->joint_type[j] == MH_IJOINT_REVOLUTE || sc->joint_type[j] == MH_IJOINT_PRISMATIC) ? 5 : 6));
         }
       }
       if (ij.empty()) continue;
@@ -1277,7 +1278,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
   d.nj = nj; d.kk_nisl = (int)kk_nbod.size(); d.kk_mmax = kk_mmax;
   if (nj > 0) {
     std::vector<int> jrow0((size_t)nj); int rows = 0;
-    for (int j = 0; j < nj; j++) { jrow0[(size_t)j] = rows; rows += (sc->joint_type[j] == MH_IJOINT_SPHERICAL || sc->joint_type[j] == MH_IJOINT_PLANAR) ? 3 : (sc->joint_type[j] == MH_IJOINT_UNIVERSAL ? 4 : (sc->joint_type[j] == MH_IJOINT_REVOLUTE ? 5 : 6)); }
+    for (int j = 0; j < nj; j++) { jrow0[(size_t)j] = rows; rows += (sc->joint_type[j] == MH_IJOINT_SPHERICAL || sc->joint_type[j] == MH_IJOINT_PLANAR) ? 3 : (sc->joint_type[j] == MH_IJOINT_UNIVERSAL ? 4 : ((sc->joint_type[j] == MH_IJOINT_REVOLUTE || sc->joint_type[j] == MH_IJOINT_PRISMATIC) ? 5 : 6)); }
     d.jrows = rows; d.jrow0 = (const int*)U(jrow0.data(), nj * 4);
 
     d.jtype = (const int*)U(sc->joint_type, nj * 4); d.jin = (const int*)U(sc->joint_inboard, nj * 4); d.jout = (const int*)U(sc->joint_outboard, nj * 4);

@@ -79,15 +79,16 @@ MH_DEV P3 jt_body_vec(const double* st, int nb, int b, const double* u) {      /
   R[6] = 2.0 * (x*z - y*w);       R[7] = 2.0 * (y*z + x*w);       R[8] = 1.0 - 2.0 * (x*x + y*y);
   return p3((R[0]*u[0] + R[1]*u[1]) + R[2]*u[2], (R[3]*u[0] + R[4]*u[1]) + R[5]*u[2], (R[6]*u[0] + R[7]*u[1]) + R[8]*u[2]);
 }
-MH_DEV int jt_rows(int type) { return (type == 0 || type == 3) ? 3 : (type == 4 ? 4 : (type == 1 ? 5 : 6)); }   // MH_IJOINT_SPHERICAL / _REVOLUTE / _FIXED / _PLANAR / _UNIVERSAL
-MH_DEV int jt_pos_rows(int type) { return type == 3 ? 1 : 3; }
+MH_DEV int jt_rows(int type) { return (type == 0 || type == 3) ? 3 : (type == 4 ? 4 : ((type == 1 || type == 5) ? 5 : 6)); }   // MH_IJOINT_SPHERICAL 0, _REVOLUTE 1, _FIXED 2, _PLANAR 3, _UNIVERSAL 4, _PRISMATIC 5
+MH_DEV int jt_pos_rows(int type) { return type == 3 ? 1 : (type == 5 ? 2 : 3); }
+MH_DEV int jt_dir_slot(int type, int k) { return type == 3 ? 2 : k; }
 MH_DEV void jt_eval(const JointTab& jt, const double* st, int nb, int j, double* C) {
   const int bi = jt.in[j], bo = jt.out[j];
   const P3 ri = jt_body_vec(st, nb, bi, jt.anchor_in + 3 * j), ro = jt_body_vec(st, nb, bo, jt.anchor_out + 3 * j);
   const P3 pi = (bi >= 0 && bi < nb) ? ld3(st + 13 * bi) + ri : ri, po = (bo >= 0 && bo < nb) ? ld3(st + 13 * bo) + ro : ro;
   const P3 dd = pi - po;
   const int np = jt_pos_rows(jt.type[j]);
-  if (np == 1) C[0] = dot3(jt_body_vec(st, nb, bi, jt.vec_in + 9 * j + 6), dd);
+  if (np != 3) for (int k = 0; k < np; k++) C[k] = dot3(jt_body_vec(st, nb, bi, jt.vec_in + 9 * j + 3 * jt_dir_slot(jt.type[j], k)), dd);
   else { C[0] = dd.x; C[1] = dd.y; C[2] = dd.z; }
   const int nori = jt_rows(jt.type[j]) - np;
   for (int k = 0; k < nori; k++) C[np + k] = dot3(jt_body_vec(st, nb, bi, jt.vec_in + 9 * j + 3 * k), jt_body_vec(st, nb, bo, jt.vec_out + 9 * j + 3 * k));
@@ -97,14 +98,14 @@ MH_DEV void jt_jac(const JointTab& jt, const double* st, int nb, int j, bool inb
   const P3 r = inboard ? jt_body_vec(st, nb, bi, jt.anchor_in + 3 * j) : jt_body_vec(st, nb, bo, jt.anchor_out + 3 * j);
   const double sg = inboard ? 1.0 : -1.0;
   const int np = jt_pos_rows(jt.type[j]);
-  if (np == 1) {
-    const P3 u = jt_body_vec(st, nb, bi, jt.vec_in + 9 * j + 6);
+  if (np != 3) for (int k = 0; k < np; k++) {
+    const P3 u = jt_body_vec(st, nb, bi, jt.vec_in + 9 * j + 3 * jt_dir_slot(jt.type[j], k));
     const P3 ri = jt_body_vec(st, nb, bi, jt.anchor_in + 3 * j), ro = jt_body_vec(st, nb, bo, jt.anchor_out + 3 * j);
     const P3 pi = (bi >= 0 && bi < nb) ? ld3(st + 13 * bi) + ri : ri, po = (bo >= 0 && bo < nb) ? ld3(st + 13 * bo) + ro : ro;
     const P3 e = u * sg;
     P3 ang = cross3(r, e);
     if (inboard) ang = ang + cross3(u, pi - po);
-    Cq[0] = e.x; Cq[1] = e.y; Cq[2] = e.z; Cq[3] = ang.x; Cq[4] = ang.y; Cq[5] = ang.z;
+    Cq[6*k] = e.x; Cq[6*k+1] = e.y; Cq[6*k+2] = e.z; Cq[6*k+3] = ang.x; Cq[6*k+4] = ang.y; Cq[6*k+5] = ang.z;
   } else for (int k = 0; k < 3; k++) {
     const P3 e = p3(k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0);
     const P3 rxe = cross3(r, e);

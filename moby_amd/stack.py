@@ -13,8 +13,8 @@ from . import _lib
 from . import scene as S
 
 MH_PAIR_CLOSED_FORM, MH_PAIR_VERTEX_FACE = 0, 1
-MH_IJOINT_SPHERICAL, MH_IJOINT_REVOLUTE, MH_IJOINT_FIXED, MH_IJOINT_PLANAR, MH_IJOINT_UNIVERSAL = 0, 1, 2, 3, 4        # moby_hip_stack.h
-IJOINT_ROWS = {MH_IJOINT_SPHERICAL: 3, MH_IJOINT_REVOLUTE: 5, MH_IJOINT_FIXED: 6, MH_IJOINT_PLANAR: 3, MH_IJOINT_UNIVERSAL: 4}
+MH_IJOINT_SPHERICAL, MH_IJOINT_REVOLUTE, MH_IJOINT_FIXED, MH_IJOINT_PLANAR, MH_IJOINT_UNIVERSAL, MH_IJOINT_PRISMATIC = 0, 1, 2, 3, 4, 5        # moby_hip_stack.h
+IJOINT_ROWS = {MH_IJOINT_SPHERICAL: 3, MH_IJOINT_REVOLUTE: 5, MH_IJOINT_FIXED: 6, MH_IJOINT_PLANAR: 3, MH_IJOINT_UNIVERSAL: 4, MH_IJOINT_PRISMATIC: 5}
 _dp, _ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
 
 
@@ -119,6 +119,12 @@ def make_joint(kind, inboard, outboard, location, state, nb, axis=(0.0, 0.0, 1.0
         v1, v2 = orthonormal_basis(a)                               # two directions orthogonal to the axis
         vin[0] = Ri.T @ a; vin[1] = Ri.T @ a
         vout[0] = Ro.T @ np.asarray(v1); vout[1] = Ro.T @ np.asarray(v2)
+    elif kind == MH_IJOINT_PRISMATIC:                               # axis = the sliding direction
+        from .synth import orthonormal_basis
+        t1, t2 = (np.asarray(v) for v in orthonormal_basis(a))
+        tri = [t1, t2, a]                                           # a_0, a_1: the two position rows' directions; a_k . b_k = 0 with b_k = a_{k+1}
+        for k in range(3):
+            vin[k] = Ri.T @ tri[k]; vout[k] = Ro.T @ tri[(k + 1) % 3]
     elif kind == MH_IJOINT_UNIVERSAL:                               # axis (inboard) and axis2 (outboard) stay orthogonal
         from .synth import orthonormal_basis
         a2 = np.asarray(orthonormal_basis(a)[0] if axis2 is None else axis2, dtype=np.float64)

@@ -574,8 +574,9 @@ class World {
   // rows [e_k, r x e_k] (inboard, + ; outboard, -) exactly like a contact row (ICH:1847-1895); orientation rows
   // C = a . b with a fixed in the inboard and b in the outboard frame, Jacobian rows [0, a x b] (+ / -).
   int njoints() const { return sc ? sc->njoints : 0; }
-  static int joint_rows(int type) { return (type == MH_IJOINT_SPHERICAL || type == MH_IJOINT_PLANAR) ? 3 : (type == MH_IJOINT_UNIVERSAL ? 4 : (type == MH_IJOINT_REVOLUTE ? 5 : 6)); }
-  static int joint_pos_rows(int type) { return type == MH_IJOINT_PLANAR ? 1 : 3; }
+  static int joint_rows(int type) { return (type == MH_IJOINT_SPHERICAL || type == MH_IJOINT_PLANAR) ? 3 : (type == MH_IJOINT_UNIVERSAL ? 4 : ((type == MH_IJOINT_REVOLUTE || type == MH_IJOINT_PRISMATIC) ? 5 : 6)); }
+  static int joint_pos_rows(int type) { return type == MH_IJOINT_PLANAR ? 1 : (type == MH_IJOINT_PRISMATIC ? 2 : 3); }
+  static int joint_dir_slot(int type, int k) { return type == MH_IJOINT_PLANAR ? 2 : k; }   // which a_k a direction row uses
   V3 body_vec(int b, const double* u) const {           // R u for a dynamic body, u for the static world
     if (!enabled(b)) return v3(u[0], u[1], u[2]);
     double R[9]; rot(b, R);
@@ -587,7 +588,7 @@ class World {
     const V3 pi = enabled(bi) ? X(bi) + ri : ri, po = enabled(bo) ? X(bo) + ro : ro;
     const V3 d = pi - po;
     const int np = joint_pos_rows(sc->joint_type[j]);
-    if (np == 1) C[0] = dot(body_vec(bi, sc->joint_vec_in[j] + 6), d);          // planar: the distance along the normal a_2
+    if (np != 3) for (int k = 0; k < np; k++) C[k] = dot(body_vec(bi, sc->joint_vec_in[j] + 3 * joint_dir_slot(sc->joint_type[j], k)), d);   // planar / prismatic: along inboard-fixed directions
     else { C[0] = d.x; C[1] = d.y; C[2] = d.z; }
     const int nori = joint_rows(sc->joint_type[j]) - np;
     for (int k = 0; k < nori; k++) C[np + k] = dot(body_vec(bi, sc->joint_vec_in[j] + 3 * k), body_vec(bo, sc->joint_vec_out[j] + 3 * k));
@@ -597,15 +598,15 @@ class World {
     const V3 r = inboard ? body_vec(bi, sc->joint_anchor_in[j]) : body_vec(bo, sc->joint_anchor_out[j]);
     const double sg = inboard ? 1.0 : -1.0;
     const int np = joint_pos_rows(sc->joint_type[j]);
-    if (np == 1) {
+    if (np != 3) for (int k = 0; k < np; k++) {
       // C = u . (p_in - p_out), u fixed in the inboard frame: dC/dt = u . (v_pin - v_pout) + (w_in x u) . d
-      const V3 u = body_vec(bi, sc->joint_vec_in[j] + 6);
+      const V3 u = body_vec(bi, sc->joint_vec_in[j] + 3 * joint_dir_slot(sc->joint_type[j], k));
       const V3 ri = body_vec(bi, sc->joint_anchor_in[j]), ro = body_vec(bo, sc->joint_anchor_out[j]);
       const V3 pi = enabled(bi) ? X(bi) + ri : ri, po = enabled(bo) ? X(bo) + ro : ro;
       const V3 e = u * sg;
       V3 ang = cross(r, e);
       if (inboard) ang = ang + cross(u, pi - po);
-      Cq[0][0] = e.x; Cq[0][1] = e.y; Cq[0][2] = e.z; Cq[0][3] = ang.x; Cq[0][4] = ang.y; Cq[0][5] = ang.z;
+      Cq[k][0] = e.x; Cq[k][1] = e.y; Cq[k][2] = e.z; Cq[k][3] = ang.x; Cq[k][4] = ang.y; Cq[k][5] = ang.z;
     } else for (int k = 0; k < 3; k++) {
       const V3 e = v3(k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0);
       const V3 rxe = cross(r, e);

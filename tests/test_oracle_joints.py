@@ -35,7 +35,7 @@ def advance(st, v, eps):
     return out
 
 
-@pytest.mark.parametrize("kind", [K.MH_IJOINT_SPHERICAL, K.MH_IJOINT_REVOLUTE, K.MH_IJOINT_FIXED, K.MH_IJOINT_PLANAR, K.MH_IJOINT_UNIVERSAL])
+@pytest.mark.parametrize("kind", [K.MH_IJOINT_SPHERICAL, K.MH_IJOINT_REVOLUTE, K.MH_IJOINT_FIXED, K.MH_IJOINT_PLANAR, K.MH_IJOINT_UNIVERSAL, K.MH_IJOINT_PRISMATIC])
 def test_jacobian_is_the_derivative_of_the_constraint_function(oracle, kind):
     rng = np.random.default_rng(3 + kind)
     nb = 2

@@ -27,7 +27,7 @@ for case in range(cases):
     for b in range(1, nb):                                          # a random tree (some bodies stay free)
         if rng.random() < 0.25: continue
         a = int(rng.integers(0, b))
-        kind = int(rng.choice([K.MH_IJOINT_SPHERICAL, K.MH_IJOINT_REVOLUTE, K.MH_IJOINT_FIXED, K.MH_IJOINT_UNIVERSAL, K.MH_IJOINT_PLANAR], p=[0.35, 0.3, 0.15, 0.15, 0.05]))
+        kind = int(rng.choice([K.MH_IJOINT_SPHERICAL, K.MH_IJOINT_REVOLUTE, K.MH_IJOINT_FIXED, K.MH_IJOINT_UNIVERSAL, K.MH_IJOINT_PLANAR, K.MH_IJOINT_PRISMATIC], p=[0.3, 0.25, 0.15, 0.1, 0.05, 0.15]))
         pair = (a, b) if rng.random() < 0.5 else (b, a)
         joints.append(K.make_joint(kind, pair[0], pair[1], 0.5 * (pos[a] + pos[b]), st, nb, axis=rng.standard_normal(3)))
     if rng.random() < 0.4:
