@@ -499,7 +499,7 @@ void k_post(Dev d, int r, int phase)
 
 // apply_ap_model_to_connected_constraints around its LCPs (ICH-AP:36-92, 336-350) for the islands of model 2, in two
 // small kernels (a single one needed spilled SGPRs, and came out of the compiler with a wrong execution mask after its
-// min-reduction: tools/ap_case.py found it).
+// min-reduction: tests/tools/ap_case.py found it).
 // k_post_ap, phase 0: after the first solve -- impulses from z, propagate_impulse_data, constraint velocities,
 // restitution, the second-solve test; phase 1: after the second solve.  It leaves need2[b] = 1 when the island's wrenches
 // are final; k_apply_ap then does apply_impulses (ICH:676-745) and clears the flag.

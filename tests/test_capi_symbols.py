@@ -92,14 +92,15 @@ def test_argument_validation_without_gpu():
 
 
 def test_product_never_imports_oracle():
-    """The product package must not reference oracle/ (no CPU fallback)."""
-    pkg = os.path.join(ROOT, "moby_amd")
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".h", ".hip", ".hpp", ".cpp")):
-                txt = open(os.path.join(dirpath, f)).read()
-                assert "liboracle" not in txt and "oracle_api" not in txt, f
-                assert not re.search(r'#include\s+"[^"]*oracle', txt), f
+    """The product package must not reference oracle/ (no CPU fallback); neither do the measurement scripts under tools/
+    (checkers that run next to the oracle live in tests/tools/)."""
+    for top in ("moby_amd", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".hpp", ".cpp", ".sh")):
+                    txt = open(os.path.join(dirpath, f)).read()
+                    assert "liboracle" not in txt and "oracle_api" not in txt, f
+                    assert not re.search(r'#include\s+"[^"]*oracle', txt), f
 
 
 def test_cpp_adapter_compiles_and_fails_loudly_without_gpu(tmp_path):

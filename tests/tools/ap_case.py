@@ -1,4 +1,4 @@
-"""Debug driver: one A-P impact batch on the GPU next to the oracle (python tools/ap_case.py nbx B eps mu nk calls)."""
+"""Debug driver: one A-P impact batch on the GPU next to the oracle (python tests/tools/ap_case.py nbx B eps mu nk calls)."""
 import sys, os, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from moby_amd import impact as I, scene as S

@@ -5,7 +5,7 @@ Counts, over random LCPs of the block-solver range and over box-stack impact LCP
 status / pivot count / pivot trace / solution bits."""
 import json, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from moby_amd import synth, impact as I
 from tests.oracle_api import Oracle, FAST, FAST_REG, LEMKE, LEMKE_REG

@@ -1,8 +1,8 @@
 """Fuzz of the impact-handler entry against the oracle: random single-island contact multigraphs, random poses /
-velocities / parameters, two calls each (cold + warm).  python tools/fuzz_impact.py [seed0] [cases] [ds|ap]"""
+velocities / parameters, two calls each (cold + warm).  python tests/tools/fuzz_impact.py [seed0] [cases] [ds|ap]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from moby_amd import scene as S, impact as I
 from tests.oracle_api import Oracle

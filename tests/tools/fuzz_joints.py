@@ -1,10 +1,10 @@
 """Fuzz of the implicit-joint path of the large-world stepper against the oracle: random trees / loops of spheres tied by
 spherical, revolute and fixed joints (some to the world, some doubled), random poses and velocities, with and without
 ground contact pairs and stabilisation, a few steps each -- states and counters bit for bit.
-python tools/fuzz_joints.py [seed0] [cases]"""
+python tests/tools/fuzz_joints.py [seed0] [cases]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from moby_amd import scene as S, stack as K
 from tests.oracle_api import Oracle

@@ -1,7 +1,7 @@
 """One-off fuzz of the LCP entry (wave and block solvers) against the oracle."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from moby_amd import synth
 from tests.oracle_api import Oracle

@@ -1,7 +1,7 @@
 """One-off fuzz: randomised sphere / box scenes, GPU (C ABI) against the oracle, bit for bit."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from moby_amd import scene as S
 from moby_amd.world import WorldBatch

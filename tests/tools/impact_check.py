@@ -1,7 +1,7 @@
 """GPU impact handler vs the oracle on box stacks (debug / parity tool): python tools/impact_check.py nboxes [B] [eps] [mu]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from moby_amd import scene as S, impact as I
 from tests.oracle_api import Oracle
