@@ -192,21 +192,25 @@ def config4_full_step_leg(torch, nboxes, B, steps):
         return {"error": repr(e)}
 
 
-def config5_leg(torch, B=8192, steps=200):
+def config5_leg(torch, B=8192, steps=200, cpu=True):
     """BASELINE config 5: the ur10 arm (tests/scenes/ten_joint_arm.sdf = the numbers of example/ur10/model.sdf) x B random
     states, dt = 5e-4 (ur10.xml:2), `steps` steps in one launch: CRBA + RNEA + Cholesky forward dynamics and the joint-limit
-    LCP every step.  Also times the CPU oracle (oracle/artic.hpp, one thread) on a sample of the same batch."""
+    LCP every step.  With the CPU baseline on, the oracle (oracle/artic.hpp, one thread) is timed on a sample of the same batch --
+    beside the GPU run, never inside it."""
     try:
         from moby_amd import artic as A
-        from tests.oracle_api import Oracle
         from tests.test_artic_gpu import ur10_states
         from moby_amd import scene as S
         m, _, _ = A.load_sdf(os.path.join(ROOT, "tests", "scenes", "ten_joint_arm.sdf"))
         q0, qd0 = ur10_states(m, B)
-        oracle = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
-        nw = min(B, 256)
-        qo, qdo, auxo = q0[:nw].copy(), qd0[:nw].copy(), S.new_aux(nw)
-        secs = oracle.artic_step(m, qo, qdo, auxo, 5e-4, steps)
+        cpu_part = None
+        if cpu:
+            from tests.oracle_api import Oracle
+            oracle = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+            nw = min(B, 256)
+            qo, qdo, auxo = q0[:nw].copy(), qd0[:nw].copy(), S.new_aux(nw)
+            secs = oracle.artic_step(m, qo, qdo, auxo, 5e-4, steps)
+            cpu_part = {"world_steps_per_sec": nw * steps / secs, "cores": 1, "kind": "port", "sample": "%d worlds x %d steps" % (nw, steps)}
         ab = A.ArticBatch(m, q0, qd0)
         stream = torch.cuda.current_stream().cuda_stream
         ab.step(5e-4, 10, stream); torch.cuda.synchronize()
@@ -222,7 +226,7 @@ def config5_leg(torch, B=8192, steps=200):
                 "world_steps_per_sec": B * steps / (ms * 1e-3), "lcp_rows_per_sec": rows / (ms * 1e-3),
                 "worlds_with_errors": int(((a1["status"] & ~2) != 0).sum()),
                 "flops_per_world_step_est": 21000, "gflops_est": 21000.0 * B * steps / (ms * 1e-3) / 1e9,
-                "cpu_oracle": {"world_steps_per_sec": nw * steps / secs, "cores": 1, "sample": "%d worlds x %d steps" % (nw, steps)}}
+                "cpu_baseline": cpu_part}
     except Exception as e:          # noqa: BLE001 -- informational leg
         return {"error": repr(e)}
 
@@ -407,7 +411,7 @@ def main():
         out["config4_impact_handler"] = config4_leg(torch)             # after the timed region; informational
         out["config4_full_step"] = config4_full_step_leg(torch, args.config4_boxes, args.config4_worlds, args.config4_steps)
     if rank == 0 and world_size == 1 and not args.no_config5:
-        out["config5_ur10"] = config5_leg(torch)
+        out["config5_ur10"] = config5_leg(torch, cpu=not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(out))
     if world_size > 1:
