@@ -118,7 +118,7 @@ def test_cpp_adapter_compiles_and_fails_loudly_without_gpu(tmp_path):
     assert p.returncode == 2 and b"no HIP device" in p.stdout
 
 
-@pytest.mark.parametrize("example,libs", [("example_stack", ["-lmoby_hip"]), ("example_articulated", ["-lmoby_hip", "-lmoby_hip_io"])])
+@pytest.mark.parametrize("example,libs", [("example_stack", ["-lmoby_hip"]), ("example_joints", ["-lmoby_hip"]), ("example_articulated", ["-lmoby_hip", "-lmoby_hip_io"])])
 def test_new_cpp_adapters_compile_and_fail_loudly_without_gpu(tmp_path, example, libs):
     """MobyHipStackSimulator.h (seams B5 / B3 for large worlds) and MobyHipArticulatedBody.h (seam B4) build with plain
     g++ against the C ABI; without a device they report the error (no fallback)."""

@@ -259,3 +259,16 @@ def test_thousand_jointed_chains_properties():
         worst = max(worst, np.abs(pt(j["inboard"], j["anchor_in"]) - pt(j["outboard"], j["anchor_out"])).max())
     assert worst < 1e-6
     assert b[:, 3, 1].min() < -0.05 and np.abs(b[:, :, 2]).max() < 1e-6        # they fell, in the plane of the hinge
+
+
+def test_cpp_implicit_joints_adapter_example():
+    """moby_amd/cpp/MobyHipStackSimulator.h::ImplicitJoints (what a binding fills from Moby::Joint objects) through its example:
+    a revolute + universal pendulum and a box on a planar joint, 200 stabilised steps."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = os.path.join(root, "moby_amd", "cpp")
+    exe = os.path.join(cpp, "example_joints")
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", os.path.join(cpp, "example_joints.cpp"), "-L" + os.path.join(root, "moby_amd"),
+                           "-lmoby_hip", "-Wl,-rpath," + os.path.join(root, "moby_amd"), "-o", exe])
+    p = subprocess.run([exe], capture_output=True, timeout=120)
+    assert p.returncode == 0 and b"status=0/0" in p.stdout, p.stdout
