@@ -190,3 +190,29 @@ def test_box_stacks_step_with_the_anitescu_potra_model(oracle):
     r_ds = run_both(oracle, sc_ds, st0, 1e-3, 5)
     assert (r_ds[1]["zlast_size"] > 0).all()
     assert np.abs(r[0] - r_ds[0]).max() < 1e-3             # two models of the same resting stack
+
+
+def test_anitescu_potra_box_stacks_properties_at_scale(oracle):
+    """256 worlds of 4-box stacks with the A-P impact model, three full steps: nothing sinks or flies, identical worlds give
+    identical results wherever they sit in the batch.  On the redundant corner contacts the A-P Lemke ladder (capped at
+    lambda = 1e-3, ICH-AP:333) now and then fails on every rung -- the reference throws there; those worlds are flagged
+    MH_WORLD_LCP_FAILED exactly where the oracle flags them."""
+    N, B = 4, 256
+    sc = K.box_stack_scene(N, mu=0.3, impact_model=1)
+    st0 = K.box_stack_state(N, B)
+    st0[B // 2:] = st0[:B // 2]
+    bb = K.BigBatch(sc, st0)
+    bb.step(1e-3, 3)
+    st, aux = bb.download()
+    bb.close()
+    assert np.array_equal(st[B // 2:], st[:B // 2]) and np.array_equal(aux["lcp_pivots"][B // 2:], aux["lcp_pivots"][:B // 2])
+    failed = (aux["status"] & S.MH_WORLD_LCP_FAILED) != 0
+    assert ((aux["status"] & ~(S.MH_WORLD_IMPACT_TOL | S.MH_WORLD_LCP_FAILED)) == 0).all() and (aux["steps"] == 3).all() and failed.sum() <= B // 16
+    assert (aux["zlast_size"] == 0).all() and (aux["lcp_rows"] > 0).all()
+    b = st.reshape(B, N, 13)
+    assert np.abs(b[:, :, 1] - 0.5 - np.arange(N)).max() < 1e-4 and np.abs(b[:, :, 7:13]).max() < 5e-2
+    check = sorted(set(list(np.where(failed)[0][:2]) + [0, 5, 17]))
+    for w in check:                                              # the oracle agrees world by world, failures included
+        so = st0[w].copy(); ao = S.new_aux(1)
+        oracle.big_step(sc, so, ao, 1e-3, 3)
+        assert ao["status"][0] == aux["status"][w] and ao["lcp_pivots"][0] == aux["lcp_pivots"][w] and np.array_equal(so, st[w])
