@@ -31,6 +31,8 @@ extern "C" {
 #define MH_ARTIC_MAX_JOINTS 16
 #define MH_JOINT_REVOLUTE 0
 #define MH_JOINT_PRISMATIC 1
+#define MH_ARTIC_CRB  0
+#define MH_ARTIC_FSAB 1
 
 /* Joint i carries link i; joints are listed parents first.  All quantities are LOCAL (constant), as a reader of
  * model.sdf derives them once at q = 0 (mh_io_load_sdf, moby_amd/host/mh_io.cpp):
@@ -52,6 +54,11 @@ typedef struct mh_artic_model {
   double hilimit[MH_ARTIC_MAX_JOINTS];
   double limit_restitution[MH_ARTIC_MAX_JOINTS];   /* restitution-coeff, default 0 (src/Joint.cpp:33) */
   double gravity[3];
+  int    algorithm;      /* RCArticulatedBody::algorithm_type (include/Moby/RCArticulatedBody.h: eFeatherstone / eCRB; the SDF
+                            reader sets eCRB, src/SDFReader.cpp:934): MH_ARTIC_CRB (0) or MH_ARTIC_FSAB -- forward dynamics by
+                            Featherstone's articulated-body recursion; the impact handler's X = H^-1 is the generalized inertia's
+                            inverse either way (ICH:1600-1607) */
+  int    pad;
 } mh_artic_model;
 
 /* B worlds resident on the GPU: joint positions q and velocities qd (B x nj each) + mh_world_aux (rand() stream, time,

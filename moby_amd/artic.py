@@ -24,7 +24,10 @@ class mh_artic_model(ctypes.Structure):
                 ("Rrel", (ctypes.c_double * 9) * _NJ), ("trel", (ctypes.c_double * 3) * _NJ), ("axis", (ctypes.c_double * 3) * _NJ),
                 ("com", (ctypes.c_double * 3) * _NJ), ("inertia", (ctypes.c_double * 9) * _NJ), ("mass", ctypes.c_double * _NJ),
                 ("lolimit", ctypes.c_double * _NJ), ("hilimit", ctypes.c_double * _NJ), ("limit_restitution", ctypes.c_double * _NJ),
-                ("gravity", ctypes.c_double * 3)]
+                ("gravity", ctypes.c_double * 3), ("algorithm", ctypes.c_int), ("pad", ctypes.c_int)]
+
+
+MH_ARTIC_CRB, MH_ARTIC_FSAB = 0, 1      # moby_hip_artic.h: RCArticulatedBody::algorithm_type
 
 
 class mh_io_artic(ctypes.Structure):

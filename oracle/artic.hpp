@@ -174,6 +174,46 @@ class Artic {
     chol_solve(nj, L.data(), nj, qdd);
     return true;
   }
+  // calc_fwd_dyn, eFeatherstone: the articulated-body algorithm (Featherstone, Rigid Body Dynamics Algorithms, table 7.1) with
+  // every spatial quantity expressed at the world origin like the rest of this file (no link-to-link transforms).  Ravelin's
+  // FSAB source is not in the tree: parity unpinned; the order below is the kernel's.  d_i = S' IA S > 0 for a physical body.
+  bool fwd_dyn_aba(const double* tau, double* qdd) {
+    using namespace artic;
+    kinematics();
+    double v[NJ][6], c[NJ][6], IA[NJ][36], pA[NJ][6], U[NJ][6], d[NJ], u[NJ], a[NJ][6];
+    for (int i = 0; i < nj; i++) {                                   // pass 1, outward: velocities, bias accelerations and forces
+      const int p = m->parent[i];
+      double vj[6], Iv[6];
+      for (int k = 0; k < 6; k++) vj[k] = S[i][k] * qd[i];
+      for (int k = 0; k < 6; k++) v[i][k] = (p < 0) ? vj[k] : v[p][k] + vj[k];
+      crm(v[i], vj, c[i]);
+      for (int e = 0; e < 36; e++) IA[i][e] = Is[i][e];
+      mat6vec(Is[i], v[i], Iv); crf(v[i], Iv, pA[i]);
+    }
+    for (int i = nj - 1; i >= 0; i--) {                              // pass 2, inward: articulated inertias and bias forces
+      const int p = m->parent[i];
+      mat6vec(IA[i], S[i], U[i]);
+      d[i] = dot6(S[i], U[i]);
+      if (!(d[i] > 0.0)) return false;
+      u[i] = (tau ? tau[i] : 0.0) - dot6(S[i], pA[i]);
+      if (p >= 0) {
+        double Ia[36], Iac[6];
+        for (int r = 0; r < 6; r++) for (int cc = 0; cc < 6; cc++) { double t = U[i][r] * U[i][cc]; t = t / d[i]; Ia[6*r+cc] = IA[i][6*r+cc] - t; }
+        mat6vec(Ia, c[i], Iac);
+        for (int r = 0; r < 6; r++) { double e = U[i][r] * u[i]; e = e / d[i]; const double pa = (pA[i][r] + Iac[r]) + e; pA[p][r] = pA[p][r] + pa; }
+        for (int e = 0; e < 36; e++) IA[p][e] = IA[p][e] + Ia[e];
+      }
+    }
+    for (int i = 0; i < nj; i++) {                                   // pass 3, outward: accelerations
+      const int p = m->parent[i];
+      double ap[6];
+      for (int k = 0; k < 6; k++) { const double base = (p < 0) ? ((k < 3) ? 0.0 : -m->gravity[k - 3]) : a[p][k]; ap[k] = base + c[i][k]; }
+      double t = u[i] - dot6(U[i], ap);
+      qdd[i] = t / d[i];
+      for (int k = 0; k < 6; k++) a[i][k] = ap[k] + S[i][k] * qdd[i];
+    }
+    return true;
+  }
   void lcp_account(int n, unsigned pivots) { aux->lcp_solves++; aux->lcp_rows += (unsigned long long)n; aux->lcp_pivots += pivots; aux->lcp_alg_bytes += 8ull * ((unsigned long long)n * n + 2ull * n); }
 
   // find_limit_constraints + calc_impacting_unilateral_constraint_forces for the limits of this body
@@ -188,6 +228,7 @@ class Artic {
     for (int k = 0; k < nl; k++) { const double v = upper[k] ? -qd[idx[k]] : qd[idx[k]]; if (v < -A_NEAR_ZERO) impacting = true; }
     if (!impacting) return;
     if (nl > MH_NOSLIP_MAX) { aux->status |= MH_WORLD_UNSUPPORTED; return; }
+    if (m->algorithm == MH_ARTIC_FSAB) crba();                       // get_generalized_inertia (ICH:1600-1607): CRB whatever the forward dynamics used
     // compute_X: X = inverse_SPD(H) (ICH:1607); compute_limit_components (ICH:1755-1781)
     std::vector<double> X(H, H + nj * nj);
     if (!inverse_spd(nj, X.data(), nj)) { aux->status |= MH_WORLD_LCP_FAILED; return; }
@@ -239,7 +280,7 @@ class Artic {
   void step(double dt) {
     for (int i = 0; i < nj; i++) { double qn = qd[i] * dt; qn = qn + q[i]; q[i] = qn; }        // positions with the OLD velocity (TSS:156-164)
     double qdd[NJ];
-    if (!fwd_dyn(nullptr, qdd)) { aux->status |= MH_WORLD_LCP_FAILED; for (int i = 0; i < nj; i++) qdd[i] = 0.0; }
+    if (!((m->algorithm == MH_ARTIC_FSAB) ? fwd_dyn_aba(nullptr, qdd) : fwd_dyn(nullptr, qdd))) { aux->status |= MH_WORLD_LCP_FAILED; for (int i = 0; i < nj; i++) qdd[i] = 0.0; }
     for (int i = 0; i < nj; i++) qd[i] = qd[i] + qdd[i] * dt;                                      // TSS:182-192
     handle_limits();
     aux->time += dt; aux->mini_steps++; aux->steps++;

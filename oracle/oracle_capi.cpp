@@ -300,7 +300,9 @@ int oracle_artic_fwd_dyn(const mh_artic_model* m, const double* q, const double*
   mh_world_aux aux; std::memset(&aux, 0, sizeof(aux));
   std::vector<double> qq(q, q + m->nj), qv(qd, qd + m->nj);
   Artic w(m, qq.data(), qv.data(), &aux);
-  const bool ok = w.fwd_dyn(tau, qdd);
+  bool ok;
+  if (m->algorithm == MH_ARTIC_FSAB) { ok = w.fwd_dyn_aba(tau, qdd); w.crba(); w.bias(); }   // H / C as get_generalized_inertia would give them
+  else ok = w.fwd_dyn(tau, qdd);
   if (H) for (int e = 0; e < m->nj * m->nj; e++) H[e] = w.H[e];
   if (C) for (int i = 0; i < m->nj; i++) C[i] = w.C[i];
   if (poses) for (int i = 0; i < m->nj; i++) { for (int k = 0; k < 9; k++) poses[12 * i + k] = w.R[i][k]; for (int k = 0; k < 3; k++) poses[12 * i + 9 + k] = w.x[i][k]; }

@@ -172,3 +172,41 @@ def test_sdf_loader_reads_the_ur10_model():
     np.testing.assert_allclose(r["poses"][3, 9:], [0.612, 0.049041, 0.1273], atol=1e-12)
     np.testing.assert_allclose(r["poses"][9, 9:], [1.1843, 0.256, 0.0116], atol=1e-12)
     assert r["ok"] and np.linalg.eigvalsh(r["H"]).min() > 0
+
+
+@pytest.mark.parametrize("which", ["chain", "branch", "ur10"])
+def test_articulated_body_algorithm_equals_crb_plus_cholesky(oracle, which):
+    """RCArticulatedBody's other algorithm_type, eFeatherstone (FSAB): the O(n) articulated-body recursion gives the accelerations
+    of H qdd = tau - C -- with and without joint torques --, and a stepped trajectory stays with the CRB one to round-off."""
+    import copy
+    rng = np.random.default_rng(8)
+    if which == "chain":
+        m = A.chain_model(6, prismatic_last=True)
+    elif which == "ur10":
+        m, _, _ = A.load_sdf(UR10)
+    else:
+        links = []
+        for i, p in enumerate([-1, 0, 0, 1, 1, 2, 4]):
+            Q, _ = np.linalg.qr(rng.standard_normal((3, 3))); Q = Q * np.sign(np.linalg.det(Q))
+            J0 = rng.standard_normal((3, 3)); J0 = J0 @ J0.T + np.eye(3)
+            links.append(dict(parent=p, type=int(i % 3 == 2), R0=Q, x0=rng.standard_normal(3), axis=rng.standard_normal(3),
+                              com=0.2 * rng.standard_normal(3), inertia=0.05 * J0, mass=float(rng.uniform(0.5, 3.0))))
+        m = A.model_from_links(links)
+    ma = copy.deepcopy(m) if not hasattr(m, "_b_needsfree_") else type(m).from_buffer_copy(m)
+    ma.algorithm = A.MH_ARTIC_FSAB
+    for trial in range(4):
+        q = rng.uniform(-1.5, 1.5, m.nj); qd = rng.standard_normal(m.nj)
+        tau = None if trial % 2 == 0 else rng.standard_normal(m.nj)
+        r_crb = oracle.artic_fwd_dyn(m, q, qd, tau)
+        r_aba = oracle.artic_fwd_dyn(ma, q, qd, tau)
+        assert r_crb["ok"] and r_aba["ok"]
+        scale = max(1.0, np.abs(r_crb["qdd"]).max())
+        np.testing.assert_allclose(r_aba["qdd"], r_crb["qdd"], atol=1e-9 * scale)
+        assert np.array_equal(r_aba["H"], r_crb["H"])               # the generalized inertia is CRB's either way
+    B = 3
+    q0 = rng.uniform(-0.3, 0.3, (B, m.nj)); qd0 = rng.uniform(-0.5, 0.5, (B, m.nj))
+    qa, qda, auxa = q0.copy(), qd0.copy(), S.new_aux(B)
+    qc, qdc, auxc = q0.copy(), qd0.copy(), S.new_aux(B)
+    oracle.artic_step(ma, qa, qda, auxa, 5e-4, 200); oracle.artic_step(m, qc, qdc, auxc, 5e-4, 200)
+    np.testing.assert_allclose(qa, qc, atol=1e-8); np.testing.assert_allclose(qda, qdc, atol=1e-6)
+    assert np.array_equal(auxa["status"], auxc["status"])
