@@ -5,7 +5,8 @@
  * Replaces, per world (one Moby::RCArticulatedBody with a fixed base and 1-DOF revolute / prismatic joints, which is
  * what SDFReader::read_model builds: eCRB + eLinkCOM, src/SDFReader.cpp:934-935),
  *   TimeSteppingSimulator::step / do_mini_step                        src/TimeSteppingSimulator.cpp:52-222
- *   Ravelin::RCArticulatedBodyd::calc_fwd_dyn (CRB)  [seam B4]         call site src/Simulator.cpp:552 -- Ravelin's source is
+ *   Ravelin::RCArticulatedBodyd::calc_fwd_dyn (CRB or FSAB, mh_artic_model.algorithm)  [seam B4]
+ *                                                                      call site src/Simulator.cpp:552 -- Ravelin's source is
  *                                                                      NOT in the reference tree: the algorithm is
  *                                                                      Featherstone's (CRBA for H, RNEA for the bias), "parity unpinned"
  *   ArticulatedBody::find_limit_constraints                            include/Moby/ArticulatedBody.inl:9-43

@@ -93,8 +93,8 @@ static size_t lds_bytes(int nj) {
   return sizeof(double) * (size_t)(4 * n + 3 * n * n + (dyn > lim ? dyn : lim));
 }
 
-// kinematics + spatial inertias + bias + H + Cholesky + qdd for the q / qd in LDS.  Returns false if H is not PD.
-MH_DEV bool dynamics(const Model& M, const Lay& Y, double* g, const double* tau_w)
+// link frames, motion subspaces and spatial inertias about the world origin for the q in LDS (oracle Artic::kinematics)
+MH_DEV void kin_inertia(const Model& M, const Lay& Y, double* g)
 {
   const mh_artic_model& m = M.m;
   const int nj = Y.nj, lane = lane_id();
@@ -169,6 +169,14 @@ MH_DEV bool dynamics(const Model& M, const Lay& Y, double* g, const double* tau_
     }
   }
   wave_sync();
+}
+
+// kinematics + spatial inertias + bias + H + Cholesky + qdd for the q / qd in LDS.  Returns false if H is not PD.
+MH_DEV bool dynamics(const Model& M, const Lay& Y, double* g, const double* tau_w)
+{
+  const mh_artic_model& m = M.m;
+  const int nj = Y.nj, lane = lane_id();
+  kin_inertia(M, Y, g);
   // recursive Newton-Euler with qdd = 0 (the links' OWN inertias): lanes 0..5 = spatial components
   for (int i = 0; i < nj; i++) {
     const int p = m.parent[i];
@@ -267,6 +275,74 @@ MH_DEV bool dynamics(const Model& M, const Lay& Y, double* g, const double* tau_
   return true;
 }
 
+// calc_fwd_dyn, eFeatherstone (RCArticulatedBody::algorithm_type): the articulated-body recursion, every spatial quantity at the
+// world origin (oracle Artic::fwd_dyn_aba, same operation order).  In place: I6 becomes the articulated inertias, `a` holds the
+// bias accelerations c_i and then the accelerations, `f` the bias forces, `F` the U_i; d_i and u_i sit in the (unused) H region.
+// Returns false when some d_i = S' IA S is not positive.
+MH_DEV bool dynamics_aba(const Model& M, const Lay& Y, double* g, const double* tau_w)
+{
+  const mh_artic_model& m = M.m;
+  const int nj = Y.nj, lane = lane_id();
+  kin_inertia(M, Y, g);
+  double* dd = g + Y.H; double* uu = g + Y.H + nj;
+  for (int i = 0; i < nj; i++) {                          // pass 1, outward
+    const int p = m.parent[i];
+    const double* S = g + Y.S + 6 * i;
+    const double qdi = g[Y.qd + i];
+    double* vj = g + Y.Iv;                                // S_i qd_i (6), then I v (6)
+    if (lane < 6) { const double e = S[lane] * qdi; vj[lane] = e; g[Y.v + 6 * i + lane] = (p < 0) ? e : g[Y.v + 6 * p + lane] + e; }
+    wave_sync();
+    if (lane < 6) {
+      g[Y.a + 6 * i + lane] = crm_c(g + Y.v + 6 * i, vj, lane);
+      const double* I6 = g + Y.I6 + 36 * i + 6 * lane; const double* v = g + Y.v + 6 * i;
+      double acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + I6[k] * v[k];
+      g[Y.Iv + 6 + lane] = acc;
+    }
+    wave_sync();
+    if (lane < 6) g[Y.f + 6 * i + lane] = crf_c(g + Y.v + 6 * i, g + Y.Iv + 6, lane);
+    wave_sync();
+  }
+  bool pd = true;
+  for (int i = nj - 1; i >= 0; i--) {                     // pass 2, inward
+    const int p = m.parent[i];
+    const double* S = g + Y.S + 6 * i;
+    double* IA = g + Y.I6 + 36 * i;
+    double* U = g + Y.F + 6 * i;
+    if (lane < 6) { double acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + IA[6 * lane + k] * S[k]; U[lane] = acc; }
+    wave_sync();
+    if (lane == 0) { dd[i] = dot6(S, U); uu[i] = (tau_w ? tau_w[i] : 0.0) - dot6(S, g + Y.f + 6 * i); }
+    wave_sync();
+    const double d = dd[i], u = uu[i];
+    if (!(d > 0.0)) { pd = false; break; }
+    if (p >= 0) {
+      if (lane < 36) { const int r = lane / 6, c = lane - 6 * r; double t = U[r] * U[c]; t = t / d; IA[lane] = IA[lane] - t; }   // Ia, in place
+      wave_sync();
+      if (lane < 36) g[Y.I6 + 36 * p + lane] = g[Y.I6 + 36 * p + lane] + IA[lane];
+      else if (lane < 42) {
+        const int r = lane - 36;
+        const double* c = g + Y.a + 6 * i;
+        double acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + IA[6 * r + k] * c[k];
+        double e = U[r] * u; e = e / d;
+        const double pa = (g[Y.f + 6 * i + r] + acc) + e;
+        g[Y.f + 6 * p + r] = g[Y.f + 6 * p + r] + pa;
+      }
+      wave_sync();
+    }
+  }
+  if (!pd) return false;
+  for (int i = 0; i < nj; i++) {                          // pass 3, outward
+    const int p = m.parent[i];
+    double* ap = g + Y.Iv;
+    if (lane < 6) { const double base = (p < 0) ? ((lane < 3) ? 0.0 : -m.gravity[lane - 3]) : g[Y.a + 6 * p + lane]; ap[lane] = base + g[Y.a + 6 * i + lane]; }
+    wave_sync();
+    if (lane == 0) { const double t = uu[i] - dot6(g + Y.F + 6 * i, ap); g[Y.qdd + i] = t / dd[i]; }
+    wave_sync();
+    if (lane < 6) g[Y.a + 6 * i + lane] = ap[lane] + g[Y.S + 6 * i + lane] * g[Y.qdd + i];
+    wave_sync();
+  }
+  return true;
+}
+
 // X = inverse_SPD(H) from the factor in Y.L (linalg.hpp inverse_spd): lane = column
 MH_DEV void inverse_from_factor(const Lay& Y, double* g)
 {
@@ -296,15 +372,19 @@ MH_DEV void handle_limits(const Model& M, const Lay& Y, double* g, mh_world_aux*
   const uint64_t mu = ballot(up), ml = ballot(lo);
   const int nl = popc(mu) + popc(ml);
   if (nl == 0) return;
-  int* idx = reinterpret_cast<int*>(g + Y.idx);                  // idx[k] = joint | (upper << 8)
-  if (lane < nj) {
-    const int base = popc(mu & lanes_below(lane)) + popc(ml & lanes_below(lane));
-    if (nl <= NLMAX) { if (up) idx[base] = lane | 256; if (lo) idx[base + (up ? 1 : 0)] = lane; }
-  }
   const double qdi = (lane < nj) ? g[Y.qd + lane] : 0.0;
   const bool impacting = ballot((up && -qdi < -NEAR_ZERO_) || (lo && qdi < -NEAR_ZERO_)) != 0ull;   // CSim:313-323
   if (!impacting) return;
   if (nl > NLMAX) { status |= MH_WORLD_UNSUPPORTED; return; }
+  // eFeatherstone bodies: the handler's X is still the inverse of the generalized inertia (get_generalized_inertia + inverse_SPD,
+  // ICH:1600-1607): H and its factor by the CRB path, at the current q (before the limit storage below reuses the link arrays)
+  if (m.algorithm == MH_ARTIC_FSAB) { wave_sync(); if (!dynamics(M, Y, g, nullptr)) { status |= MH_WORLD_LCP_FAILED; return; } }
+  int* idx = reinterpret_cast<int*>(g + Y.idx);                  // idx[k] = joint | (upper << 8)
+  if (lane < nj) {
+    const int base = popc(mu & lanes_below(lane)) + popc(ml & lanes_below(lane));
+    if (up) idx[base] = lane | 256;
+    if (lo) idx[base + (up ? 1 : 0)] = lane;
+  }
   wave_sync();
   inverse_from_factor(Y, g);                                     // compute_X (ICH:1607)
   const double* X = g + Y.X;
@@ -398,7 +478,7 @@ MH_DEV void artic_step_body(const Model* __restrict__ Mg, int B, double dt, int 
     // positions with the OLD velocity (TSS:156-164)
     if (lane < nj) { double qn = g[Y.qd + lane] * dt; qn = qn + g[Y.q + lane]; g[Y.q + lane] = qn; }
     wave_sync();
-    const bool ok = dynamics(M, Y, g, nullptr);
+    const bool ok = (M.m.algorithm == MH_ARTIC_FSAB) ? dynamics_aba(M, Y, g, nullptr) : dynamics(M, Y, g, nullptr);
     if (!ok) status |= MH_WORLD_LCP_FAILED;
     if (lane < nj) { const double qdd = ok ? g[Y.qdd + lane] : 0.0; g[Y.qd + lane] = g[Y.qd + lane] + qdd * dt; }   // TSS:182-192
     wave_sync();
@@ -443,8 +523,17 @@ void k_artic_fwd_dyn(const Model* __restrict__ Mg, int B, const double* __restri
   const Lay Y(nj);
   if (lane < nj) { g[Y.q + lane] = qg[(size_t)b * nj + lane]; g[Y.qd + lane] = qdg[(size_t)b * nj + lane]; }
   wave_sync();
-  const bool ok = dynamics(M, Y, g, tau ? tau + (size_t)b * nj : nullptr);
-  if (qdd_out && lane < nj) qdd_out[(size_t)b * nj + lane] = ok ? g[Y.qdd + lane] : 0.0;
+  const double* tw = tau ? tau + (size_t)b * nj : nullptr;
+  bool ok;
+  if (M.m.algorithm == MH_ARTIC_FSAB) {
+    ok = dynamics_aba(M, Y, g, tw);
+    if (qdd_out && lane < nj) qdd_out[(size_t)b * nj + lane] = ok ? g[Y.qdd + lane] : 0.0;
+    wave_sync();
+    if (H_out) (void)dynamics(M, Y, g, tw);                // the generalized inertia is CRB's whatever the algorithm
+  } else {
+    ok = dynamics(M, Y, g, tw);
+    if (qdd_out && lane < nj) qdd_out[(size_t)b * nj + lane] = ok ? g[Y.qdd + lane] : 0.0;
+  }
   if (H_out) for (int e = lane; e < nj * nj; e += 64) H_out[(size_t)b * nj * nj + e] = g[Y.H + e];
   if (poses) for (int e = lane; e < 12 * nj; e += 64) { const int i = e / 12, k = e - 12 * i; poses[(size_t)b * 12 * nj + e] = (k < 9) ? g[Y.R + 9 * i + k] : g[Y.x + 3 * i + k - 9]; }
   if (okflag && lane == 0) okflag[b] = ok ? 1 : 0;

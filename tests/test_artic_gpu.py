@@ -125,3 +125,47 @@ def test_cpp_articulated_adapter_example():
                            "-lmoby_hip", "-lmoby_hip_io", "-Wl,-rpath," + os.path.join(root, "moby_amd"), "-o", exe])
     out = subprocess.check_output([exe, UR10]).decode()
     assert "joints=10 world_joint..r_finger_actuator same=1" in out, out
+
+
+def fsab(m):
+    ma = type(m).from_buffer_copy(m)
+    ma.algorithm = A.MH_ARTIC_FSAB
+    return ma
+
+
+@pytest.mark.parametrize("which", ["chain", "chain_pris", "ur10"])
+def test_articulated_body_algorithm_steps_like_the_oracle(oracle, which):
+    """RCArticulatedBody::algorithm_type = eFeatherstone: forward dynamics by the articulated-body recursion (three passes over the
+    chain instead of H and its Cholesky factor), the limit handler's X still from the generalized inertia -- bit for bit against
+    the oracle, limits and restitution included; and close to the CRB trajectory, as two algorithms for one equation must be."""
+    if which == "ur10":
+        m, _, _ = A.load_sdf(UR10); B = 8; q0, qd0 = ur10_states(m, B); dt, n = 5e-4, 100
+    else:
+        nl = 5
+        m = A.chain_model(nl, lo=-0.6, hi=0.6, restitution=0.3, prismatic_last=(which == "chain_pris")); B = 6
+        rng = np.random.default_rng(4); q0 = rng.uniform(-0.5, 0.5, (B, nl)); qd0 = rng.uniform(-3.0, 3.0, (B, nl)); dt, n = 1e-3, 120
+    ma = fsab(m)
+    ab = A.ArticBatch(ma, q0, qd0)
+    aux = assert_parity(ab, oracle, ma, q0, qd0, dt, n, chunks=2)
+    q_a, qd_a, _ = ab.download()
+    ab.close()
+    assert (aux["lcp_solves"] > 0).any()
+    ac = A.ArticBatch(m, q0, qd0); ac.step(dt, 2 * n); q_c, qd_c, _ = ac.download(); ac.close()
+    if which == "ur10":
+        assert np.abs(q_a - q_c).max() < 1e-7
+
+
+def test_forward_dynamics_seam_with_the_articulated_body_algorithm(oracle):
+    m, _, _ = A.load_sdf(UR10)
+    ma = fsab(m)
+    B = 16
+    q0, qd0 = ur10_states(m, B, seed=9)
+    tau = np.random.default_rng(2).uniform(-5, 5, (B, m.nj))
+    ab = A.ArticBatch(ma, q0, qd0)
+    qdd, H = ab.fwd_dyn(tau)
+    for w in range(B):
+        r = oracle.artic_fwd_dyn(ma, q0[w], qd0[w], tau[w])
+        assert np.array_equal(qdd[w], r["qdd"]) and np.array_equal(H[w], r["H"])
+        rc = oracle.artic_fwd_dyn(m, q0[w], qd0[w], tau[w])
+        np.testing.assert_allclose(qdd[w], rc["qdd"], atol=1e-9 * max(1.0, np.abs(rc["qdd"]).max()))
+    ab.close()
