@@ -79,6 +79,12 @@ int mh_artic_batch_download(mh_artic_batch* ab, double* q, double* qd, mh_world_
 /* link poses of the resident states (B x nj x 12: row-major R (9), origin (3), model frame): what a viewer or a
  * collision front end on the host needs */
 int mh_artic_batch_link_poses(mh_artic_batch* ab, double* poses);
+/* RCArticulatedBodyd::calc_jacobian(frame at a point, link, J) of the resident states: the 6 x nj map from joint velocities to
+ * the velocity of link `link` at the given points (B x 3, model frame) -- rows 0..2 the linear velocity of the point, rows 3..5
+ * the angular velocity, global axes; column j is zero unless joint j lies between the link and the base.  What a contact on a
+ * link multiplies its direction row [d, r x d] with (ImpactConstraintHandler::add_contact_dir_to_Jacobian, ICH:1817-1845).
+ * J_out: B x 6 x nj, row-major. */
+int mh_artic_batch_jacobian(mh_artic_batch* ab, int link, const double* points, double* J_out);
 
 #ifdef __cplusplus
 }

@@ -90,6 +90,7 @@ SYMBOLS = {
     "mh_artic_batch_fwd_dyn": (_i, [_vp, _vp, _vp, _vp]),
     "mh_artic_batch_download": (_i, [_vp, _vp, _vp, _vp]),
     "mh_artic_batch_link_poses": (_i, [_vp, _vp]),
+    "mh_artic_batch_jacobian": (_i, [_vp, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -116,6 +116,13 @@ class ArticBatch:
         _lib.check(_lib.load().mh_artic_batch_link_poses(self.handle, P.ctypes.data))
         return P
 
+    def jacobian(self, link, points):
+        """calc_jacobian for every resident state: (B, 6, nj); points (B, 3) in the model frame."""
+        p = np.ascontiguousarray(points, dtype=np.float64); assert p.shape == (self.B, 3)
+        J = np.zeros((self.B, 6, self.nj))
+        _lib.check(_lib.load().mh_artic_batch_jacobian(self.handle, int(link), p.ctypes.data, J.ctypes.data))
+        return J
+
     def download(self):
         q = np.zeros((self.B, self.nj)); qd = np.zeros((self.B, self.nj)); aux = np.zeros(self.B, dtype=S.AUX_DTYPE)
         _lib.check(_lib.load().mh_artic_batch_download(self.handle, q.ctypes.data, qd.ctypes.data, aux.ctypes.data))

@@ -539,6 +539,33 @@ void k_artic_fwd_dyn(const Model* __restrict__ Mg, int B, const double* __restri
   if (okflag && lane == 0) okflag[b] = ok ? 1 : 0;
 }
 
+// calc_jacobian: column j = the twist of joint j (S_j, about the world origin) moved to the point, for j on the link's path
+__global__ __launch_bounds__(64)
+void k_artic_jacobian(const Model* __restrict__ Mg, int B, const double* __restrict__ qg, int link, const double* __restrict__ points,
+                      double* __restrict__ J_out)
+{
+  extern __shared__ double g[];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const Model& M = *Mg;
+  const int nj = M.m.nj, lane = lane_id();
+  const Lay Y(nj);
+  if (lane < nj) { g[Y.q + lane] = qg[(size_t)b * nj + lane]; g[Y.qd + lane] = 0.0; }
+  wave_sync();
+  kin_inertia(M, Y, g);
+  const double* p = points + (size_t)b * 3;
+  for (int e = lane; e < 6 * nj; e += 64) {
+    const int r = e / nj, j = e - r * nj;
+    double v = 0.0;
+    if ((M.anc[link] >> j) & 1u) {
+      const double* S = g + Y.S + 6 * j;                  // [angular; linear at the origin]
+      if (r >= 3) v = S[r - 3];
+      else { const int k1 = (r + 1) % 3, k2 = (r + 2) % 3; v = S[3 + r] + (S[k1] * p[k2] - S[k2] * p[k1]); }   // v_o + w x p
+    }
+    J_out[(size_t)b * 6 * nj + e] = v;
+  }
+}
+
 }} // namespace mh::artic
 
 struct mh_artic_batch {
@@ -667,6 +694,27 @@ int mh_artic_batch_link_poses(mh_artic_batch* ab, double* poses)
   if (e == hipSuccess) e = hipMemcpy(poses, d_p, bytes, hipMemcpyDeviceToHost);
   (void)hipFree(d_p);
   if (e != hipSuccess) return fail(MH_ERR_HIP, "link pose launch failed: %s", hipGetErrorString(e));
+  return MH_OK;
+}
+
+int mh_artic_batch_jacobian(mh_artic_batch* ab, int link, const double* points, double* J_out)
+{
+  namespace ar = mh::artic;
+  if (!ab || !points || !J_out) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  if (link < 0 || link >= ab->nj) return fail(MH_ERR_INVALID_ARG, "link %d outside [0, %d)", link, ab->nj);
+  const size_t pb = (size_t)ab->B * 3 * 8, jb = (size_t)ab->B * 6 * ab->nj * 8;
+  double* d_p = nullptr; double* d_J = nullptr;
+  MH_HIP(hipMalloc((void**)&d_p, pb));
+  hipError_t e = hipMalloc((void**)&d_J, jb);
+  if (e == hipSuccess) e = hipMemcpy(d_p, points, pb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(ar::k_artic_jacobian, dim3(ab->B), dim3(64), ar::lds_bytes(ab->nj), (hipStream_t)nullptr,
+                       (const ar::Model*)ab->d_model, ab->B, (const double*)ab->d_q, link, (const double*)d_p, d_J);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(J_out, d_J, jb, hipMemcpyDeviceToHost);
+  (void)hipFree(d_p); if (d_J) (void)hipFree(d_J);
+  if (e != hipSuccess) return fail(MH_ERR_HIP, "Jacobian launch failed: %s", hipGetErrorString(e));
   return MH_OK;
 }
 

@@ -129,6 +129,15 @@ class Artic {
       }
     }
   }
+  // RCArticulatedBodyd::calc_jacobian at a point p (model frame) of link `link` (call kinematics() first): rows 0..2 the linear
+  // velocity of the point, 3..5 the angular velocity; column j = S_j moved to p for j between the link and the base, else 0
+  void jacobian(int link, const double p[3], double* J /* 6 x nj row-major */) const {
+    for (int e = 0; e < 6 * nj; e++) J[e] = 0.0;
+    for (int j = link; j >= 0; j = m->parent[j]) {
+      const double* s = S[j];
+      for (int r = 0; r < 3; r++) { const int k1 = (r + 1) % 3, k2 = (r + 2) % 3; J[r * nj + j] = s[3 + r] + (s[k1] * p[k2] - s[k2] * p[k1]); J[(3 + r) * nj + j] = s[r]; }
+    }
+  }
   // composite-rigid-body algorithm: H(i, j) = S_j' Ic_i S_i for j on the path from i to the base
   void crba() {
     using namespace artic;

@@ -309,6 +309,15 @@ int oracle_artic_fwd_dyn(const mh_artic_model* m, const double* q, const double*
   return ok ? 1 : 0;
 }
 
+void oracle_artic_jacobian(const mh_artic_model* m, const double* q, int link, const double* p, double* J)
+{
+  mh_world_aux aux; std::memset(&aux, 0, sizeof(aux));
+  std::vector<double> qq(q, q + m->nj), qv(m->nj, 0.0);
+  Artic w(m, qq.data(), qv.data(), &aux);
+  w.kinematics();
+  w.jacobian(link, p, J);
+}
+
 void oracle_sincos(double x, double* s, double* c) { sincos_kernel(x, *s, *c); }
 
 } // extern "C"

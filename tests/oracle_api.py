@@ -204,6 +204,16 @@ def oracle_artic_fwd_dyn(self, model, q, qd, tau=None):
     return dict(ok=bool(ok), qdd=qdd, H=H, C=C, poses=poses)
 
 
+def oracle_artic_jacobian(self, model, q, link, point):
+    """calc_jacobian of one state: (6, nj), rows 0..2 linear velocity of the point (model frame), 3..5 angular."""
+    J = np.zeros((6, model.nj))
+    q = np.ascontiguousarray(q, dtype=np.float64); p = np.ascontiguousarray(point, dtype=np.float64)
+    self.lib.oracle_artic_jacobian.restype = None
+    self.lib.oracle_artic_jacobian(ctypes.byref(model), q.ctypes.data_as(ctypes.c_void_p), int(link), p.ctypes.data_as(ctypes.c_void_p),
+                                   J.ctypes.data_as(ctypes.c_void_p))
+    return J
+
+
 def oracle_sincos(self, x):
     s = ctypes.c_double(0.0); c = ctypes.c_double(0.0)
     self.lib.oracle_sincos.restype = None
@@ -213,4 +223,5 @@ def oracle_sincos(self, x):
 
 Oracle.artic_step = oracle_artic_step
 Oracle.artic_fwd_dyn = oracle_artic_fwd_dyn
+Oracle.artic_jacobian = oracle_artic_jacobian
 Oracle.sincos = oracle_sincos

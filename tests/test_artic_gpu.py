@@ -169,3 +169,20 @@ def test_forward_dynamics_seam_with_the_articulated_body_algorithm(oracle):
         rc = oracle.artic_fwd_dyn(m, q0[w], qd0[w], tau[w])
         np.testing.assert_allclose(qdd[w], rc["qdd"], atol=1e-9 * max(1.0, np.abs(rc["qdd"]).max()))
     ab.close()
+
+
+def test_link_jacobian_seam_matches_oracle(oracle):
+    """RCArticulatedBodyd::calc_jacobian of the resident states (mh_artic_batch_jacobian): what a contact on a link multiplies
+    its direction rows with."""
+    m, _, _ = A.load_sdf(UR10)
+    B = 12
+    q0, qd0 = ur10_states(m, B, seed=11)
+    pts = np.random.default_rng(3).uniform(-1, 1, (B, 3))
+    ab = A.ArticBatch(m, q0, qd0)
+    for link in (0, 4, m.nj - 1):
+        J = ab.jacobian(link, pts)
+        for w in range(B):
+            assert np.array_equal(J[w], oracle.artic_jacobian(m, q0[w], link, pts[w]))
+    with pytest.raises(Exception):
+        ab.jacobian(m.nj, pts)
+    ab.close()

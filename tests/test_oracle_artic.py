@@ -210,3 +210,28 @@ def test_articulated_body_algorithm_equals_crb_plus_cholesky(oracle, which):
     oracle.artic_step(ma, qa, qda, auxa, 5e-4, 200); oracle.artic_step(m, qc, qdc, auxc, 5e-4, 200)
     np.testing.assert_allclose(qa, qc, atol=1e-8); np.testing.assert_allclose(qda, qdc, atol=1e-6)
     assert np.array_equal(auxa["status"], auxc["status"])
+
+
+@pytest.mark.parametrize("which", ["chain", "ur10"])
+def test_link_jacobian_is_the_derivative_of_the_link_pose(oracle, which):
+    """calc_jacobian: J qd = the velocity of a point carried by the link (central differences of the numpy kinematics) and its
+    angular velocity; columns of joints off the link's path are zero."""
+    rng = np.random.default_rng(12)
+    m = A.chain_model(5, prismatic_last=True) if which == "chain" else A.load_sdf(UR10)[0]
+    for link in (0, m.nj // 2, m.nj - 1):
+        q = rng.uniform(-1.0, 1.0, m.nj); qd = rng.standard_normal(m.nj)
+        R, x, _ = numpy_kinematics(m, q)
+        pl = 0.3 * rng.standard_normal(3)
+        p = x[link] + R[link] @ pl
+        J = oracle.artic_jacobian(m, q, link, p)
+        eps = 1e-6
+        Rp, xp, _ = numpy_kinematics(m, q + eps * qd); Rm, xm, _ = numpy_kinematics(m, q - eps * qd)
+        v_num = ((xp[link] + Rp[link] @ pl) - (xm[link] + Rm[link] @ pl)) / (2 * eps)
+        W = (Rp[link] - Rm[link]) / (2 * eps) @ R[link].T          # [w]x
+        w_num = np.array([W[2, 1], W[0, 2], W[1, 0]])
+        np.testing.assert_allclose(J[:3] @ qd, v_num, atol=1e-7); np.testing.assert_allclose(J[3:] @ qd, w_num, atol=1e-7)
+        on_path = set(); j = link
+        while j >= 0:
+            on_path.add(j); j = m.parent[j]
+        for j in range(m.nj):
+            assert (j in on_path) or not J[:, j].any()
