@@ -87,14 +87,18 @@ class BigScene:
         return len(self.pair_a)
 
     def lcp_capacity(self):
-        """Largest LCP a world of this scene can ask for: every candidate pair with 4 contacts (a box face) -- the
-        bound mh_big_batch_create uses when lcp_n_max is 0."""
+        """The capacity mh_big_batch_create gives the handlers' LCPs (mh_big_batch_lcp_capacity): lcp_n_max, or when that is 0
+        the rule of mh_big.hip -- 4 contacts per pair with a box, 3 per pin, 1 otherwise, doubled (a box inside the tolerance band
+        can show all 8 vertices), at least 8, at most MH_BIG_MAX_CONTACTS; n = 6 nc + nc nk/2, at most MH_LCP_MAX_N_BLOCK."""
         if self.c.lcp_n_max:
             return int(self.c.lcp_n_max)
-        per = [4 if (m == MH_PAIR_VERTEX_FACE or self.geom_type[a] == S.MH_GEOM_BOX) else (6 if self.geom_type[a] == S.MH_GEOM_PIN else 1)
-               for a, m in zip(self.pair_a, self.pair_model)]
-        nc = int(sum(per))
-        return min(4096, max(64, 6 * nc + nc * (self.c.nk // 2)))
+        nb = len(self.geom_type)
+        nc = 0
+        for a, b in zip(self.pair_a, self.pair_b):
+            box = self.geom_type[a] == S.MH_GEOM_BOX or (b < nb and self.geom_type[b] == S.MH_GEOM_BOX)
+            nc += 4 if box else (3 if self.geom_type[a] == S.MH_GEOM_PIN else 1)
+        nc = min(512, max(8, 2 * nc))
+        return min(4096, 6 * nc + nc * (self.c.nk // 2))
 
 
 def make_joint(kind, inboard, outboard, location, state, nb, axis=(0.0, 0.0, 1.0), axis2=None):
