@@ -17,8 +17,8 @@
  *   ::update_from_stacked, update_constraint_velocities_from_impulses, apply_restitution   src/ImpactConstraintHandler.cpp:298-525
  * One wavefront per world; H, its Cholesky factor, H^-1 and the limit LCP live in LDS.
  *
- * Scope: no collision geometry on the links (the robot alone, self-collision disabled as in ur10.xml:12; so no contact
- * rows and one mini-step per step), no actuator torques (controller plugins stay on the host side of the seam: add them
+ * Scope: config 5 is the robot alone (self-collision disabled as in ur10.xml:12: no contact rows, one mini-step per step);
+ * optionally sphere primitives on links against a static plane (mh_artic_model.nspheres, no-slip contacts), no actuator torques (controller plugins stay on the host side of the seam: add them
  * through qdd = H^-1 (tau - C) by passing tau), constraint stabilisation off (ur10.xml:11 sets
  * constraint-stabilization-max-iterations = 0).
  */
@@ -34,6 +34,7 @@ extern "C" {
 #define MH_JOINT_PRISMATIC 1
 #define MH_ARTIC_CRB  0
 #define MH_ARTIC_FSAB 1
+#define MH_ARTIC_MAX_SPHERES 4    /* sphere primitives carried by links (contacts against the one static plane) */
 
 /* Joint i carries link i; joints are listed parents first.  All quantities are LOCAL (constant), as a reader of
  * model.sdf derives them once at q = 0 (mh_io_load_sdf, moby_amd/host/mh_io.cpp):
@@ -60,6 +61,22 @@ typedef struct mh_artic_model {
                             Featherstone's articulated-body recursion; the impact handler's X = H^-1 is the generalized inertia's
                             inverse either way (ICH:1600-1607) */
   int    pad;
+  /* Collision geometry (optional; nspheres = 0 is the robot alone: no pairs, one mini-step per step).  Sphere primitives fixed to
+   * links against ONE static plane -- the closed-form pair of CCD.inl:804-847; the body's own pairs are disabled as ur10.xml:12
+   * does.  With spheres the step is TimeSteppingSimulator::step in full: conservative advancement over the pairs
+   * (CCD::calc_CA_Euler_step_sphere, the ARTICULATED CCD::calc_max_dist, CCD.cpp:545-583), mini-steps, contact + limit rows in one
+   * island.  Contact rows are [d, r x d] . calc_jacobian(link) (ICH:1817-1895); the impact model built for them is the no-slip
+   * one (every contact mu-coulomb >= 100 -- what ur10.xml:19 gives the robot's contacts -- ICH:123-135, 1009-1417) with
+   * NC + NL <= MH_NOSLIP_MAX rows; a finite mu_coulomb flags MH_WORLD_UNSUPPORTED when a contact is impacting. */
+  int    nspheres;
+  int    sphere_link[MH_ARTIC_MAX_SPHERES];
+  double sphere_center[MH_ARTIC_MAX_SPHERES][3];   /* link frame */
+  double sphere_radius[MH_ARTIC_MAX_SPHERES];
+  double plane_R[9];                               /* as mh_scene: row-major rotation of the plane frame, its +Y is the normal */
+  double plane_o[3];
+  double cp_epsilon, cp_mu_coulomb;                /* ContactParameters of the (robot, plane) pair */
+  double min_step_size;                            /* TimeSteppingSimulator.cpp:48 (sqrt eps) */
+  double contact_dist_thresh;                      /* ConstraintSimulator.cpp:56 (1e-6) */
 } mh_artic_model;
 
 /* B worlds resident on the GPU: joint positions q and velocities qd (B x nj each) + mh_world_aux (rand() stream, time,

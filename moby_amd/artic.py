@@ -16,7 +16,9 @@ from . import scene as S
 
 MH_ARTIC_MAX_JOINTS = 16
 MH_JOINT_REVOLUTE, MH_JOINT_PRISMATIC = 0, 1
+MH_ARTIC_MAX_SPHERES = 4
 _NJ = MH_ARTIC_MAX_JOINTS
+_NS = MH_ARTIC_MAX_SPHERES
 
 
 class mh_artic_model(ctypes.Structure):
@@ -24,7 +26,11 @@ class mh_artic_model(ctypes.Structure):
                 ("Rrel", (ctypes.c_double * 9) * _NJ), ("trel", (ctypes.c_double * 3) * _NJ), ("axis", (ctypes.c_double * 3) * _NJ),
                 ("com", (ctypes.c_double * 3) * _NJ), ("inertia", (ctypes.c_double * 9) * _NJ), ("mass", ctypes.c_double * _NJ),
                 ("lolimit", ctypes.c_double * _NJ), ("hilimit", ctypes.c_double * _NJ), ("limit_restitution", ctypes.c_double * _NJ),
-                ("gravity", ctypes.c_double * 3), ("algorithm", ctypes.c_int), ("pad", ctypes.c_int)]
+                ("gravity", ctypes.c_double * 3), ("algorithm", ctypes.c_int), ("pad", ctypes.c_int),
+                ("nspheres", ctypes.c_int), ("sphere_link", ctypes.c_int * _NS), ("sphere_center", (ctypes.c_double * 3) * _NS),
+                ("sphere_radius", ctypes.c_double * _NS), ("plane_R", ctypes.c_double * 9), ("plane_o", ctypes.c_double * 3),
+                ("cp_epsilon", ctypes.c_double), ("cp_mu_coulomb", ctypes.c_double), ("min_step_size", ctypes.c_double),
+                ("contact_dist_thresh", ctypes.c_double)]
 
 
 MH_ARTIC_CRB, MH_ARTIC_FSAB = 0, 1      # moby_hip_artic.h: RCArticulatedBody::algorithm_type
@@ -72,6 +78,31 @@ def model_from_links(links, gravity=(0.0, 0.0, -9.81)):
     for k in range(3):
         m.gravity[k] = gravity[k]
     return m
+
+
+def add_spheres(model, spheres, plane_normal=(0.0, 0.0, 1.0), plane_point=(0.0, 0.0, 0.0), epsilon=0.0, mu_coulomb=100.0):
+    """Sphere primitives on links against one static plane: spheres = [(link, centre in the link frame, radius), ...]; the
+    plane through plane_point with the given normal (the +Y axis of the plane frame, as PlanePrimitive has it); the
+    ContactParameters of the (robot, plane) pair (ur10.xml:19: epsilon 0, mu-coulomb 100).  Returns the model."""
+    assert 0 < len(spheres) <= MH_ARTIC_MAX_SPHERES
+    model.nspheres = len(spheres)
+    for i, (link, c, r) in enumerate(spheres):
+        assert 0 <= link < model.nj and r > 0
+        model.sphere_link[i] = int(link); model.sphere_radius[i] = float(r)
+        for k in range(3):
+            model.sphere_center[i][k] = float(c[k])
+    n = np.asarray(plane_normal, dtype=float); n = n / np.linalg.norm(n)
+    e = np.eye(3)[int(np.argmin(np.abs(n)))]
+    xax = np.cross(n, e); xax = xax / np.linalg.norm(xax); zax = np.cross(xax, n)
+    Rp = np.column_stack([xax, n, zax])                       # columns: the plane frame's axes; +Y = normal
+    for k in range(9):
+        model.plane_R[k] = Rp.flat[k]
+    for k in range(3):
+        model.plane_o[k] = float(plane_point[k])
+    model.cp_epsilon = float(epsilon); model.cp_mu_coulomb = float(mu_coulomb)
+    model.min_step_size = S.NEAR_ZERO
+    model.contact_dist_thresh = 1e-6
+    return model
 
 
 def chain_model(n, length=0.5, mass=1.0, lo=-1.0, hi=1.0, restitution=0.0, gravity=(0.0, 0.0, -9.81), prismatic_last=False):

@@ -285,8 +285,328 @@ class Artic {
     for (int k = 0; k < nl; k++) { const double v = upper[k] ? -qd[idx[k]] : qd[idx[k]]; if (v < -A_NEAR_ZERO) aux->status |= MH_WORLD_IMPACT_TOL; }   // ICH:157-167
   }
 
-  // TimeSteppingSimulator::step for this world: no collision geometry => one mini-step of dt (TSS:114-222)
+  // ---- sphere primitives on links against the static plane (mh_artic_model.nspheres) -------------------------------------
+  // Restated from the reference: find_contacts / signed distance of a sphere and a plane (CCD.inl:804-847, PlanePrimitive.cpp),
+  // CCD::calc_CA_Euler_step_sphere / _generic / calc_next_CA_Euler_step_generic (CCD.cpp:138-405), the ARTICULATED
+  // CCD::calc_max_dist (CCD.cpp:545-583), TimeSteppingSimulator::do_mini_step (TSS:114-222), the contact rows
+  // [d, r x d] . calc_jacobian(link) of add_contact_dir_to_Jacobian (ICH:1847-1895), compute_problem_data's products
+  // (ICH:2110-2160), apply_no_slip_model with contacts AND limits (ICH:1009-1417).  Link velocities / calc_jacobian are Ravelin's:
+  // parity unpinned, spatial velocities about the world origin like the rest of this file.
+  struct AContact { int s, link; double p[3], n[3], sv[3], tv[3], dist; };
+  static constexpr double A_INF = 1.7976931348623157e308;
+  void plane_n(double n[3]) const { n[0] = m->plane_R[1]; n[1] = m->plane_R[4]; n[2] = m->plane_R[7]; }
+  void to_plane(const double p[3], double o[3]) const {
+    const double* Rp = m->plane_R; const double d[3] = { p[0] - m->plane_o[0], p[1] - m->plane_o[1], p[2] - m->plane_o[2] };
+    o[0] = (Rp[0]*d[0] + Rp[3]*d[1]) + Rp[6]*d[2]; o[1] = (Rp[1]*d[0] + Rp[4]*d[1]) + Rp[7]*d[2]; o[2] = (Rp[2]*d[0] + Rp[5]*d[1]) + Rp[8]*d[2];
+  }
+  void from_plane(double px, double py, double pz, double o[3]) const {
+    const double* Rp = m->plane_R;
+    o[0] = m->plane_o[0] + ((Rp[0]*px + Rp[1]*py) + Rp[2]*pz); o[1] = m->plane_o[1] + ((Rp[3]*px + Rp[4]*py) + Rp[5]*pz); o[2] = m->plane_o[2] + ((Rp[6]*px + Rp[7]*py) + Rp[8]*pz);
+  }
+  void sphere_center(int s, double c[3]) const {
+    const int l = m->sphere_link[s]; double rc[3]; artic::mat3vec(R[l], m->sphere_center[s], rc);
+    for (int k = 0; k < 3; k++) c[k] = x[l][k] + rc[k];
+  }
+  // spatial velocity of every link about the world origin, [angular; linear] (kinematics() first)
+  void link_velocities(double V[][6]) const {
+    for (int i = 0; i < nj; i++) { const int p = m->parent[i]; for (int k = 0; k < 6; k++) { const double vj = S[i][k] * qd[i]; V[i][k] = (p < 0) ? vj : V[p][k] + vj; } }
+  }
+  static double point_vel_dir(const double* V6, const double* p, const double* d) {
+    double wxp[3]; artic::cross3(V6, p, wxp);
+    const double v[3] = { V6[3] + wxp[0], V6[4] + wxp[1], V6[5] + wxp[2] };
+    return artic::dot3(d, v);
+  }
+  static void orthonormal_basis(const double n[3], double s[3], double t[3]) {      // as world.hpp (Ravelin's: pinned choice)
+    const double ax = std::fabs(n[0]), ay = std::fabs(n[1]), az = std::fabs(n[2]);
+    double e[3] = { 0.0, 0.0, 0.0 };
+    if (ax <= ay && ax <= az) e[0] = 1.0; else if (ay <= az) e[1] = 1.0; else e[2] = 1.0;
+    artic::cross3(n, e, s);
+    const double len = std::sqrt((s[0]*s[0] + s[1]*s[1]) + s[2]*s[2]);
+    for (int k = 0; k < 3; k++) s[k] = s[k] / len;
+    artic::cross3(n, s, t);
+  }
+  // find_contacts_sphere_plane (CCD.inl:804-847): at most one contact, midway between the closest points
+  bool find_contact(int s, double TOL, AContact& c) const {
+    double ctr[3], cp[3]; sphere_center(s, ctr); to_plane(ctr, cp);
+    const double r = m->sphere_radius[s];
+    const double dist = cp[1] - r;
+    if (dist > TOL) return false;
+    c.s = s; c.link = m->sphere_link[s]; c.dist = dist;
+    from_plane(cp[0], 0.5 * (cp[1] - r), cp[2], c.p);
+    plane_n(c.n); orthonormal_basis(c.n, c.sv, c.tv);
+    return true;
+  }
+  // the articulated CCD::calc_max_dist (CCD.cpp:545-583): fixed base (velocity 0), the chain of inner joints up to the base;
+  // a joint's pose is its link's frame origin
+  double calc_max_dist(int link, double rmax) const {
+    double mv = 0.0;
+    int inner = link;
+    mv = mv + (2.0 * rmax) * std::fabs(qd[inner]);
+    while (m->parent[inner] >= 0) {
+      const int nxt = m->parent[inner];
+      const double d[3] = { x[nxt][0] - x[inner][0], x[nxt][1] - x[inner][1], x[nxt][2] - x[inner][2] };
+      mv = mv + std::fabs(qd[nxt]) * std::sqrt((d[0]*d[0] + d[1]*d[1]) + d[2]*d[2]);
+      inner = nxt;
+    }
+    return mv;
+  }
+  // CollisionGeometry::get_farthest_point_distance (CollisionGeometry.cpp:52-68): primitive radius + its offset from the link's
+  // pose (the link COM frame, eLinkCOM)
+  double rmax_of(int s) const {
+    const int l = m->sphere_link[s];
+    const double d[3] = { m->sphere_center[s][0] - m->com[l][0], m->sphere_center[s][1] - m->com[l][1], m->sphere_center[s][2] - m->com[l][2] };
+    return m->sphere_radius[s] + std::sqrt((d[0]*d[0] + d[1]*d[1]) + d[2]*d[2]);
+  }
+  // CCD::calc_CA_Euler_step_sphere (CCD.cpp:138-166) -> _generic (:169-235) -> calc_next_CA_Euler_step_generic (:238-405)
+  double CA_step(int s, const double V[][6]) const {
+    double ctr[3], cp[3]; sphere_center(s, ctr); to_plane(ctr, cp);
+    const double dist = cp[1] + (-1.0 * m->sphere_radius[s]);
+    AContact c;
+    if (!(dist > A_NEAR_ZERO)) {
+      const bool has = find_contact(s, A_NEAR_ZERO, c);
+      if (has && std::fabs(point_vel_dir(V[c.link], c.p, c.n)) < A_NEAR_ZERO * 10) return A_INF;
+    }
+    if (dist <= 0.0) {                                               // bodies in contact: the "next" step
+      if (!find_contact(s, A_NEAR_ZERO, c)) return A_INF;
+      if (point_vel_dir(V[c.link], c.p, c.n) < -A_NEAR_ZERO) return 0.0;
+      return A_INF;
+    }
+    const double tA = calc_max_dist(m->sphere_link[s], rmax_of(s));   // the plane's body is disabled: 0
+    double total = tA + 0.0;
+    if (total < 0.0) total = 0.0;
+    const double cand = dist / total;
+    return (cand < A_INF) ? cand : A_INF;
+  }
+
+  // calc_impacting_unilateral_constraint_forces (CSim:298-355) -> process_constraints: one island (every constraint touches the
+  // articulated body) -> apply_no_slip_model_to_connected_constraints (ICH:236-295)
+  void handle_impacts(const std::vector<AContact>& cs) {
+    using namespace artic;
+    const int nc = (int)cs.size();
+    int idx[2 * NJ]; bool upper[2 * NJ]; int nl = 0;
+    for (int i = 0; i < nj; i++) {                                   // ArticulatedBody.inl:9-43 (q_tare = 0)
+      if (q[i] >= m->hilimit[i]) { idx[nl] = i; upper[nl] = true; nl++; }
+      if (q[i] <= m->lolimit[i]) { idx[nl] = i; upper[nl] = false; nl++; }
+    }
+    if (nc + nl == 0) return;
+    double V[NJ][6]; link_velocities(V);
+    bool impacting = false;                                          // CSim:313-323
+    for (int i = 0; i < nc; i++) if (point_vel_dir(V[cs[i].link], cs[i].p, cs[i].n) < -A_NEAR_ZERO) impacting = true;
+    for (int k = 0; k < nl; k++) { const double v = upper[k] ? -qd[idx[k]] : qd[idx[k]]; if (v < -A_NEAR_ZERO) impacting = true; }
+    if (!impacting) return;
+    if (nc > 0 && !(m->cp_mu_coulomb >= 1e2)) { aux->status |= MH_WORLD_UNSUPPORTED; return; }   // Drumwright-Shell rows of an articulated body: not built
+    const int n = nc + nl;
+    if (n > MH_NOSLIP_MAX) { aux->status |= MH_WORLD_UNSUPPORTED; return; }
+    if (m->algorithm == MH_ARTIC_FSAB) crba();                       // get_generalized_inertia (ICH:1600-1607)
+    std::vector<double> X(H, H + nj * nj);
+    if (!inverse_spd(nj, X.data(), nj)) { aux->status |= MH_WORLD_LCP_FAILED; return; }
+    // contact rows (ICH:1847-1895): wrench [d, r x d] about the link's COM times calc_jacobian at the COM (rows: linear, angular)
+    std::vector<double> C[3], XC[3];                                 // C[d]: nc x nj; XC[d] = C[d] X (rows of X_CdT')
+    for (int d = 0; d < 3; d++) { C[d].assign((size_t)nc * nj, 0.0); XC[d].assign((size_t)nc * nj, 0.0); }
+    for (int i = 0; i < nc; i++) {
+      const int l = cs[i].link;
+      double rc[3], com[3], r[3], J[6 * NJ];
+      mat3vec(R[l], m->com[l], rc);
+      for (int k = 0; k < 3; k++) { com[k] = x[l][k] + rc[k]; r[k] = cs[i].p[k] - com[k]; }
+      jacobian(l, com, J);
+      const double* dirs[3] = { cs[i].n, cs[i].sv, cs[i].tv };
+      for (int d = 0; d < 3; d++) {
+        double w[6]; cross3(r, dirs[d], w + 3);
+        for (int k = 0; k < 3; k++) w[k] = dirs[d][k];
+        for (int j = 0; j < nj; j++) { double acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + w[k] * J[k * nj + j]; C[d][(size_t)i * nj + j] = acc; }
+      }
+    }
+    for (int d = 0; d < 3; d++) for (int i = 0; i < nc; i++) for (int c = 0; c < nj; c++) {
+      double acc = 0.0; for (int k = 0; k < nj; k++) acc = acc + C[d][(size_t)i * nj + k] * X[k * nj + c];
+      XC[d][(size_t)i * nj + c] = acc;
+    }
+    // the cross blocks (ICH:2127-2147) and vectors (:2153-2156); compute_limit_components (ICH:1755-1781), signs as there
+    std::vector<double> G[3][3], CL[3], Cv[3];
+    for (int a = 0; a < 3; a++) for (int b = a; b < 3; b++) {
+      G[a][b].assign((size_t)nc * nc, 0.0);
+      for (int i = 0; i < nc; i++) for (int j = 0; j < nc; j++) { double acc = 0.0; for (int k = 0; k < nj; k++) acc = acc + C[a][(size_t)i * nj + k] * XC[b][(size_t)j * nj + k]; G[a][b][(size_t)i * nc + j] = acc; }
+    }
+    for (int d = 0; d < 3; d++) {
+      CL[d].assign((size_t)nc * (nl > 0 ? nl : 1), 0.0); Cv[d].assign(nc, 0.0);
+      for (int i = 0; i < nc; i++) {
+        for (int k2 = 0; k2 < nl; k2++) { double acc = 0.0; for (int k = 0; k < nj; k++) acc = acc + C[d][(size_t)i * nj + k] * X[idx[k2] * nj + k]; CL[d][(size_t)i * nl + k2] = acc; }
+        double acc = 0.0; for (int k = 0; k < nj; k++) acc = acc + C[d][(size_t)i * nj + k] * qd[k];
+        Cv[d][i] = acc;
+      }
+    }
+    std::vector<double> LL((size_t)nl * nl + 1), Lv(nl + 1);
+    for (int a = 0; a < nl; a++) for (int b = a; b < nl; b++) { const double e = X[idx[a] * nj + idx[b]]; LL[a + (size_t)nl * b] = e; LL[b + (size_t)nl * a] = e; }
+    for (int k = 0; k < nl; k++) { Lv[k] = qd[idx[k]]; if (upper[k]) Lv[k] = -Lv[k]; }
+
+    std::vector<double> cn(nc, 0.0), csv(nc, 0.0), ctv(nc, 0.0), l(nl, 0.0);
+    // apply_no_slip_model (ICH:1009-1417)
+    std::vector<int> Sx, Tx; std::vector<double> Y;
+    auto build_Y = [&](bool skew) -> int {
+      const int ns = (int)Sx.size(), nt = (int)Tx.size(), mm = ns + nt;
+      Y.assign((size_t)mm * mm + 1, 0.0);
+      for (int a = 0; a < ns; a++) for (int b = 0; b < ns; b++) Y[a + (size_t)mm * b] = G[1][1][(size_t)Sx[a] * nc + Sx[b]];
+      for (int a = 0; a < nt; a++) for (int b = 0; b < nt; b++) Y[(ns + a) + (size_t)mm * (ns + b)] = G[2][2][(size_t)Tx[a] * nc + Tx[b]];
+      for (int a = 0; a < ns; a++) for (int b = 0; b < nt; b++) { const double g = G[1][2][(size_t)Sx[a] * nc + Tx[b]]; Y[a + (size_t)mm * (ns + b)] = g; Y[(ns + b) + (size_t)mm * a] = g; }
+      if (skew) for (int j = 0; j < mm; j++) Y[j + (size_t)mm * j] = Y[j + (size_t)mm * j] - A_NEAR_ZERO;
+      return mm;
+    };
+    for (int i = 0; i < nc; i++) {                                   // greedy largest non-singular tangent set (ICH:1087-1145)
+      Sx.push_back(i); int mm = build_Y(true); if (!chol_factor(mm, Y.data(), mm)) Sx.pop_back();
+      Tx.push_back(i); mm = build_Y(true);     if (!chol_factor(mm, Y.data(), mm)) Tx.pop_back();
+    }
+    const int ns = (int)Sx.size(), nt = (int)Tx.size();
+    const int mm = build_Y(false);
+    if (mm > 0 && !chol_factor(mm, Y.data(), mm)) { aux->status |= MH_WORLD_LCP_FAILED; return; }   // assert(success)
+    // Q X X' (n x mm): contact rows [Cn X Cs'(:,S)  Cn X Ct'(:,T)], limit rows [Cs X L'(S,:)'  Ct X L'(T,:)'] (ICH:1198-1207)
+    std::vector<double> QX((size_t)n * mm + 1);
+    for (int i = 0; i < nc; i++) {
+      for (int a = 0; a < ns; a++) QX[(size_t)i * mm + a] = G[0][1][(size_t)i * nc + Sx[a]];
+      for (int a = 0; a < nt; a++) QX[(size_t)i * mm + ns + a] = G[0][2][(size_t)i * nc + Tx[a]];
+    }
+    for (int k = 0; k < nl; k++) {
+      for (int a = 0; a < ns; a++) QX[(size_t)(nc + k) * mm + a] = CL[1][(size_t)Sx[a] * nl + k];
+      for (int a = 0; a < nt; a++) QX[(size_t)(nc + k) * mm + ns + a] = CL[2][(size_t)Tx[a] * nl + k];
+    }
+    std::vector<double> W((size_t)mm * n + 1), col(mm + 1);
+    for (int j = 0; j < n; j++) {
+      for (int a = 0; a < mm; a++) col[a] = QX[(size_t)j * mm + a];
+      if (mm > 0) chol_solve(mm, Y.data(), mm, col.data());
+      for (int a = 0; a < mm; a++) W[a + (size_t)mm * j] = col[a];
+    }
+    std::vector<double> MM((size_t)n * n), qq(n);
+    auto QMQ = [&](int i, int j) -> double {                         // Q inv(M) Q' (ICH:1190-1196)
+      if (i < nc && j < nc) return G[0][0][(size_t)i * nc + j];
+      if (i < nc) return CL[0][(size_t)i * nl + (j - nc)];
+      if (j < nc) return CL[0][(size_t)j * nl + (i - nc)];
+      return LL[(i - nc) + (size_t)nl * (j - nc)];
+    };
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) {
+      double acc = 0.0; for (int a = 0; a < mm; a++) acc = acc + QX[(size_t)i * mm + a] * W[a + (size_t)mm * j];
+      MM[i + (size_t)n * j] = QMQ(i, j) - acc;
+    }
+    std::vector<double> YXv(mm + 1);
+    for (int a = 0; a < ns; a++) YXv[a] = Cv[1][Sx[a]];
+    for (int a = 0; a < nt; a++) YXv[ns + a] = Cv[2][Tx[a]];
+    if (mm > 0) chol_solve(mm, Y.data(), mm, YXv.data());
+    for (int i = 0; i < n; i++) {
+      double acc = 0.0; for (int a = 0; a < mm; a++) acc = acc + QX[(size_t)i * mm + a] * YXv[a];
+      qq[i] = ((i < nc) ? Cv[0][i] : Lv[i - nc]) - acc;
+    }
+    Vec z; z.d.assign(aux->vns, aux->vns + MH_NOSLIP_MAX); z.len = (unsigned)aux->vns_size;
+    oracle_rand_t rs; std::memcpy(&rs, aux->rng, sizeof(rs));
+    LCP lcp; lcp.rng = &rs;
+    Trace tr; tr.buf = trace ? trace + trace_len : nullptr; tr.cap = trace ? ((trace_cap - trace_len > 0) ? trace_cap - trace_len : 0) : 0;
+    lcp.trace = &tr;
+    unsigned piv = 0;
+    bool ok = lcp.lcp_fast(n, MM.data(), n, qq.data(), z, -1.0);
+    piv += lcp.pivots;
+    if (!ok) { ok = lcp.lcp_lemke_regularized(n, MM.data(), n, qq.data(), z); piv += lcp.pivots; }
+    trace_len += tr.len;
+    std::memcpy(aux->rng, &rs, sizeof(rs));
+    lcp_account(n, piv);
+    if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; return; }
+    for (int k = 0; k < n; k++) aux->vns[k] = z[k];
+    aux->vns_size = n;
+    std::vector<double> t2(mm + 1);                                  // [cs; ct] = -(Y^-1 X v + Y^-1 (QX)' z) (ICH:1293-1298)
+    for (int a = 0; a < mm; a++) { double acc = 0.0; for (int i = 0; i < n; i++) acc = acc + QX[(size_t)i * mm + a] * z[i]; t2[a] = acc; }
+    if (mm > 0) chol_solve(mm, Y.data(), mm, t2.data());
+    for (int i = 0; i < nc; i++) cn[i] = z[i];
+    for (int k = 0; k < nl; k++) l[k] = z[nc + k];
+    for (int a = 0; a < ns; a++) csv[Sx[a]] = -(YXv[a] + t2[a]);
+    for (int a = 0; a < nt; a++) ctv[Tx[a]] = -(YXv[ns + a] + t2[ns + a]);
+    // dv = X_CnT cn + X_CsT cs + X_CtT ct + X_LT sl (ICH:1365-1373, 345-352): four products, added in this order
+    auto apply = [&]() {
+      std::vector<double> dv(nj, 0.0), t(nj);
+      const std::vector<double>* imp[3] = { &cn, &csv, &ctv };
+      for (int d = 0; d < 3; d++) {
+        for (int r = 0; r < nj; r++) { double acc = 0.0; for (int i = 0; i < nc; i++) acc = acc + XC[d][(size_t)i * nj + r] * (*imp[d])[i]; t[r] = acc; }
+        for (int r = 0; r < nj; r++) dv[r] = (d == 0) ? t[r] : dv[r] + t[r];
+      }
+      for (int r = 0; r < nj; r++) { double acc = 0.0; for (int k = 0; k < nl; k++) { const double ls = upper[k] ? -l[k] : l[k]; acc = acc + ls * X[idx[k] * nj + r]; } t[r] = acc; }
+      for (int r = 0; r < nj; r++) dv[r] = dv[r] + t[r];
+      for (int r = 0; r < nj; r++) qd[r] = qd[r] + dv[r];
+    };
+    // update_constraint_velocities_from_impulses (ICH:427-464)
+    auto Gs = [&](int a, int b, int i, int j) -> double { return (a <= b) ? G[a][b][(size_t)i * nc + j] : G[b][a][(size_t)j * nc + i]; };
+    auto update_vels = [&]() {
+      const std::vector<double>* imp[3] = { &cn, &csv, &ctv };
+      for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) {
+          std::vector<double> t(nc, 0.0);
+          for (int i = 0; i < nc; i++) { double acc = 0.0; for (int j = 0; j < nc; j++) acc = acc + Gs(a, b, i, j) * (*imp[b])[j]; t[i] = acc; }
+          for (int i = 0; i < nc; i++) Cv[a][i] = Cv[a][i] + t[i];
+        }
+        for (int i = 0; i < nc; i++) { double acc = 0.0; for (int k = 0; k < nl; k++) acc = acc + CL[a][(size_t)i * nl + k] * l[k]; Cv[a][i] = Cv[a][i] + acc; }
+      }
+      const std::vector<double>* imp2[3] = { &cn, &csv, &ctv };
+      for (int d = 0; d < 3; d++) for (int k = 0; k < nl; k++) { double acc = 0.0; for (int i = 0; i < nc; i++) acc = acc + CL[d][(size_t)i * nl + k] * (*imp2[d])[i]; Lv[k] = Lv[k] + acc; }
+      std::vector<double> t(nl + 1, 0.0);
+      for (int r = 0; r < nl; r++) { double acc = 0.0; for (int k = 0; k < nl; k++) acc = acc + LL[r + (size_t)nl * k] * l[k]; t[r] = acc; }
+      for (int r = 0; r < nl; r++) Lv[r] = Lv[r] + t[r];
+    };
+    auto minv_of = [&]() {                                           // calc_min_constraint_velocity (ICH:413-424)
+      double mn = A_INF;
+      for (int i = 0; i < nc; i++) mn = (i == 0 || Cv[0][i] < mn) ? Cv[0][i] : mn;
+      if (nl > 0) { double ml = Lv[0]; for (int k = 1; k < nl; k++) ml = (Lv[k] < ml) ? Lv[k] : ml; mn = (ml < mn) ? ml : mn; }
+      return mn;
+    };
+    apply(); update_vels();
+    const double minv = minv_of();
+    bool changed = false;                                            // apply_restitution(q) (ICH:497-525)
+    for (int i = 0; i < nc; i++) { cn[i] = cn[i] * m->cp_epsilon; if (!changed && cn[i] > A_NEAR_ZERO) changed = true; }
+    for (int k = 0; k < nl; k++) { l[k] = l[k] * m->limit_restitution[idx[k]]; if (!changed && l[k] > A_NEAR_ZERO) changed = true; }
+    if (changed) {
+      for (int i = 0; i < nc; i++) { csv[i] = 0.0; ctv[i] = 0.0; }
+      apply(); update_vels();
+      const double minv_plus = minv_of();
+      // ICH:284-291 would re-solve and then read the Drumwright-Shell solver's _z, which this path never sized
+      if (minv_plus < 0.0 && minv_plus < minv - A_NEAR_ZERO) aux->status |= MH_WORLD_UNSUPPORTED;
+    }
+    link_velocities(V);                                              // ICH:157-167
+    for (int i = 0; i < nc; i++) if (point_vel_dir(V[cs[i].link], cs[i].p, cs[i].n) < -A_NEAR_ZERO) aux->status |= MH_WORLD_IMPACT_TOL;
+    for (int k = 0; k < nl; k++) { const double v = upper[k] ? -qd[idx[k]] : qd[idx[k]]; if (v < -A_NEAR_ZERO) aux->status |= MH_WORLD_IMPACT_TOL; }
+  }
+
+  // TimeSteppingSimulator::do_mini_step (TSS:114-222) for a body with sphere primitives
+  double do_mini_step(double dt) {
+    double qsave[NJ], V[NJ][6];
+    for (int i = 0; i < nj; i++) qsave[i] = q[i];
+    double h = 0.0;
+    unsigned long guard = 0;
+    while (h < dt) {
+      if (++guard > MH_CA_HARD_CAP) { aux->status |= MH_WORLD_STALLED; break; }
+      kinematics(); link_velocities(V);
+      double CA = A_INF;                                             // calc_next_CA_Euler_step (TSS:272-331): every (sphere, plane) pair -- the plane's DummyBV is infinite
+      for (int s = 0; s < m->nspheres; s++) { const double e = CA_step(s, V); CA = (e < CA) ? e : CA; }
+      if (CA <= 0.0) break;
+      double tc = (m->min_step_size > CA) ? m->min_step_size : CA;
+      tc = ((dt - h) < tc) ? (dt - h) : tc;
+      for (int i = 0; i < nj; i++) { double qn = qd[i] * (h + tc); qn = qn + qsave[i]; q[i] = qn; }
+      h += tc;
+    }
+    double qdd[NJ];
+    if (!((m->algorithm == MH_ARTIC_FSAB) ? fwd_dyn_aba(nullptr, qdd) : fwd_dyn(nullptr, qdd))) { aux->status |= MH_WORLD_LCP_FAILED; for (int i = 0; i < nj; i++) qdd[i] = 0.0; }
+    for (int i = 0; i < nj; i++) qd[i] = qd[i] + qdd[i] * h;                                       // TSS:182-192
+    std::vector<AContact> cs;                                        // find_unilateral_constraints (CSim:488-537)
+    for (int s = 0; s < m->nspheres; s++) {
+      double ctr[3], cp[3]; sphere_center(s, ctr); to_plane(ctr, cp);
+      const double dist = cp[1] + (-1.0 * m->sphere_radius[s]);
+      AContact c;
+      if (dist < m->contact_dist_thresh && find_contact(s, m->contact_dist_thresh, c)) cs.push_back(c);
+    }
+    handle_impacts(cs);
+    aux->time += h; aux->mini_steps++;
+    return h;
+  }
+
+  // TimeSteppingSimulator::step (TSS:52-111).  Without collision geometry: one mini-step of dt.
   void step(double dt) {
+    if (m->nspheres > 0 || force_general) {
+      double h = 0.0; unsigned guard = 0;
+      while (h < dt) { h += do_mini_step(dt - h); if (++guard > 100000u) { aux->status |= MH_WORLD_STALLED; break; } }
+      aux->steps++;
+      return;
+    }
     for (int i = 0; i < nj; i++) { double qn = qd[i] * dt; qn = qn + q[i]; q[i] = qn; }        // positions with the OLD velocity (TSS:156-164)
     double qdd[NJ];
     if (!((m->algorithm == MH_ARTIC_FSAB) ? fwd_dyn_aba(nullptr, qdd) : fwd_dyn(nullptr, qdd))) { aux->status |= MH_WORLD_LCP_FAILED; for (int i = 0; i < nj; i++) qdd[i] = 0.0; }
@@ -294,6 +614,7 @@ class Artic {
     handle_limits();
     aux->time += dt; aux->mini_steps++; aux->steps++;
   }
+  bool force_general = false;     // tests: run a body without spheres through do_mini_step / handle_impacts (must agree with the path above)
 };
 
 }  // namespace oracle

@@ -294,6 +294,17 @@ double oracle_artic_step(const mh_artic_model* m, int B, double dt, int nsteps, 
   return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
 }
 
+// the same through do_mini_step / handle_impacts even without spheres (tests: must agree bit for bit with oracle_artic_step)
+double oracle_artic_step_general(const mh_artic_model* m, int B, double dt, int nsteps, double* q, double* qd, mh_world_aux* aux)
+{
+  for (int b = 0; b < B; b++) {
+    Artic w(m, q + (size_t)b * m->nj, qd + (size_t)b * m->nj, aux + b);
+    w.force_general = true;
+    for (int s = 0; s < nsteps; s++) w.step(dt);
+  }
+  return 0.0;
+}
+
 // qdd = H^-1 (tau - C) of one state; H (nj x nj, row-major), C (nj) and the link poses (nj x 12) optional.  Returns 1 / 0 (H not PD).
 int oracle_artic_fwd_dyn(const mh_artic_model* m, const double* q, const double* qd, const double* tau, double* qdd, double* H, double* C, double* poses)
 {

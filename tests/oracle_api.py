@@ -192,6 +192,13 @@ def oracle_artic_step(self, model, q, qd, aux, dt, nsteps=1):
     return self.lib.oracle_artic_step(ctypes.byref(model), int(q.shape[0]), ctypes.c_double(dt), int(nsteps), P(q), P(qd), P(aux))
 
 
+def oracle_artic_step_general(self, model, q, qd, aux, dt, nsteps=1):
+    """the same through do_mini_step / handle_impacts (what a body WITH spheres runs), whatever nspheres is"""
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    self.lib.oracle_artic_step_general.restype = ctypes.c_double
+    return self.lib.oracle_artic_step_general(ctypes.byref(model), int(q.shape[0]), ctypes.c_double(dt), int(nsteps), P(q), P(qd), P(aux))
+
+
 def oracle_artic_fwd_dyn(self, model, q, qd, tau=None):
     """One state -> dict(ok, qdd, H (nj, nj), C (nj), poses (nj, 12))."""
     nj = model.nj
@@ -222,6 +229,7 @@ def oracle_sincos(self, x):
 
 
 Oracle.artic_step = oracle_artic_step
+Oracle.artic_step_general = oracle_artic_step_general
 Oracle.artic_fwd_dyn = oracle_artic_fwd_dyn
 Oracle.artic_jacobian = oracle_artic_jacobian
 Oracle.sincos = oracle_sincos
