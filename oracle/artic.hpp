@@ -602,8 +602,15 @@ class Artic {
   // TimeSteppingSimulator::step (TSS:52-111).  Without collision geometry: one mini-step of dt.
   void step(double dt) {
     if (m->nspheres > 0 || force_general) {
+      // a world whose contacts need a model this build does not have is frozen (the reference would throw out of step()); without
+      // this it would burn the mini-step cap on every step, its impacting contact never resolved
+      if (m->nspheres > 0 && (aux->status & MH_WORLD_UNSUPPORTED)) return;
       double h = 0.0; unsigned guard = 0;
-      while (h < dt) { h += do_mini_step(dt - h); if (++guard > 100000u) { aux->status |= MH_WORLD_STALLED; break; } }
+      while (h < dt) {
+        h += do_mini_step(dt - h);
+        if (m->nspheres > 0 && (aux->status & MH_WORLD_UNSUPPORTED)) break;
+        if (++guard > 100000u) { aux->status |= MH_WORLD_STALLED; break; }
+      }
       aux->steps++;
       return;
     }
