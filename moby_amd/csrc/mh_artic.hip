@@ -566,10 +566,12 @@ void k_artic_jacobian(const Model* __restrict__ Mg, int B, const double* __restr
   }
 }
 
+#include "mh_artic_contacts.inc"
+
 }} // namespace mh::artic
 
 struct mh_artic_batch {
-  int B, nj;
+  int B, nj, nspheres;
   mh::artic::Model* d_model;
   double* d_q; double* d_qd; mh_world_aux* d_aux;
 };
@@ -606,6 +608,17 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
     if (!(model->lolimit[i] <= model->hilimit[i])) return fail(MH_ERR_INVALID_ARG, "joint %d: lower limit above the upper one", i);
     hm.anc[i] = (1u << i) | (p >= 0 ? hm.anc[p] : 0u);
   }
+  if (model->nspheres < 0 || model->nspheres > MH_ARTIC_MAX_SPHERES) return fail(MH_ERR_INVALID_ARG, "nspheres = %d outside [0, %d]", model->nspheres, MH_ARTIC_MAX_SPHERES);
+  for (int s = 0; s < model->nspheres; s++) {
+    if (model->sphere_link[s] < 0 || model->sphere_link[s] >= nj) return fail(MH_ERR_INVALID_ARG, "sphere %d: link %d outside [0, %d)", s, model->sphere_link[s], nj);
+    if (!(model->sphere_radius[s] > 0.0)) return fail(MH_ERR_INVALID_ARG, "sphere %d: radius must be > 0", s);
+  }
+  if (model->nspheres > 0) {
+    const double* Rp = model->plane_R; const double nn = Rp[1]*Rp[1] + Rp[4]*Rp[4] + Rp[7]*Rp[7];
+    if (!(nn > 0.999999 && nn < 1.000001)) return fail(MH_ERR_INVALID_ARG, "plane_R is not a rotation (its +Y column is the plane normal)");
+    if (!(model->min_step_size > 0.0) || !(model->contact_dist_thresh > 0.0)) return fail(MH_ERR_INVALID_ARG, "min_step_size and contact_dist_thresh must be > 0 when spheres are present");
+    if (!(model->cp_epsilon >= 0.0) || !(model->cp_mu_coulomb >= 0.0)) return fail(MH_ERR_INVALID_ARG, "contact parameters must be >= 0");
+  }
   if (mh_device_count() <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
   {
     static bool once = false;
@@ -616,7 +629,7 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
     }
   }
   mh_artic_batch* ab = new mh_artic_batch();
-  ab->B = B; ab->nj = nj; ab->d_model = nullptr; ab->d_q = nullptr; ab->d_qd = nullptr; ab->d_aux = nullptr;
+  ab->B = B; ab->nj = nj; ab->nspheres = model->nspheres; ab->d_model = nullptr; ab->d_q = nullptr; ab->d_qd = nullptr; ab->d_aux = nullptr;
   const size_t sB = (size_t)B;
   bool ok = hipMalloc((void**)&ab->d_model, sizeof(ar::Model)) == hipSuccess && hipMalloc((void**)&ab->d_q, sB * nj * 8) == hipSuccess
          && hipMalloc((void**)&ab->d_qd, sB * nj * 8) == hipSuccess && hipMalloc((void**)&ab->d_aux, sB * sizeof(mh_world_aux)) == hipSuccess;
@@ -650,6 +663,12 @@ int mh_artic_batch_step(mh_artic_batch* ab, void* stream, double dt, int nsteps)
   if (nsteps < 0) return fail(MH_ERR_INVALID_ARG, "negative step count");
   if (nsteps == 0) return MH_OK;
   if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
+  if (ab->nspheres > 0) {                                     // bodies with collision geometry: the full step with mini-steps and contact rows
+    hipLaunchKernelGGL(ar::k_artic_step_contacts, dim3(ab->B), dim3(64), ar::lds_bytes_contacts(ab->nj), (hipStream_t)stream,
+                       (const ar::Model*)ab->d_model, ab->B, dt, nsteps, ab->d_q, ab->d_qd, ab->d_aux);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+  }
   static const int waves = [] { const char* e = std::getenv("MH_ARTIC_WAVES"); const int w = e ? std::atoi(e) : 4; return (w == 2 || w == 3) ? w : 4; }();
   hipLaunchKernelGGL(waves == 4 ? ar::k_artic_step_w4 : (waves == 2 ? ar::k_artic_step_w2 : ar::k_artic_step_w3), dim3(ab->B), dim3(64), ar::lds_bytes(ab->nj), (hipStream_t)stream,
                      (const ar::Model*)ab->d_model, ab->B, dt, nsteps, ab->d_q, ab->d_qd, ab->d_aux);

@@ -1,0 +1,113 @@
+"""GPU parity of contacts on articulated links (mh_artic_model.nspheres > 0: the kernel k_artic_step_contacts through the C ABI)
+against oracle/artic.hpp: joint positions / velocities, rand() streams, the no-slip LCP's warm start and the counters bit for
+bit, over conservative-advancement mini-steps, landings, resting contacts, contact + limit rows, restitution, both forward
+dynamics algorithms; then a batch at scale through size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+
+from moby_amd import artic as A
+from moby_amd import scene as S
+from tests.test_artic_gpu import assert_parity, ur10_states
+from tests.test_oracle_artic_contacts import tip_height, tip_model
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+UR10 = os.path.join(HERE, "scenes", "ten_joint_arm.sdf")
+
+
+def run(oracle, m, q0, qd0, nsteps=150, chunks=4, dt=1e-3):
+    ab = A.ArticBatch(m, q0, qd0)
+    aux = assert_parity(ab, oracle, m, q0, qd0, dt, nsteps, chunks)
+    ab.close()
+    return aux
+
+
+def test_ball_on_a_rail_lands_like_the_oracle(oracle):
+    links = [dict(parent=-1, type=A.MH_JOINT_PRISMATIC, R0=np.eye(3), x0=(0, 0, 0), axis=(0, 0, 1), com=(0, 0, 0),
+                  inertia=np.diag([0.1, 0.1, 0.1]), mass=2.0)]
+    for eps in (0.0, 0.5):
+        m = A.add_spheres(A.model_from_links(links), [(0, (0, 0, 0), 0.25)], epsilon=eps)
+        q0 = 0.25 + np.array([[0.02], [0.001], [1e-7], [0.3]]); qd0 = np.array([[0.0], [-0.5], [0.0], [-2.0]])
+        aux = run(oracle, m, q0, qd0, nsteps=60, chunks=4)
+        assert (aux["lcp_solves"][:3] > 0).all() and (aux["mini_steps"] > aux["steps"]).any()
+
+
+@pytest.mark.parametrize("n,alg", [(2, A.MH_ARTIC_CRB), (3, A.MH_ARTIC_CRB), (2, A.MH_ARTIC_FSAB), (4, A.MH_ARTIC_FSAB)])
+def test_arm_tip_hits_the_floor_like_the_oracle(oracle, n, alg):
+    """planar n-pendulums whose tip sphere lands on a floor: mini-steps at the landing, the no-slip LCP every step afterwards"""
+    m = tip_model(n, floor=-0.5 * n + 0.1)
+    m.algorithm = alg
+    B = 8
+    rng = np.random.default_rng(40 + n)
+    q0 = np.zeros((B, n)); q0[:, 0] = rng.uniform(0.5, 0.9, B); q0[:, 1:] = rng.uniform(0.0, 0.3, (B, n - 1)); qd0 = rng.uniform(-0.5, 0.5, (B, n))
+    aux = run(oracle, m, q0, qd0, nsteps=150, chunks=5)
+    assert (aux["lcp_solves"] > 0).all() and (aux["mini_steps"] > aux["steps"]).all()
+    assert (aux["status"] & ~S.MH_WORLD_IMPACT_TOL == 0).all(), aux["status"]
+
+
+def test_contact_and_limit_rows_share_one_lcp(oracle):
+    """lower and upper elbow limits with the tip on the floor (the upper one shows the reference's unsigned X L' coupling), with
+    restitution at the limits and at the contact"""
+    for lo, hi, sgn, eps, er in ((-0.25, 3.0, -1.0, 0.0, 0.0), (-3.0, 0.25, 1.0, 0.0, 0.0), (-0.25, 3.0, -1.0, 0.3, 0.5)):
+        m = tip_model(2, floor=-0.9, hi=hi, lo=lo, eps=eps, restitution=er)
+        m.lolimit[0] = -3.0; m.hilimit[0] = 3.0
+        B = 4
+        rng = np.random.default_rng(7)
+        q0 = np.column_stack([sgn * rng.uniform(0.7, 0.8, B), sgn * rng.uniform(0.15, 0.22, B)]); qd0 = np.column_stack([np.zeros(B), sgn * rng.uniform(1.0, 2.0, B)])
+        aux = run(oracle, m, q0, qd0, nsteps=175, chunks=4)
+        assert (aux["lcp_rows"] > aux["lcp_solves"]).all()              # some 2-row LCPs
+
+
+def test_two_spheres_on_different_links(oracle):
+    m = A.chain_model(3, lo=-3.0, hi=3.0)
+    A.add_spheres(m, [(1, (0.0, 0.0, -0.5), 0.08), (2, (0.0, 0.0, -0.5), 0.05), (2, (0.1, 0.0, -0.25), 0.04)],
+                  plane_normal=(0.1, 0.0, 1.0), plane_point=(0.0, 0.0, -1.0))
+    B = 6
+    rng = np.random.default_rng(3)
+    q0 = np.column_stack([rng.uniform(0.8, 1.2, B), rng.uniform(0.2, 0.6, B), rng.uniform(0.2, 0.6, B)]); qd0 = rng.uniform(-0.5, 0.5, (B, 3))
+    aux = run(oracle, m, q0, qd0, nsteps=200, chunks=5)
+    assert (aux["lcp_solves"] > 0).all()
+    assert (aux["lcp_rows"] > aux["lcp_solves"]).any()                  # two contacts at once somewhere
+
+
+def test_finite_friction_is_flagged_and_the_world_frozen(oracle):
+    m = tip_model(2, floor=-0.9, mu=0.5)
+    q0 = np.array([[0.7, -0.2], [0.8, 0.1]]); qd0 = np.zeros((2, 2))
+    aux = run(oracle, m, q0, qd0, nsteps=300, chunks=3)
+    assert (aux["status"] & S.MH_WORLD_UNSUPPORTED != 0).all() and (aux["steps"] < 900).all()
+
+
+def test_ur10_fingers_on_a_table(oracle):
+    """the ten-joint arm of config 5 with a sphere on each finger and one on the forearm, over a table: limits and contacts"""
+    m, links, _ = A.load_sdf(UR10)
+    poses0 = None
+    B = 16
+    q0, qd0 = ur10_states(m, B, seed=77)
+    ab = A.ArticBatch(m, q0, qd0); P = ab.link_poses(); ab.close()
+    lf, rf, fa = links.index("l_finger"), links.index("r_finger"), links.index("forearm_link")
+    zmin = min(P[:, lf, 11].min(), P[:, rf, 11].min(), P[:, fa, 11].min())
+    A.add_spheres(m, [(lf, (0.0, 0.0, 0.0), 0.03), (rf, (0.0, 0.0, 0.0), 0.03), (fa, (0.0, 0.0, 0.0), 0.06)],
+                  plane_normal=(0.0, 0.0, 1.0), plane_point=(0.0, 0.0, float(zmin) - 0.15))
+    aux = run(oracle, m, q0, qd0, nsteps=100, chunks=4, dt=5e-4)
+    assert (aux["lcp_solves"] > 0).all()
+    assert ((aux["status"] & S.MH_WORLD_UNSUPPORTED) == 0).all()
+
+
+def test_many_worlds_properties():
+    """2048 three-link arms over a floor, 600 steps: nothing sinks beyond the landing overshoot, worlds are independent of their
+    position in the batch, every world ends up resting on the floor or swinging above it."""
+    m = tip_model(3, floor=-1.4)
+    B = 2048
+    rng = np.random.default_rng(9)
+    q0 = np.column_stack([rng.uniform(0.4, 1.0, B), rng.uniform(0.0, 0.4, B), rng.uniform(0.0, 0.4, B)]); qd0 = rng.uniform(-0.5, 0.5, (B, 3))
+    ab = A.ArticBatch(m, q0, qd0); ab.step(1e-3, 600); q, qd, aux = ab.download(); ab.close()
+    assert (aux["status"] & ~S.MH_WORLD_IMPACT_TOL == 0).all() and (aux["steps"] == 600).all()
+    h = np.array([tip_height(m, q[b]) for b in range(0, B, 16)])
+    assert (h > -3e-3).all()
+    assert (aux["lcp_solves"] > 0).mean() > 0.9
+    perm = rng.permutation(B)[:256]
+    ab = A.ArticBatch(m, q0[perm], qd0[perm]); ab.step(1e-3, 600); q2, qd2, aux2 = ab.download(); ab.close()
+    assert np.array_equal(q2, q[perm]) and np.array_equal(qd2, qd[perm]) and np.array_equal(aux2["rng"], aux["rng"][perm])
