@@ -602,13 +602,15 @@ class Artic {
   // TimeSteppingSimulator::step (TSS:52-111).  Without collision geometry: one mini-step of dt.
   void step(double dt) {
     if (m->nspheres > 0 || force_general) {
-      // a world whose contacts need a model this build does not have is frozen (the reference would throw out of step()); without
-      // this it would burn the mini-step cap on every step, its impacting contact never resolved
-      if (m->nspheres > 0 && (aux->status & MH_WORLD_UNSUPPORTED)) return;
+      // a world whose contacts need a model this build does not have (the reference would throw out of step()), or whose step ran
+      // into the mini-step cap (the reference would never return from step()), is frozen; without this it would burn the cap on
+      // every following step, its impacting contact never resolved
+      const int FROZEN = MH_WORLD_UNSUPPORTED | MH_WORLD_STALLED;
+      if (m->nspheres > 0 && (aux->status & FROZEN)) return;
       double h = 0.0; unsigned guard = 0;
       while (h < dt) {
         h += do_mini_step(dt - h);
-        if (m->nspheres > 0 && (aux->status & MH_WORLD_UNSUPPORTED)) break;
+        if (m->nspheres > 0 && (aux->status & FROZEN)) break;
         if (++guard > 100000u) { aux->status |= MH_WORLD_STALLED; break; }
       }
       aux->steps++;
