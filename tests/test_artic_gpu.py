@@ -125,6 +125,7 @@ def test_cpp_articulated_adapter_example():
                            "-lmoby_hip", "-lmoby_hip_io", "-Wl,-rpath," + os.path.join(root, "moby_amd"), "-o", exe])
     out = subprocess.check_output([exe, UR10]).decode()
     assert "joints=10 world_joint..r_finger_actuator same=1" in out, out
+    assert "contacts: same=1" in out and "lcp_solves=0" not in out, out          # link spheres over a table: contacts were handled
 
 
 def fsab(m):
