@@ -221,8 +221,39 @@ def config5_leg(torch, B=8192, steps=200, cpu=True):
         _, _, a1 = ab.download()
         rows = float(a1["lcp_rows"].astype(np.int64).sum() - a0["lcp_rows"].astype(np.int64).sum())
         ab.close()
+        # the same arms with link contacts: a sphere on each finger and on the forearm, a table 15 cm below the lowest of them
+        # (kernel k_artic_step_contacts: conservative advancement, mini-steps, contact + limit rows in one no-slip LCP)
+        contacts = None
+        try:
+            ab = A.ArticBatch(m, q0[:64], qd0[:64]); P = ab.link_poses(); ab.close()
+            _, links, _ = A.load_sdf(os.path.join(ROOT, "tests", "scenes", "ten_joint_arm.sdf"))
+            ids = [links.index(n) for n in ("l_finger", "r_finger", "forearm_link")]
+            zmin = float(min(P[:, i, 11].min() for i in ids))
+            mc = type(m).from_buffer_copy(m)
+            A.add_spheres(mc, [(ids[0], (0.0, 0.0, 0.0), 0.03), (ids[1], (0.0, 0.0, 0.0), 0.03), (ids[2], (0.0, 0.0, 0.0), 0.06)],
+                          plane_point=(0.0, 0.0, zmin - 0.15))
+            ab = A.ArticBatch(mc, q0, qd0)
+            ab.step(5e-4, 10, stream); torch.cuda.synchronize()
+            _, _, c0 = ab.download()
+            e0.record(); ab.step(5e-4, steps, stream); e1.record(); torch.cuda.synchronize()
+            msc = e0.elapsed_time(e1)
+            _, _, c1 = ab.download()
+            d = lambda a, b, f: float(b[f].astype(np.int64).sum() - a[f].astype(np.int64).sum())
+            part = lambda a, b, t: {"ms": t, "world_steps_per_sec": d(a, b, "steps") / (t * 1e-3), "mini_steps_per_sec": d(a, b, "mini_steps") / (t * 1e-3),
+                                    "lcp_rows_per_sec": d(a, b, "lcp_rows") / (t * 1e-3), "lcp_solves": d(a, b, "lcp_solves"),
+                                    "worlds_that_split_a_step": int((b["mini_steps"] - a["mini_steps"] > b["steps"] - a["steps"]).sum())}
+            contacts = {"workload": "the same arms, spheres on both fingers and the forearm over a table 15 cm below the lowest of them",
+                        "falling": part(c0, c1, msc),
+                        "note": "the first 0.1 s only: once spheres REST on the table the reference's conservative advancement crawls (step = distance / "
+                                "(2 rmax |qd| + ...), CCD.cpp:545-583, with distances of 1e-7 inside the contact band) and a lockstep launch lasts as long as its slowest world"}
+            ab.close()
+            c3 = c1
+            contacts["worlds_frozen"] = int(((c3["status"] & (4 | 16)) != 0).sum())
+            contacts["worlds_with_errors"] = int(((c3["status"] & ~(2 | 4 | 16)) != 0).sum())
+        except Exception as e:      # noqa: BLE001 -- informational
+            contacts = {"error": repr(e)}
         # algorithmic bytes of one world-step: q, qd in and out once per LAUNCH (state stays in LDS between steps)
-        return {"workload": "ur10 (10 joints) x%d, dt = 5e-4, %d steps in one launch" % (B, steps), "ms": ms,
+        return {"workload": "ur10 (10 joints) x%d, dt = 5e-4, %d steps in one launch" % (B, steps), "ms": ms, "with_link_contacts": contacts,
                 "world_steps_per_sec": B * steps / (ms * 1e-3), "lcp_rows_per_sec": rows / (ms * 1e-3),
                 "worlds_with_errors": int(((a1["status"] & ~2) != 0).sum()),
                 "flops_per_world_step_est": 21000, "gflops_est": 21000.0 * B * steps / (ms * 1e-3) / 1e9,
