@@ -65,9 +65,11 @@ typedef struct mh_artic_model {
    * links against ONE static plane -- the closed-form pair of CCD.inl:804-847; the body's own pairs are disabled as ur10.xml:12
    * does.  With spheres the step is TimeSteppingSimulator::step in full: conservative advancement over the pairs
    * (CCD::calc_CA_Euler_step_sphere, the ARTICULATED CCD::calc_max_dist, CCD.cpp:545-583), mini-steps, contact + limit rows in one
-   * island.  Contact rows are [d, r x d] . calc_jacobian(link) (ICH:1817-1895); the impact model built for them is the no-slip
-   * one (every contact mu-coulomb >= 100 -- what ur10.xml:19 gives the robot's contacts -- ICH:123-135, 1009-1417) with
-   * NC + NL <= MH_NOSLIP_MAX rows; a finite mu_coulomb flags MH_WORLD_UNSUPPORTED when a contact is impacting. */
+   * island.  Contact rows are [d, r x d] . calc_jacobian(link) (ICH:1817-1895).  Impact models as the reference picks them
+   * (ICH:123-146): every contact mu-coulomb >= 100 (what ur10.xml:19 gives the robot's contacts) -> the no-slip model
+   * (ICH:1009-1417) over NC + NL <= MH_NOSLIP_MAX rows; otherwise the Drumwright-Shell QP -> LCP with contact AND limit variables
+   * (ICH-QP:94-497: n = 6 NC + NC nk/2 + 2 NL <= MH_LCP_MAX_N_WAVE rows, lcp_fast_regularized(-20, 4, -8) on the persistent _z /
+   * _zlast, then the Lemke ladder). */
   int    nspheres;
   int    sphere_link[MH_ARTIC_MAX_SPHERES];
   double sphere_center[MH_ARTIC_MAX_SPHERES][3];   /* link frame */
@@ -77,6 +79,9 @@ typedef struct mh_artic_model {
   double cp_epsilon, cp_mu_coulomb;                /* ContactParameters of the (robot, plane) pair */
   double min_step_size;                            /* TimeSteppingSimulator.cpp:48 (sqrt eps) */
   double contact_dist_thresh;                      /* ConstraintSimulator.cpp:56 (1e-6) */
+  double cp_mu_viscous, cp_compliance;             /* used by the Drumwright-Shell model only (mu_coulomb < 100) */
+  int    cp_nk;                                    /* friction-cone-edges (>= 4, even; ur10.xml:19 has 4); 0 is read as 4 */
+  int    pad2;
 } mh_artic_model;
 
 /* B worlds resident on the GPU: joint positions q and velocities qd (B x nj each) + mh_world_aux (rand() stream, time,

@@ -30,7 +30,8 @@ class mh_artic_model(ctypes.Structure):
                 ("nspheres", ctypes.c_int), ("sphere_link", ctypes.c_int * _NS), ("sphere_center", (ctypes.c_double * 3) * _NS),
                 ("sphere_radius", ctypes.c_double * _NS), ("plane_R", ctypes.c_double * 9), ("plane_o", ctypes.c_double * 3),
                 ("cp_epsilon", ctypes.c_double), ("cp_mu_coulomb", ctypes.c_double), ("min_step_size", ctypes.c_double),
-                ("contact_dist_thresh", ctypes.c_double)]
+                ("contact_dist_thresh", ctypes.c_double), ("cp_mu_viscous", ctypes.c_double), ("cp_compliance", ctypes.c_double),
+                ("cp_nk", ctypes.c_int), ("pad2", ctypes.c_int)]
 
 
 MH_ARTIC_CRB, MH_ARTIC_FSAB = 0, 1      # moby_hip_artic.h: RCArticulatedBody::algorithm_type
@@ -80,7 +81,8 @@ def model_from_links(links, gravity=(0.0, 0.0, -9.81)):
     return m
 
 
-def add_spheres(model, spheres, plane_normal=(0.0, 0.0, 1.0), plane_point=(0.0, 0.0, 0.0), epsilon=0.0, mu_coulomb=100.0):
+def add_spheres(model, spheres, plane_normal=(0.0, 0.0, 1.0), plane_point=(0.0, 0.0, 0.0), epsilon=0.0, mu_coulomb=100.0, mu_viscous=0.0,
+                compliance=0.0, nk=4):
     """Sphere primitives on links against one static plane: spheres = [(link, centre in the link frame, radius), ...]; the
     plane through plane_point with the given normal (the +Y axis of the plane frame, as PlanePrimitive has it); the
     ContactParameters of the (robot, plane) pair (ur10.xml:19: epsilon 0, mu-coulomb 100).  Returns the model."""
@@ -100,6 +102,7 @@ def add_spheres(model, spheres, plane_normal=(0.0, 0.0, 1.0), plane_point=(0.0, 
     for k in range(3):
         model.plane_o[k] = float(plane_point[k])
     model.cp_epsilon = float(epsilon); model.cp_mu_coulomb = float(mu_coulomb)
+    model.cp_mu_viscous = float(mu_viscous); model.cp_compliance = float(compliance); model.cp_nk = int(nk)
     model.min_step_size = S.NEAR_ZERO
     model.contact_dist_thresh = 1e-6
     return model

@@ -47,7 +47,7 @@ inline void set_ground_plane(mh_artic_model& m, const double normal[3], const do
   for (int k = 0; k < 3; k++) x[k] /= xl;
   const double z[3] = { x[1]*n[2] - x[2]*n[1], x[2]*n[0] - x[0]*n[2], x[0]*n[1] - x[1]*n[0] };
   for (int k = 0; k < 3; k++) { m.plane_R[3*k] = x[k]; m.plane_R[3*k+1] = n[k]; m.plane_R[3*k+2] = z[k]; m.plane_o[k] = point[k]; }
-  m.cp_epsilon = epsilon; m.cp_mu_coulomb = mu_coulomb;
+  m.cp_epsilon = epsilon; m.cp_mu_coulomb = mu_coulomb; m.cp_mu_viscous = 0.0; m.cp_compliance = 0.0; m.cp_nk = 4;   // set the last three directly for the D-S model
   m.min_step_size = 1.4901161193847656e-08; m.contact_dist_thresh = 1e-6;
 }
 

@@ -394,9 +394,13 @@ class Artic {
     for (int i = 0; i < nc; i++) if (point_vel_dir(V[cs[i].link], cs[i].p, cs[i].n) < -A_NEAR_ZERO) impacting = true;
     for (int k = 0; k < nl; k++) { const double v = upper[k] ? -qd[idx[k]] : qd[idx[k]]; if (v < -A_NEAR_ZERO) impacting = true; }
     if (!impacting) return;
-    if (nc > 0 && !(m->cp_mu_coulomb >= 1e2)) { aux->status |= MH_WORLD_UNSUPPORTED; return; }   // Drumwright-Shell rows of an articulated body: not built
+    // ICH:123-146: the no-slip model when every CONTACT has mu_coulomb >= 100 (limits do not count: an island of limits alone
+    // takes it too), otherwise the Drumwright-Shell QP
+    const bool noslip = (nc == 0) || (m->cp_mu_coulomb >= 1e2);
     const int n = nc + nl;
-    if (n > MH_NOSLIP_MAX) { aux->status |= MH_WORLD_UNSUPPORTED; return; }
+    const int nk = (m->cp_nk > 0) ? m->cp_nk : 4, kh = nk / 2;
+    const int nvars = 5 * nc + nl, N = nvars + nc + nl + nc * kh;    // ICH-QP:97-112
+    if (noslip ? (n > MH_NOSLIP_MAX) : (N > MH_LCP_MAX_N_WAVE)) { aux->status |= MH_WORLD_UNSUPPORTED; return; }
     if (m->algorithm == MH_ARTIC_FSAB) crba();                       // get_generalized_inertia (ICH:1600-1607)
     std::vector<double> X(H, H + nj * nj);
     if (!inverse_spd(nj, X.data(), nj)) { aux->status |= MH_WORLD_LCP_FAILED; return; }
@@ -439,6 +443,43 @@ class Artic {
     for (int k = 0; k < nl; k++) { Lv[k] = qd[idx[k]]; if (upper[k]) Lv[k] = -Lv[k]; }
 
     std::vector<double> cn(nc, 0.0), csv(nc, 0.0), ctv(nc, 0.0), l(nl, 0.0);
+    // dv = X_CnT cn + X_CsT cs + X_CtT ct + X_LT sl (ICH:1365-1373, 345-352): four products, added in this order
+    auto apply = [&]() {
+      std::vector<double> dv(nj, 0.0), t(nj);
+      const std::vector<double>* imp[3] = { &cn, &csv, &ctv };
+      for (int d = 0; d < 3; d++) {
+        for (int r = 0; r < nj; r++) { double acc = 0.0; for (int i = 0; i < nc; i++) acc = acc + XC[d][(size_t)i * nj + r] * (*imp[d])[i]; t[r] = acc; }
+        for (int r = 0; r < nj; r++) dv[r] = (d == 0) ? t[r] : dv[r] + t[r];
+      }
+      for (int r = 0; r < nj; r++) { double acc = 0.0; for (int k = 0; k < nl; k++) { const double ls = upper[k] ? -l[k] : l[k]; acc = acc + ls * X[idx[k] * nj + r]; } t[r] = acc; }
+      for (int r = 0; r < nj; r++) dv[r] = dv[r] + t[r];
+      for (int r = 0; r < nj; r++) qd[r] = qd[r] + dv[r];
+    };
+    // update_constraint_velocities_from_impulses (ICH:427-464)
+    auto Gs = [&](int a, int b, int i, int j) -> double { return (a <= b) ? G[a][b][(size_t)i * nc + j] : G[b][a][(size_t)j * nc + i]; };
+    auto update_vels = [&]() {
+      const std::vector<double>* imp[3] = { &cn, &csv, &ctv };
+      for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) {
+          std::vector<double> t(nc, 0.0);
+          for (int i = 0; i < nc; i++) { double acc = 0.0; for (int j = 0; j < nc; j++) acc = acc + Gs(a, b, i, j) * (*imp[b])[j]; t[i] = acc; }
+          for (int i = 0; i < nc; i++) Cv[a][i] = Cv[a][i] + t[i];
+        }
+        for (int i = 0; i < nc; i++) { double acc = 0.0; for (int k = 0; k < nl; k++) acc = acc + CL[a][(size_t)i * nl + k] * l[k]; Cv[a][i] = Cv[a][i] + acc; }
+      }
+      const std::vector<double>* imp2[3] = { &cn, &csv, &ctv };
+      for (int d = 0; d < 3; d++) for (int k = 0; k < nl; k++) { double acc = 0.0; for (int i = 0; i < nc; i++) acc = acc + CL[d][(size_t)i * nl + k] * (*imp2[d])[i]; Lv[k] = Lv[k] + acc; }
+      std::vector<double> t(nl + 1, 0.0);
+      for (int r = 0; r < nl; r++) { double acc = 0.0; for (int k = 0; k < nl; k++) acc = acc + LL[r + (size_t)nl * k] * l[k]; t[r] = acc; }
+      for (int r = 0; r < nl; r++) Lv[r] = Lv[r] + t[r];
+    };
+    auto minv_of = [&]() {                                           // calc_min_constraint_velocity (ICH:413-424)
+      double mn = A_INF;
+      for (int i = 0; i < nc; i++) mn = (i == 0 || Cv[0][i] < mn) ? Cv[0][i] : mn;
+      if (nl > 0) { double ml = Lv[0]; for (int k = 1; k < nl; k++) ml = (Lv[k] < ml) ? Lv[k] : ml; mn = (ml < mn) ? ml : mn; }
+      return mn;
+    };
+    auto solve_noslip = [&]() -> bool {
     // apply_no_slip_model (ICH:1009-1417)
     std::vector<int> Sx, Tx; std::vector<double> Y;
     auto build_Y = [&](bool skew) -> int {
@@ -456,7 +497,7 @@ class Artic {
     }
     const int ns = (int)Sx.size(), nt = (int)Tx.size();
     const int mm = build_Y(false);
-    if (mm > 0 && !chol_factor(mm, Y.data(), mm)) { aux->status |= MH_WORLD_LCP_FAILED; return; }   // assert(success)
+    if (mm > 0 && !chol_factor(mm, Y.data(), mm)) { aux->status |= MH_WORLD_LCP_FAILED; return false; }   // assert(success)
     // Q X X' (n x mm): contact rows [Cn X Cs'(:,S)  Cn X Ct'(:,T)], limit rows [Cs X L'(S,:)'  Ct X L'(T,:)'] (ICH:1198-1207)
     std::vector<double> QX((size_t)n * mm + 1);
     for (int i = 0; i < nc; i++) {
@@ -504,7 +545,7 @@ class Artic {
     trace_len += tr.len;
     std::memcpy(aux->rng, &rs, sizeof(rs));
     lcp_account(n, piv);
-    if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; return; }
+    if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; return false; }
     for (int k = 0; k < n; k++) aux->vns[k] = z[k];
     aux->vns_size = n;
     std::vector<double> t2(mm + 1);                                  // [cs; ct] = -(Y^-1 X v + Y^-1 (QX)' z) (ICH:1293-1298)
@@ -514,53 +555,105 @@ class Artic {
     for (int k = 0; k < nl; k++) l[k] = z[nc + k];
     for (int a = 0; a < ns; a++) csv[Sx[a]] = -(YXv[a] + t2[a]);
     for (int a = 0; a < nt; a++) ctv[Tx[a]] = -(YXv[ns + a] + t2[ns + a]);
-    // dv = X_CnT cn + X_CsT cs + X_CtT ct + X_LT sl (ICH:1365-1373, 345-352): four products, added in this order
-    auto apply = [&]() {
-      std::vector<double> dv(nj, 0.0), t(nj);
-      const std::vector<double>* imp[3] = { &cn, &csv, &ctv };
-      for (int d = 0; d < 3; d++) {
-        for (int r = 0; r < nj; r++) { double acc = 0.0; for (int i = 0; i < nc; i++) acc = acc + XC[d][(size_t)i * nj + r] * (*imp[d])[i]; t[r] = acc; }
-        for (int r = 0; r < nj; r++) dv[r] = (d == 0) ? t[r] : dv[r] + t[r];
-      }
-      for (int r = 0; r < nj; r++) { double acc = 0.0; for (int k = 0; k < nl; k++) { const double ls = upper[k] ? -l[k] : l[k]; acc = acc + ls * X[idx[k] * nj + r]; } t[r] = acc; }
-      for (int r = 0; r < nj; r++) dv[r] = dv[r] + t[r];
-      for (int r = 0; r < nj; r++) qd[r] = qd[r] + dv[r];
+      return true;
     };
-    // update_constraint_velocities_from_impulses (ICH:427-464)
-    auto Gs = [&](int a, int b, int i, int j) -> double { return (a <= b) ? G[a][b][(size_t)i * nc + j] : G[b][a][(size_t)j * nc + i]; };
-    auto update_vels = [&]() {
-      const std::vector<double>* imp[3] = { &cn, &csv, &ctv };
-      for (int a = 0; a < 3; a++) {
-        for (int b = 0; b < 3; b++) {
-          std::vector<double> t(nc, 0.0);
-          for (int i = 0; i < nc; i++) { double acc = 0.0; for (int j = 0; j < nc; j++) acc = acc + Gs(a, b, i, j) * (*imp[b])[j]; t[i] = acc; }
-          for (int i = 0; i < nc; i++) Cv[a][i] = Cv[a][i] + t[i];
+    // ---- Drumwright-Shell QP -> LCP with contact and limit variables (ICH-QP:94-497) on the persistent _z / _zlast -------
+    // variables [cn cs ct ncs nct l], inequality rows [Cn v+ >= 0 (NC); L v+ >= 0 (NL); friction polygons (NC nk/2)]
+    auto solve_qp = [&]() -> bool {
+      std::vector<double> MM((size_t)N * N, 0.0), qq(N, 0.0);
+      auto at = [&](int r, int c2) -> double& { return MM[(size_t)r + (size_t)N * c2]; };
+      const int dirs[5] = { 0, 1, 2, 1, 2 }; const double sgn[5] = { 1, 1, 1, -1, -1 };
+      for (int a2 = 0; a2 < 5; a2++) {
+        for (int b2 = 0; b2 < 5; b2++) for (int i = 0; i < nc; i++) for (int j = 0; j < nc; j++) {
+          double g = Gs(dirs[a2], dirs[b2], i, j);
+          if (sgn[a2] * sgn[b2] < 0) g = -g;
+          at(a2 * nc + i, b2 * nc + j) = g;
         }
-        for (int i = 0; i < nc; i++) { double acc = 0.0; for (int k = 0; k < nl; k++) acc = acc + CL[a][(size_t)i * nl + k] * l[k]; Cv[a][i] = Cv[a][i] + acc; }
+        for (int i = 0; i < nc; i++) for (int k = 0; k < nl; k++) {      // Cd X L' and its transpose (ICH-QP:411-434)
+          double g = CL[dirs[a2]][(size_t)i * nl + k];
+          if (sgn[a2] < 0) g = -g;
+          at(a2 * nc + i, 5 * nc + k) = g; at(5 * nc + k, a2 * nc + i) = g;
+        }
       }
-      const std::vector<double>* imp2[3] = { &cn, &csv, &ctv };
-      for (int d = 0; d < 3; d++) for (int k = 0; k < nl; k++) { double acc = 0.0; for (int i = 0; i < nc; i++) acc = acc + CL[d][(size_t)i * nl + k] * (*imp2[d])[i]; Lv[k] = Lv[k] + acc; }
-      std::vector<double> t(nl + 1, 0.0);
-      for (int r = 0; r < nl; r++) { double acc = 0.0; for (int k = 0; k < nl; k++) acc = acc + LL[r + (size_t)nl * k] * l[k]; t[r] = acc; }
-      for (int r = 0; r < nl; r++) Lv[r] = Lv[r] + t[r];
+      for (int a2 = 0; a2 < nl; a2++) for (int b2 = 0; b2 < nl; b2++) at(5 * nc + a2, 5 * nc + b2) = LL[a2 + (size_t)nl * b2];
+      for (int i = 0; i < nc; i++) at(i, i) = at(i, i) + m->cp_compliance;                          // ICH-QP:438-440
+      for (int i = 0; i < nc; i++) { qq[i] = Cv[0][i]; qq[nc + i] = Cv[1][i]; qq[2*nc + i] = Cv[2][i]; qq[3*nc + i] = -Cv[1][i]; qq[4*nc + i] = -Cv[2][i]; }
+      for (int k = 0; k < nl; k++) qq[5 * nc + k] = Lv[k];
+      for (int i = 0; i < nc; i++) { for (int c2 = 0; c2 < nvars; c2++) at(nvars + i, c2) = at(i, c2); qq[nvars + i] = Cv[0][i]; }
+      for (int k = 0; k < nl; k++) { for (int c2 = 0; c2 < nvars; c2++) at(nvars + nc + k, c2) = at(5 * nc + k, c2); qq[nvars + nc + k] = Lv[k]; }
+      int row = nvars + nc + nl;
+      for (int i = 0; i < nc; i++) {
+        const double vel = std::sqrt(Cv[1][i] * Cv[1][i] + Cv[2][i] * Cv[2][i]);
+        for (int j = 0; j < kh; j++) {
+          const double theta = (double)j / (kh - 1) * M_PI_2;
+          const double ct = std::cos(theta), st_ = std::sin(theta);
+          at(row, i) = m->cp_mu_coulomb;
+          at(row, nc + i) = -ct; at(row, 3*nc + i) = -ct;
+          at(row, 2*nc + i) = -st_; at(row, 4*nc + i) = -st_;
+          qq[row] = m->cp_mu_viscous * vel;
+          row++;
+        }
+      }
+      for (int r = nvars; r < N; r++) for (int c2 = 0; c2 < nvars; c2++) at(c2, r) = -at(r, c2);
+      // solve_qp_work's chain (ICH-QP:157-233)
+      Vec z; z.d.assign(aux->zbuf, aux->zbuf + aux->zbuf_cap); z.len = (unsigned)aux->zbuf_size;
+      z.resize((unsigned)N);
+      if ((int)z.size() == aux->zlast_size) for (int i = 0; i < N; i++) z[i] = aux->zlast[i];
+      oracle_rand_t rs; std::memcpy(&rs, aux->rng, sizeof(rs));
+      LCP lcp; lcp.rng = &rs;
+      Trace tr; tr.buf = trace ? trace + trace_len : nullptr; tr.cap = trace ? ((trace_cap - trace_len > 0) ? trace_cap - trace_len : 0) : 0;
+      lcp.trace = &tr;
+      unsigned piv = 0;
+      bool ok = lcp.lcp_fast_regularized(N, MM.data(), N, qq.data(), z, -20, 4, -8);
+      piv += lcp.pivots;
+      if (!ok) { z.set_zero(); ok = lcp.lcp_lemke_regularized(N, MM.data(), N, qq.data(), z); piv += lcp.pivots; }
+      trace_len += tr.len;
+      std::memcpy(aux->rng, &rs, sizeof(rs));
+      lcp_account(N, piv);
+      if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; return false; }   // LCPSolverException
+      aux->zlast_size = N;
+      for (int i = 0; i < N; i++) { aux->zlast[i] = z[i]; aux->zbuf[i] = z[i]; }
+      if (aux->zbuf_cap < N) aux->zbuf_cap = N;
+      aux->zbuf_size = nvars;                                          // z repacked to the epd layout = its first N_VARS entries (ICH-QP:236-250)
+      return true;
     };
-    auto minv_of = [&]() {                                           // calc_min_constraint_velocity (ICH:413-424)
-      double mn = A_INF;
-      for (int i = 0; i < nc; i++) mn = (i == 0 || Cv[0][i] < mn) ? Cv[0][i] : mn;
-      if (nl > 0) { double ml = Lv[0]; for (int k = 1; k < nl; k++) ml = (Lv[k] < ml) ? Lv[k] : ml; mn = (ml < mn) ? ml : mn; }
-      return mn;
+    auto from_stacked = [&]() {                                        // update_from_stacked(q, z) (UCPD:218-228)
+      for (int i = 0; i < nc; i++) {
+        cn[i] = aux->zbuf[i];
+        double sv2 = aux->zbuf[nc + i];   sv2 = sv2 - aux->zbuf[3*nc + i]; csv[i] = sv2;
+        double tv2 = aux->zbuf[2*nc + i]; tv2 = tv2 - aux->zbuf[4*nc + i]; ctv[i] = tv2;
+      }
+      for (int k = 0; k < nl; k++) l[k] = aux->zbuf[5 * nc + k];
     };
-    apply(); update_vels();
-    const double minv = minv_of();
-    bool changed = false;                                            // apply_restitution(q) (ICH:497-525)
-    for (int i = 0; i < nc; i++) { cn[i] = cn[i] * m->cp_epsilon; if (!changed && cn[i] > A_NEAR_ZERO) changed = true; }
-    for (int k = 0; k < nl; k++) { l[k] = l[k] * m->limit_restitution[idx[k]]; if (!changed && l[k] > A_NEAR_ZERO) changed = true; }
-    if (changed) {
-      for (int i = 0; i < nc; i++) { csv[i] = 0.0; ctv[i] = 0.0; }
+    if (noslip) {
+      if (!solve_noslip()) return;
       apply(); update_vels();
-      const double minv_plus = minv_of();
-      // ICH:284-291 would re-solve and then read the Drumwright-Shell solver's _z, which this path never sized
-      if (minv_plus < 0.0 && minv_plus < minv - A_NEAR_ZERO) aux->status |= MH_WORLD_UNSUPPORTED;
+      const double minv = minv_of();
+      bool changed = false;                                            // apply_restitution(q) (ICH:497-525)
+      for (int i = 0; i < nc; i++) { cn[i] = cn[i] * m->cp_epsilon; if (!changed && cn[i] > A_NEAR_ZERO) changed = true; }
+      for (int k = 0; k < nl; k++) { l[k] = l[k] * m->limit_restitution[idx[k]]; if (!changed && l[k] > A_NEAR_ZERO) changed = true; }
+      if (changed) {
+        for (int i = 0; i < nc; i++) { csv[i] = 0.0; ctv[i] = 0.0; }
+        apply(); update_vels();
+        const double minv_plus = minv_of();
+        // ICH:284-291 would re-solve and then read the Drumwright-Shell solver's _z, which this path never sized
+        if (minv_plus < 0.0 && minv_plus < minv - A_NEAR_ZERO) aux->status |= MH_WORLD_UNSUPPORTED;
+      }
+    } else {                                                           // apply_model_to_connected_constraints (ICH:530-626)
+      if (!solve_qp()) return;
+      from_stacked(); apply(); update_vels();
+      const double minv = minv_of();
+      bool changed = false;                                            // apply_restitution(q, z) (ICH:470-491): cn and l entries of z only
+      for (int i = 0; i < nc; i++) { aux->zbuf[i] = aux->zbuf[i] * m->cp_epsilon; if (!changed && aux->zbuf[i] > A_NEAR_ZERO) changed = true; }
+      for (int k = 0; k < nl; k++) { double& zl = aux->zbuf[5 * nc + k]; zl = zl * m->limit_restitution[idx[k]]; if (!changed && zl > A_NEAR_ZERO) changed = true; }
+      if (changed) {
+        from_stacked(); apply(); update_vels();                        // the tangential impulses are applied again in full, as the reference does
+        const double minv_plus = minv_of();
+        if (minv_plus < 0.0 && minv_plus < minv - A_NEAR_ZERO) {       // ICH:591-600: second solve on the updated C v vectors
+          if (!solve_qp()) return;
+          from_stacked(); apply();
+        }
+      }
     }
     link_velocities(V);                                              // ICH:157-167
     for (int i = 0; i < nc; i++) if (point_vel_dir(V[cs[i].link], cs[i].p, cs[i].n) < -A_NEAR_ZERO) aux->status |= MH_WORLD_IMPACT_TOL;

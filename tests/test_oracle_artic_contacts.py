@@ -126,14 +126,42 @@ def test_no_slip_contact_holds_the_tip_in_place(oracle):
     assert max(slid[5:]) < 1e-3, max(slid[5:])     # gravity re-accelerates the tangential direction by g dt per step at most
 
 
-def test_finite_friction_on_a_link_contact_is_flagged(oracle):
-    m = tip_model(2, floor=-0.9, mu=0.5)
-    q = np.array([[0.7, -0.2]]); qd = np.zeros((1, 2)); aux = S.new_aux(1)
-    for _ in range(900):                                # one step at a time: a flagged world then burns its mini-step cap every step
+def test_drumwright_shell_model_on_a_link_contact(oracle):
+    """mu_coulomb < 100: the QP -> LCP model with contact variables [cn cs ct ncs nct] (ICH-QP:94-497): n = 6 + nk/2 rows per
+    contact.  Frictionless, the tip slides along the floor after landing; with mu = 0.8 it sticks where it landed; never an
+    approach velocity left, never an energy gain."""
+    ends = {}
+    for mu in (0.0, 0.8):
+        m = tip_model(2, floor=-0.9, mu=mu)
+        q = np.array([[0.7, 0.1]]); qd = np.zeros((1, 2)); aux = S.new_aux(1)
+        e_prev = numpy_H_and_energy(m, q[0], qd[0])[1]; rows = set(); slide = []
+        for step in range(700):
+            b0 = int(aux["lcp_rows"][0]); s0 = int(aux["lcp_solves"][0])
+            oracle.artic_step(m, q, qd, aux, 1e-3, 1)
+            if int(aux["lcp_solves"][0]) - s0 == 1: rows.add(int(aux["lcp_rows"][0]) - b0)
+            e = numpy_H_and_energy(m, q[0], qd[0])[1]
+            assert e < e_prev + 2e-3 * (1 + abs(e_prev)); e_prev = e
+            if tip_height(m, q[0]) < 1e-6 and aux["lcp_solves"][0] > 0:
+                v = tip_velocity(m, q[0], qd[0]); assert v[2] > -1e-6; slide.append(abs(v[0]))
+        assert rows == {8}, rows                                   # 5 + 1 + nk/2 = 8 rows for one contact with a 4-edge cone
+        assert aux["status"][0] & ~S.MH_WORLD_IMPACT_TOL == 0 and aux["zlast_size"][0] == 8 and aux["zbuf_size"][0] == 5
+        ends[mu] = (q.copy(), max(slide[20:]))
+    assert ends[0.0][1] > 0.05 and ends[0.8][1] < 2e-3, (ends[0.0][1], ends[0.8][1])      # slides / sticks
+
+
+def test_drumwright_shell_with_limit_variables(oracle):
+    """contact + limit in the QP: variables [cn cs ct ncs nct l], rows Cn v+ >= 0, L v+ >= 0, friction: n = 8 + 2 = 10"""
+    m = tip_model(2, floor=-0.9, hi=3.0, lo=-0.25, mu=0.5)
+    m.lolimit[0] = -3.0
+    q = np.array([[-0.75, -0.2]]); qd = np.array([[0.0, -1.5]]); aux = S.new_aux(1)
+    rows = set()
+    for step in range(700):
+        b0 = int(aux["lcp_rows"][0]); s0 = int(aux["lcp_solves"][0])
         oracle.artic_step(m, q, qd, aux, 1e-3, 1)
-        if aux["status"][0]:
-            break
-    assert aux["status"][0] & S.MH_WORLD_UNSUPPORTED
+        if int(aux["lcp_solves"][0]) - s0 == 1: rows.add(int(aux["lcp_rows"][0]) - b0)
+        assert q[0, 1] > -0.25 - 4e-3 and tip_height(m, q[0]) > -2e-3
+    assert 10 in rows and 8 in rows and 1 in rows, rows           # limit alone still goes through the no-slip path (n = 1)
+    assert aux["status"][0] & ~S.MH_WORLD_IMPACT_TOL == 0 and np.abs(qd).max() < 1e-6
 
 
 def test_contact_and_limit_rows_in_one_lcp(oracle):
