@@ -30,6 +30,7 @@ constexpr double NEAR_ZERO_ = 1.4901161193847656e-08;
 struct Model {            // mh_artic_model + what the kernel wants precomputed: ancestor masks
   mh_artic_model m;
   unsigned anc[NJ];       // bit j: joint j lies on the path from joint i to the base (i itself included)
+  double fcos[32], fsin[32];   // friction polygon of the Drumwright-Shell model: cos / sin(j / (nk/2 - 1) pi/2) by the HOST's libm (ICH-QP:462-470)
 };
 
 __constant__ Pow10Table c_pow10a;
@@ -574,6 +575,7 @@ struct mh_artic_batch {
   int B, nj, nspheres;
   mh::artic::Model* d_model;
   double* d_q; double* d_qd; mh_world_aux* d_aux;
+  double* d_ws;           // link contacts with the Drumwright-Shell model: _MM + LU workspace, 2 x 64 x 64 doubles per world
 };
 
 extern "C" {
@@ -582,7 +584,7 @@ int mh_artic_batch_destroy(mh_artic_batch* ab)
 {
   if (!ab) return MH_OK;
   (void)hipDeviceSynchronize();
-  void* ps[] = { ab->d_model, ab->d_q, ab->d_qd, ab->d_aux };
+  void* ps[] = { ab->d_model, ab->d_q, ab->d_qd, ab->d_aux, ab->d_ws };
   for (void* p : ps) if (p) (void)hipFree(p);
   delete ab;
   return MH_OK;
@@ -618,6 +620,13 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
     if (!(nn > 0.999999 && nn < 1.000001)) return fail(MH_ERR_INVALID_ARG, "plane_R is not a rotation (its +Y column is the plane normal)");
     if (!(model->min_step_size > 0.0) || !(model->contact_dist_thresh > 0.0)) return fail(MH_ERR_INVALID_ARG, "min_step_size and contact_dist_thresh must be > 0 when spheres are present");
     if (!(model->cp_epsilon >= 0.0) || !(model->cp_mu_coulomb >= 0.0)) return fail(MH_ERR_INVALID_ARG, "contact parameters must be >= 0");
+    if (!(model->cp_mu_coulomb >= 1e2)) {                         // the Drumwright-Shell model's parameters
+      const int nk = model->cp_nk > 0 ? model->cp_nk : 4;
+      if (nk < 4 || nk > 64 || (nk & 1)) return fail(MH_ERR_INVALID_ARG, "cp_nk = %d: friction-cone-edges must be even, in [4, 64]", nk);
+      if (!(model->cp_mu_viscous >= 0.0) || !(model->cp_compliance >= 0.0)) return fail(MH_ERR_INVALID_ARG, "contact parameters must be >= 0");
+      const int kh = nk / 2;
+      for (int j = 0; j < kh; j++) { const double theta = (double)j / (kh - 1) * M_PI_2; hm.fcos[j] = std::cos(theta); hm.fsin[j] = std::sin(theta); }
+    }
   }
   if (mh_device_count() <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
   {
@@ -629,10 +638,12 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
     }
   }
   mh_artic_batch* ab = new mh_artic_batch();
-  ab->B = B; ab->nj = nj; ab->nspheres = model->nspheres; ab->d_model = nullptr; ab->d_q = nullptr; ab->d_qd = nullptr; ab->d_aux = nullptr;
+  ab->B = B; ab->nj = nj; ab->nspheres = model->nspheres; ab->d_model = nullptr; ab->d_q = nullptr; ab->d_qd = nullptr; ab->d_aux = nullptr; ab->d_ws = nullptr;
   const size_t sB = (size_t)B;
   bool ok = hipMalloc((void**)&ab->d_model, sizeof(ar::Model)) == hipSuccess && hipMalloc((void**)&ab->d_q, sB * nj * 8) == hipSuccess
          && hipMalloc((void**)&ab->d_qd, sB * nj * 8) == hipSuccess && hipMalloc((void**)&ab->d_aux, sB * sizeof(mh_world_aux)) == hipSuccess;
+  if (ok && model->nspheres > 0 && !(model->cp_mu_coulomb >= 1e2))
+    ok = hipMalloc((void**)&ab->d_ws, sB * 2 * MH_LCP_MAX_N_WAVE * MH_LCP_MAX_N_WAVE * sizeof(double)) == hipSuccess;
   if (ok) {
     std::vector<mh_world_aux> a(sB);
     mh_world_aux_init(&a[0], 1);
@@ -665,7 +676,7 @@ int mh_artic_batch_step(mh_artic_batch* ab, void* stream, double dt, int nsteps)
   if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
   if (ab->nspheres > 0) {                                     // bodies with collision geometry: the full step with mini-steps and contact rows
     hipLaunchKernelGGL(ar::k_artic_step_contacts, dim3(ab->B), dim3(64), ar::lds_bytes_contacts(ab->nj), (hipStream_t)stream,
-                       (const ar::Model*)ab->d_model, ab->B, dt, nsteps, ab->d_q, ab->d_qd, ab->d_aux);
+                       (const ar::Model*)ab->d_model, ab->B, dt, nsteps, ab->d_q, ab->d_qd, ab->d_aux, ab->d_ws);
     MH_HIP(hipGetLastError());
     return MH_OK;
   }

@@ -73,11 +73,31 @@ def test_two_spheres_on_different_links(oracle):
     assert (aux["lcp_rows"] > aux["lcp_solves"]).any()                  # two contacts at once somewhere
 
 
-def test_finite_friction_is_flagged_and_the_world_frozen(oracle):
-    m = tip_model(2, floor=-0.9, mu=0.5)
-    q0 = np.array([[0.7, -0.2], [0.8, 0.1]]); qd0 = np.zeros((2, 2))
-    aux = run(oracle, m, q0, qd0, nsteps=300, chunks=3)
-    assert (aux["status"] & S.MH_WORLD_UNSUPPORTED != 0).all() and (aux["steps"] < 900).all()
+@pytest.mark.parametrize("mu,nk,eps,compl,visc", [(0.0, 4, 0.0, 0.0, 0.0), (0.5, 4, 0.0, 1e-6, 0.0), (0.8, 8, 0.3, 0.0, 0.05), (5.0, 6, 0.0, 0.0, 0.0)])
+def test_drumwright_shell_model_on_link_contacts(oracle, mu, nk, eps, compl, visc):
+    """mu_coulomb < 100: the QP -> LCP model over [cn cs ct ncs nct l] with friction polygons of nk edges, compliance, viscous
+    friction, restitution (second solve included), warm starts from _zlast -- 3-link arms landing on a floor"""
+    m = A.chain_model(3, lo=-3.0, hi=3.0)
+    A.add_spheres(m, [(2, (0.0, 0.0, -0.5), 0.05), (1, (0.0, 0.0, -0.5), 0.07)], plane_point=(0.0, 0.0, -1.3), epsilon=eps, mu_coulomb=mu,
+                  mu_viscous=visc, compliance=compl, nk=nk)
+    B = 8
+    rng = np.random.default_rng(int(10 * mu) + nk)
+    q0 = np.column_stack([rng.uniform(0.5, 1.0, B), rng.uniform(0.0, 0.4, B), rng.uniform(0.0, 0.4, B)]); qd0 = rng.uniform(-0.5, 0.5, (B, 3))
+    aux = run(oracle, m, q0, qd0, nsteps=150, chunks=5)
+    assert (aux["lcp_solves"] > 0).all() and (aux["zlast_size"] >= 6 + nk // 2).all()
+    assert (aux["status"] & ~(S.MH_WORLD_IMPACT_TOL | S.MH_WORLD_LCP_FAILED) == 0).all(), aux["status"]
+
+
+def test_drumwright_shell_with_limit_variables(oracle):
+    """contact + limit rows in the QP (n = 8 + 2 per limit), lower and upper limits, restitution at the limit"""
+    for lo, hi, sgn, er in ((-0.25, 3.0, -1.0, 0.0), (-3.0, 0.25, 1.0, 0.4)):
+        m = tip_model(2, floor=-0.9, hi=hi, lo=lo, mu=0.5, restitution=er)
+        m.lolimit[0] = -3.0; m.hilimit[0] = 3.0
+        B = 4
+        rng = np.random.default_rng(17)
+        q0 = np.column_stack([sgn * rng.uniform(0.7, 0.8, B), sgn * rng.uniform(0.15, 0.22, B)]); qd0 = np.column_stack([np.zeros(B), sgn * rng.uniform(1.0, 2.0, B)])
+        aux = run(oracle, m, q0, qd0, nsteps=175, chunks=4)
+        assert (aux["zlast_size"] == 10).any() or (aux["zlast_size"] == 8).all()
 
 
 def test_ur10_fingers_on_a_table(oracle):

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 UR10 = os.path.join(HERE, "scenes", "ten_joint_arm.sdf")
-FIELDS = ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "lcp_alg_bytes", "vns_size")
+FIELDS = ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "lcp_alg_bytes", "vns_size", "zlast_size", "zbuf_size", "zbuf_cap")
 
 
 def ur10_states(m, B, seed=0x4D4F4259):
@@ -37,6 +37,8 @@ def assert_parity(ab, oracle, m, q0, qd0, dt, nsteps, chunks):
         for w in range(q0.shape[0]):
             n = int(aux_o["vns_size"][w])
             assert np.array_equal(aux_g["vns"][w, :n], aux_o["vns"][w, :n])
+            n = int(aux_o["zlast_size"][w]); c = int(aux_o["zbuf_cap"][w])
+            assert np.array_equal(aux_g["zlast"][w, :n], aux_o["zlast"][w, :n]) and np.array_equal(aux_g["zbuf"][w, :c], aux_o["zbuf"][w, :c])
     return aux_o
 
 

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 from moby_amd import artic as A, scene as S  # noqa: E402
 from tests.oracle_api import Oracle          # noqa: E402
 
-FIELDS = ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "lcp_alg_bytes", "vns_size")
+FIELDS = ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "lcp_alg_bytes", "vns_size", "zlast_size", "zbuf_size", "zbuf_cap")
 
 
 def rot(rng):
@@ -59,7 +59,8 @@ if __name__ == "__main__":
         nrm = np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), 1.0]); nrm /= np.linalg.norm(nrm)
         low = min(float(nrm @ (P[b, l, 9:12] + P[b, l, :9].reshape(3, 3) @ c)) - r for b in range(B) for (l, c, r) in sph)
         A.add_spheres(m, sph, plane_normal=nrm, plane_point=nrm * (low - float(rng.uniform(0.0, 0.05))), epsilon=float(rng.choice([0.0, 0.0, 0.4])),
-                      mu_coulomb=float(rng.choice([100.0, 100.0, 100.0, 1e4, 0.5])))
+                      mu_coulomb=float(rng.choice([100.0, 100.0, 1e4, 0.5, 0.0, 2.0])), mu_viscous=float(rng.choice([0.0, 0.0, 0.1])),
+                      compliance=float(rng.choice([0.0, 1e-6])), nk=int(rng.choice([4, 4, 6, 8])))
         nsteps = int(rng.integers(100, 400))
         # the oracle first, in chunks: a world that keeps hitting the mini-step cap costs minutes on either side -- skip such a case
         q_o, qd_o, aux_o = q0.copy(), qd0.copy(), S.new_aux(B)
@@ -75,6 +76,8 @@ if __name__ == "__main__":
         same = np.array_equal(q_g, q_o, equal_nan=True) and np.array_equal(qd_g, qd_o, equal_nan=True) and all(np.array_equal(aux_g[f], aux_o[f]) for f in FIELDS)
         for w in range(B):
             k = int(aux_o["vns_size"][w]); same = same and np.array_equal(aux_g["vns"][w, :k], aux_o["vns"][w, :k])
+            k = int(aux_o["zlast_size"][w]); c = int(aux_o["zbuf_cap"][w])
+            same = same and np.array_equal(aux_g["zlast"][w, :k], aux_o["zlast"][w, :k]) and np.array_equal(aux_g["zbuf"][w, :c], aux_o["zbuf"][w, :c])
         solves += int(aux_o["lcp_solves"].sum()); minis += int((aux_o["mini_steps"] - aux_o["steps"]).sum())
         multi += int((aux_o["lcp_rows"] > aux_o["lcp_solves"]).sum()); flagged += int((aux_o["status"] & ~S.MH_WORLD_IMPACT_TOL != 0).sum())
         if not same:
