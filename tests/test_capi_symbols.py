@@ -48,6 +48,23 @@ def test_headers_are_plain_c(tmp_path):
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I" + inc, "-fsyntax-only", "-x", "c++", str(src)])
 
 
+def test_ctypes_mirrors_have_the_c_struct_sizes(tmp_path):
+    """moby_amd/{scene,stack,artic,io}.py mirror the structs of include/*.h by hand: compile a probe that prints sizeof / a few
+    offsets and compare (a stale mirror would shift every field after the first mismatch)."""
+    import subprocess
+    from moby_amd import artic as A, scene as S, stack as K
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "moby_hip.h"\n#include "moby_hip_impact.h"\n#include "moby_hip_stack.h"\n#include "moby_hip_artic.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mh_scene), sizeof(mh_world_aux), sizeof(mh_big_scene), sizeof(mh_artic_model),\n'
+                   '  offsetof(mh_artic_model, nspheres), offsetof(mh_artic_model, plane_R), offsetof(mh_artic_model, cp_nk)); return 0; }\n')
+    exe = str(tmp_path / "sz")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe])
+    got = [int(x) for x in subprocess.check_output([exe]).split()]
+    M = A.mh_artic_model
+    want = [ctypes.sizeof(S.mh_scene), ctypes.sizeof(S.mh_world_aux), ctypes.sizeof(K.mh_big_scene), ctypes.sizeof(M), M.nspheres.offset, M.plane_R.offset, M.cp_nk.offset]
+    assert got == want, (got, want)
+
+
 def test_rand_seed_matches_libc():
     from moby_amd import _lib
     lib = _lib.load()
