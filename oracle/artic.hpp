@@ -400,7 +400,8 @@ class Artic {
     const int n = nc + nl;
     const int nk = (m->cp_nk > 0) ? m->cp_nk : 4, kh = nk / 2;
     const int nvars = 5 * nc + nl, N = nvars + nc + nl + nc * kh;    // ICH-QP:97-112
-    if (noslip ? (n > MH_NOSLIP_MAX) : (N > MH_LCP_MAX_N_WAVE)) { aux->status |= MH_WORLD_UNSUPPORTED; return; }
+    // capacities of the build: the no-slip LCP's warm start _v holds MH_NOSLIP_MAX rows, the wave solver MH_LCP_MAX_N_WAVE, the limit tables MH_NOSLIP_MAX limits
+    if (noslip ? (n > MH_NOSLIP_MAX) : (N > MH_LCP_MAX_N_WAVE || nl > MH_NOSLIP_MAX)) { aux->status |= MH_WORLD_UNSUPPORTED; return; }
     if (m->algorithm == MH_ARTIC_FSAB) crba();                       // get_generalized_inertia (ICH:1600-1607)
     std::vector<double> X(H, H + nj * nj);
     if (!inverse_spd(nj, X.data(), nj)) { aux->status |= MH_WORLD_LCP_FAILED; return; }
