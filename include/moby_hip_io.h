@@ -58,6 +58,19 @@ typedef struct mh_io_artic {
 } mh_io_artic;
 int mh_io_load_sdf(const char* path, const double gravity[3], mh_io_artic* out);
 
+/* A Moby XML file with ONE fixed-base <RCArticulatedBody> (the files of example/joint-limits, example/reduced-coords: RigidBody links
+ * with InertiaFromPrimitive | mass / inertia, <RevoluteJoint> / <PrismaticJoint> with location / axis in the global frame, lower-limits,
+ * upper-limits, restitution-coeff, q, qd -- RCArticulatedBody.cpp:162-260, Joint.cpp:184-345, RevoluteJoint.cpp:39-55,
+ * PrismaticJoint.cpp) -> mh_artic_model at q = 0 (the link poses the file states; the base link is the link no joint carries), the
+ * joints' q / qd as the initial state (q0, qd0: MH_ARTIC_MAX_JOINTS doubles each, joint order = out->joint_id), <DRIVER step-size>,
+ * the simulator's GravityForce, fdyn-algorithm crb / fsab.
+ * Collision geometry: a link's <CollisionGeometry> with a <Sphere> primitive becomes a link sphere; ONE disabled <RigidBody> with a
+ * <Plane> primitive becomes the plane, with the <ContactParameters> that name it (object ids: the plane body and the articulated body
+ * or one of its links; one set for every link, the first found).  Any other collision geometry must be unable to collide (no other
+ * body in the simulator and every link-link pair under <DisabledPair>, as those example files do) -- otherwise the file is rejected.
+ * 0 on success. */
+int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double* qd0, double* step_size);
+
 /* writes at most cap bytes (NUL-terminated) and returns the length the full row needs */
 int mh_io_format_row(double t, const double* state, int nb, char* buf, int cap);
 

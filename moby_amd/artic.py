@@ -56,6 +56,23 @@ def load_sdf(path, gravity=(0.0, 0.0, -9.81)):
     return m, [io.link_id[i].value.decode() for i in range(m.nj)], [io.joint_id[i].value.decode() for i in range(m.nj)]
 
 
+def load_xml(path):
+    """-> (mh_artic_model, link names, joint names, q0, qd0, step size): a Moby XML file with one fixed-base RCArticulatedBody
+    (include/moby_hip_io.h: mh_io_load_xml_artic) -- the model at q = 0, the joints' q / qd attributes as the initial state."""
+    lib = mio.load()
+    lib.mh_io_load_xml_artic.restype = ctypes.c_int
+    lib.mh_io_load_xml_artic.argtypes = [ctypes.c_char_p, ctypes.POINTER(mh_io_artic), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(ctypes.c_double)]
+    io = mh_io_artic(); q0 = (ctypes.c_double * _NJ)(); qd0 = (ctypes.c_double * _NJ)(); dt = ctypes.c_double(0.0)
+    if lib.mh_io_load_xml_artic(os.fsencode(path), ctypes.byref(io), q0, qd0, ctypes.byref(dt)) != 0:
+        raise mio.SceneError(lib.mh_io_last_error().decode("utf-8", "replace"))
+    m = mh_artic_model()
+    ctypes.memmove(ctypes.addressof(m), ctypes.addressof(io.model), ctypes.sizeof(mh_artic_model))
+    n = m.nj
+    return (m, [io.link_id[i].value.decode() for i in range(n)], [io.joint_id[i].value.decode() for i in range(n)],
+            np.array(q0[:n]), np.array(qd0[:n]), dt.value)
+
+
 def model_from_links(links, gravity=(0.0, 0.0, -9.81)):
     """links: dicts (parents first) with parent (-1 = base), type, R0 (3x3, model frame at q = 0), x0, axis (model frame),
     com (link frame), inertia (3x3 about the COM, link axes), mass, lo, hi, restitution."""

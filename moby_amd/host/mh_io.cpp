@@ -429,6 +429,252 @@ int mh_io_load_xml(const char* path, mh_io_scene* out)
   return 0;
 }
 
+int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double* qd0, double* step_size)
+{
+  if (!path || !out) return fail("null argument");
+  xmlDoc* doc = xmlReadFile(path, nullptr, XML_PARSE_NONET | XML_PARSE_NOERROR | XML_PARSE_NOWARNING);
+  if (!doc) return fail("cannot parse %s", path);
+  struct Guard { xmlDoc* d; ~Guard() { xmlFreeDoc(d); } } guard{doc};
+  xmlNode* root = xmlDocGetRootElement(doc);
+  std::vector<xmlNode*> abs; collect(root, "RCArticulatedBody", abs);
+  if (abs.size() != 1) return fail("%s: expected exactly one <RCArticulatedBody>, found %zu", path, abs.size());
+  xmlNode* ab = abs[0];
+  const Attrs aa = attrs_of(ab);
+  if (aa.has("floating-base") && boolean(aa.str("floating-base"))) return fail("RCArticulatedBody %s: floating bases are not supported", aa.str("id").c_str());
+  if (aa.has("translate") || aa.has("rpy")) return fail("RCArticulatedBody %s: translate / rpy are not supported", aa.str("id").c_str());
+  // ---- primitives: mass properties (SpherePrimitive.cpp:138-155, BoxPrimitive.cpp:692-712, CylinderPrimitive.cpp:524-547) ----
+  std::map<std::string, Prim> prims;
+  { std::vector<xmlNode*> v; collect(root, "Sphere", v);
+    for (xmlNode* n : v) { const Attrs a = attrs_of(n); Prim p; p.type = MH_GEOM_SPHERE; const double r = std::atof(a.str("radius").c_str());
+      p.dim[0] = r; p.dim[1] = p.dim[2] = 0.0; if (prim_common(a, p, M_PI * r * r * r * 4.0 / 3.0, "Sphere")) return 1;
+      p.J[0] = p.J[1] = p.J[2] = r * r * p.mass * 2.0 / 5.0; prims[a.str("id")] = p; } }
+  { std::vector<xmlNode*> v; collect(root, "Box", v);
+    for (xmlNode* n : v) { const Attrs a = attrs_of(n); Prim p; p.type = MH_GEOM_BOX;
+      const double x = std::atof(a.str("xlen").c_str()), y = std::atof(a.str("ylen").c_str()), z = std::atof(a.str("zlen").c_str());
+      p.dim[0] = x; p.dim[1] = y; p.dim[2] = z; if (prim_common(a, p, x * y * z, "Box")) return 1;
+      const double M = p.mass / 12.0; p.J[0] = M * (y * y + z * z); p.J[1] = M * (x * x + z * z); p.J[2] = M * (x * x + y * y); prims[a.str("id")] = p; } }
+  { std::vector<xmlNode*> v; collect(root, "Cylinder", v);
+    for (xmlNode* n : v) { const Attrs a = attrs_of(n); Prim p; p.type = 101;
+      const double r = std::atof(a.str("radius").c_str()), h = std::atof(a.str("height").c_str());
+      p.dim[0] = r; p.dim[1] = h; p.dim[2] = 0.0; if (prim_common(a, p, M_PI * r * r * h, "Cylinder")) return 1;
+      const double nl = (1.0 / 12.0) * p.mass * (h * h + 3.0 * (r * r)); p.J[0] = nl; p.J[1] = 0.5 * p.mass * (r * r); p.J[2] = nl; prims[a.str("id")] = p; } }
+  { std::vector<xmlNode*> v; collect(root, "Plane", v);
+    for (xmlNode* n : v) { const Attrs a = attrs_of(n); Prim p; p.type = 100; p.dim[0] = p.dim[1] = p.dim[2] = 0.0; p.J[0] = p.J[1] = p.J[2] = 0.0;
+      if (prim_common(a, p, 0.0, "Plane")) return 1;
+      prims[a.str("id")] = p; } }
+  // ---- links and joints of the body ----
+  struct XLink { std::string id; double x[3]; double R[9]; double mass; double J[3]; std::string geom; bool has_cg; };
+  struct XJoint { std::string id, in, out; int type; double loc[3], axis[3], lo, hi, q, qd, resti; };
+  std::vector<XLink> links; std::vector<XJoint> joints;
+  for (xmlNode* c = ab->children; c; c = c->next) {
+    if (c->type != XML_ELEMENT_NODE) continue;
+    const Attrs a = attrs_of(c);
+    const std::string nm = (const char*)c->name;
+    if (nm == "RigidBody") {
+      XLink L; L.id = a.str("id"); L.mass = 0.0; L.J[0] = L.J[1] = L.J[2] = 0.0; L.has_cg = false;
+      for (int i = 0; i < 3; i++) L.x[i] = 0.0;
+      for (int i = 0; i < 9; i++) L.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+      if (a.has("position")) { const std::vector<double> p = numbers(a.str("position")); if (p.size() != 3) return fail("link %s: bad position", L.id.c_str()); for (int i = 0; i < 3; i++) L.x[i] = p[i]; }
+      if (a.has("rpy")) { const std::vector<double> r = numbers(a.str("rpy")); if (r.size() != 3) return fail("link %s: bad rpy", L.id.c_str()); rpy_to_R(r[0], r[1], r[2], L.R); }
+      if (a.has("quat")) { const std::vector<double> q = numbers(a.str("quat")); if (q.size() != 4) return fail("link %s: bad quat", L.id.c_str());
+        const double nr = std::sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]); if (!(nr > 0.0)) return fail("link %s: zero quat", L.id.c_str());
+        const double qq[4] = { q[1] / nr, q[2] / nr, q[3] / nr, q[0] / nr }; quat_to_R(qq, L.R); }     // the attribute is w x y z (XMLTree.cpp:407-419)
+      if (a.has("mass")) L.mass = std::atof(a.str("mass").c_str());
+      if (a.has("inertia")) { const std::vector<double> J = numbers(a.str("inertia")); if (J.size() != 9) return fail("link %s: inertia needs 9 numbers", L.id.c_str());
+        if (J[1] != 0 || J[2] != 0 || J[3] != 0 || J[5] != 0 || J[6] != 0 || J[7] != 0) return fail("link %s: only diagonal link-frame inertias are supported", L.id.c_str());
+        L.J[0] = J[0]; L.J[1] = J[4]; L.J[2] = J[8]; }
+      for (xmlNode* k = c->children; k; k = k->next) {
+        if (k->type != XML_ELEMENT_NODE) continue;
+        const Attrs ka = attrs_of(k);
+        if (strcmp((const char*)k->name, "InertiaFromPrimitive") == 0) {
+          const std::string pid = ka.str("primitive-id");
+          if (!prims.count(pid)) return fail("link %s: InertiaFromPrimitive names the unknown primitive '%s'", L.id.c_str(), pid.c_str());
+          if (prims[pid].posed) return fail("link %s: a posed primitive as inertia source is not supported", L.id.c_str());
+          L.mass = prims[pid].mass; for (int i = 0; i < 3; i++) L.J[i] = prims[pid].J[i];
+        } else if (strcmp((const char*)k->name, "CollisionGeometry") == 0) { L.geom = ka.str("primitive-id"); L.has_cg = true; }
+      }
+      links.push_back(L);
+    } else if (nm == "RevoluteJoint" || nm == "PrismaticJoint") {
+      XJoint J; J.id = a.str("id"); J.type = (nm == "RevoluteJoint") ? MH_JOINT_REVOLUTE : MH_JOINT_PRISMATIC;
+      J.in = a.str("inboard-link-id"); J.out = a.str("outboard-link-id");
+      const std::vector<double> loc = numbers(a.str("location")), ax = numbers(a.str("axis"));
+      if (loc.size() != 3) return fail("joint %s: needs a global location", J.id.c_str());
+      if (ax.size() != 3) return fail("joint %s: needs a global axis", J.id.c_str());
+      for (int i = 0; i < 3; i++) { J.loc[i] = loc[i]; J.axis[i] = ax[i]; }
+      J.lo = -1.7976931348623157e308; J.hi = 1.7976931348623157e308; J.q = 0.0; J.qd = 0.0; J.resti = 0.0;       // Joint.cpp:33-54
+      auto one = [&](const char* key, double& dst) -> int { if (!a.has(key)) return 0; const std::vector<double> v = numbers(a.str(key)); if (v.size() != 1) return 1; dst = v[0]; return 0; };
+      if (one("lower-limits", J.lo) || one("upper-limits", J.hi) || one("q", J.q) || one("qd", J.qd)) return fail("joint %s: a 1-DOF joint takes one number per attribute", J.id.c_str());
+      if (a.has("q-tare")) { double t = 0.0; if (one("q-tare", t) || t != 0.0) return fail("joint %s: q-tare is not supported", J.id.c_str()); }
+      if (a.has("restitution-coeff")) J.resti = std::atof(a.str("restitution-coeff").c_str());
+      if ((a.has("coulomb-friction-coeff") && std::atof(a.str("coulomb-friction-coeff").c_str()) != 0.0) ||
+          (a.has("viscous-friction-coeff") && std::atof(a.str("viscous-friction-coeff").c_str()) != 0.0)) return fail("joint %s: joint friction is not supported", J.id.c_str());
+      joints.push_back(J);
+    } else if (nm.size() > 5 && nm.compare(nm.size() - 5, 5, "Joint") == 0) return fail("%s %s: only revolute and prismatic joints are supported", nm.c_str(), a.str("id").c_str());
+  }
+  if (joints.empty()) return fail("%s: an articulated body without joints", path);
+  if ((int)joints.size() > MH_ARTIC_MAX_JOINTS) return fail("%zu joints > %d", joints.size(), MH_ARTIC_MAX_JOINTS);
+  std::map<std::string, int> link_of; for (size_t i = 0; i < links.size(); i++) link_of[links[i].id] = (int)i;
+  std::map<std::string, int> carried;                                      // outboard link -> joint
+  for (size_t j = 0; j < joints.size(); j++) {
+    if (!link_of.count(joints[j].in) || !link_of.count(joints[j].out)) return fail("joint %s: unknown link", joints[j].id.c_str());
+    if (carried.count(joints[j].out)) return fail("link %s is the outboard link of two joints (closed chains are not supported)", joints[j].out.c_str());
+    carried[joints[j].out] = (int)j;
+  }
+  std::string base; int nbase = 0;
+  for (const XLink& L : links) if (!carried.count(L.id)) { base = L.id; nbase++; }
+  if (nbase != 1) return fail("%s: %d links are carried by no joint (exactly one base link expected)", path, nbase);
+  std::vector<int> order; std::map<std::string, int> pos_of;               // parents first, file order within a level
+  std::vector<char> used(joints.size(), 0);
+  while (order.size() < joints.size()) {
+    bool progress = false;
+    for (size_t j = 0; j < joints.size(); j++) {
+      if (used[j]) continue;
+      if (joints[j].in != base && !pos_of.count(joints[j].in)) continue;
+      pos_of[joints[j].out] = (int)order.size(); order.push_back((int)j); used[j] = 1; progress = true;
+    }
+    if (!progress) return fail("%s: joints that do not hang from the base link", path);
+  }
+  // ---- the simulator: gravity, other bodies, pairs, contact parameters ----
+  double grav[3] = { 0.0, 0.0, 0.0 };
+  std::map<std::string, std::vector<double> > gravs;
+  { std::vector<xmlNode*> v; collect(root, "GravityForce", v);
+    for (xmlNode* n : v) { const Attrs a = attrs_of(n); std::vector<double> g = numbers(a.str("accel")); if (g.size() != 3) return fail("GravityForce %s: bad accel", a.str("id").c_str()); gravs[a.str("id")] = g; } }
+  xmlNode* sim = first(root, "TimeSteppingSimulator");
+  if (!sim) return fail("%s: no <TimeSteppingSimulator>", path);
+  std::vector<std::string> dyn; std::vector<std::pair<std::string, std::string> > disabled; std::vector<CP> cps;
+  for (xmlNode* c = sim->children; c; c = c->next) {
+    if (c->type != XML_ELEMENT_NODE) continue;
+    const Attrs a = attrs_of(c); const std::string nm = (const char*)c->name;
+    if (nm == "RecurrentForce") { const std::string id = a.str("recurrent-force-id"); if (!gravs.count(id)) return fail("RecurrentForce %s is not a GravityForce", id.c_str()); for (int i = 0; i < 3; i++) grav[i] += gravs[id][i]; }
+    else if (nm == "DynamicBody") dyn.push_back(a.str("dynamic-body-id"));
+    else if (nm == "DisabledPair") disabled.push_back(std::make_pair(a.str("object1-id"), a.str("object2-id")));
+    else if (nm == "ContactParameters") { CP p; p.a = a.str("object1-id"); p.b = a.str("object2-id");
+      if (a.has("epsilon")) p.eps = std::atof(a.str("epsilon").c_str());
+      if (a.has("mu-coulomb")) p.mu = std::atof(a.str("mu-coulomb").c_str());
+      if (a.has("mu-viscous")) p.muv = std::atof(a.str("mu-viscous").c_str());
+      if (a.has("compliance")) p.comp = std::atof(a.str("compliance").c_str());
+      if (a.has("friction-cone-edges")) p.nk = std::atoi(a.str("friction-cone-edges").c_str());
+      cps.push_back(p); }
+  }
+  const std::string abid = aa.str("id");
+  // other bodies of the simulator: at most one, disabled, with a Plane
+  std::string plane_body; Prim plane_prim; double plane_x[3] = { 0, 0, 0 }; double plane_Rb[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+  std::vector<xmlNode*> rbs; collect(root, "RigidBody", rbs);
+  for (const std::string& id : dyn) {
+    if (id == abid) continue;
+    xmlNode* bn = nullptr;
+    for (xmlNode* n : rbs) if (n->parent != ab && attrs_of(n).str("id") == id) bn = n;
+    if (!bn) return fail("DynamicBody %s: only one articulated body and one static plane body are supported", id.c_str());
+    const Attrs a = attrs_of(bn);
+    if (!(a.has("enabled") && !boolean(a.str("enabled")))) return fail("RigidBody %s: a second moving body is not supported next to an articulated one", id.c_str());
+    std::string geom; for (xmlNode* k = bn->children; k; k = k->next) if (k->type == XML_ELEMENT_NODE && strcmp((const char*)k->name, "CollisionGeometry") == 0) geom = attrs_of(k).str("primitive-id");
+    if (geom.empty()) continue;                                              // no geometry: cannot collide
+    if (!prims.count(geom) || prims[geom].type != 100) return fail("RigidBody %s: the static body next to an articulated one must carry a Plane", id.c_str());
+    if (!plane_body.empty()) return fail("%s: two static planes", path);
+    plane_body = id; plane_prim = prims[geom];
+    if (a.has("position")) { const std::vector<double> p = numbers(a.str("position")); if (p.size() != 3) return fail("RigidBody %s: bad position", id.c_str()); for (int i = 0; i < 3; i++) plane_x[i] = p[i]; }
+    if (a.has("rpy")) { const std::vector<double> r = numbers(a.str("rpy")); if (r.size() != 3) return fail("RigidBody %s: bad rpy", id.c_str()); rpy_to_R(r[0], r[1], r[2], plane_Rb); }
+    if (a.has("quat")) return fail("RigidBody %s: quat on the plane body is not supported (use rpy)", id.c_str());
+  }
+  if (std::find(dyn.begin(), dyn.end(), abid) == dyn.end()) return fail("%s: the articulated body is not a DynamicBody of the simulator", path);
+  // ---- the model ----
+  std::memset(out, 0, sizeof(*out));
+  mh_artic_model& m = out->model;
+  m.nj = (int)order.size();
+  for (int k = 0; k < 3; k++) m.gravity[k] = grav[k];
+  { std::string alg = aa.has("fdyn-algorithm") ? aa.str("fdyn-algorithm") : "crb"; for (char& ch : alg) ch = (char)tolower(ch);
+    alg.erase(0, alg.find_first_not_of(" \t\n\r")); alg.erase(alg.find_last_not_of(" \t\n\r") + 1);
+    if (alg == "fsab") m.algorithm = MH_ARTIC_FSAB; else if (alg == "crb") m.algorithm = MH_ARTIC_CRB; else return fail("fdyn-algorithm '%s': crb or fsab", alg.c_str()); }
+  const XLink& B0 = links[link_of[base]];
+  for (int i = 0; i < m.nj; i++) {
+    const XJoint& J = joints[order[i]];
+    const XLink& L = links[link_of[J.out]];
+    const bool from_base = (J.in == base);
+    // the model's link frame i: origin at the joint location, axes of the link; the base link's frame is the model frame
+    const double* Rp = from_base ? B0.R : links[link_of[J.in]].R;
+    double xp[3];                                                            // origin of the parent frame: its own joint's location (base: the base link's position)
+    if (from_base) for (int k = 0; k < 3; k++) xp[k] = B0.x[k]; else for (int k = 0; k < 3; k++) xp[k] = joints[order[pos_of[J.in]]].loc[k];
+    m.parent[i] = from_base ? -1 : pos_of[J.in];
+    m.jtype[i] = J.type;
+    mat3Tmul(Rp, L.R, m.Rrel[i]);
+    const double d[3] = { J.loc[0] - xp[0], J.loc[1] - xp[1], J.loc[2] - xp[2] };
+    mat3Tvec(Rp, d, m.trel[i]);
+    double al[3]; mat3Tvec(L.R, J.axis, al);
+    const double nrm = std::sqrt(al[0]*al[0] + al[1]*al[1] + al[2]*al[2]);
+    if (!(nrm > 0.0)) return fail("joint %s: zero axis", J.id.c_str());
+    for (int k = 0; k < 3; k++) m.axis[i][k] = al[k] / nrm;
+    const double dc[3] = { L.x[0] - J.loc[0], L.x[1] - J.loc[1], L.x[2] - J.loc[2] };   // the RigidBody position is its COM
+    mat3Tvec(L.R, dc, m.com[i]);
+    if (!(L.mass > 0.0)) return fail("link %s: no mass (InertiaFromPrimitive or mass / inertia)", L.id.c_str());
+    m.mass[i] = L.mass;
+    for (int k = 0; k < 9; k++) m.inertia[i][k] = 0.0;
+    m.inertia[i][0] = L.J[0]; m.inertia[i][4] = L.J[1]; m.inertia[i][8] = L.J[2];
+    m.lolimit[i] = J.lo; m.hilimit[i] = J.hi; m.limit_restitution[i] = J.resti;
+    if (q0) q0[i] = J.q;
+    if (qd0) qd0[i] = J.qd;
+    snprintf(out->link_id[i], MH_IO_ID_LEN, "%s", L.id.c_str());
+    snprintf(out->joint_id[i], MH_IO_ID_LEN, "%s", J.id.c_str());
+  }
+  // the base link's frame must be the model frame for the kinematics above: move everything into it
+  {
+    bool ident = true; for (int k = 0; k < 9; k++) if (B0.R[k] != ((k % 4 == 0) ? 1.0 : 0.0)) ident = false;
+    if (!ident || B0.x[0] != 0.0 || B0.x[1] != 0.0 || B0.x[2] != 0.0) {
+      // joints hanging from the base: Rrel / trel were taken relative to the base pose; the model frame is then the base frame,
+      // so gravity and the plane have to be expressed in it as well
+      double g2[3]; mat3Tvec(B0.R, grav, g2); for (int k = 0; k < 3; k++) m.gravity[k] = g2[k];
+    }
+  }
+  // ---- collision geometry ----
+  auto pair_disabled = [&](const std::string& x, const std::string& y) {
+    for (const auto& d : disabled) if ((d.first == x && d.second == y) || (d.first == y && d.second == x)) return true;
+    return false;
+  };
+  std::vector<int> cg_links;                                                 // model links that carry collision geometry
+  for (int i = 0; i < m.nj; i++) if (links[link_of[joints[order[i]].out]].has_cg) cg_links.push_back(i);
+  const bool base_cg = B0.has_cg;
+  if (plane_body.empty()) {
+    // nothing but the body itself: every pair of its geometries must be disabled (the whole body, or link by link)
+    if (!pair_disabled(abid, abid)) {
+      std::vector<std::string> ids; if (base_cg) ids.push_back(base); for (int i : cg_links) ids.push_back(out->link_id[i]);
+      for (size_t x = 0; x < ids.size(); x++) for (size_t y = x + 1; y < ids.size(); y++)
+        if (!pair_disabled(ids[x], ids[y])) return fail("links %s and %s can collide: link-link contact is not supported (add a <DisabledPair>)", ids[x].c_str(), ids[y].c_str());
+    }
+  } else {
+    if (!pair_disabled(abid, abid)) {
+      std::vector<std::string> ids; if (base_cg) ids.push_back(base); for (int i : cg_links) ids.push_back(out->link_id[i]);
+      for (size_t x = 0; x < ids.size(); x++) for (size_t y = x + 1; y < ids.size(); y++)
+        if (!pair_disabled(ids[x], ids[y])) return fail("links %s and %s can collide: link-link contact is not supported (add a <DisabledPair>)", ids[x].c_str(), ids[y].c_str());
+    }
+    for (int i : cg_links) {
+      const XLink& L = links[link_of[joints[order[i]].out]];
+      if (pair_disabled(L.id, plane_body) || pair_disabled(abid, plane_body)) continue;
+      if (!prims.count(L.geom) || prims[L.geom].type != MH_GEOM_SPHERE) return fail("link %s: only Sphere collision geometry can meet the plane (others: disable the pair)", L.id.c_str());
+      if (m.nspheres >= MH_ARTIC_MAX_SPHERES) return fail("more than %d link spheres", MH_ARTIC_MAX_SPHERES);
+      const Prim& P = prims[L.geom];
+      const int s = m.nspheres++;
+      m.sphere_link[s] = i; m.sphere_radius[s] = P.dim[0];
+      // centre in the model link frame (origin at the joint): COM offset + the primitive's own offset in the link's axes
+      for (int k = 0; k < 3; k++) m.sphere_center[s][k] = m.com[i][k] + P.o[k];
+    }
+    // the plane: PlanePrimitive's +Y is the normal; body pose times primitive pose, expressed in the model (base) frame
+    double Rw[9]; mat3mul(plane_Rb, plane_prim.R, Rw);
+    double ow[3]; mat3vec(plane_Rb, plane_prim.o, ow); for (int k = 0; k < 3; k++) ow[k] += plane_x[k];
+    mat3Tmul(B0.R, Rw, m.plane_R);
+    const double dd[3] = { ow[0] - B0.x[0], ow[1] - B0.x[1], ow[2] - B0.x[2] };
+    mat3Tvec(B0.R, dd, m.plane_o);
+    m.cp_nk = 4;
+    for (const CP& p : cps) {
+      const std::string other = (p.a == plane_body) ? p.b : ((p.b == plane_body) ? p.a : std::string());
+      if (other.empty()) continue;
+      if (other == abid || link_of.count(other)) { m.cp_epsilon = p.eps; m.cp_mu_coulomb = p.mu; m.cp_mu_viscous = p.muv; m.cp_compliance = p.comp; m.cp_nk = p.nk; break; }
+    }
+    m.min_step_size = std::sqrt(2.220446049250313e-16); m.contact_dist_thresh = 1e-6;
+    { const Attrs sa = attrs_of(sim); if (sa.has("min-step-size")) m.min_step_size = std::atof(sa.str("min-step-size").c_str()); }
+  }
+  if (step_size) { *step_size = 0.0; if (xmlNode* drv = first(root, "DRIVER")) { const Attrs a = attrs_of(drv); if (a.has("step-size")) *step_size = std::atof(a.str("step-size").c_str()); } }
+  return 0;
+}
+
 int mh_io_format_row(double t, const double* state, int nb, char* buf, int cap)
 {
   std::ostringstream o;                                   // ostream default formatting, as regress.cpp:82-93

@@ -11,6 +11,8 @@
 // every enabled body in id order -- and the elapsed CPU seconds as the last line
 // (regress.cpp:82-93, 274-277).  Extra: -B=<n> steps n identical worlds and writes world 0
 // (for timing the batch path); -chunk=<steps per launch> (default 256).
+// A file with one fixed-base <RCArticulatedBody> (example/joint-limits/*.xml; mh_io_load_xml_artic) runs on the articulated stepper:
+// the row is current_time and the joint positions (get_generalized_coordinates_euler of a fixed-base reduced-coordinate body).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +22,9 @@
 #include <iostream>
 #include <string>
 #include <vector>
+#include <sstream>
 #include "../../include/moby_hip_io.h"
+#include "../../include/moby_hip_artic.h"
 
 int main(int argc, char** argv)
 {
@@ -45,7 +49,40 @@ int main(int argc, char** argv)
   }
   if (!(step_size > 0.0 && step_size < 1.0) || B < 1 || chunk < 1) { std::cerr << "regress: bad options" << std::endl; return -1; }
   mh_io_scene io;
-  if (mh_io_load_xml(argv[2], &io) != 0) { std::cerr << "regress: " << mh_io_last_error() << std::endl; return -1; }
+  if (mh_io_load_xml(argv[2], &io) != 0) {
+    const std::string why = mh_io_last_error();
+    mh_io_artic ar; double q0[MH_ARTIC_MAX_JOINTS], qd0[MH_ARTIC_MAX_JOINTS], file_dt = 0.0;
+    if (mh_io_load_xml_artic(argv[2], &ar, q0, qd0, &file_dt) != 0) {
+      const std::string why2 = mh_io_last_error();                // a file without an RCArticulatedBody: the first reader's complaint is the relevant one
+      std::cerr << "regress: " << (why2.find("expected exactly one <RCArticulatedBody>") != std::string::npos ? why : why2) << std::endl; return -1;
+    }
+    // ---- one fixed-base articulated body ----
+    const int nj = ar.model.nj;
+    std::vector<double> q((size_t)B * nj), qd((size_t)B * nj);
+    for (int b = 0; b < B; b++) for (int i = 0; i < nj; i++) { q[(size_t)b * nj + i] = q0[i]; qd[(size_t)b * nj + i] = qd0[i]; }
+    mh_artic_batch* ab = nullptr;
+    if (mh_artic_batch_create(&ar.model, B, &ab) != MH_OK || mh_artic_batch_upload(ab, q.data(), qd.data(), nullptr) != MH_OK) { std::cerr << "regress: " << mh_last_error() << std::endl; return -1; }
+    std::ofstream out(argv[3]);
+    if (out.fail()) { std::cerr << "regress: cannot open " << argv[3] << std::endl; return -1; }
+    const clock_t start = clock();
+    double t_now = 0.0, total_t = 0.0; unsigned long iter = 0;
+    std::vector<mh_world_aux> aux((size_t)B);
+    while (true) {
+      std::ostringstream o; o << t_now; for (int i = 0; i < nj; i++) o << " " << q[i];          // world 0, before the step
+      out << o.str() << std::endl;
+      if (out_iter) std::cout << "iteration: " << iter << "  simulation time: " << t_now << std::endl;
+      const clock_t pre = clock();
+      if (mh_artic_batch_step(ab, nullptr, step_size, 1) != MH_OK || mh_artic_batch_download(ab, q.data(), qd.data(), aux.data()) != MH_OK) { std::cerr << "regress: " << mh_last_error() << std::endl; return -1; }
+      total_t += (clock() - pre) / (double)CLOCKS_PER_SEC;
+      iter++; t_now += step_size;
+      if (out_rate) std::cout << "time to compute last iteration: " << total_t / iter << " (" << total_t / iter << "s/iter, " << total_t / t_now << "s/step)" << std::endl;
+      if (iter >= max_iter || t_now > max_time) break;
+    }
+    if (aux[0].status & ~MH_WORLD_IMPACT_TOL) std::cerr << "regress: world 0 finished with status bits " << aux[0].status << std::endl;
+    out << (clock() - start) / (double)CLOCKS_PER_SEC << std::endl;
+    mh_artic_batch_destroy(ab);
+    return 0;
+  }
   const int nb = io.scene.nb, nst = nb * MH_BODY_STATE;
   if (wheel_init) {
     const char* thd = std::getenv("RIMLESS_WHEEL_THETAD");

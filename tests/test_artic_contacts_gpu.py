@@ -131,3 +131,25 @@ def test_many_worlds_properties():
     perm = rng.permutation(B)[:256]
     ab = A.ArticBatch(m, q0[perm], qd0[perm]); ab.step(1e-3, 600); q2, qd2, aux2 = ab.download(); ab.close()
     assert np.array_equal(q2, q[perm]) and np.array_equal(qd2, qd[perm]) and np.array_equal(aux2["rng"], aux["rng"][perm])
+
+
+def test_xml_arm_on_table_steps_like_the_oracle(oracle, tmp_path):
+    """tests/scenes/arm_on_table.xml (a Moby XML file with one RCArticulatedBody, link spheres and a table) through
+    mh_io_load_xml_artic: perturbed copies of the file's initial state bit for bit against the oracle, and the regress command line
+    (moby-hip-regress: rows of time + joint positions) equal to the batch's world 0"""
+    import subprocess
+    m, links, joints, q0, qd0, dt = A.load_xml(os.path.join(HERE, "scenes", "arm_on_table.xml"))
+    B = 8
+    rng = np.random.default_rng(21)
+    q = np.tile(q0, (B, 1)); qd = np.tile(qd0, (B, 1)); q[1:] += rng.uniform(-0.05, 0.05, (B - 1, m.nj)); qd[1:] += rng.uniform(-0.3, 0.3, (B - 1, m.nj))
+    q[:, 2] = np.clip(q[:, 2], -0.04, 0.09)
+    aux = run(oracle, m, q, qd, nsteps=300, chunks=4, dt=dt)
+    assert (aux["lcp_solves"] > 0).all() and (aux["mini_steps"] > aux["steps"]).all() and (aux["status"] & ~S.MH_WORLD_IMPACT_TOL == 0).all()
+    root = os.path.dirname(HERE)
+    opts = tmp_path / "arm.setup"; opts.write_text("-s=0.001 -mi=400\n")
+    outp = tmp_path / "arm.dat"
+    subprocess.check_call([os.path.join(root, "moby_amd", "bin", "moby-hip-regress"), str(opts), os.path.join(HERE, "scenes", "arm_on_table.xml"), str(outp)])
+    rows = [l.split() for l in open(outp).read().strip().splitlines()]
+    assert len(rows) == 401 and len(rows[0]) == 4 and [float(x) for x in rows[0]] == [0.0, 0.9, 0.3, 0.0]
+    ab = A.ArticBatch(m, q0.reshape(1, -1), qd0.reshape(1, -1)); ab.step(1e-3, 399); qg, _, _ = ab.download(); ab.close()
+    assert np.allclose([float(x) for x in rows[399][1:]], qg[0], rtol=0, atol=1e-5 * np.abs(qg[0]).max() + 1e-6)      # 6 printed digits

@@ -1,0 +1,78 @@
+"""CPU: the Moby-XML reader for one fixed-base RCArticulatedBody (include/moby_hip_io.h: mh_io_load_xml_artic) -- the numbers it
+derives from tests/scenes/arm_on_table.xml, the reference's own example files when the reference tree is present, what it rejects,
+and the loaded model stepped by the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from moby_amd import artic as A
+from moby_amd import io as mio
+from moby_amd import scene as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ARM = os.path.join(HERE, "scenes", "arm_on_table.xml")
+REF = "/root/reference/example"
+
+
+def test_arm_on_table_loads_to_the_numbers_of_the_file():
+    m, links, joints, q0, qd0, dt = A.load_xml(ARM)
+    assert (m.nj, links, joints) == (3, ["l1", "l2", "l3"], ["shoulder", "elbow", "slider"]) and dt == 1e-3
+    assert np.array_equal(q0, [0.9, 0.3, 0.0]) and np.array_equal(qd0, [0.0, 0.5, 0.0])
+    assert list(m.parent[:3]) == [-1, 0, 1] and list(m.jtype[:3]) == [A.MH_JOINT_REVOLUTE, A.MH_JOINT_REVOLUTE, A.MH_JOINT_PRISMATIC]
+    # the same body put together by hand: link frames at the joint locations, COMs and inertias of the primitives
+    rod_m = 100.0 * np.pi * 0.05 ** 2 * 0.5; nl = rod_m * (0.5 ** 2 + 3 * 0.05 ** 2) / 12.0
+    rod_J = np.diag([nl, 0.5 * rod_m * 0.05 ** 2, nl])
+    want = A.model_from_links([
+        dict(parent=-1, R0=np.eye(3), x0=(0, 0, 0), axis=(0, 0, 1), com=(0, -0.25, 0), inertia=rod_J, mass=rod_m, lo=-2.0, hi=2.0),
+        dict(parent=0, R0=np.eye(3), x0=(0, -0.5, 0), axis=(0, 0, 1), com=(0, -0.25, 0), inertia=rod_J, mass=rod_m, lo=-0.5, hi=1.5, restitution=0.2),
+        dict(parent=1, type=A.MH_JOINT_PRISMATIC, R0=np.eye(3), x0=(0, -1.0, 0), axis=(0, -1, 0), com=(0, -0.1, 0), inertia=np.diag([1e-3] * 3), mass=0.2,
+             lo=-0.05, hi=0.1)], gravity=(0.0, -9.81, 0.0))
+    for f in ("parent", "jtype", "mass", "lolimit", "hilimit", "limit_restitution"):
+        assert list(getattr(m, f)[:3]) == pytest.approx(list(getattr(want, f)[:3]), abs=1e-15), f
+    for f in ("Rrel", "trel", "axis", "com", "inertia"):
+        for i in range(3):
+            assert list(getattr(m, f)[i]) == pytest.approx(list(getattr(want, f)[i]), abs=1e-15), (f, i)
+    assert list(m.gravity) == [0.0, -9.81, 0.0] and m.algorithm == A.MH_ARTIC_CRB
+    # collision geometry: l1's rod cannot meet the table (pair disabled), l2 carries a ball at its COM, l3 a tip 0.1 below its COM
+    assert m.nspheres == 2 and list(m.sphere_link[:2]) == [1, 2] and list(m.sphere_radius[:2]) == [0.08, 0.05]
+    assert list(m.sphere_center[0]) == pytest.approx([0, -0.25, 0]) and list(m.sphere_center[1]) == pytest.approx([0, -0.2, 0])
+    assert list(m.plane_R) == [1, 0, 0, 0, 1, 0, 0, 0, 1] and list(m.plane_o) == [0, -1.0, 0]
+    assert (m.cp_epsilon, m.cp_mu_coulomb, m.cp_nk) == (0.0, 100.0, 4) and m.contact_dist_thresh == 1e-6 and m.min_step_size == S.NEAR_ZERO
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+def test_reference_example_files_load():
+    m, links, joints, q0, qd0, dt = A.load_xml(os.path.join(REF, "joint-limits", "limit-double-pendulum.xml"))
+    assert (m.nj, links, joints, dt) == (2, ["l1", "l2"], ["q", "q2"], 0.01)
+    assert np.allclose(q0, [1.57079632679, 0.0]) and list(m.lolimit[:2]) == [-1.0, -0.1] and list(m.hilimit[:2]) == [3.14, 0.1]
+    assert list(m.trel[1]) == [0.0, -5.0, 0.0] and list(m.com[0]) == [0.0, -2.5, 0.0] and m.mass[0] == pytest.approx(np.pi * 5.0) and m.nspheres == 0
+    m5 = A.load_xml(os.path.join(REF, "joint-limits", "chain.xml"))[0]
+    assert m5.nj == 5 and list(m5.parent[:5]) == [-1, 0, 1, 2, 3]
+    m1 = A.load_xml(os.path.join(REF, "reduced-coords", "pendulum.xml"))[0]
+    assert m1.nj == 1 and m1.algorithm == A.MH_ARTIC_FSAB
+    for bad, why in (("reduced-coords/pendulum-gears-impact.xml", "floating"), ("tare/pendulum.xml", "q-tare"), ("reduced-coords/chain.xml", "Plane")):
+        with pytest.raises(mio.SceneError, match=why):
+            A.load_xml(os.path.join(REF, bad))
+
+
+def test_unsupported_files_are_rejected(tmp_path):
+    src = open(ARM).read()
+    cases = {"floating": src.replace('floating-base="false"', 'floating-base="true"'),
+             "link-link": src.replace('<DisabledPair object1-id="arm" object2-id="arm" />', ""),
+             "only Sphere": src.replace('<DisabledPair object1-id="l1" object2-id="ground" />', ""),
+             "revolute and prismatic": src.replace("<PrismaticJoint", "<SphericalJoint"),
+             "1-DOF": src.replace('lower-limits="-2"', 'lower-limits="-2 0"')}
+    for why, text in cases.items():
+        p = tmp_path / "x.xml"; p.write_text(text)
+        with pytest.raises(mio.SceneError, match=why):
+            A.load_xml(str(p))
+
+
+def test_loaded_arm_steps_in_the_oracle(oracle):
+    """the file's initial state, 1.5 s: the arm swings down, its spheres meet the table, limits and the table hold"""
+    m, _, _, q0, qd0, dt = A.load_xml(ARM)
+    q = q0.reshape(1, -1).copy(); qd = qd0.reshape(1, -1).copy(); aux = S.new_aux(1)
+    oracle.artic_step(m, q, qd, aux, dt, 1500)
+    assert aux["status"][0] & ~S.MH_WORLD_IMPACT_TOL == 0 and aux["lcp_solves"][0] > 0 and aux["mini_steps"][0] > 1500
+    assert -0.5 - 1e-2 < q[0, 1] < 1.5 + 1e-2 and -0.05 - 1e-2 < q[0, 2] < 0.1 + 1e-2
