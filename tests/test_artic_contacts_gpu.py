@@ -153,3 +153,26 @@ def test_xml_arm_on_table_steps_like_the_oracle(oracle, tmp_path):
     assert len(rows) == 401 and len(rows[0]) == 4 and [float(x) for x in rows[0]] == [0.0, 0.9, 0.3, 0.0]
     ab = A.ArticBatch(m, q0.reshape(1, -1), qd0.reshape(1, -1)); ab.step(1e-3, 399); qg, _, _ = ab.download(); ab.close()
     assert np.allclose([float(x) for x in rows[399][1:]], qg[0], rtol=0, atol=1e-5 * np.abs(qg[0]).max() + 1e-6)      # 6 printed digits
+
+
+@pytest.mark.parametrize("mu,nk,want_flag", [(100.0, 4, False), (0.5, 4, False), (0.5, 16, False), (0.5, 20, True), (0.0, 64, True)])
+def test_capacity_edges_four_contacts_and_limits(oracle, mu, nk, want_flag):
+    """all MH_ARTIC_MAX_SPHERES spheres of one link land together while a second joint sits on its limit: the no-slip LCP has
+    4 + 1 rows, the Drumwright-Shell LCP 24 + 2 nk + 2 rows -- 34 (nk 4), 58 (nk 16), beyond the 64-row wave solver from nk 20 on:
+    flagged MH_WORLD_UNSUPPORTED and frozen, identically on both sides"""
+    I = np.diag([0.05, 0.05, 0.05])
+    links = [dict(parent=-1, type=A.MH_JOINT_PRISMATIC, R0=np.eye(3), x0=(0, 0, 0), axis=(0, 0, 1), com=(0, 0, 0), inertia=I, mass=2.0),
+             dict(parent=0, type=A.MH_JOINT_REVOLUTE, R0=np.eye(3), x0=(0, 0, 0.3), axis=(0, 1, 0), com=(0, 0, 0.1), inertia=I, mass=0.5, lo=-0.2, hi=0.2)]
+    m = A.model_from_links(links)
+    A.add_spheres(m, [(0, (0.3, 0.2, 0.0), 0.1), (0, (-0.3, 0.2, 0.0), 0.1), (0, (0.3, -0.2, 0.0), 0.1), (0, (-0.3, -0.2, 0.0), 0.1)],
+                  plane_point=(0.0, 0.0, -0.1), epsilon=0.0, mu_coulomb=mu, nk=nk)
+    B = 4
+    q0 = np.column_stack([np.array([0.02, 0.01, 0.005, 0.03]), np.full(B, -0.2)]); qd0 = np.column_stack([np.zeros(B), np.array([-0.5, -1.0, -0.2, -0.8])])
+    aux = run(oracle, m, q0, qd0, nsteps=60, chunks=3)
+    flagged = (aux["status"] & S.MH_WORLD_UNSUPPORTED) != 0
+    assert flagged.all() if want_flag else not flagged.any(), aux["status"]
+    if not want_flag:
+        n_full = 5 if mu >= 100 else 24 + 2 * nk + 2
+        assert (aux["lcp_rows"] >= n_full).all() and (aux["steps"] == 180).all()
+    else:
+        assert (aux["steps"] < 180).all()
