@@ -1,8 +1,10 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
 //
 // CPU restatement of one Moby world that holds ONE fixed-base RCArticulatedBody with 1-DOF joints (BASELINE config 5,
-// example/ur10): TimeSteppingSimulator::step -> forward dynamics (CRB algorithm) -> joint-limit constraints -> the
-// impact handler's no-slip path with NC = 0.
+// example/ur10): TimeSteppingSimulator::step -> forward dynamics (CRB or articulated-body algorithm) -> joint-limit constraints ->
+// the impact handler's no-slip path with NC = 0; and, when links carry sphere primitives (mh_artic_model.nspheres), the full step:
+// conservative advancement, mini-steps, contact rows through calc_jacobian, the no-slip model or the Drumwright-Shell QP over
+// contact AND limit rows (handle_impacts / do_mini_step below).
 //
 // PARITY UNPINNED for the dynamics: Ravelin::RCArticulatedBodyd (calc_fwd_dyn, get_generalized_inertia) is not in the
 // reference tree and no reference artefact holds an articulated trajectory of a scene this build covers
