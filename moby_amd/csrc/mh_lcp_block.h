@@ -638,9 +638,12 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
     sync();
     bp_tock(BP_GATHER, tq);
     if (lu_solve(n, W.A, W.d) != 0) return false;                   // singular basis (:840-850), size stays 2n
-    double th = inf(); int any = 0;
-    for (int p = t; p < n; p += T) { const double dp = W.d[p]; if (dp > PIV_TOL) { any = 1; const double r = (W.x[p] + zero_tol) / dp; th = (r < th) ? r : th; } }
+    double th = inf(); int any = 0, cand0 = 0x7fffffff;
+    for (int p = t; p < n; p += T) { const double dp = W.d[p]; if (dp > PIV_TOL) { any = 1; if (p < cand0) cand0 = p; const double r = (W.x[p] + zero_tol) / dp; th = (r < th) ? r : th; } }
     if (red_sum_int(any) == 0) return false;                        // ray termination (:892-903)
+    // theta = *std::min_element(ratios) (LCP.cpp:920): NaN ratios are skipped by the scan unless the FIRST candidate's is one --
+    // it then stays the "minimum" and the set below comes out empty (:946-958)
+    { double dm; int c0; red_min_first(0.0, cand0, dm, c0); const double r0 = (W.x[c0] + zero_tol) / W.d[c0]; if (r0 != r0) { zsize = n; return false; } }
     const double theta = red_min(th);
     int first_keep = 0x7fffffff, tkeep = 0x7fffffff;
     for (int p = t; p < n; p += T) {

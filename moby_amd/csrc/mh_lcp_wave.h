@@ -567,7 +567,11 @@ MH_DEV bool lcp_lemke_wave(int n, const MatT& M, double lam, LuScratch S, double
     const uint64_t jm = ballot(valid && d > PIV_TOL);
     if (jm == 0ull) return false;                              // ray termination (:892-903)
     const bool inj = (jm >> lane) & 1ull;
-    const double theta = wave_min(inj ? (x + zero_tol) / d : INF);
+    // theta = *std::min_element(ratios) (LCP.cpp:920): a NaN ratio is skipped by the scan unless it is the FIRST candidate's, which
+    // then stays the "minimum" and empties the set below -- a degenerate basis late in a regularised attempt does produce that
+    const double rat = inj ? (x + zero_tol) / d : INF;
+    { const double r0 = read_lane(rat, ctz(jm)); if (r0 != r0) { zsize = n; return false; } }
+    const double theta = wave_min(rat);
     const uint64_t keep = ballot(inj && (x / d <= theta));
     if (keep == 0ull) { zsize = n; return false; }            // (:946-958)
     const uint64_t tm = ballot(valid && bv == t);

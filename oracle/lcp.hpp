@@ -46,6 +46,7 @@ static unsigned long long g_lu_hist[130] = {0};   // diagnostic: LU sizes (lcp_f
 
 
 // Ravelin::VectorNd stand-in: contents survive a shrinking resize.
+static int g_lemke_exit = 0;   // diagnostic: why the last failing lcp_lemke gave up (1000 + LAPACK info: singular basis; 2: ray; 3: empty ratio set)
 struct Vec {
   std::vector<double> d; // capacity storage
   unsigned len = 0;
@@ -326,10 +327,10 @@ class LCP {
       _dl = _Be;
       _Al = _Bl;
       g_lu_hist[65 + (n < 65 ? n : 64)]++;                                     // diagnostic
-      if (lu_solve(n, _Al.data(), n, _dl.data()) != 0) return false; // z keeps size 2n (:840-850)
+      { const int info = lu_solve(n, _Al.data(), n, _dl.data()); if (info != 0) { g_lemke_exit = 1000 + info; return false; } } // z keeps size 2n (:840-850)
       _j.clear();
       for (unsigned i = 0; i < n; i++) if (_dl[i] > PIV_TOL) _j.push_back(i);
-      if (_j.empty()) return false;                                   // ray termination, size 2n (:892-903)
+      if (_j.empty()) { g_lemke_exit = 2; return false; }             // ray termination, size 2n (:892-903)
       // min ratio with zero_tol slack (:915-924)
       double theta = std::numeric_limits<double>::max();
       bool first = true;
@@ -338,7 +339,7 @@ class LCP {
       _jkeep.clear();
       for (unsigned jj : _j) if (_x[jj] / _dl[jj] <= theta) _jkeep.push_back(jj);
       _j.swap(_jkeep);
-      if (_j.empty()) { z.resize(n, true); return false; }             // (:946-958)
+      if (_j.empty()) { g_lemke_exit = 3; z.resize(n, true); return false; }   // (:946-958)
       // artificial variable among candidates? (:961-975)
       bool has_t = false;
       for (unsigned jj : _j) if (_bas[jj] == t) has_t = true;

@@ -118,6 +118,9 @@ double oracle_world_step(const mh_scene* sc, double dt, int nsteps, double* stat
 }
 
 unsigned long long oracle_dbg_ca_iters(void) { return g_ca_iters; }
+int oracle_dbg_lemke_exit(void) { return g_lemke_exit; }
+// diagnostic: write every impact LCP solve_impact_lcp sees (inputs, rand() state, pivot counts) to `path`; NULL stops
+void oracle_dbg_lcp_dump(const char* path) { if (g_lcp_dump) { std::fclose(g_lcp_dump); g_lcp_dump = nullptr; } if (path) g_lcp_dump = std::fopen(path, "wb"); }
 void oracle_dbg_lu_hist(unsigned long long* out) { for (int i = 0; i < 130; i++) out[i] = g_lu_hist[i]; }
 
 // B worlds sequentially on one thread (CPU baseline); returns elapsed seconds

@@ -70,6 +70,7 @@ struct PairDist { int pair, a, b; double dist; V3 pa, pb; };  // PairwiseDistInf
 static int g_impact_model = MH_IMPACT_MODEL_DS;   // what the next World is built with: the reference's USE_AP build option
 static inline int oracle_impact_model() { return g_impact_model; }
 static const double BILATERAL_EPS = 1e-6;          // ConstraintStabilization::bilateral_eps (CStab:62)
+static FILE* g_lcp_dump = nullptr;         // diagnostic (oracle_dbg_lcp_dump): every impact LCP of solve_impact_lcp with its inputs and pivot counts
 static unsigned long long g_ca_iters = 0;   // diagnostic: conservative-advancement sub-steps taken
 
 // What the stepper reads of a scene: the members of mh_scene under the same names, as pointers, so that scenes of any
@@ -984,16 +985,24 @@ class World {
     Trace tr; tr.buf = trace ? trace + trace_len : nullptr; tr.cap = trace ? trace_cap - trace_len : 0; if (tr.cap < 0) tr.cap = 0;
     lcp.trace = &tr;
     unsigned piv = 0;
+    std::vector<double> z_in(z.d.begin(), z.d.begin() + n); oracle_rand_t rs_in = rs;
     bool ok = lcp.lcp_fast_regularized(n, MM.data(), n, qq.data(), z, -20, 4, -8);
     piv += lcp.pivots;
+    const unsigned piv_fast = lcp.pivots; const bool ok_fast = ok; unsigned piv_lemke = 0;
     if (!ok) {
       z.set_zero();                                          // ICH-QP:222
       ok = lcp.lcp_lemke_regularized(n, MM.data(), n, qq.data(), z);
-      piv += lcp.pivots;
+      piv += lcp.pivots; piv_lemke = lcp.pivots;
     }
     trace_len += tr.len;
     std::memcpy(aux->rng, &rs, sizeof(rs));
     lcp_account(n, piv);
+    if (g_lcp_dump) {                                        // int n, ok_fast, piv_fast, piv_lemke, ok; rng (32 words); MM, qq, z_in
+      const int hdr[5] = { n, ok_fast ? 1 : 0, (int)piv_fast, (int)piv_lemke, ok ? 1 : 0 };
+      std::fwrite(hdr, sizeof(int), 5, g_lcp_dump); std::fwrite(&rs_in, sizeof(rs_in), 1, g_lcp_dump);
+      std::fwrite(MM.data(), 8, (size_t)n * n, g_lcp_dump); std::fwrite(qq.data(), 8, n, g_lcp_dump); std::fwrite(z_in.data(), 8, n, g_lcp_dump);
+      std::fflush(g_lcp_dump);
+    }
     if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; return false; }   // LCPSolverException
     // _zlast = z (ICH-QP:233)
     aux->zlast_size = n;

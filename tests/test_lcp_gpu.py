@@ -1,8 +1,11 @@
 """GPU parity: the HIP LCP solvers (through the C ABI) against the CPU oracle,
 bit-exact on status / pivots / pivot trace / rand() state / z."""
+import os
+
 import numpy as np
 import pytest
 
+from moby_amd import lcp as L
 from moby_amd import synth
 from moby_amd.lcp import LCP
 from tests.oracle_api import FAST, FAST_REG, LEMKE, LEMKE_REG, DEFAULT_EXPS
@@ -242,3 +245,22 @@ def test_block_solver_both_thread_geometries(oracle, geometry, kind, n, fam):
         assert_parity(oracle, kind, M, q, z_size=np.zeros(B, dtype=np.int32))
     finally:
         _lib.check(lib.mh_debug_set(2, 0))
+
+
+def test_nan_ratio_in_the_lemke_ladder_ends_the_attempt_like_min_element(oracle):
+    """tests/golden/lemke_ladder_n96_case.npz (an impact LCP of two box stacks with compliance, found by tests/tools/fuzz_big.py): on
+    the rung lambda = 1e-13 the ratio of the FIRST candidate turns NaN after 453 pivots; std::min_element (LCP.cpp:920) keeps a NaN
+    that comes first, the candidate set empties and the attempt fails there (:946-958) -- a NaN-ignoring minimum would pivot on.
+    Block solver (n = 96): status, pivot counts, the whole pivot trace and z against the oracle, for the ladder and for that rung."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lemke_ladder_n96_case.npz"))
+    MM, qq, rng = d["MM"], d["qq"], d["rng"]; n = len(qq)
+    lam = MM.copy(); lam[np.arange(n), np.arange(n)] += 10.0 ** -13
+    for kind, M, exps in ((LEMKE_REG, MM, None), (LEMKE, lam, None)):
+        ro = oracle.lcp(kind, M, qq, z=np.zeros(n), z_size=n, rng=rng, exps=exps, trace_cap=8192)
+        g = L.LCP(1); g.rng[0] = rng; z = np.zeros((1, n))
+        ok = g._solve(kind, M, qq, z, DEFAULT_EXPS[kind] if kind == LEMKE_REG else None, z_size=np.array([n], dtype=np.int32), trace_cap=8192)
+        assert bool(ok[0]) == ro["ok"] and int(g.pivots[0]) == ro["pivots"], (kind, ok, g.pivots, ro["pivots"])
+        assert int(g.trace_len[0]) == ro["trace_len"] and np.array_equal(g.trace[0][:len(ro["trace"])], ro["trace"])
+        if ro["ok"]:
+            assert np.array_equal(z[0], ro["z"])
+    assert ro["ok"] is False and ro["pivots"] == 453          # the rung alone: gives up at the NaN

@@ -150,3 +150,17 @@ def test_fast_singular_falls_to_ladder(oracle):
     # first ladder rung (lambda = 1e-20): z0 = 1/lambda
     assert r["ok"] and r["trace_len"] > 1
     np.testing.assert_allclose(r["z"], [1e20, 1.0], rtol=1e-15)
+
+
+def test_lemke_keeps_a_nan_ratio_that_comes_first(oracle):
+    """LCP.cpp:920 takes theta = *std::min_element(ratios): a NaN that comes FIRST stays the minimum, every `ratio <= theta` test is
+    then false and the attempt fails with an empty candidate set (:946-958).  tests/golden/lemke_ladder_n96_case.npz reaches that
+    state on the rung lambda = 1e-13 after 453 pivots (the whole ladder: 1518 pivots, solved on a later rung)."""
+    import ctypes, os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lemke_ladder_n96_case.npz"))
+    MM, qq, rng = d["MM"], d["qq"], d["rng"]; n = len(qq)
+    lam = MM.copy(); lam[np.arange(n), np.arange(n)] += 10.0 ** -13
+    r = oracle.lcp(LEMKE, lam, qq, z=np.zeros(n), z_size=n, rng=rng)
+    assert r["ok"] is False and r["pivots"] == 453 and oracle.lib.oracle_dbg_lemke_exit() == 3
+    full = oracle.lcp(LEMKE_REG, MM, qq, z=np.zeros(n), z_size=n, rng=rng, trace_cap=8192)
+    assert full["ok"] and full["pivots"] == 1518
