@@ -37,7 +37,6 @@ while off < len(raw):
         # where do the pivot traces part?  (per attempt: 0x40000000 | attempt, then entering / leaving ids per pivot)
         from tests.oracle_api import LEMKE_REG
         cap_t = 200000
-        rng_l = g2_rng if False else None
         ro = o.lcp(LEMKE_REG, MM, qq, z=np.zeros(n), z_size=n, rng=rng_after_fast, trace_cap=cap_t)
         g3 = L.LCP(1); g3.rng[0] = rng_after_fast; z3 = np.zeros((1, n))
         g3._solve(L.MH_LCP_LEMKE_REG, MM, qq, z3, (-20, 1, 1), z_size=np.array([n], dtype=np.int32), trace_cap=cap_t)
