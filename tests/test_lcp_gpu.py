@@ -189,9 +189,10 @@ def test_block_solver_lists_beyond_the_lds_caps(oracle):
     assert ok[0]
 
 
-@pytest.mark.parametrize("n", [1024, 2048])
+@pytest.mark.parametrize("n", [1024, 2048, 4096])
 def test_block_solver_config4_sizes_properties(n):
-    """The sizes BASELINE config 4 rests on (n = 1024: 32-box stacks, n = 2048: 64-box stacks), beyond what the oracle
+    """The sizes BASELINE config 4 rests on (n = 1024: 32-box stacks, n = 2048: 64-box stacks) and the entry's advertised maximum
+    (MH_LCP_MAX_N_BLOCK = 4096), beyond what the oracle
     finishes in seconds: the LCP conditions on every accepted solution, the known solution recovered, identical
     problems giving identical answers (batch-order independence), for lcp_fast (warm) and lcp_lemke (cold)."""
     B = 2
