@@ -136,6 +136,8 @@ def cpu_baseline(B, steps, warmup):
                             "world_steps_per_sec": sum(r[1] for r in res) / wall,
                             "sample": "%d processes (usable CPUs of %d hardware threads) x %d worlds x %d steps x %d passes, wall clock incl. process start"
                                       % (ncores, os.cpu_count() or 1, per, ns, jobs[0][3])}
+    # for context only (SURVEY 8d iii): the timing footer of the reference's own recording of this scene, ONE world, unknown hardware
+    out["reference_recording"] = {"world_steps_per_sec": 1000.0 / 0.408651, "source": "regress/sphere-stack.dat:1001 (0.408651 s per 1000 steps)"}
     return out
 
 
