@@ -12,11 +12,6 @@
 // and the limit LCP share one region: 10 KB at 10 joints => 16 worlds per CU); HBM sees q, qd and the aux record once per launch.
 // The dynamics algorithm is Featherstone's (Ravelin's source is not in the reference tree: SURVEY F2); operation
 // order = oracle/artic.hpp, checked bit for bit.  sin / cos: the same explicit kernel as the oracle (no libm call).
-// wave_sync() as a wavefront-scope fence pair instead of __syncthreads(): the latter also waits for every outstanding VMEM operation
-// (vmcnt(0)) -- at ~250 sync points per step that serialises the scratch traffic of the 128-VGPR build (measured below)
-#ifndef MH_ARTIC_SYNC_BARRIER
-#define MH_WAVE_SYNC_FENCE 1
-#endif
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdlib>

@@ -607,9 +607,17 @@ class Artic {
       Trace tr; tr.buf = trace ? trace + trace_len : nullptr; tr.cap = trace ? ((trace_cap - trace_len > 0) ? trace_cap - trace_len : 0) : 0;
       lcp.trace = &tr;
       unsigned piv = 0;
+      std::vector<double> z_in(z.d.begin(), z.d.begin() + N); const oracle_rand_t rs_in = rs;
       bool ok = lcp.lcp_fast_regularized(N, MM.data(), N, qq.data(), z, -20, 4, -8);
       piv += lcp.pivots;
-      if (!ok) { z.set_zero(); ok = lcp.lcp_lemke_regularized(N, MM.data(), N, qq.data(), z); piv += lcp.pivots; }
+      const unsigned piv_fast = lcp.pivots; const bool ok_fast = ok; unsigned piv_lemke = 0;
+      if (!ok) { z.set_zero(); ok = lcp.lcp_lemke_regularized(N, MM.data(), N, qq.data(), z); piv += lcp.pivots; piv_lemke = lcp.pivots; }
+      if (g_lcp_dump) {                                                // diagnostic (oracle_dbg_lcp_dump), same record as world.hpp's
+        const int hdr[5] = { N, ok_fast ? 1 : 0, (int)piv_fast, (int)piv_lemke, ok ? 1 : 0 };
+        std::fwrite(hdr, sizeof(int), 5, g_lcp_dump); std::fwrite(&rs_in, sizeof(rs_in), 1, g_lcp_dump);
+        std::fwrite(MM.data(), 8, (size_t)N * N, g_lcp_dump); std::fwrite(qq.data(), 8, N, g_lcp_dump); std::fwrite(z_in.data(), 8, N, g_lcp_dump);
+        std::fflush(g_lcp_dump);
+      }
       trace_len += tr.len;
       std::memcpy(aux->rng, &rs, sizeof(rs));
       lcp_account(N, piv);

@@ -176,3 +176,16 @@ def test_capacity_edges_four_contacts_and_limits(oracle, mu, nk, want_flag):
         assert (aux["lcp_rows"] >= n_full).all() and (aux["steps"] == 180).all()
     else:
         assert (aux["steps"] < 180).all()
+
+
+def test_lemke_in_a_wide_drumwright_shell_lcp(oracle):
+    """tests/tools/fuzz_artic.py's case 20050 (5 joints, 3 spheres, articulated-body algorithm, mu 2, compliance): at step 214 one world's
+    18-row LCP (two contacts + a limit) fails lcp_fast_regularized and goes to the Lemke ladder -- whose artificial column needs as many
+    entries as the LCP has rows (the first build gave it the no-slip capacity of 16 and the tail clobbered the limit tables)."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "tools"))
+    import fuzz_artic as F
+    m, q0, qd0, nsteps = F.complete_case(oracle, 20050)
+    assert (m.nj, m.nspheres, m.algorithm, m.cp_mu_coulomb) == (5, 3, A.MH_ARTIC_FSAB, 2.0)
+    aux = run(oracle, m, q0, qd0, nsteps=87, chunks=3)
+    assert (aux["zbuf_cap"] >= 18).any() and aux["lcp_pivots"].max() > 1000

@@ -45,6 +45,20 @@ def make_case(seed):
     return m, links, sph, q0, qd0, rng
 
 
+def complete_case(o, seed):
+    """make_case + the plane (just below the lowest sphere of the start states, tilted), the contact parameters and the run length:
+    -> (model, q0, qd0, nsteps).  `o`: the oracle (link poses of the start states)."""
+    m, links, sph, q0, qd0, rng = make_case(seed)
+    B = q0.shape[0]
+    P = np.array([o.artic_fwd_dyn(m, q0[b], qd0[b])["poses"] for b in range(B)])
+    nrm = np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), 1.0]); nrm /= np.linalg.norm(nrm)
+    low = min(float(nrm @ (P[b, l, 9:12] + P[b, l, :9].reshape(3, 3) @ c)) - r for b in range(B) for (l, c, r) in sph)
+    A.add_spheres(m, sph, plane_normal=nrm, plane_point=nrm * (low - float(rng.uniform(0.0, 0.05))), epsilon=float(rng.choice([0.0, 0.0, 0.4])),
+                  mu_coulomb=float(rng.choice([100.0, 100.0, 1e4, 0.5, 0.0, 2.0])), mu_viscous=float(rng.choice([0.0, 0.0, 0.1])),
+                  compliance=float(rng.choice([0.0, 1e-6])), nk=int(rng.choice([4, 4, 6, 8])))
+    return m, q0, qd0, int(rng.integers(100, 400))
+
+
 if __name__ == "__main__":
     o = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
     seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 900
@@ -52,16 +66,8 @@ if __name__ == "__main__":
     SKIP_AFTER = 5.0
     bad = solves = minis = multi = flagged = skipped = 0
     for case in range(cases):
-        m, links, sph, q0, qd0, rng = make_case(seed0 + case)
+        m, q0, qd0, nsteps = complete_case(o, seed0 + case)
         B = q0.shape[0]
-        # the plane: just below the lowest sphere of the start states, so that something lands within the run
-        P = np.array([o.artic_fwd_dyn(m, q0[b], qd0[b])["poses"] for b in range(B)])
-        nrm = np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), 1.0]); nrm /= np.linalg.norm(nrm)
-        low = min(float(nrm @ (P[b, l, 9:12] + P[b, l, :9].reshape(3, 3) @ c)) - r for b in range(B) for (l, c, r) in sph)
-        A.add_spheres(m, sph, plane_normal=nrm, plane_point=nrm * (low - float(rng.uniform(0.0, 0.05))), epsilon=float(rng.choice([0.0, 0.0, 0.4])),
-                      mu_coulomb=float(rng.choice([100.0, 100.0, 1e4, 0.5, 0.0, 2.0])), mu_viscous=float(rng.choice([0.0, 0.0, 0.1])),
-                      compliance=float(rng.choice([0.0, 1e-6])), nk=int(rng.choice([4, 4, 6, 8])))
-        nsteps = int(rng.integers(100, 400))
         # the oracle first, in chunks: a world that keeps hitting the mini-step cap costs minutes on either side -- skip such a case
         q_o, qd_o, aux_o = q0.copy(), qd0.copy(), S.new_aux(B)
         t0 = time.time(); done = 0
