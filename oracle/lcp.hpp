@@ -40,12 +40,18 @@
 #include <cstdint>
 #include "glibc_rand.h"
 #include "linalg.hpp"
+#include "compact_lu.hpp"
 
 namespace oracle {
 static unsigned long long g_lu_hist[130] = {0};   // diagnostic: LU sizes (lcp_fast: [k], Lemke: [65 + n])
 
 
 // Ravelin::VectorNd stand-in: contents survive a shrinking resize.
+// diagnostic (oracle_dbg_compact_check): every basis lcp_lemke factorises is ALSO solved by the model of the device's
+// structure-exploiting LU (compact_lu.hpp); [0] factorisations compared, [1] that differ in info or in any bit of the solution
+// other than the sign of a zero, [2] fallbacks requested, [3] dense steps, [4] fill-ins, [5] panels, [6] truncated panels
+static int g_compact_check = 0;
+static unsigned long long g_compact_stats[8] = {0};
 static int g_lemke_exit = 0;   // diagnostic: why the last failing lcp_lemke gave up (1000 + LAPACK info: singular basis; 2: ray; 3: empty ratio set)
 struct Vec {
   std::vector<double> d; // capacity storage
@@ -327,7 +333,25 @@ class LCP {
       _dl = _Be;
       _Al = _Bl;
       g_lu_hist[65 + (n < 65 ? n : 64)]++;                                     // diagnostic
-      { const int info = lu_solve(n, _Al.data(), n, _dl.data()); if (info != 0) { g_lemke_exit = 1000 + info; return false; } } // z keeps size 2n (:840-850)
+      std::vector<double> chk_b; std::vector<int> chk_kind, chk_idx;
+      if (g_compact_check) {
+        chk_b = _Be; chk_kind.resize(n); chk_idx.resize(n);
+        for (unsigned p = 0; p < n; p++) { const unsigned id = _bas[p]; if (id >= n && id != t) { chk_kind[p] = CL_UNIT; chk_idx[p] = (int)(id - n); } else { chk_kind[p] = CL_DENSE; chk_idx[p] = (int)p; } }
+      }
+      { const int info = lu_solve(n, _Al.data(), n, _dl.data());
+        if (g_compact_check) {
+          CompactLuStats cs;
+          const int ci = lu_solve_compact((int)n, chk_kind.data(), chk_idx.data(), _Bl.data(), (int)n, chk_b.data(), g_compact_check, nullptr, &cs);
+          g_compact_stats[0]++;
+          if (ci == CL_FALLBACK) g_compact_stats[2]++;
+          else {
+            bool same = (ci == info);
+            if (same && info == 0) for (unsigned i = 0; i < n; i++) if (!(chk_b[i] == _dl[i])) same = false;
+            if (!same) g_compact_stats[1]++;
+            g_compact_stats[3] += cs.dense_steps; g_compact_stats[4] += cs.fill_ins; g_compact_stats[5] += cs.panels; g_compact_stats[6] += cs.truncated_panels;
+          }
+        }
+        if (info != 0) { g_lemke_exit = 1000 + info; return false; } } // z keeps size 2n (:840-850)
       _j.clear();
       for (unsigned i = 0; i < n; i++) if (_dl[i] > PIV_TOL) _j.push_back(i);
       if (_j.empty()) { g_lemke_exit = 2; return false; }             // ray termination, size 2n (:892-903)

@@ -121,6 +121,12 @@ unsigned long long oracle_dbg_ca_iters(void) { return g_ca_iters; }
 int oracle_dbg_lemke_exit(void) { return g_lemke_exit; }
 // diagnostic: write every impact LCP solve_impact_lcp sees (inputs, rand() state, pivot counts) to `path`; NULL stops
 void oracle_dbg_lcp_dump(const char* path) { if (g_lcp_dump) { std::fclose(g_lcp_dump); g_lcp_dump = nullptr; } if (path) g_lcp_dump = std::fopen(path, "wb"); }
+// the model of the device's structure-exploiting LU (compact_lu.hpp): nb = panel width of the check (0 = off)
+void oracle_dbg_compact_check(int nb) { g_compact_check = nb; for (auto& v : g_compact_stats) v = 0; }
+void oracle_dbg_compact_stats(unsigned long long* out) { for (int i = 0; i < 8; i++) out[i] = g_compact_stats[i]; }
+// kind / idx: n entries (CL_UNIT: -e_idx, CL_DENSE: column idx of dense (n x *, ld)); b in/out; returns info or CL_FALLBACK
+int oracle_lu_solve_compact(int n, const int* kind, const int* idx, const double* dense, int ld, double* b, int nb, int* rows_out)
+{ return lu_solve_compact(n, kind, idx, dense, ld, b, nb, rows_out, nullptr); }
 void oracle_dbg_lu_hist(unsigned long long* out) { for (int i = 0; i < 130; i++) out[i] = g_lu_hist[i]; }
 
 // B worlds sequentially on one thread (CPU baseline); returns elapsed seconds

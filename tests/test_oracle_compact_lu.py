@@ -1,0 +1,95 @@
+"""The structure-exploiting LU the device runs on Lemke's bases (moby_amd/csrc/mh_lu_compact.h), as the sequential model
+oracle/compact_lu.hpp, held to the oracle's dgesv (oracle/linalg.hpp: dgetf2 + dgetrs, the routine behind
+LinAlgd::solve_fast at /root/reference/src/LCP.cpp:837-838): same info, same solution bit for bit (up to the sign of a zero)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from tests.oracle_api import Oracle, LEMKE_REG
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CL_UNIT, CL_DENSE, CL_FALLBACK = 0, 1, -1
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+
+
+def compact(o, kind, idx, dense, b, nb):
+    n = len(b)
+    k = np.ascontiguousarray(kind, dtype=np.int32); i = np.ascontiguousarray(idx, dtype=np.int32)
+    Df = np.asfortranarray(dense); x = np.array(b, dtype=np.float64); rows = np.zeros(n, dtype=np.int32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    o.lib.oracle_lu_solve_compact.restype = ctypes.c_int
+    info = o.lib.oracle_lu_solve_compact(n, P(k), P(i), P(Df), Df.shape[0], P(x), int(nb), P(rows))
+    return info, x, rows
+
+
+def random_basis(rng, n, frac_dense, integer_values, scatter):
+    """A Lemke-like basis: position p holds -e_r (r = p mostly, a few slacks away from home) or a dense column."""
+    rows = np.arange(n)
+    kind = np.full(n, CL_UNIT, dtype=np.int32); idx = rows.copy().astype(np.int32)
+    dense_pos = np.sort(rng.choice(n, size=max(1, int(frac_dense * n)), replace=False))
+    cols = rng.integers(-3, 4, (n, len(dense_pos))).astype(float) if integer_values else rng.standard_normal((n, len(dense_pos)))
+    if not integer_values:
+        cols[rng.random(cols.shape) < 0.6] = 0.0        # block-sparse columns like the impact LCP's M
+    for j, p in enumerate(dense_pos):
+        kind[p] = CL_DENSE; idx[p] = j
+    # slacks away from home: the rows whose slack is NOT in the basis are those of the dense positions; unit columns keep distinct rows
+    unit_pos = np.array([p for p in range(n) if kind[p] == CL_UNIT], dtype=int)
+    free_rows = list(dense_pos)
+    for p in unit_pos[rng.random(len(unit_pos)) < scatter]:
+        j = rng.integers(len(free_rows)); r_new = free_rows[j]; free_rows[j] = idx[p]; idx[p] = r_new
+    A = np.zeros((n, n))
+    for p in range(n):
+        if kind[p] == CL_UNIT: A[idx[p], p] = -1.0
+        else: A[:, p] = cols[:, idx[p]]
+    return kind, idx, cols, A
+
+
+@pytest.mark.parametrize("nb", [1, 3, 8])
+def test_compact_lu_equals_dgesv_on_random_bases(oracle, nb):
+    rng = np.random.default_rng(20 + nb)
+    checked = singular = 0
+    for trial in range(120):
+        n = int(rng.integers(2, 70))
+        kind, idx, cols, A = random_basis(rng, n, rng.choice([0.1, 0.3, 0.6, 1.0]), trial % 3 == 0, rng.choice([0.0, 0.2, 0.5]))
+        b = rng.integers(-2, 3, n).astype(float) if trial % 3 == 0 else rng.standard_normal(n)
+        info_d, x_d = oracle.lu_solve(A, b)
+        info_c, x_c, rows = compact(oracle, kind, idx, cols, b, nb)
+        assert info_c != CL_FALLBACK
+        assert info_c == info_d, (trial, n)
+        if info_d == 0:
+            assert np.array_equal(x_c, x_d), (trial, n, np.abs(x_c - x_d).max())
+            checked += 1
+        else:
+            singular += 1
+    assert checked > 60 and singular > 0       # integer columns with ties and exact singularities are in the mix
+
+
+def test_compact_lu_requests_the_dense_routine_on_non_finite_data(oracle):
+    kind = [CL_DENSE, CL_UNIT, CL_DENSE]; idx = [0, 1, 1]
+    cols = np.array([[1.0, 2.0], [np.inf, 1.0], [3.0, 4.0]])
+    info, _, _ = compact(oracle, kind, idx, cols, np.ones(3), 8)
+    assert info == CL_FALLBACK
+
+
+def test_every_lemke_basis_of_a_box_stack_matches(oracle):
+    """lcp_lemke_regularized on config 4's impact LCP (4 and 6 boxes): every basis it factorises goes through both routines."""
+    from moby_amd import impact as I
+    for nbx, w, nb in ((4, 1, 8), (6, 2, 8), (4, 0, 5)):
+        mass, J, st, cs = I.box_stack(nbx, B=3)
+        n = I.lcp_size(4 * nbx, 4)
+        nn, MM, qq = oracle.impact_lcp(nbx, mass, J, st[w], cs[w], n)
+        oracle.lib.oracle_dbg_compact_check(nb)
+        try:
+            r = oracle.lcp(LEMKE_REG, MM, qq, z=np.zeros(n), z_size=n)
+            stt = np.zeros(8, dtype=np.uint64); oracle.lib.oracle_dbg_compact_stats(stt.ctypes.data_as(ctypes.c_void_p))
+        finally:
+            oracle.lib.oracle_dbg_compact_check(0)
+        assert r["ok"]
+        assert stt[0] >= r["pivots"] > 0 and stt[1] == 0 and stt[2] == 0, stt
+        assert stt[3] < 0.5 * n * stt[0]            # the structure is there: well under n/2 dense steps per factorisation
