@@ -19,23 +19,27 @@
 #define MH_BLK_T 256
 #define MH_BLK_UCH 128
 #define MH_BLK_PANEL_CAP 1792
+#define MH_BLK_CN 512
 #define MH_BLK_KATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #include "mh_lcp_block.h"
 #undef MH_BLK_NS
 #undef MH_BLK_T
 #undef MH_BLK_UCH
 #undef MH_BLK_PANEL_CAP
+#undef MH_BLK_CN
 #undef MH_BLK_KATTR
 #define MH_BLK_NS blkw
 #define MH_BLK_T 1024
 #define MH_BLK_UCH 256
 #define MH_BLK_PANEL_CAP 3584
+#define MH_BLK_CN 1024
 #define MH_BLK_KATTR
 #include "mh_lcp_block.h"
 #undef MH_BLK_NS
 #undef MH_BLK_T
 #undef MH_BLK_UCH
 #undef MH_BLK_PANEL_CAP
+#undef MH_BLK_CN
 #undef MH_BLK_KATTR
 
 static thread_local char g_err[512] = "";
@@ -183,6 +187,7 @@ int mh_rand_next(uint32_t* st)
   return (int)(v >> 1);
 }
 
+int mh_g_debug_compact = 1;  // mh_debug_set(3, v): 1 = Lemke's bases through the structure-exploiting LU (mh_lu_compact.inc), 0 = dense LU only
 int mh_g_debug_blk = 0;      // mh_debug_set(2, v): 0 = choose, 1 = 256-thread block solver, 2 = 1024-thread block solver
 int mh_g_debug_ka = 64;          // LDS LU block edge of the world kernel (clamped to the variant MHW_KA_V); mh_debug_set(1, 0) forces the HBM workspace path
 int mh_cu_count()
@@ -251,10 +256,10 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     if (wsd && wsi) {
       if (wide) hipLaunchKernelGGL(mh::blkw::k_lcp_block, dim3(B), dim3(mh::blkw::T), 0, (hipStream_t)stream,
                          B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                         trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr);
+                         trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact);
       else hipLaunchKernelGGL(mh::blk::k_lcp_block, dim3(B), dim3(mh::blk::T), 0, (hipStream_t)stream,
                          B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                         trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr);
+                         trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact);
       MH_HIP(hipGetLastError());
       if (n_arr) {          // the problems of this call that fit one wavefront (n_arr[b] <= 64) take the wave solver
         const size_t ldsw = (size_t)(2 * MH_LCP_MAX_N_WAVE * MH_LCP_MAX_N_WAVE + MH_LCP_MAX_N_WAVE) * sizeof(double);
@@ -272,10 +277,10 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     if (e != hipSuccess) { (void)hipFreeAsync(wsd, (hipStream_t)stream); return fail(MH_ERR_HIP, "workspace allocation failed: %s", hipGetErrorString(e)); }
     if (wide) hipLaunchKernelGGL(mh::blkw::k_lcp_block, dim3(B), dim3(mh::blkw::T), 0, (hipStream_t)stream,
                        B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                       trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr);
+                       trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact);
     else hipLaunchKernelGGL(mh::blk::k_lcp_block, dim3(B), dim3(mh::blk::T), 0, (hipStream_t)stream,
                        B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                       trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr);
+                       trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact);
     e = hipGetLastError();
     (void)hipFreeAsync(wsd, (hipStream_t)stream); (void)hipFreeAsync(wsi, (hipStream_t)stream);
     if (e != hipSuccess) return fail(MH_ERR_HIP, "block LCP launch failed: %s", hipGetErrorString(e));
@@ -344,5 +349,6 @@ extern "C" int mh_debug_set(int key, int value)
 {
   if (key == 1) { if (value < 0 || value > 64) return fail(MH_ERR_INVALID_ARG, "LU block edge outside [0, 64]"); mh_g_debug_ka = value; return MH_OK; }
   if (key == 2) { if (value < 0 || value > 2) return fail(MH_ERR_INVALID_ARG, "block solver geometry outside {0, 1, 2}"); mh_g_debug_blk = value; return MH_OK; }
+  if (key == 3) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "compact-LU switch outside {0, 1}"); mh_g_debug_compact = value; return MH_OK; }
   return fail(MH_ERR_INVALID_ARG, "unknown debug key %d", key);
 }

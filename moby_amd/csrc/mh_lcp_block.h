@@ -26,8 +26,8 @@
 // No include guard: mh_capi.hip includes this file once per thread geometry (MH_BLK_NS / MH_BLK_T).
 #include "mh_lcp_wave.h"
 
-#if !defined(MH_BLK_NS) || !defined(MH_BLK_T) || !defined(MH_BLK_UCH) || !defined(MH_BLK_PANEL_CAP) || !defined(MH_BLK_KATTR)
-#error "define MH_BLK_NS, MH_BLK_T, MH_BLK_UCH, MH_BLK_PANEL_CAP and MH_BLK_KATTR before including mh_lcp_block.h"
+#if !defined(MH_BLK_NS) || !defined(MH_BLK_T) || !defined(MH_BLK_UCH) || !defined(MH_BLK_PANEL_CAP) || !defined(MH_BLK_KATTR) || !defined(MH_BLK_CN)
+#error "define MH_BLK_NS, MH_BLK_T, MH_BLK_UCH, MH_BLK_PANEL_CAP, MH_BLK_CN and MH_BLK_KATTR before including mh_lcp_block.h"
 #endif
 namespace mh { namespace MH_BLK_NS {
 
@@ -55,7 +55,7 @@ __shared__ unsigned s_rng[32];
 
 MH_DEV int tid() { return (int)threadIdx.x; }
 // -DMH_BLK_PROF: per-phase cycle totals of block 0, printed by the kernel (diagnostic builds only)
-enum { BP_LIST = 0, BP_GATHER, BP_PANEL, BP_SWAP, BP_TRAIL, BP_SOLVE, BP_GEMV, BP_RANDMIN, BP_COUNT };
+enum { BP_LIST = 0, BP_GATHER, BP_PANEL, BP_SWAP, BP_TRAIL, BP_SOLVE, BP_GEMV, BP_RANDMIN, BP_COMPACT, BP_COUNT };
 #ifdef MH_BLK_PROF
 __shared__ unsigned long long s_prof[BP_COUNT];
 MH_DEV unsigned long long bp_tick() { return __builtin_amdgcn_s_memtime(); }
@@ -434,6 +434,8 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
   return 0;
 }
 
+#include "mh_lu_compact.inc"
+
 // LCP.cpp:199-209 over the variables i with member(i) (list order = index order); val(i) reads
 // the candidate.  Consumes exactly one rand().  Returns the chosen variable (uniform).
 template <class Val, class Mem>
@@ -578,8 +580,13 @@ MH_DEV bool verify(const Mat& M, double lam, const Ws& W, const double* q, const
 }
 
 // LCP.cpp:545-1003 (dense)
+// the basis of lcp_lemke by columns, for lu_compact: position p holds the slack -e_{id-n}, the artificial column, or column id of M
+struct LemkeCol { const Mat* M; const int* bv; const double* art; double lam; int n, tt;
+  MH_DEV int unit_row(int p) const { const int id = bv[p]; return (id >= n && id != tt) ? id - n : -1; }
+  MH_DEV double load(int p, int i) const { const int id = bv[p]; return (id == tt) ? art[i] : M->at(i, id, lam); } };
+
 MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, double* z, int& zsize, double piv_tol, double zero_tol,
-                      double nrm_lam, unsigned& pivots, Trace2& tr)
+                      double nrm_lam, unsigned& pivots, Trace2& tr, bool compact)
 {
   const int n = M.n, t = tid();
   const unsigned MAXITER = (50u * (unsigned)n < 1000u) ? 50u * (unsigned)n : 1000u;
@@ -621,7 +628,17 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
     }
     if (leaving < n) { entering = n + leaving; for (int p = t; p < n; p += T) W.d[p] = (p == leaving) ? -1.0 : 0.0; }
     else { entering = leaving - n; for (int p = t; p < n; p += T) W.d[p] = M.at(p, entering, lam); }
-    // Al = Bl from the basis description; solve Al d = Be
+    // solve Bl d = Be (LCP.cpp:837-838).  The structure-exploiting routine first; the dense one on the assembled basis when the
+    // problem is too large for it or it met a non-finite value
+    sync();
+    int info = LUC_FALLBACK;
+    if (compact && n <= CN) {
+      const unsigned long long tc = bp_tick();
+      LemkeCol colv; colv.M = &M; colv.bv = W.bv; colv.art = W.art; colv.lam = lam; colv.n = n; colv.tt = tt;
+      info = lu_compact(n, colv, W.A, W.d);
+      bp_tock(BP_COMPACT, tc);
+    }
+    if (info == LUC_FALLBACK) {
     const unsigned long long tq = bp_tick();
     const long nn = (long)n * n;
     { int r = t % n, p = t / n;                             // element e = t + m T, walked without a division per element
@@ -637,7 +654,9 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
       } }
     sync();
     bp_tock(BP_GATHER, tq);
-    if (lu_solve(n, W.A, W.d) != 0) return false;                   // singular basis (:840-850), size stays 2n
+    info = lu_solve(n, W.A, W.d);
+    }
+    if (info != 0) return false;                                    // singular basis (:840-850), size stays 2n
     double th = inf(); int any = 0, cand0 = 0x7fffffff;
     for (int p = t; p < n; p += T) { const double dp = W.d[p]; if (dp > PIV_TOL) { any = 1; if (p < cand0) cand0 = p; const double r = (W.x[p] + zero_tol) / dp; th = (r < th) ? r : th; } }
     if (red_sum_int(any) == 0) return false;                        // ray termination (:892-903)
@@ -670,7 +689,7 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
 
 // the four public solvers (lcp_solve_wave's attempt loop)
 MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, const Ws& W, const double* q, double* z, int& zsize,
-                      unsigned& pivots, Trace2& tr)
+                      unsigned& pivots, Trace2& tr, bool compact)
 {
   const int n = M.n, t = tid();
   const bool reg = (P.kind == MH_LCP_FAST_REG) || (P.kind == MH_LCP_LEMKE_REG);
@@ -700,7 +719,7 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
     }
     if (reg) tr.push(0x40000000 | attempt);
     const bool ok = fast ? lcp_fast(M, lam, W, q, z, zsize, P.zero_tol, nrm, pivots, tr)
-                         : lcp_lemke(M, lam, W, q, z, zsize, P.piv_tol, P.zero_tol, nrm, pivots, tr);
+                         : lcp_lemke(M, lam, W, q, z, zsize, P.piv_tol, P.zero_tol, nrm, pivots, tr, compact);
     if (!reg) return ok;
     const bool good = ok && verify(M, lam, W, q, z, ZERO_TOL, attempt > 0);
     if (attempt == 0) { if (good) return true; total += pivots; }
@@ -718,7 +737,7 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
                     uint32_t* __restrict__ rngg, int* __restrict__ status, unsigned* __restrict__ pivots_out,
                     int32_t* __restrict__ trace, int trace_cap, int* __restrict__ trace_len,
                     LcpParams P, Pow10Table p10, double* __restrict__ wsd, int* __restrict__ wsi,
-                    const int* __restrict__ run_if, const int* __restrict__ n_arr)
+                    const int* __restrict__ run_if, const int* __restrict__ n_arr, int flags)
 {
   const int b = blockIdx.x;
   if (b >= B) return;
@@ -746,11 +765,11 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   if (t < BP_COUNT) s_prof[t] = 0ull;
   sync();
 #endif
-  const bool ok = lcp_solve(P, p10, M, W, q, z, zsize, piv, tr);
+  const bool ok = lcp_solve(P, p10, M, W, q, z, zsize, piv, tr, (flags & 1) != 0);
   sync();
 #ifdef MH_BLK_PROF
-  if (t == 0 && (b == 0 || b == 5)) printf("blk prof (cycles, block %d, %u pivots): list %llu gather %llu panel %llu swap %llu trail %llu solve %llu gemv %llu randmin %llu\n", b, piv,
-                               s_prof[0], s_prof[1], s_prof[2], s_prof[3], s_prof[4], s_prof[5], s_prof[6], s_prof[7]);
+  if (t == 0 && (b == 0 || b == 5)) printf("blk prof (cycles, block %d, %u pivots): list %llu gather %llu panel %llu swap %llu trail %llu solve %llu gemv %llu randmin %llu compact %llu\n", b, piv,
+                               s_prof[0], s_prof[1], s_prof[2], s_prof[3], s_prof[4], s_prof[5], s_prof[6], s_prof[7], s_prof[8]);
 #endif
   if (t < 32) rngg[(size_t)b * MH_RAND_WORDS + t] = s_rng[t];
   if (t == 0) {
