@@ -9,38 +9,9 @@
 #include "../../include/moby_hip.h"
 #include "mh_host.h"
 #include "mh_lcp_wave.h"
-// the workgroup-per-problem solver in two thread geometries: 256 threads (two problems per CU: throughput when the
-// batch is larger than the chip) and 1024 threads (one problem per CU with 16 waves to hide its round trips:
-// 1.2x / 1.4x faster per problem at n = 256 / 512, slower at n = 128)
-// The 256-thread geometry is the throughput one (batches larger than the chip): half the LDS staging (panel 14 KB,
-// pivot-row chunk 128 columns) and a 128-VGPR budget let FOUR problems share a CU instead of two -- 4-box stacks x8192:
-// 8.4 s -> 5.6 s per cold call; a single problem is 3 % slower.
-#define MH_BLK_NS blk
-#define MH_BLK_T 256
-#define MH_BLK_UCH 128
-#define MH_BLK_PANEL_CAP 1792
-#define MH_BLK_CN 512
-#define MH_BLK_KATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
-#include "mh_lcp_block.h"
-#undef MH_BLK_NS
-#undef MH_BLK_T
-#undef MH_BLK_UCH
-#undef MH_BLK_PANEL_CAP
-#undef MH_BLK_CN
-#undef MH_BLK_KATTR
-#define MH_BLK_NS blkw
-#define MH_BLK_T 1024
-#define MH_BLK_UCH 256
-#define MH_BLK_PANEL_CAP 3584
-#define MH_BLK_CN 1024
-#define MH_BLK_KATTR
-#include "mh_lcp_block.h"
-#undef MH_BLK_NS
-#undef MH_BLK_T
-#undef MH_BLK_UCH
-#undef MH_BLK_PANEL_CAP
-#undef MH_BLK_CN
-#undef MH_BLK_KATTR
+// the workgroup-per-problem solver (n > 64) lives in mh_lcp_blk.hip / mh_lcp_blkw.hip: two thread geometries, 256 threads (four
+// problems per CU: throughput when the batch is larger than the chip) and 1024 threads (one problem per CU with 16 waves to hide
+// its round trips: 1.2x / 1.4x faster per problem at n = 256 / 512, slower at n = 128)
 
 static thread_local char g_err[512] = "";
 
@@ -254,13 +225,9 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     bool wide = n >= 384 || (n >= 192 && B <= 2 * mh_cu_count());
     if (mh_g_debug_blk == 1) wide = false; else if (mh_g_debug_blk == 2) wide = true;
     if (wsd && wsi) {
-      if (wide) hipLaunchKernelGGL(mh::blkw::k_lcp_block, dim3(B), dim3(mh::blkw::T), 0, (hipStream_t)stream,
-                         B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                         trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact);
-      else hipLaunchKernelGGL(mh::blk::k_lcp_block, dim3(B), dim3(mh::blk::T), 0, (hipStream_t)stream,
-                         B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                         trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact);
-      MH_HIP(hipGetLastError());
+      const hipError_t le = (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
+                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact);
+      MH_HIP(le);
       if (n_arr) {          // the problems of this call that fit one wavefront (n_arr[b] <= 64) take the wave solver
         const size_t ldsw = (size_t)(2 * MH_LCP_MAX_N_WAVE * MH_LCP_MAX_N_WAVE + MH_LCP_MAX_N_WAVE) * sizeof(double);
         hipLaunchKernelGGL(mh_k_lcp_wave, dim3(B), dim3(64), ldsw, (hipStream_t)stream,
@@ -275,13 +242,9 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     MH_HIP(hipMallocAsync((void**)&wsd, nd * sizeof(double), (hipStream_t)stream));
     hipError_t e = hipMallocAsync((void**)&wsi, ni * sizeof(int), (hipStream_t)stream);
     if (e != hipSuccess) { (void)hipFreeAsync(wsd, (hipStream_t)stream); return fail(MH_ERR_HIP, "workspace allocation failed: %s", hipGetErrorString(e)); }
-    if (wide) hipLaunchKernelGGL(mh::blkw::k_lcp_block, dim3(B), dim3(mh::blkw::T), 0, (hipStream_t)stream,
-                       B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                       trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact);
-    else hipLaunchKernelGGL(mh::blk::k_lcp_block, dim3(B), dim3(mh::blk::T), 0, (hipStream_t)stream,
-                       B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                       trace, trace_cap, trace_len, P, p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact);
-    e = hipGetLastError();
+    const hipError_t le = (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
+                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact);
+    e = le;
     (void)hipFreeAsync(wsd, (hipStream_t)stream); (void)hipFreeAsync(wsi, (hipStream_t)stream);
     if (e != hipSuccess) return fail(MH_ERR_HIP, "block LCP launch failed: %s", hipGetErrorString(e));
     return MH_OK;

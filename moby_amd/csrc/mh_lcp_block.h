@@ -23,8 +23,10 @@
 // columns per barrier round with the diagonal blocks on lanes.  Measured (n = 256,
 // 512 pivots in the slowest problem): 296 ms -> 177 ms; per-phase cycles with
 // -DMH_BLK_PROF: panel 30 %, trailing update 27 %, solves 12 %.
-// No include guard: mh_capi.hip includes this file once per thread geometry (MH_BLK_NS / MH_BLK_T).
+// No include guard: one translation unit per thread geometry (mh_lcp_blk.hip, mh_lcp_blkw.hip) defines MH_BLK_NS / MH_BLK_T / ...
+// and MH_BLK_LAUNCHER and includes this file; each compiles two kernels (the lcp_fast kinds, the lcp_lemke kinds).
 #include "mh_lcp_wave.h"
+#include "mh_host.h"
 
 #if !defined(MH_BLK_NS) || !defined(MH_BLK_T) || !defined(MH_BLK_UCH) || !defined(MH_BLK_PANEL_CAP) || !defined(MH_BLK_KATTR) || !defined(MH_BLK_CN)
 #error "define MH_BLK_NS, MH_BLK_T, MH_BLK_UCH, MH_BLK_PANEL_CAP, MH_BLK_CN and MH_BLK_KATTR before including mh_lcp_block.h"
@@ -55,7 +57,7 @@ __shared__ unsigned s_rng[32];
 
 MH_DEV int tid() { return (int)threadIdx.x; }
 // -DMH_BLK_PROF: per-phase cycle totals of block 0, printed by the kernel (diagnostic builds only)
-enum { BP_LIST = 0, BP_GATHER, BP_PANEL, BP_SWAP, BP_TRAIL, BP_SOLVE, BP_GEMV, BP_RANDMIN, BP_COMPACT, BP_COUNT };
+enum { BP_LIST = 0, BP_GATHER, BP_PANEL, BP_SWAP, BP_TRAIL, BP_SOLVE, BP_GEMV, BP_RANDMIN, BP_COMPACT, BP_C_SETUP, BP_C_PANEL, BP_C_U12, BP_C_TRAIL, BP_C_BACK, BP_C_STEPS, BP_C_PANELS, BP_COUNT };
 #ifdef MH_BLK_PROF
 __shared__ unsigned long long s_prof[BP_COUNT];
 MH_DEV unsigned long long bp_tick() { return __builtin_amdgcn_s_memtime(); }
@@ -65,6 +67,13 @@ MH_DEV unsigned long long bp_tick() { return 0ull; }
 MH_DEV void bp_tock(int, unsigned long long) {}
 #endif
 MH_DEV void sync() { __syncthreads(); }
+// barrier that orders LDS traffic only: __syncthreads() also drains the wave's outstanding global stores (s_waitcnt vmcnt(0)),
+// a microsecond each time one is in flight; where the threads exchange nothing through global memory this one is enough
+#ifdef MH_BLK_NO_LSYNC
+MH_DEV void lsync() { __syncthreads(); }
+#else
+MH_DEV void lsync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 // ordering point between the lanes of ONE wave of the block (compiler ordering; ds_ ops of a wave execute in order)
 MH_DEV void wsync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 MH_DEV double inf() { return __longlong_as_double(0x7ff0000000000000ll); }
@@ -174,8 +183,8 @@ constexpr int UCH = MH_BLK_UCH;          // columns of the pivot-row block stage
 #endif
 constexpr int TCOLS = MH_BLK_TCOLS;      // trailing-update columns a thread has in flight
 constexpr int PANEL_CAP = MH_BLK_PANEL_CAP;   // doubles (14 / 28 KB): rows x NB of the panel held in LDS
-__shared__ double s_u[NB][UCH];
-__shared__ int s_li[UCH];
+__shared__ double s_u[NB][UCH + 8];          // (+ 8: the padding group of the compact LU's update lists)
+__shared__ int s_li[UCH + 16];
 constexpr int LIST_CAP = 1024;
 __shared__ int s_list[LIST_CAP];
 __shared__ double s_panel[PANEL_CAP];
@@ -635,7 +644,7 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
     if (compact && n <= CN) {
       const unsigned long long tc = bp_tick();
       LemkeCol colv; colv.M = &M; colv.bv = W.bv; colv.art = W.art; colv.lam = lam; colv.n = n; colv.tt = tt;
-      info = lu_compact(n, colv, W.A, W.d);
+      info = lu_compact(n, colv, W.A, W.d, W.w);   // W.w: unused by lcp_lemke, the trash column of the update lists
       bp_tock(BP_COMPACT, tc);
     }
     if (info == LUC_FALLBACK) {
@@ -688,12 +697,12 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
 }
 
 // the four public solvers (lcp_solve_wave's attempt loop)
+template <int FAM>      // 0: the lcp_fast kinds, 1: the lcp_lemke kinds -- one kernel each, so that neither carries the other's registers
 MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, const Ws& W, const double* q, double* z, int& zsize,
                       unsigned& pivots, Trace2& tr, bool compact)
 {
   const int n = M.n, t = tid();
   const bool reg = (P.kind == MH_LCP_FAST_REG) || (P.kind == MH_LCP_LEMKE_REG);
-  const bool fast = (P.kind == MH_LCP_FAST) || (P.kind == MH_LCP_FAST_REG);
   double m0 = 0.0;
   const long nn = (long)n * n;
   for (long e = t; e < nn; e += T) { const double a = fabs(M.M[(e % n) + (size_t)M.ld * (e / n)]); m0 = (a > m0) ? a : m0; }
@@ -718,8 +727,9 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
       nrm = (md > offmax) ? md : offmax;
     }
     if (reg) tr.push(0x40000000 | attempt);
-    const bool ok = fast ? lcp_fast(M, lam, W, q, z, zsize, P.zero_tol, nrm, pivots, tr)
-                         : lcp_lemke(M, lam, W, q, z, zsize, P.piv_tol, P.zero_tol, nrm, pivots, tr, compact);
+    bool ok;
+    if constexpr (FAM == 0) ok = lcp_fast(M, lam, W, q, z, zsize, P.zero_tol, nrm, pivots, tr);
+    else ok = lcp_lemke(M, lam, W, q, z, zsize, P.piv_tol, P.zero_tol, nrm, pivots, tr, compact);
     if (!reg) return ok;
     const bool good = ok && verify(M, lam, W, q, z, ZERO_TOL, attempt > 0);
     if (attempt == 0) { if (good) return true; total += pivots; }
@@ -730,6 +740,7 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
 }
 
 // n > 64: one T-thread workgroup per LCP, M read in place from HBM, everything else in a per-problem HBM workspace.
+template <int FAM>
 __global__ __launch_bounds__(T) MH_BLK_KATTR
 void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strideM,
                     const double* __restrict__ qg, double* __restrict__ zg,
@@ -753,6 +764,7 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   W.A = wd; W.b = wd + (size_t)n * n; W.w = W.b + n; W.x = W.w + n; W.d = W.x + n; W.art = W.d + n;
   W.list = wi; W.flag = wi + n; W.pos = wi + 2 * (size_t)n; W.bv = wi + 3 * (size_t)n;
   if (t < 32) s_rng[t] = rngg[(size_t)b * MH_RAND_WORDS + t];
+  if (t == 0) s_luc_bug = 0;
   Mat M; M.M = Mg + (size_t)b * strideM; M.ld = ld; M.n = n;
   const double* q = qg + (size_t)b * nstride;
   double* z = zg + (size_t)b * nstride;
@@ -764,16 +776,18 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
 #ifdef MH_BLK_PROF
   if (t < BP_COUNT) s_prof[t] = 0ull;
   sync();
+  const unsigned long long t_kernel = bp_tick();
 #endif
-  const bool ok = lcp_solve(P, p10, M, W, q, z, zsize, piv, tr, (flags & 1) != 0);
+  const bool ok = lcp_solve<FAM>(P, p10, M, W, q, z, zsize, piv, tr, (flags & 1) != 0);
   sync();
 #ifdef MH_BLK_PROF
-  if (t == 0 && (b == 0 || b == 5)) printf("blk prof (cycles, block %d, %u pivots): list %llu gather %llu panel %llu swap %llu trail %llu solve %llu gemv %llu randmin %llu compact %llu\n", b, piv,
-                               s_prof[0], s_prof[1], s_prof[2], s_prof[3], s_prof[4], s_prof[5], s_prof[6], s_prof[7], s_prof[8]);
+  if (t == 0 && (b == 0 || b == 5)) printf("blk prof (cycles, block %d, %u pivots, %llu ticks in all): list %llu gather %llu panel %llu swap %llu trail %llu solve %llu gemv %llu randmin %llu compact %llu [setup %llu panel %llu u12 %llu trail %llu back %llu; dense steps %llu panels %llu]\n", b, piv, bp_tick() - t_kernel,
+                               s_prof[0], s_prof[1], s_prof[2], s_prof[3], s_prof[4], s_prof[5], s_prof[6], s_prof[7], s_prof[8], s_prof[9], s_prof[10], s_prof[11], s_prof[12], s_prof[13], s_prof[14], s_prof[15]);
 #endif
   if (t < 32) rngg[(size_t)b * MH_RAND_WORDS + t] = s_rng[t];
   if (t == 0) {
-    status[b] = ok ? 1 : 0;
+    if (s_luc_bug) printf("mh_lcp_block: index invariant %d of the compact LU violated (problem %d, n %d)\n", s_luc_bug & 15, b, s_luc_bug >> 4);
+    status[b] = s_luc_bug ? -7 : (ok ? 1 : 0);
     if (pivots_out) pivots_out[b] = piv;
     if (zsz_out) zsz_out[b] = zsize;
     if (trace_len) trace_len[b] = tr.len;
@@ -781,3 +795,19 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
 }
 
 } } // namespace mh::MH_BLK_NS
+
+// host side: the launcher of this geometry (declared in mh_host.h)
+extern "C" MH_HIDDEN hipError_t MH_BLK_LAUNCHER(void* stream, int kind, int B, int n, const double* M, int ld, long strideM, const double* q, double* z,
+                                     const int* zsz_in, int* zsz_out, uint32_t* rng, int* status, unsigned* pivots,
+                                     int32_t* trace, int trace_cap, int* trace_len, const mh::LcpParams* P, const mh::Pow10Table* p10,
+                                     double* wsd, int* wsi, const int* run_if, const int* n_arr, int flags)
+{
+  namespace ns = mh::MH_BLK_NS;
+  if (kind == MH_LCP_FAST || kind == MH_LCP_FAST_REG)
+    hipLaunchKernelGGL(ns::k_lcp_block<0>, dim3(B), dim3(ns::T), 0, (hipStream_t)stream, B, n, M, ld, strideM, q, z, zsz_in, zsz_out, rng, status, pivots,
+                       trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags);
+  else
+    hipLaunchKernelGGL(ns::k_lcp_block<1>, dim3(B), dim3(ns::T), 0, (hipStream_t)stream, B, n, M, ld, strideM, q, z, zsz_in, zsz_out, rng, status, pivots,
+                       trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags);
+  return hipGetLastError();
+}

@@ -45,6 +45,8 @@ def case(nbx, B, warm_calls=5):
 
 
 if __name__ == "__main__":
+    if os.environ.get("MH_BLK_GEOM"):          # 1 = 256-thread block solver, 2 = 1024-thread (mh_debug_set key 2)
+        _lib.check(_lib.load().mh_debug_set(2, int(os.environ["MH_BLK_GEOM"])))
     for a in sys.argv[1:]:
         p = [int(x) for x in a.split(":")]
         case(p[0], p[1], p[2] if len(p) > 2 else 5)
