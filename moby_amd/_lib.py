@@ -80,6 +80,8 @@ SYMBOLS = {
     "mh_big_batch_stabilize": (_i, [_vp, _vp]),
     "mh_big_batch_download": (_i, [_vp, _vp, _vp]),
     "mh_big_batch_lcp_capacity": (_i, [_vp]),
+    "mh_big_batch_lu_work": (_i, [_vp, _vp, _i]),
+    "mh_impact_batch_lu_work": (_i, [_vp, _vp, _i]),
     "mh_big_batch_save_solver_state": (_i, [_vp, _vp, _vp, _vp]),
     "mh_big_batch_load_solver_state": (_i, [_vp, _vp, _vp, _vp]),
     # include/moby_hip_artic.h

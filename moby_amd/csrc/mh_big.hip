@@ -1159,6 +1159,12 @@ int mh_big_batch_destroy(mh_big_batch* bb)
 
 int mh_big_batch_lcp_capacity(const mh_big_batch* bb) { return bb ? bb->cap : 0; }
 
+int mh_big_batch_lu_work(mh_big_batch* bb, double* work, int reset)
+{
+  if (!bb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  return mh_imp_core_lu_work(&bb->core, work, reset);
+}
+
 int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
 {
   namespace bg = mh::big;

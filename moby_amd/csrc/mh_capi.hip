@@ -201,7 +201,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
                            const int* z_size_in, int* z_size_out,
                            uint32_t* rng, int* status, unsigned* pivots,
                            int32_t* trace, int trace_cap, int* trace_len,
-                           const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i, const int* n_arr)
+                           const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i, const int* n_arr, double* work)
 {
   mh::LcpParams P;
   int rc = lcp_params(kind, opts, P);
@@ -223,10 +223,14 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     // problems, still 1.09x at 1024), below that only while the batch does not fill the chip twice over with the narrow one
     // (n = 256: 1.34x at 256 problems, 1.07x at 512, 0.80x at 1024; n = 128 x 1024: 0.85x)
     bool wide = n >= 384 || (n >= 192 && B <= 2 * mh_cu_count());
+    // the lcp_lemke kinds run the structure-exploiting LU (mh_lu_compact.inc), which is bound by its chain of round trips, not
+    // by arithmetic: four narrow problems per CU overlap theirs (8-box stacks x 1024: 5.7 s narrow, 10.8 s wide); the wide geometry
+    // keeps the sizes the narrow one's compact path does not take (n > 512) and batches of at most one problem per CU
+    if (kind == MH_LCP_LEMKE || kind == MH_LCP_LEMKE_REG) wide = n > 512 || (n >= 192 && B <= mh_cu_count());
     if (mh_g_debug_blk == 1) wide = false; else if (mh_g_debug_blk == 2) wide = true;
     if (wsd && wsi) {
       const hipError_t le = (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact);
+                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact, work);
       MH_HIP(le);
       if (n_arr) {          // the problems of this call that fit one wavefront (n_arr[b] <= 64) take the wave solver
         const size_t ldsw = (size_t)(2 * MH_LCP_MAX_N_WAVE * MH_LCP_MAX_N_WAVE + MH_LCP_MAX_N_WAVE) * sizeof(double);
@@ -243,7 +247,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     hipError_t e = hipMallocAsync((void**)&wsi, ni * sizeof(int), (hipStream_t)stream);
     if (e != hipSuccess) { (void)hipFreeAsync(wsd, (hipStream_t)stream); return fail(MH_ERR_HIP, "workspace allocation failed: %s", hipGetErrorString(e)); }
     const hipError_t le = (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact);
+                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact, work);
     e = le;
     (void)hipFreeAsync(wsd, (hipStream_t)stream); (void)hipFreeAsync(wsi, (hipStream_t)stream);
     if (e != hipSuccess) return fail(MH_ERR_HIP, "block LCP launch failed: %s", hipGetErrorString(e));

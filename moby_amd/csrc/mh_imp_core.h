@@ -49,6 +49,7 @@ struct mh_imp_core {
   double* bXCn;                                     // B x ncmax x 96
   double* bJiM; double* blam; int* bact; int* bk;   // B x 48 x 96, B x 48, B x 48, B
   double* ws_d; int* ws_i;                          // block-solver workspace (nmax > 64)
+  double* work;                                     // B x 2: SURVEY 8(d)'s model work of the block solver's factorisations (2/3 k^3 flops, 8 k^2 bytes), accumulated
   int* hmax;                                        // pinned host copy of maxisl
   void* allocs[64]; int nallocs;
 };
@@ -66,4 +67,6 @@ MH_HIDDEN int mh_imp_core_enable_joints(mh_imp_core* c, int nj, const int* jtype
 // restitution / second solve) + the impact-tolerance check.  Synchronises `stream` once, after the island search, to
 // learn how many rounds the batch needs.
 MH_HIDDEN int mh_imp_core_process(mh_imp_core* c, void* stream, int mode);
+// host copy of c->work (B x 2 doubles), optionally zeroing the device counters afterwards
+MH_HIDDEN int mh_imp_core_lu_work(mh_imp_core* c, double* work, int reset);
 }

@@ -1211,6 +1211,7 @@ int mh_imp_core_create(mh_imp_core* c, int B, int nb, int ncmax, int nk, int nma
   c->piv1 = (unsigned*)A(sB * 4, true); c->piv2 = (unsigned*)A(sB * 4, true);
   c->imp = (double*)A(sB * snc * 3 * 8, true);
   c->cnt = (unsigned long long*)A(sB * 5 * 8, true);
+  c->work = (double*)A(sB * 2 * 8, true);
   double* dcos = (double*)A(c->kh * 8, false); double* dsin = (double*)A(c->kh * 8, false);
   c->nk4 = (nk > 4) ? (nk + 4) / 4 : 1;                                     // ICH-AP:113-118
   double* acos_ = (double*)A(c->nk4 * 8, false); double* asin_ = (double*)A(c->nk4 * 8, false);
@@ -1273,21 +1274,21 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
     // every island the mask selects takes the Anitescu-Potra model: lcp_lemke_regularized(_MM, _qq, z, -20, 1, -2) alone (ICH-AP:333)
     mh_lcp_opts oa; oa.min_exp = -20; oa.step_exp = 1u; oa.max_exp = -2; oa.piv_tol = -1.0; oa.zero_tol = -1.0;
     return mh_lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, c->lst1, c->piv1,
-                                   nullptr, 0, nullptr, &oa, run_if, c->ws_d, c->ws_i, c->ncur);
+                                   nullptr, 0, nullptr, &oa, run_if, c->ws_d, c->ws_i, c->ncur, c->work);
   }
   if (mode == MH_CORE_IMPACT) {
     mh_lcp_opts o1; o1.min_exp = -20; o1.step_exp = 4u; o1.max_exp = -8; o1.piv_tol = -1.0; o1.zero_tol = -1.0;   // ICH-QP:219
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, nullptr, c->rng, c->lst1, c->piv1,
-                                 nullptr, 0, nullptr, &o1, run_if, c->ws_d, c->ws_i, c->ncur);
+                                 nullptr, 0, nullptr, &o1, run_if, c->ws_d, c->ws_i, c->ncur, c->work);
   } else {
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, c->lst1, c->piv1,
-                                 nullptr, 0, nullptr, nullptr, run_if, c->ws_d, c->ws_i, c->ncur);                        // CStab:954
+                                 nullptr, 0, nullptr, nullptr, run_if, c->ws_d, c->ws_i, c->ncur, c->work);               // CStab:954
   }
   if (rc != MH_OK) return rc;
   hipLaunchKernelGGL(im::k_lemke_prep, dim3(B), dim3(im::T), 0, s, *c, run_if, mode);
   MH_HIP(hipGetLastError());
   return mh_lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, c->lst2, c->piv2,
-                                 nullptr, 0, nullptr, nullptr, c->need2, c->ws_d, c->ws_i, c->ncur);                      // ICH-QP:224, CStab:955
+                                 nullptr, 0, nullptr, nullptr, c->need2, c->ws_d, c->ws_i, c->ncur, c->work);             // ICH-QP:224, CStab:955
 }
 
 int mh_imp_core_process(mh_imp_core* c, void* stream, int mode)
@@ -1455,6 +1456,20 @@ int mh_impact_batch_download(mh_impact_batch* ib, double* state, double* impulse
     for (size_t b = 0; b < B; b++) { if (solves) solves[b] = (int)cnt[5 * b]; if (pivots) pivots[b] = (unsigned)cnt[5 * b + 2]; }
   }
   return MH_OK;
+}
+
+int mh_imp_core_lu_work(mh_imp_core* c, double* work, int reset)
+{
+  MH_HIP(hipDeviceSynchronize());
+  if (work) MH_HIP(hipMemcpy(work, c->work, (size_t)c->B * 2 * 8, hipMemcpyDeviceToHost));
+  if (reset) MH_HIP(hipMemset(c->work, 0, (size_t)c->B * 2 * 8));
+  return MH_OK;
+}
+
+int mh_impact_batch_lu_work(mh_impact_batch* ib, double* work, int reset)
+{
+  if (!ib) return fail(MH_ERR_INVALID_ARG, "null batch");
+  return mh_imp_core_lu_work(&ib->c, work, reset);
 }
 
 int mh_impact_batch_debug_lcp(mh_impact_batch* ib, double* MM, double* qq)

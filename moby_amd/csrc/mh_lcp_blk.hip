@@ -6,6 +6,9 @@
 #define MH_BLK_UCH 128
 #define MH_BLK_PANEL_CAP 1792
 #define MH_BLK_CN 512
-#define MH_BLK_KATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef MH_BLK_WAVES
+#define MH_BLK_WAVES 4
+#endif
+#define MH_BLK_KATTR __attribute__((amdgpu_waves_per_eu(MH_BLK_WAVES, MH_BLK_WAVES)))
 #define MH_BLK_LAUNCHER mh_launch_lcp_blk
 #include "mh_lcp_block.h"

@@ -51,6 +51,10 @@ struct Ws {
 MH_DEV size_t ws_doubles(int n) { return (size_t)n * n + 5 * (size_t)n; }
 MH_DEV size_t ws_ints(int n) { return 4 * (size_t)n; }
 
+// SURVEY 8(d)'s model of one factorisation (LCP.cpp:120, :837-838): dgesv of a k x k matrix = 2/3 k^3 flops over 8 k^2 bytes,
+// whatever this build skips of it; summed per problem for the roofline figures of bench.py (thread 0 only)
+__shared__ double s_work[2];
+MH_DEV void account_lu(int k) { if (threadIdx.x == 0) { const double kk = (double)k; s_work[0] += (2.0 / 3.0) * kk * kk * kk; s_work[1] += 8.0 * kk * kk; } }
 __shared__ double s_bd[4];
 __shared__ int s_bi[4];
 __shared__ unsigned s_rng[32];
@@ -500,6 +504,7 @@ MH_DEV bool lcp_fast(const Mat& M, double lam, const Ws& W, const double* q, dou
       for (int r = t; r < k; r += T) W.b[r] = -q[W.list[r]];
       sync();
       bp_tock(BP_GATHER, tq);
+      account_lu(k);
       if (lu_solve(k, W.A, W.b) != 0) return false;
     }
     tq = bp_tick();
@@ -592,7 +597,8 @@ MH_DEV bool verify(const Mat& M, double lam, const Ws& W, const double* q, const
 // the basis of lcp_lemke by columns, for lu_compact: position p holds the slack -e_{id-n}, the artificial column, or column id of M
 struct LemkeCol { const Mat* M; const int* bv; const double* art; double lam; int n, tt;
   MH_DEV int unit_row(int p) const { const int id = bv[p]; return (id >= n && id != tt) ? id - n : -1; }
-  MH_DEV double load(int p, int i) const { const int id = bv[p]; return (id == tt) ? art[i] : M->at(i, id, lam); } };
+  MH_DEV int id(int p) const { return bv[p]; }
+  MH_DEV double load_id(int id, int i) const { return (id == tt) ? art[i] : M->at(i, id, lam); } };
 
 MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, double* z, int& zsize, double piv_tol, double zero_tol,
                       double nrm_lam, unsigned& pivots, Trace2& tr, bool compact)
@@ -640,6 +646,7 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
     // solve Bl d = Be (LCP.cpp:837-838).  The structure-exploiting routine first; the dense one on the assembled basis when the
     // problem is too large for it or it met a non-finite value
     sync();
+    account_lu(n);
     int info = LUC_FALLBACK;
     if (compact && n <= CN) {
       const unsigned long long tc = bp_tick();
@@ -748,7 +755,7 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
                     uint32_t* __restrict__ rngg, int* __restrict__ status, unsigned* __restrict__ pivots_out,
                     int32_t* __restrict__ trace, int trace_cap, int* __restrict__ trace_len,
                     LcpParams P, Pow10Table p10, double* __restrict__ wsd, int* __restrict__ wsi,
-                    const int* __restrict__ run_if, const int* __restrict__ n_arr, int flags)
+                    const int* __restrict__ run_if, const int* __restrict__ n_arr, int flags, double* __restrict__ work)
 {
   const int b = blockIdx.x;
   if (b >= B) return;
@@ -764,7 +771,7 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   W.A = wd; W.b = wd + (size_t)n * n; W.w = W.b + n; W.x = W.w + n; W.d = W.x + n; W.art = W.d + n;
   W.list = wi; W.flag = wi + n; W.pos = wi + 2 * (size_t)n; W.bv = wi + 3 * (size_t)n;
   if (t < 32) s_rng[t] = rngg[(size_t)b * MH_RAND_WORDS + t];
-  if (t == 0) s_luc_bug = 0;
+  if (t == 0) { s_luc_bug = 0; s_work[0] = 0.0; s_work[1] = 0.0; }
   Mat M; M.M = Mg + (size_t)b * strideM; M.ld = ld; M.n = n;
   const double* q = qg + (size_t)b * nstride;
   double* z = zg + (size_t)b * nstride;
@@ -785,6 +792,7 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
                                s_prof[0], s_prof[1], s_prof[2], s_prof[3], s_prof[4], s_prof[5], s_prof[6], s_prof[7], s_prof[8], s_prof[9], s_prof[10], s_prof[11], s_prof[12], s_prof[13], s_prof[14], s_prof[15]);
 #endif
   if (t < 32) rngg[(size_t)b * MH_RAND_WORDS + t] = s_rng[t];
+  if (t == 0 && work) { work[2 * (size_t)b] += s_work[0]; work[2 * (size_t)b + 1] += s_work[1]; }
   if (t == 0) {
     if (s_luc_bug) printf("mh_lcp_block: index invariant %d of the compact LU violated (problem %d, n %d)\n", s_luc_bug & 15, b, s_luc_bug >> 4);
     status[b] = s_luc_bug ? -7 : (ok ? 1 : 0);
@@ -800,14 +808,14 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
 extern "C" MH_HIDDEN hipError_t MH_BLK_LAUNCHER(void* stream, int kind, int B, int n, const double* M, int ld, long strideM, const double* q, double* z,
                                      const int* zsz_in, int* zsz_out, uint32_t* rng, int* status, unsigned* pivots,
                                      int32_t* trace, int trace_cap, int* trace_len, const mh::LcpParams* P, const mh::Pow10Table* p10,
-                                     double* wsd, int* wsi, const int* run_if, const int* n_arr, int flags)
+                                     double* wsd, int* wsi, const int* run_if, const int* n_arr, int flags, double* work)
 {
   namespace ns = mh::MH_BLK_NS;
   if (kind == MH_LCP_FAST || kind == MH_LCP_FAST_REG)
     hipLaunchKernelGGL(ns::k_lcp_block<0>, dim3(B), dim3(ns::T), 0, (hipStream_t)stream, B, n, M, ld, strideM, q, z, zsz_in, zsz_out, rng, status, pivots,
-                       trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags);
+                       trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags, work);
   else
     hipLaunchKernelGGL(ns::k_lcp_block<1>, dim3(B), dim3(ns::T), 0, (hipStream_t)stream, B, n, M, ld, strideM, q, z, zsz_in, zsz_out, rng, status, pivots,
-                       trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags);
+                       trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags, work);
   return hipGetLastError();
 }

@@ -118,6 +118,12 @@ class ImpactBatch:
             assert v.shape == (self.B, S.MH_NOSLIP_MAX)
             _lib.check(_lib.load().mh_impact_batch_load_noslip_state(self.handle, v.ctypes.data, vs.ctypes.data))
 
+    def lu_work(self, reset=False):
+        """(B, 2): flops and bytes of the block solver's factorisations priced as dense dgesv calls (mh_impact_batch_lu_work)."""
+        w = np.zeros((self.B, 2))
+        _lib.check(_lib.load().mh_impact_batch_lu_work(self.handle, w.ctypes.data, int(bool(reset))))
+        return w
+
     def close(self):
         if self.handle:
             _lib.load().mh_impact_batch_destroy(self.handle)

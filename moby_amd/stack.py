@@ -249,6 +249,12 @@ class BigBatch:
         assert zl.shape == (self.B, self.cap) and zb.shape == (self.B, self.cap) and sz.shape == (self.B, 3)
         _lib.check(_lib.load().mh_big_batch_load_solver_state(self.handle, zl.ctypes.data, zb.ctypes.data, sz.ctypes.data))
 
+    def lu_work(self, reset=False):
+        """(B, 2): flops and bytes of the block solver's factorisations priced as dense dgesv calls (mh_big_batch_lu_work)."""
+        w = np.zeros((self.B, 2))
+        _lib.check(_lib.load().mh_big_batch_lu_work(self.handle, w.ctypes.data, int(bool(reset))))
+        return w
+
     def close(self):
         if self.handle:
             _lib.load().mh_big_batch_destroy(self.handle)

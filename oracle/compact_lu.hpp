@@ -71,7 +71,7 @@ inline int lu_solve_compact(int n, const int* kind, const int* idx, const double
   };
   int cur = 0;
   std::vector<double> P((size_t)n * NB), Lpp((size_t)NB * NB), u(NB);
-  std::vector<int> pcols;
+  std::vector<int> pcols, freerows, reachv(n), rowsv;
   while (true) {
     pcols.clear();
     for (int p = cur; p < n && (int)pcols.size() < NB; p++) if (ptype[p] == DENSE) pcols.push_back(p);
@@ -110,13 +110,15 @@ inline int lu_solve_compact(int n, const int* kind, const int* idx, const double
       const double piv = P[r + (size_t)n * jj];
       const bool big = std::fabs(piv) >= DBL_MIN;
       const double rcp = 1.0 / piv;
-      for (int i = 0; i < n; i++) if (pivstep[i] > p) {
-        double l = P[i + (size_t)n * jj];
-        l = big ? l * rcp : l / piv;
-        if (!fin(l)) return CL_FALLBACK;
-        P[i + (size_t)n * jj] = l;
-        for (int c2 = jj + 1; c2 < npc; c2++) P[i + (size_t)n * c2] = P[i + (size_t)n * c2] - l * P[r + (size_t)n * c2];
-      }
+      // (column by column: the same per-element operations in an order the CPU's caches like)
+      freerows.clear();
+      for (int i = 0; i < n; i++) if (pivstep[i] > p) freerows.push_back(i);
+      { double* pj = &P[(size_t)n * jj];
+        for (int i : freerows) { double l = pj[i]; l = big ? l * rcp : l / piv; if (!fin(l)) return CL_FALLBACK; pj[i] = l; }
+        for (int c2 = jj + 1; c2 < npc; c2++) {
+          double* pc = &P[(size_t)n * c2]; const double uu = pc[r];
+          if (uu != 0.0) for (int i : freerows) pc[i] = pc[i] - pj[i] * uu;
+        } }
       nbk++;
     }
     cur = p;
@@ -125,23 +127,28 @@ inline int lu_solve_compact(int n, const int* kind, const int* idx, const double
     for (int s = 0; s < nbk; s++) for (int t = 0; t < s; t++) Lpp[s + (size_t)NB * t] = P[drow[first_step + s] + (size_t)n * t];
     auto reach = [&](int i) { int c = 0; while (c < nbk && dpos[first_step + c] < pivstep[i]) c++; return c; };
     const int plast = dpos.back();
+    // per row: how many of the panel's steps reach it (0 for the panel's own pivot rows, whose prefix is the U12 part)
+    rowsv.clear();
+    for (int i = 0; i < n; i++) {
+      bool is_dense_pivot_row = false;
+      if (pivstep[i] <= plast && pivstep[i] >= dpos[first_step]) for (int s = 0; s < nbk; s++) if (drow[first_step + s] == i) is_dense_pivot_row = true;
+      reachv[i] = is_dense_pivot_row ? 0 : reach(i);
+      if (reachv[i] > 0) rowsv.push_back(i);
+    }
     auto update_column = [&](double* x) -> bool {
+      bool any = false;
       for (int s = 0; s < nbk; s++) {
         double a = x[drow[first_step + s]];
         for (int t = 0; t < s; t++) a = a - Lpp[s + (size_t)NB * t] * u[t];
         if (!fin(a)) return false;
         u[s] = a; x[drow[first_step + s]] = a;
+        any = any || (a != 0.0);
       }
-      for (int i = 0; i < n; i++) {
-        if (pivstep[i] <= plast && rowofstep[pivstep[i]] == i) {   // pivoted inside or before the panel
-          bool is_dense_pivot_row = false;
-          for (int s = 0; s < nbk; s++) if (drow[first_step + s] == i) is_dense_pivot_row = true;
-          if (is_dense_pivot_row) continue;                        // done above
-        }
-        const int cnt = reach(i);
-        double v = x[i];
-        for (int s = 0; s < cnt; s++) v = v - P[i + (size_t)n * s] * u[s];
-        x[i] = v;
+      if (!any) return true;                                       // every update is a - l * 0 with finite l
+      for (int s = 0; s < nbk; s++) {                              // (per element still ascending in s)
+        const double us = u[s]; if (us == 0.0) continue;
+        const double* ls = &P[(size_t)n * s];
+        for (int i : rowsv) if (s < reachv[i]) x[i] = x[i] - ls[i] * us;
       }
       return true;
     };

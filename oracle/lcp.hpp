@@ -50,6 +50,9 @@ static unsigned long long g_lu_hist[130] = {0};   // diagnostic: LU sizes (lcp_f
 // diagnostic (oracle_dbg_compact_check): every basis lcp_lemke factorises is ALSO solved by the model of the device's
 // structure-exploiting LU (compact_lu.hpp); [0] factorisations compared, [1] that differ in info or in any bit of the solution
 // other than the sign of a zero, [2] fallbacks requested, [3] dense steps, [4] fill-ins, [5] panels, [6] truncated panels
+// diagnostic (oracle_dbg_lemke_compact): lcp_lemke solves its bases with the structure-exploiting model ALONE (the dense routine only
+// when the model asks for it) -- bit-equal by tests/test_oracle_compact_lu.py, and what makes n = 2048 bases affordable on the CPU
+static int g_lemke_compact = 0;
 static int g_compact_check = 0;
 static unsigned long long g_compact_stats[8] = {0};
 static int g_lemke_exit = 0;   // diagnostic: why the last failing lcp_lemke gave up (1000 + LAPACK info: singular basis; 2: ray; 3: empty ratio set)
@@ -338,7 +341,14 @@ class LCP {
         chk_b = _Be; chk_kind.resize(n); chk_idx.resize(n);
         for (unsigned p = 0; p < n; p++) { const unsigned id = _bas[p]; if (id >= n && id != t) { chk_kind[p] = CL_UNIT; chk_idx[p] = (int)(id - n); } else { chk_kind[p] = CL_DENSE; chk_idx[p] = (int)p; } }
       }
-      { const int info = lu_solve(n, _Al.data(), n, _dl.data());
+      { int info = CL_FALLBACK;
+        if (g_lemke_compact) {
+          std::vector<int> kd(n), ix(n);
+          for (unsigned p = 0; p < n; p++) { const unsigned id = _bas[p]; if (id >= n && id != t) { kd[p] = CL_UNIT; ix[p] = (int)(id - n); } else { kd[p] = CL_DENSE; ix[p] = (int)p; } }
+          info = lu_solve_compact((int)n, kd.data(), ix.data(), _Bl.data(), (int)n, _dl.data(), g_lemke_compact);
+          if (info == CL_FALLBACK) _dl = _Be;
+        }
+        if (info == CL_FALLBACK) info = lu_solve(n, _Al.data(), n, _dl.data());
         if (g_compact_check) {
           CompactLuStats cs;
           const int ci = lu_solve_compact((int)n, chk_kind.data(), chk_idx.data(), _Bl.data(), (int)n, chk_b.data(), g_compact_check, nullptr, &cs);

@@ -122,6 +122,7 @@ int oracle_dbg_lemke_exit(void) { return g_lemke_exit; }
 // diagnostic: write every impact LCP solve_impact_lcp sees (inputs, rand() state, pivot counts) to `path`; NULL stops
 void oracle_dbg_lcp_dump(const char* path) { if (g_lcp_dump) { std::fclose(g_lcp_dump); g_lcp_dump = nullptr; } if (path) g_lcp_dump = std::fopen(path, "wb"); }
 // the model of the device's structure-exploiting LU (compact_lu.hpp): nb = panel width of the check (0 = off)
+void oracle_dbg_lemke_compact(int nb) { g_lemke_compact = nb; }
 void oracle_dbg_compact_check(int nb) { g_compact_check = nb; for (auto& v : g_compact_stats) v = 0; }
 void oracle_dbg_compact_stats(unsigned long long* out) { for (int i = 0; i < 8; i++) out[i] = g_compact_stats[i]; }
 // kind / idx: n entries (CL_UNIT: -e_idx, CL_DENSE: column idx of dense (n x *, ld)); b in/out; returns info or CL_FALLBACK

@@ -153,6 +153,58 @@ def test_config4_stated_size_properties():
     assert np.abs(b[:, :, 7:13]).max() < 5e-2
 
 
+def test_config4_stated_size_full_batch():
+    """BASELINE config 4 at the stated size AND the batch size the configuration names: 16 boxes (impact LCP n = 512) x 1024
+    worlds, one full TimeSteppingSimulator::step (the size bench.py's `config4_full_step` leg runs; about a minute and a half).
+    No world fails, identical worlds give identical results wherever they sit in the batch, the stacks stay put, momentum
+    is what gravity put in, and the solver chain did the work the CPU oracle does on such worlds (thousands of pivots each)."""
+    N, B = CONFIG4_BOXES, 1024
+    sc = K.box_stack_scene(N)
+    st0 = K.box_stack_state(N, B)
+    st0[B // 2:] = st0[:B // 2]
+    bb = K.BigBatch(sc, st0)
+    bb.step(1e-3, 1)
+    st, aux = bb.download()
+    bb.close()
+    assert ((aux["status"] & ~S.MH_WORLD_IMPACT_TOL) == 0).all()                   # no failed world
+    assert ((aux["status"] & S.MH_WORLD_IMPACT_TOL) != 0).sum() <= B // 50         # the handler's tolerance warning stays rare
+    assert np.array_equal(st[B // 2:], st[:B // 2])
+    for f in ("lcp_pivots", "lcp_rows", "lcp_solves", "rng", "stab_iters", "status"):
+        assert np.array_equal(aux[f][B // 2:], aux[f][:B // 2]), f
+    assert (aux["steps"] == 1).all() and (aux["lcp_rows"] >= 32 * N).all()
+    b = st.reshape(B, N, 13)
+    assert np.abs(b[:, :, 1] - 0.5 - np.arange(N)).max() < 1e-5                    # heights (measured 4.8e-7)
+    assert np.abs(b[:, :, 7:13]).max() < 5e-3                                       # at rest up to one step of gravity
+    mom = (sc.mass[None, :] * b[:, :, 8]).sum(axis=1)                               # what is left is carried by the ground
+    assert np.abs(mom).max() < 1e-3 * sc.mass.sum() * 9.81e-3 * 10
+    piv = aux["lcp_pivots"].astype(np.int64)
+    assert 2000 < piv.mean() < 40000 and piv.max() < 200000                        # measured: mean 11 534, max 27 286
+    assert aux["lcp_solves"].min() >= 2 and aux["stab_rows"].mean() > 100          # impact + stabilisation LCPs were solved
+
+
+def test_structure_exploiting_lu_route_equals_the_dense_route_in_full_steps():
+    """The block solver's two LU routes for Lemke's bases (mh_lu_compact.inc / the dense dgesv on the assembled basis, mh_debug_set
+    key 3) through the same 16-box worlds, full steps: states, rand() streams, pivot counts and flags equal bit for bit."""
+    from moby_amd import _lib
+    N, B = CONFIG4_BOXES, 12
+    sc = K.box_stack_scene(N)
+    st0 = K.box_stack_state(N, B)
+    res = {}
+    try:
+        for route in (1, 0):
+            _lib.check(_lib.load().mh_debug_set(3, route))
+            bb = K.BigBatch(sc, st0)
+            bb.step(1e-3, 1)
+            res[route] = bb.download()
+            bb.close()
+    finally:
+        _lib.check(_lib.load().mh_debug_set(3, 1))
+    assert np.array_equal(res[1][0], res[0][0])
+    for f in FIELDS:
+        assert np.array_equal(res[1][1][f], res[0][1][f]), f
+    assert (res[1][1]["lcp_pivots"] > 1000).all()
+
+
 def test_cpp_stack_simulator_adapter_example():
     """moby_amd/cpp/MobyHipStackSimulator.h (TimeSteppingSimulator::step and ConstraintStabilization::stabilize for
     large worlds) through its example program."""
