@@ -168,27 +168,81 @@ def config4_leg(torch, nboxes=4, B=1024):
         return {"error": repr(e)}
 
 
-def config4_full_step_leg(torch, nboxes, B, steps):
-    """BASELINE config 4 as FULL simulator steps (include/moby_hip_stack.h): B stacks of `nboxes` boxes, each step =
-    conservative advancement + contact generation + process_constraints over every island + stabilisation, all on the
-    device.  The first step is cold, the rest warm-started.  Informational; the stated size of this configuration is
-    16 boxes (n = 512) -- tests/test_big_gpu.py -- and is measured in profiles/ (a step there takes tens of seconds)."""
+FP64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: FP64 vector = FP64 matrix peak (fused multiply-add); this build runs unfused (parity), i.e. against half of it
+
+
+def config4_cpu_sample_start(nboxes, worlds=2):
+    """The CPU side of the config-4 leg: the oracle (oracle/world.hpp, one thread) stepping `worlds` box-stack worlds once, in a
+    CHILD process that runs beside the GPU legs (about 80 s of CPU work for 16 boxes) and is collected at the end."""
+    import subprocess
+    code = ("import sys, json, os; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from tests.oracle_api import Oracle\n"
+            "from moby_amd import scene as S, stack as K\n"
+            "o = Oracle(os.path.join(%r, 'oracle', 'liboracle.so'))\n"
+            "N, W = %d, %d\n"
+            "sc = K.box_stack_scene(N); st = K.box_stack_state(N, max(W, 2))\n"
+            "secs = 0.0; rows = 0; piv = 0\n"
+            "for w in range(W):\n"
+            "    s = st[w].copy(); aux = S.new_aux(1)\n"
+            "    secs += o.big_step(sc, s, aux, 1e-3, 1)['seconds']; rows += int(aux['lcp_rows'][0]); piv += int(aux['lcp_pivots'][0])\n"
+            "print(json.dumps({'secs': secs, 'rows': rows, 'pivots': piv, 'worlds': W}))\n") % (ROOT, ROOT, nboxes, worlds)
+    try:
+        return subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    except OSError:
+        return None
+
+
+def config4_cpu_sample_collect(proc, nboxes, timeout=400):
+    if proc is None:
+        return None
+    try:
+        o, _ = proc.communicate(timeout=timeout)
+        r = json.loads(o.strip().splitlines()[-1])
+        return {"value": r["rows"] / r["secs"], "unit": "LCP rows/s", "world_steps_per_sec": r["worlds"] / r["secs"], "cores": 1, "kind": "port",
+                "sample": "worlds 0..%d of the same batch (box stack of %d), one full step each, CPU oracle (oracle/world.hpp), 1 thread, "
+                          "beside the GPU legs: %.1f s, %d pivots" % (r["worlds"] - 1, nboxes, r["secs"], r["pivots"])}
+    except Exception as e:          # noqa: BLE001
+        proc.kill()
+        return {"error": repr(e)}
+
+
+def config4_full_step_leg(torch, nboxes, B, steps, cpu_proc=None):
+    """BASELINE config 4 as FULL simulator steps (include/moby_hip_stack.h) at the size this build states and tests
+    (tests/test_big_gpu.py::test_config4_stated_size_full_batch): B stacks of `nboxes` boxes, each step = conservative advancement
+    + contact generation + process_constraints over every island + stabilisation, all on the device.  The first step is cold.
+    `roofline`: the solver chain's factorisations priced as SURVEY 8(d) does -- one dgesv per pivot (LCP.cpp:120, :837-838),
+    2/3 k^3 flops over 8 k^2 bytes, counted on the device (mh_big_batch_lu_work) -- over the wall time of the step (the block
+    solver's kernels are 98 % of it; one step is hundreds of launches, so there is no single launch to time)."""
     try:
         from moby_amd import stack as K
         sc = K.box_stack_scene(nboxes)
         bb = K.BigBatch(sc, K.box_stack_state(nboxes, B))
         res = {"workload": "box stack of %d (impact LCP n = %d) x%d worlds, full TimeSteppingSimulator::step, dt = 1e-3" % (nboxes, 32 * nboxes, B),
                "steps": []}
-        prev = None
+        prev = None; total_s = 0.0
         for k in range(steps):
-            t0 = time.perf_counter(); bb.step(DT, 1); torch.cuda.synchronize(); dt_s = time.perf_counter() - t0
+            torch.cuda.synchronize(); t0 = time.perf_counter(); bb.step(DT, 1); torch.cuda.synchronize(); dt_s = time.perf_counter() - t0
+            total_s += dt_s
             _, aux = bb.download()
             rows = float(aux["lcp_rows"].astype(np.int64).sum()) - (prev if prev is not None else 0.0)
             prev = float(aux["lcp_rows"].astype(np.int64).sum())
             res["steps"].append({"s": dt_s, "world_steps_per_sec": B / dt_s, "lcp_rows_per_sec": rows / dt_s})
+        work = bb.lu_work().sum(axis=0)
         res["worlds_with_errors"] = int(((aux["status"] & ~2) != 0).sum())
         res["pivots_per_world_step"] = float(aux["lcp_pivots"].astype(np.int64).mean()) / steps
+        res["world_steps_per_sec"] = B * steps / total_s
+        res["lcp_rows_per_sec"] = prev / total_s
+        tf = work[0] / total_s / 1e12; gbs = work[1] / total_s / 1e9
+        res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                           "traffic": None, "kernel": "mh::blk::k_lcp_block<1> / <0> (the workgroup-per-problem LCP solver: lcp_lemke / lcp_fast kinds)",
+                           "seconds": total_s, "model_flops": float(work[0]), "model_bytes": float(work[1]),
+                           "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+                           "model": "every factorisation (one per pivot) as a dense dgesv: 2/3 k^3 flops, 8 k^2 bytes (SURVEY 8d); FP64 vector = matrix peak, "
+                                    "the kernels run unfused (half of it) and skip the exact zeros of Lemke's bases, so executed flops are far fewer"}
         bb.close()
+        if cpu_proc is not None:
+            res["cpu_baseline"] = config4_cpu_sample_collect(cpu_proc, nboxes)
         return res
     except Exception as e:          # noqa: BLE001 -- informational leg
         return {"error": repr(e)}
@@ -322,9 +376,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--no-config5", action="store_true")
-    ap.add_argument("--config4-boxes", type=int, default=8, help="box stack height of the informational full-step leg (n = 32 x boxes)")
-    ap.add_argument("--config4-worlds", type=int, default=256)
-    ap.add_argument("--config4-steps", type=int, default=2)
+    ap.add_argument("--config4-boxes", type=int, default=16, help="box stack height of the config-4 full-step leg (n = 32 x boxes; 16 = the stated size)")
+    ap.add_argument("--config4-worlds", type=int, default=1024)
+    ap.add_argument("--config4-steps", type=int, default=1)
     ap.add_argument("--no-long-horizon", action="store_true")
     ap.add_argument("--long-horizon-start", type=int, default=4000)
     args = ap.parse_args()
@@ -434,6 +488,9 @@ def main():
                      "model": "LCP-entry bytes 8(n^2+2n) per solved LCP (SURVEY 8d); the fused kernel itself only moves %d B of state per launch" % int(fused_bytes)},
     }
 
+    c4cpu = None
+    if rank == 0 and world_size == 1 and not args.no_config4 and not args.no_cpu_baseline:
+        c4cpu = config4_cpu_sample_start(args.config4_boxes)             # a child on one host core, beside the legs below
     if world_size > 1:
         out["strong_scaling"] = strong_leg(torch, dist, mdist, S, WorldBatchDevice, sc, B, rank, world_size, dev, args)
     if cpu is not None:
@@ -442,7 +499,7 @@ def main():
         out["long_horizon"] = long_horizon_leg(torch, wb, stream, B, args)   # after the timed region; informational
     if rank == 0 and world_size == 1 and not args.no_config4:
         out["config4_impact_handler"] = config4_leg(torch)             # after the timed region; informational
-        out["config4_full_step"] = config4_full_step_leg(torch, args.config4_boxes, args.config4_worlds, args.config4_steps)
+        out["config4_full_step"] = config4_full_step_leg(torch, args.config4_boxes, args.config4_worlds, args.config4_steps, c4cpu)
     if rank == 0 and world_size == 1 and not args.no_config5:
         out["config5_ur10"] = config5_leg(torch, cpu=not args.no_cpu_baseline)
     if rank == 0:
