@@ -318,27 +318,42 @@ def config5_leg(torch, B=8192, steps=200, cpu=True):
         return {"error": repr(e)}
 
 
-def strong_leg(torch, dist, mdist, S, WorldBatchDevice, sc, B_total, rank, world_size, dev, args):
+def strong_leg(dist, mdist, S, make_batch, B_total, rank, world_size, dev, steps, warmup, sync, stream=None):
     """Strong scaling: ONE batch of `B_total` worlds split over the ranks (rank r owns worlds [r B/N, (r+1) B/N) of the
-    same batch the N = 1 run steps), W warmup + K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+    same batch the N = 1 run steps), W warmup + K timed steps, barrier + synchronize on both sides, MAX over ranks.
+    `make_batch(first, count)` builds the rank's share (the device batch in bench.py; tests/test_dist_gloo.py runs this very
+    function over gloo with a stand-in), `sync()` drains the device.  The ranks' ranges are gathered and must tile
+    [0, B_total) exactly once."""
+    import torch
     first, count = mdist.split_range(rank, world_size, B_total)
-    wb = WorldBatchDevice(sc, S.sphere_stack_state_range(first, count))
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    if args.warmup > 0:
-        wb.step(DT, args.warmup, stream)
-    torch.cuda.synchronize()
+    mine = torch.tensor([first, count], dtype=torch.int64, device=dev)
+    allr = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world_size)]
+    dist.all_gather(allr, mine)
+    ranges = [(int(t[0]), int(t[1])) for t in allr]
+    pos = 0
+    for f, c in ranges:
+        if f != pos or c < 0:
+            raise SystemExit("strong scaling: rank ranges %r do not tile [0, %d)" % (ranges, B_total))
+        pos += c
+    if pos != B_total:
+        raise SystemExit("strong scaling: rank ranges %r do not tile [0, %d)" % (ranges, B_total))
+    wb = make_batch(first, count)
+    if warmup > 0:
+        wb.step(DT, warmup, stream)
+    sync()
     _, aux0 = wb.download()
-    dist.barrier(); torch.cuda.synchronize()
+    dist.barrier(); sync()
     t0 = time.perf_counter()
-    wb.step(DT, args.steps, stream)
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    wb.step(DT, steps, stream)
+    sync(); dist.barrier(); sync()
     elapsed = time.perf_counter() - t0
     _, aux1 = wb.download()
     tot = mdist.counter_vector(aux0, aux1, (aux1["status"] & ~S.MH_WORLD_IMPACT_TOL) != 0)
     elapsed, tot = mdist.reduce_interval(elapsed, tot, dist, dev)
     wb.close()
-    return {"scaling": "strong", "worlds_total": B_total, "worlds_per_gpu": count, "value": float(tot[0]) / elapsed, "unit": "LCP rows/s",
-            "world_steps_per_sec": B_total * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+    return {"scaling": "strong", "n_gpus": world_size, "worlds_total": B_total, "worlds_per_gpu": count, "rank_ranges": ranges,
+            "value": float(tot[0]) / elapsed, "unit": "LCP rows/s", "lcp_rows": float(tot[0]), "lcp_solves": float(tot[1]),
+            "world_steps_per_sec": B_total * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
             "note": "%d worlds per GPU = %.1f waves per CU: below the 16 resident waves per CU the kernel needs to hide LDS latency"
                     % (count, count / 256.0)}
 
@@ -492,7 +507,8 @@ def main():
     if rank == 0 and world_size == 1 and not args.no_config4 and not args.no_cpu_baseline:
         c4cpu = config4_cpu_sample_start(args.config4_boxes)             # a child on one host core, beside the legs below
     if world_size > 1:
-        out["strong_scaling"] = strong_leg(torch, dist, mdist, S, WorldBatchDevice, sc, B, rank, world_size, dev, args)
+        out["strong_scaling"] = strong_leg(dist, mdist, S, lambda f, c: WorldBatchDevice(sc, S.sphere_stack_state_range(f, c)), B, rank, world_size, dev,
+                                           args.steps, args.warmup, torch.cuda.synchronize, stream)
     if cpu is not None:
         out["cpu_baseline"] = cpu
     if rank == 0 and world_size == 1 and not args.no_long_horizon:

@@ -1350,6 +1350,16 @@ int mh_big_batch_upload(mh_big_batch* bb, const double* state, const mh_world_au
     MH_HIP(hipMemcpy(bb->d.mini_steps, minis.data(), B * 8, hipMemcpyHostToDevice));
     MH_HIP(hipMemcpy(bb->d.stab_iters, stabs.data(), B * 8, hipMemcpyHostToDevice));
     MH_HIP(hipMemcpy(bb->core.cnt, cnt.data(), B * 40, hipMemcpyHostToDevice));
+    // the handler's warm-start SIZES travel with aux (as in the one-wavefront world batch): a fresh aux (all zero) therefore makes
+    // the next solve cold whatever ran on this batch before; the vectors themselves (_zlast, the storage of _z) are
+    // mh_big_batch_load_solver_state's -- a resume is download + save_solver_state, then upload + load_solver_state
+    { std::vector<int> zl(B), zs2(B), zc(B);
+      for (size_t b = 0; b < B; b++) { zl[b] = aux[b].zlast_size; zs2[b] = aux[b].zbuf_size; zc[b] = aux[b].zbuf_cap;
+        if (zl[b] < 0 || zl[b] > bb->cap || zs2[b] < 0 || zc[b] < 0 || zc[b] > bb->cap)
+          return fail(MH_ERR_INVALID_ARG, "aux[%zu]: warm-start sizes (%d, %d, %d) outside the batch's LCP capacity %d", b, zl[b], zs2[b], zc[b], bb->cap); }
+      MH_HIP(hipMemcpy(bb->core.zlast_size, zl.data(), B * 4, hipMemcpyHostToDevice));
+      MH_HIP(hipMemcpy(bb->core.zbuf_size, zs2.data(), B * 4, hipMemcpyHostToDevice));
+      MH_HIP(hipMemcpy(bb->core.zbuf_cap, zc.data(), B * 4, hipMemcpyHostToDevice)); }
     std::vector<int> vsz(B); std::vector<double> vns(B * MH_NOSLIP_MAX);
     for (size_t b = 0; b < B; b++) { vsz[b] = aux[b].vns_size; std::memcpy(&vns[b * MH_NOSLIP_MAX], aux[b].vns, MH_NOSLIP_MAX * 8); }
     MH_HIP(hipMemcpy(bb->core.vns_size, vsz.data(), B * 4, hipMemcpyHostToDevice));

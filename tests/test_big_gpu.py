@@ -205,6 +205,31 @@ def test_structure_exploiting_lu_route_equals_the_dense_route_in_full_steps():
     assert (res[1][1]["lcp_pivots"] > 1000).all()
 
 
+def test_upload_restores_or_resets_the_handlers_warm_start():
+    """mh_big_batch_upload(state, aux) carries the warm-start SIZES (_zlast / _z) like the one-wavefront batch's aux does:
+    (i) download + save_solver_state, a NEW batch, upload + load_solver_state, step == the uninterrupted run, bit for bit;
+    (ii) a used batch given a fresh state and a zeroed aux behaves like a fresh batch (the next solve is cold)."""
+    N, B = 3, 4
+    sc = K.box_stack_scene(N)
+    st0 = K.box_stack_state(N, B)
+    ref = K.BigBatch(sc, st0); ref.step(1e-3, 5); st_ref, aux_ref = ref.download(); ref.close()
+    a = K.BigBatch(sc, st0); a.step(1e-3, 3)
+    st_mid, aux_mid = a.download(); ss = a.solver_state()
+    assert (aux_mid["zlast_size"] > 0).all()                         # there IS a warm start to lose
+    b = K.BigBatch(sc, st0)                                          # (i) resume in another batch
+    b.upload(st_mid, aux_mid); b.load_solver_state(ss); b.step(1e-3, 2)
+    st_b, aux_b = b.download(); b.close()
+    assert np.array_equal(st_b, st_ref)
+    for f in FIELDS:
+        assert np.array_equal(aux_b[f], aux_ref[f]), f
+    fresh = K.BigBatch(sc, st0); fresh.step(1e-3, 2); st_f, aux_f = fresh.download(); fresh.close()
+    a.upload(st0, S.new_aux(B)); a.step(1e-3, 2)                     # (ii) reuse with a fresh aux
+    st_a, aux_a = a.download(); a.close()
+    assert np.array_equal(st_a, st_f)
+    for f in FIELDS:
+        assert np.array_equal(aux_a[f], aux_f[f]), f
+
+
 def test_cpp_stack_simulator_adapter_example():
     """moby_amd/cpp/MobyHipStackSimulator.h (TimeSteppingSimulator::step and ConstraintStabilization::stabilize for
     large worlds) through its example program."""

@@ -53,6 +53,55 @@ def test_two_rank_sharding_and_reduction():
         assert red[1] == 2 * world * B
 
 
+class _FakeBatch:
+    """Stand-in for the device batch of bench.py's strong_leg: world w "solves" one LCP of (w + 1) rows per step."""
+    def __init__(self, first, count):
+        self.ids = np.arange(first, first + count); self.aux = np.zeros(count, dtype=S.AUX_DTYPE)
+    def step(self, dt, n, stream=None):
+        self.aux["lcp_rows"] += (self.ids + 1).astype(np.uint64) * np.uint64(n); self.aux["lcp_solves"] += np.uint64(n)
+    def download(self):
+        return None, self.aux.copy()
+    def close(self):
+        pass
+
+
+def _strong_worker(rank, world, port, B_total, out):
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    r = bench.strong_leg(dist, mdist, S, _FakeBatch, B_total, rank, world, None, steps=3, warmup=2, sync=lambda: None)
+    out.put((rank, r))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_leg_over_gloo():
+    """bench.py's strong_leg itself (range split, gathered ranges, barriers, MAX / SUM reduction, the merged object) on two gloo
+    ranks: the ranges tile [0, B) exactly once, every rank reports the same merged figures, n_gpus and worlds_per_gpu are right."""
+    world, B_total = 2, 4097                      # odd: the remainder goes to rank 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strong_worker, args=(r, world, port, B_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]["rank_ranges"] == res[1]["rank_ranges"] == [(0, 2049), (2049, 2048)]
+    covered = np.zeros(B_total, dtype=int)
+    for f, c in res[0]["rank_ranges"]:
+        covered[f:f + c] += 1
+    assert (covered == 1).all()
+    for rank in (0, 1):
+        r = res[rank]
+        assert r["n_gpus"] == 2 and r["worlds_total"] == B_total and r["scaling"] == "strong"
+        assert r["worlds_per_gpu"] == (2049 if rank == 0 else 2048)
+        assert r["lcp_rows"] == 3 * sum(range(1, B_total + 1)) and r["lcp_solves"] == 3 * B_total      # timed steps only, all worlds
+    assert res[0]["value"] == res[1]["value"] and res[0]["ms_per_step"] == res[1]["ms_per_step"]     # MAX / SUM: one answer
+
+
 def test_split_range_covers_the_batch_once():
     """Strong scaling (one batch split N ways): contiguous, disjoint, complete; remainder on the lowest ranks."""
     for total in (4096, 4097, 7, 1):
@@ -70,11 +119,12 @@ def test_bench_launches_its_own_ranks_when_started_as_plain_python():
     environment was set up, which is what is checked here."""
     import subprocess
     import sys
+    import pytest
+    if torch.cuda.is_available():
+        pytest.skip("on a GPU box the scaling run itself is the driver's job")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
-    if torch.cuda.is_available():
-        return      # on a GPU box the scaling run itself is the driver's job
     assert p.returncode != 0
     assert "needs a GPU" in p.stderr and "WORLD_SIZE=1" not in p.stderr, p.stderr[-2000:]
