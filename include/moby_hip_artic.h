@@ -19,8 +19,8 @@
  *
  * Scope: config 5 is the robot alone (self-collision disabled as in ur10.xml:12: no contact rows, one mini-step per step);
  * optionally sphere primitives on links against a static plane (mh_artic_model.nspheres, no-slip contacts), no actuator torques (controller plugins stay on the host side of the seam: add them
- * through qdd = H^-1 (tau - C) by passing tau), constraint stabilisation off (ur10.xml:11 sets
- * constraint-stabilization-max-iterations = 0).
+ * through qdd = H^-1 (tau - C) by passing tau).  Constraint stabilisation with joint-limit rows: mh_artic_model.cstab_max_iterations
+ * (ur10.xml:11 sets constraint-stabilization-max-iterations = 0 = off).
  */
 #ifndef MOBY_HIP_ARTIC_H
 #define MOBY_HIP_ARTIC_H
@@ -81,7 +81,13 @@ typedef struct mh_artic_model {
   double contact_dist_thresh;                      /* ConstraintSimulator.cpp:56 (1e-6) */
   double cp_mu_viscous, cp_compliance;             /* used by the Drumwright-Shell model only (mu_coulomb < 100) */
   int    cp_nk;                                    /* friction-cone-edges (>= 4, even; ur10.xml:19 has 4); 0 is read as 4 */
-  int    pad2;
+  int    cstab_max_iterations;                     /* ConstraintStabilization::max_iterations ("constraint-stabilization-max-iterations"; ur10.xml:11
+                                                      sets 0 = off; the reference's own default is UINT_MAX, see MH_CSTAB_DEFAULT_MAX_ITERATIONS) */
+  /* ConstraintStabilization::stabilize after every step (TSS:97) with the body's JOINT LIMITS as rows (CStab:257-304 add_limit_constraints:
+   * one row per finite limit, signed_violation = its distance; L_v = violation - |eps| - NEAR_ZERO, CStab:434-441; MM = L X L',
+   * CStab:932-970; the line search of update_q over the limit slacks, CStab:1056-1216, 1322-1379).  Bodies WITH sphere primitives are
+   * stepped with stabilisation off only (mh_artic_batch_create refuses the combination): the contact rows of the stabiliser are not built. */
+  double cstab_eps;                                /* ConstraintStabilization::eps ("unilateral-stabilization-tol"), default NEAR_ZERO (CStab:59) */
 } mh_artic_model;
 
 /* B worlds resident on the GPU: joint positions q and velocities qd (B x nj each) + mh_world_aux (rand() stream, time,

@@ -31,7 +31,7 @@ class mh_artic_model(ctypes.Structure):
                 ("sphere_radius", ctypes.c_double * _NS), ("plane_R", ctypes.c_double * 9), ("plane_o", ctypes.c_double * 3),
                 ("cp_epsilon", ctypes.c_double), ("cp_mu_coulomb", ctypes.c_double), ("min_step_size", ctypes.c_double),
                 ("contact_dist_thresh", ctypes.c_double), ("cp_mu_viscous", ctypes.c_double), ("cp_compliance", ctypes.c_double),
-                ("cp_nk", ctypes.c_int), ("pad2", ctypes.c_int)]
+                ("cp_nk", ctypes.c_int), ("cstab_max_iterations", ctypes.c_int), ("cstab_eps", ctypes.c_double)]
 
 
 MH_ARTIC_CRB, MH_ARTIC_FSAB = 0, 1      # moby_hip_artic.h: RCArticulatedBody::algorithm_type
@@ -95,6 +95,7 @@ def model_from_links(links, gravity=(0.0, 0.0, -9.81)):
         m.limit_restitution[i] = L.get("restitution", 0.0)
     for k in range(3):
         m.gravity[k] = gravity[k]
+    m.cstab_eps = S.NEAR_ZERO              # ConstraintStabilization::eps (CStab:59); stabilisation itself off until cstab_max_iterations is set
     return m
 
 

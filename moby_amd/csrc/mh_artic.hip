@@ -74,7 +74,7 @@ struct Lay {
   // q, qd, qdd, C and H, L, X live for the whole step; the link quantities of dynamics() (R .. Iv) and the limit LCP's
   // storage (MM .. idx) are never alive together -- handle_limits reads q, qd, L, X only and the next dynamics() call
   // rebuilds everything from q, qd -- so they share one region: 10 KB per world at 10 joints = 16 worlds per CU
-  MH_DEV Lay(int n) : nj(n) {
+  MH_DEV Lay(int n, int nlcap = NLMAX) : nj(n) {     // nlcap: rows the limit LCP's storage takes (NLSTAB in the stabilising kernel)
     int o = 0;
     q = o; o += n; qd = o; o += n; qdd = o; o += n; C = o; o += n;
     H = o; o += n * n; L = o; o += n * n; X = o; o += n * n;
@@ -83,14 +83,15 @@ struct Lay {
     S = o; o += 6 * n; I6 = o; o += 36 * n; v = o; o += 6 * n; a = o; o += 6 * n; f = o; o += 6 * n; F = o; o += 6 * n; Iv = o; o += 12;
     const int end_dyn = o;
     o = u;
-    MM = o; o += NLMAX * NLMAX; A = o; o += NLMAX * NLMAX; art = o; o += NLMAX; Lv = o; o += NLMAX; l = o; o += NLMAX;
-    idx = o; o += NLMAX;           // ints stored as doubles' slots (one int each, low half)
+    MM = o; o += nlcap * nlcap; A = o; o += nlcap * nlcap; art = o; o += nlcap; Lv = o; o += nlcap; l = o; o += nlcap;
+    idx = o; o += nlcap;           // ints stored as doubles' slots (one int each, low half)
     total = (o > end_dyn) ? o : end_dyn;
   }
 };
-static size_t lds_bytes(int nj) {
+constexpr int NLSTAB = 2 * NJ;      // the stabiliser's LCP has a row for every finite limit (CStab:257-304): up to two per joint
+static size_t lds_bytes(int nj, int nlcap = NLMAX) {
   const int n = nj;
-  const int dyn = 90 * n + 12, lim = 2 * NLMAX * NLMAX + 4 * NLMAX;
+  const int dyn = 90 * n + 12, lim = 2 * nlcap * nlcap + 4 * nlcap;
   return sizeof(double) * (size_t)(4 * n + 3 * n * n + (dyn > lim ? dyn : lim));
 }
 
@@ -459,6 +460,159 @@ MH_DEV void handle_limits(const Model& M, const Lay& Y, double* g, mh_world_aux*
   if (ballot(valid && ((myup ? -qd2 : qd2) < -NEAR_ZERO_)) != 0ull) status |= MH_WORLD_IMPACT_TOL;   // ICH:157-167
 }
 
+// ConstraintStabilization::stabilize for this body, joint-limit rows (oracle Artic::stabilize; CStab:167-254, 257-304, 434-441, 932-970,
+// 1056-1216, 1322-1379).  evaluate_unilateral_constraints reads joints[i] with i the BODY's index (CStab:117) -- joint 0 here, once per
+// joint: every entry of uC is one of joint 0's two slacks, so the line search of update_q is wave-uniform scalar code on
+// (q0, dq0); the LCP has a row for every finite limit of every joint and needs H^-1 at the current configuration.
+struct StabSlack { double hi0, lo0;
+  MH_DEV double at(double q0, unsigned i) const { return (i & 1u) ? (q0 + 0.0) - lo0 : (hi0 - q0) - 0.0; }     // hilimit - q - tare / q + tare - lolimit, tare = 0
+  MH_DEV double vio(double q0) const { const double a = (hi0 - q0) - 0.0, b = (q0 + 0.0) - lo0; return (b < a) ? b : a; } };
+MH_DEV double stab_sign2(double x, double y) { return (y > 0.0) ? fabs(x) : -fabs(x); }
+MH_DEV double stab_q0_at(double t, double dq0, double qv0) { double v = dq0 * t; v = v + qv0; return v; }
+MH_DEV double stab_ridders(const StabSlack& K, double x1, double x2, double fl, double fh, unsigned idx, double dq0, double qv0) {   // CStab:1322-1379
+  const double TOL = 1e-4, INF_ = 1.7976931348623157e308;
+  double ans = INF_, fm, fnew, s2, xh, xl, xm, xnew;
+  if ((fl > 0.0 && fh < 0.0) || (fl < 0.0 && fh > 0.0)) {
+    xl = x1; xh = x2;
+    for (unsigned j = 0; j < 25; j++) {
+      xm = 0.5 * (xl + xh);
+      fm = K.at(stab_q0_at(xm, dq0, qv0), idx);
+      s2 = sqrt(fm * fm - fl * fh);
+      if (s2 == 0.0) return ans;
+      xnew = xm + (xm - xl) * ((fl >= fh ? 1.0 : -1.0) * fm / s2);
+      ans = xnew;
+      fnew = K.at(stab_q0_at(ans, dq0, qv0), idx);
+      if (fabs(fnew) < TOL && fnew >= 0.0) return xnew;
+      if (stab_sign2(fm, fnew) != fm) { xl = xm; fl = fm; xh = ans; fh = fnew; }
+      else if (stab_sign2(fl, fnew) != fl) { xh = ans; fh = fnew; }
+      else if (stab_sign2(fh, fnew) != fh) { xl = ans; fl = fnew; }
+    }
+  } else {
+    if (fl == 0.0) return x1;
+    if (fh == 0.0) return x2;
+  }
+  return 0.0;
+}
+__device__ __noinline__ void stabilize_limits(const Model& M, const Lay& Y, double* g, WaveRand& rng, int& status,
+                                              unsigned long long& solves, unsigned long long& rows, unsigned long long& pivs, unsigned long long& bytes,
+                                              unsigned long long& stab_iters, unsigned long long& stab_rows)
+{
+  const mh_artic_model& m = M.m;
+  const unsigned maxit = (unsigned)m.cstab_max_iterations;
+  if (maxit == 0) return;
+  const int nj = Y.nj, lane = lane_id();
+  const double INF_ = 1.7976931348623157e308;
+  StabSlack K; K.hi0 = m.hilimit[0]; K.lo0 = m.lolimit[0];
+  const double qd_save = (lane < nj) ? g[Y.qd + lane] : 0.0;
+  double qv = (lane < nj) ? g[Y.q + lane] : 0.0;                   // the stabiliser's q (CStab:183)
+  double max_uvio = K.vio(uni(g[Y.q]));
+  unsigned iterations = 0;
+  const bool hfin = lane < nj && m.hilimit[lane] < INF_, lfin = lane < nj && m.lolimit[lane] > -INF_;
+  const uint64_t mu = ballot(hfin), ml = ballot(lfin);
+  const int nl = popc(mu) + popc(ml);                              // a row for every finite limit (CStab:257-304), upper before lower per joint
+  while (max_uvio < m.cstab_eps) {
+    if (iterations == maxit) break;
+    if (iterations == MH_CSTAB_HARD_CAP) { status |= MH_WORLD_STALLED; break; }
+    wave_sync();
+    if (lane < nj) g[Y.qd + lane] = 0.0;
+    double dq = 0.0;
+    wave_sync();
+    if (nl > 0) {
+      if (nl > NLSTAB) { status |= MH_WORLD_UNSUPPORTED; break; }
+      // compute_X at the CURRENT configuration: H by the CRB path, its factor, the inverse (ICH:1600-1607)
+      if (!dynamics(M, Y, g, nullptr)) { status |= MH_WORLD_LCP_FAILED; break; }
+      int* idx = reinterpret_cast<int*>(g + Y.idx);              // idx[k] = joint | (upper << 8)
+      if (lane < nj) {
+        const int base = popc(mu & lanes_below(lane)) + popc(ml & lanes_below(lane));
+        if (hfin) idx[base] = lane | 256;
+        if (lfin) idx[base + (hfin ? 1 : 0)] = lane;
+      }
+      wave_sync();
+      inverse_from_factor(Y, g);
+      const double* X = g + Y.X;
+      double* MM = g + Y.MM;
+      for (int e = lane; e < nl * nl; e += 64) {                   // L X L' without the limits' signs (ICH:1763-1771)
+        const int a = e % nl, b2 = e / nl;
+        const int ia = idx[a] & 255, ib = idx[b2] & 255;
+        MM[e] = (b2 >= a) ? X[ia * nj + ib] : X[ib * nj + ia];
+      }
+      const bool valid = lane < nl;
+      const int my = valid ? idx[lane] : 0;
+      const int myj = my & 255; const bool myup = (my & 256) != 0;
+      double Lv = 0.0;
+      if (valid) { const double qj = g[Y.q + myj]; const double viol = myup ? (m.hilimit[myj] - qj) - 0.0 : (qj + 0.0) - m.lolimit[myj];
+                   Lv = (viol - fabs(m.cstab_eps)) - NEAR_ZERO_; }     // CStab:434-441
+      wave_sync();
+      double nrm0 = 0.0;
+      for (int e = lane; e < nl * nl; e += 64) { const double a = fabs(MM[e]); nrm0 = (a > nrm0) ? a : nrm0; }
+      nrm0 = wave_max(nrm0);
+      const double dii = valid ? MM[lane + nl * lane] : 0.0;
+      int zsize = 0;                                               // determine_dq's local z: cold lcp_fast, then the Lemke ladder (CStab:954-955)
+      double zi = 0.0;
+      DenseLds Md; Md.M = MM; Md.n = nl;
+      LuScratch S; S.small = g + Y.A; S.ka = nl; S.big = g + Y.A;
+      Trace tr; tr.buf = nullptr; tr.cap = 0; tr.len = 0;
+      LcpParams P; P.kind = MH_LCP_FAST; P.min_exp = -20; P.step_exp = 1u; P.max_exp = 1; P.piv_tol = -1.0; P.zero_tol = -1.0;
+      unsigned piv = 0, total = 0;
+      bool ok = lcp_solve_wave(P, c_pow10a, nl, Md, S, g + Y.art, nrm0, dii, Lv, zi, zsize, rng, piv, tr);
+      total += piv;
+      if (!ok) {
+        P.kind = MH_LCP_LEMKE_REG;
+        ok = lcp_solve_wave(P, c_pow10a, nl, Md, S, g + Y.art, nrm0, dii, Lv, zi, zsize, rng, piv, tr);
+        total += piv;
+      }
+      solves += 1ull; rows += (unsigned long long)nl; pivs += total; bytes += 8ull * ((unsigned long long)nl * nl + 2ull * nl);
+      stab_rows += (unsigned long long)nl;
+      // update_from_stacked(pd, z): l = z whatever it holds; dv = X_LT ls; v += dv; dq = the joint velocities
+      double* ll = g + Y.l;
+      wave_sync();
+      if (valid) ll[lane] = (lane < uni(zsize)) ? zi : 0.0;
+      wave_sync();
+      if (lane < nj) {
+        double dv = 0.0;
+        for (int k = 0; k < nl; k++) { const int c = idx[k]; const double ls = (c & 256) ? -ll[k] : ll[k]; dv = dv + ls * X[(c & 255) * nj + lane]; }
+        const double v = g[Y.qd + lane] + dv;
+        g[Y.qd + lane] = v; dq = v;
+      }
+      wave_sync();
+    }
+    // update_q (CStab:1056-1216): the line search lives on joint 0's slacks alone
+    { const double dq0 = read_lane(dq, 0), qv0 = read_lane(qv, 0);
+      double t = 1.0;
+      const double q1 = stab_q0_at(1.0, dq0, qv0);                 // qstar = dq + q: dq * 1.0 is dq
+      for (unsigned i = 0; i < 2u * (unsigned)nj; i++) {
+        const double fo = K.at(qv0, i), fn = K.at(q1, i);
+        if (!((fo < 0.0 && fn > 0.0) || (fo > 0.0 && fn < 0.0))) continue;
+        const double root = stab_ridders(K, 0.0, t, fo, fn, i, dq0, qv0);
+        if (root > 0.0 && root < 1.0) t = (root < t) ? root : t;
+      }
+      bool failed = false;
+      while (true) {
+        const double qt = stab_q0_at(t, dq0, qv0);
+        bool stop = true;
+        for (unsigned i = 0; i < 2u * (unsigned)nj; i++) {
+          const double fo = K.at(qv0, i), fn1 = K.at(q1, i), fc = K.at(qt, i);
+          const bool br = (fo < 0.0 && fn1 > 0.0) || (fo > 0.0 && fn1 < 0.0);
+          if (!br && fc < 0.0 && fo > fc) { stop = false; break; }
+        }
+        if (stop) break;
+        t *= 0.6;
+        if (t < NEAR_ZERO_) { failed = true; break; }
+      }
+      if (failed) { status |= MH_WORLD_STAB_FAILED; break; }
+      if (lane < nj) { double v = dq * t; v = v + qv; qv = v; g[Y.q + lane] = v; }
+      wave_sync();
+    }
+    max_uvio = K.vio(uni(g[Y.q]));
+    iterations++;
+    stab_iters += 1ull;
+  }
+  wave_sync();
+  if (lane < nj) { g[Y.qd + lane] = qd_save; g[Y.q + lane] = qv; }
+  wave_sync();
+}
+
+template <bool STAB>
 MH_DEV void artic_step_body(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
                             mh_world_aux* __restrict__ auxg)
 {
@@ -467,13 +621,13 @@ MH_DEV void artic_step_body(const Model* __restrict__ Mg, int B, double dt, int 
   if (b >= B) return;
   const Model& M = *Mg;
   const int nj = M.m.nj, lane = lane_id();
-  const Lay Y(nj);
+  const Lay Y(nj, STAB ? NLSTAB : NLMAX);
   mh_world_aux* aux = auxg + b;
   if (lane < nj) { g[Y.q + lane] = qg[(size_t)b * nj + lane]; g[Y.qd + lane] = qdg[(size_t)b * nj + lane]; }
   WaveRand rng; rng.load(aux->rng);
   if (lane == 0) g_lcp_prof_on = 0;
   int status = uni(aux->status);
-  unsigned long long solves = 0, rows = 0, pivs = 0, bytes = 0;
+  unsigned long long solves = 0, rows = 0, pivs = 0, bytes = 0, stab_iters = 0, stab_rows = 0;
   wave_sync();
   for (int s = 0; s < nsteps; s++) {
     // positions with the OLD velocity (TSS:156-164)
@@ -485,6 +639,7 @@ MH_DEV void artic_step_body(const Model* __restrict__ Mg, int B, double dt, int 
     wave_sync();
     if (ok) handle_limits(M, Y, g, aux, rng, status, solves, rows, pivs, bytes);
     wave_sync();
+    if (STAB) stabilize_limits(M, Y, g, rng, status, solves, rows, pivs, bytes, stab_iters, stab_rows);    // TSS:97
   }
   if (lane < nj) { qg[(size_t)b * nj + lane] = g[Y.q + lane]; qdg[(size_t)b * nj + lane] = g[Y.qd + lane]; }
   rng.store(aux->rng);
@@ -493,6 +648,7 @@ MH_DEV void artic_step_body(const Model* __restrict__ Mg, int B, double dt, int 
     aux->time = tm; aux->status = status;
     aux->steps += (unsigned long long)nsteps; aux->mini_steps += (unsigned long long)nsteps;
     aux->lcp_solves += solves; aux->lcp_rows += rows; aux->lcp_pivots += pivs; aux->lcp_alg_bytes += bytes;
+    aux->stab_iters += stab_iters; aux->stab_rows += stab_rows;
   }
 }
 
@@ -502,13 +658,19 @@ MH_DEV void artic_step_body(const Model* __restrict__ Mg, int B, double dt, int 
 // Default 4; MH_ARTIC_WAVES=2|3 selects the others (experiments).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_artic_step_w3(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
-                     mh_world_aux* __restrict__ auxg) { artic_step_body(Mg, B, dt, nsteps, qg, qdg, auxg); }
+                     mh_world_aux* __restrict__ auxg) { artic_step_body<false>(Mg, B, dt, nsteps, qg, qdg, auxg); }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_artic_step_w4(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
-                     mh_world_aux* __restrict__ auxg) { artic_step_body(Mg, B, dt, nsteps, qg, qdg, auxg); }
+                     mh_world_aux* __restrict__ auxg) { artic_step_body<false>(Mg, B, dt, nsteps, qg, qdg, auxg); }
 __global__ __launch_bounds__(64)
 void k_artic_step_w2(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
-                     mh_world_aux* __restrict__ auxg) { artic_step_body(Mg, B, dt, nsteps, qg, qdg, auxg); }
+                     mh_world_aux* __restrict__ auxg) { artic_step_body<false>(Mg, B, dt, nsteps, qg, qdg, auxg); }
+
+// the same step followed by ConstraintStabilization::stabilize (joint-limit rows): its own kernel, so that bodies stepped with
+// stabilisation off (ur10.xml:11) carry neither its registers nor its 20 KB LDS image (a row for every finite limit: 2 nj)
+__global__ __launch_bounds__(64)
+void k_artic_step_stab(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
+                       mh_world_aux* __restrict__ auxg) { artic_step_body<true>(Mg, B, dt, nsteps, qg, qdg, auxg); }
 
 // seam B4: qdd = H^-1 (tau - C), H, link poses of the resident states
 __global__ __launch_bounds__(64)
@@ -572,7 +734,7 @@ void k_artic_jacobian(const Model* __restrict__ Mg, int B, const double* __restr
 }} // namespace mh::artic
 
 struct mh_artic_batch {
-  int B, nj, nspheres;
+  int B, nj, nspheres, cstab;
   mh::artic::Model* d_model;
   double* d_q; double* d_qd; mh_world_aux* d_aux;
   double* d_ws;           // link contacts with the Drumwright-Shell model: _MM + LU workspace, 2 x 64 x 64 doubles per world
@@ -615,6 +777,10 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
     if (model->sphere_link[s] < 0 || model->sphere_link[s] >= nj) return fail(MH_ERR_INVALID_ARG, "sphere %d: link %d outside [0, %d)", s, model->sphere_link[s], nj);
     if (!(model->sphere_radius[s] > 0.0)) return fail(MH_ERR_INVALID_ARG, "sphere %d: radius must be > 0", s);
   }
+  if (model->cstab_max_iterations < 0) return fail(MH_ERR_INVALID_ARG, "cstab_max_iterations = %d < 0", model->cstab_max_iterations);
+  if (model->cstab_max_iterations != 0 && model->nspheres > 0)
+    return fail(MH_ERR_INVALID_ARG, "constraint stabilisation with link spheres: the stabiliser's contact rows are not built for articulated bodies; "
+                                   "set cstab_max_iterations = 0 (as example/ur10/ur10.xml:11 does)");
   if (model->nspheres > 0) {
     const double* Rp = model->plane_R; const double nn = Rp[1]*Rp[1] + Rp[4]*Rp[4] + Rp[7]*Rp[7];
     if (!(nn > 0.999999 && nn < 1.000001)) return fail(MH_ERR_INVALID_ARG, "plane_R is not a rotation (its +Y column is the plane normal)");
@@ -638,7 +804,7 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
     }
   }
   mh_artic_batch* ab = new mh_artic_batch();
-  ab->B = B; ab->nj = nj; ab->nspheres = model->nspheres; ab->d_model = nullptr; ab->d_q = nullptr; ab->d_qd = nullptr; ab->d_aux = nullptr; ab->d_ws = nullptr;
+  ab->B = B; ab->nj = nj; ab->nspheres = model->nspheres; ab->cstab = model->cstab_max_iterations != 0 ? 1 : 0; ab->d_model = nullptr; ab->d_q = nullptr; ab->d_qd = nullptr; ab->d_aux = nullptr; ab->d_ws = nullptr;
   const size_t sB = (size_t)B;
   bool ok = hipMalloc((void**)&ab->d_model, sizeof(ar::Model)) == hipSuccess && hipMalloc((void**)&ab->d_q, sB * nj * 8) == hipSuccess
          && hipMalloc((void**)&ab->d_qd, sB * nj * 8) == hipSuccess && hipMalloc((void**)&ab->d_aux, sB * sizeof(mh_world_aux)) == hipSuccess;
@@ -677,6 +843,12 @@ int mh_artic_batch_step(mh_artic_batch* ab, void* stream, double dt, int nsteps)
   if (ab->nspheres > 0) {                                     // bodies with collision geometry: the full step with mini-steps and contact rows
     hipLaunchKernelGGL(ar::k_artic_step_contacts, dim3(ab->B), dim3(64), ar::lds_bytes_contacts(ab->nj), (hipStream_t)stream,
                        (const ar::Model*)ab->d_model, ab->B, dt, nsteps, ab->d_q, ab->d_qd, ab->d_aux, ab->d_ws);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+  }
+  if (ab->cstab) {
+    hipLaunchKernelGGL(ar::k_artic_step_stab, dim3(ab->B), dim3(64), ar::lds_bytes(ab->nj, ar::NLSTAB), (hipStream_t)stream,
+                       (const ar::Model*)ab->d_model, ab->B, dt, nsteps, ab->d_q, ab->d_qd, ab->d_aux);
     MH_HIP(hipGetLastError());
     return MH_OK;
   }

@@ -703,6 +703,128 @@ class Artic {
     return h;
   }
 
+  // ---- ConstraintStabilization::stabilize for this body: joint-limit rows (CStab:167-254, 257-304, 434-441, 932-970, 1056-1216) ----
+  // evaluate_unilateral_constraints (CStab:88-131): the pairwise distances (none without collision geometry), then for every
+  // joint j of body i the limit slacks of joints[i] -- the body's index in the simulator's list, not j (CStab:117, kept): with one
+  // articulated body per world that is joint 0, nj times
+  double cstab_eval(std::vector<double>& uC) const {
+    double vio = A_INF;
+    uC.clear();
+    for (int j = 0; j < nj; j++) {
+      uC.push_back((m->hilimit[0] - q[0]) - 0.0); vio = (uC.back() < vio) ? uC.back() : vio;      // hilimit - q - tare, tare = 0
+      uC.push_back((q[0] + 0.0) - m->lolimit[0]); vio = (uC.back() < vio) ? uC.back() : vio;
+    }
+    return vio;
+  }
+  double cstab_eval_at(double t, unsigned i, const double* dq, const double* qv) {                // CStab:1281-1298
+    std::vector<double> uC;
+    for (int k = 0; k < nj; k++) { double v = dq[k] * t; v = v + qv[k]; q[k] = v; }
+    cstab_eval(uC);
+    return uC[i];
+  }
+  static double sign2(double x, double y) { return (y > 0.0) ? std::fabs(x) : -std::fabs(x); }
+  double cstab_ridders(double x1, double x2, double fl, double fh, unsigned idx, const double* dq, const double* qv) {   // CStab:1322-1379
+    const double TOL = 1e-4;
+    double ans = A_INF, fm, fnew, s2, xh, xl, xm, xnew;
+    if ((fl > 0.0 && fh < 0.0) || (fl < 0.0 && fh > 0.0)) {
+      xl = x1; xh = x2;
+      for (unsigned j = 0; j < 25; j++) {
+        xm = 0.5 * (xl + xh);
+        fm = cstab_eval_at(xm, idx, dq, qv);
+        s2 = std::sqrt(fm * fm - fl * fh);
+        if (s2 == 0.0) return ans;
+        xnew = xm + (xm - xl) * ((fl >= fh ? 1.0 : -1.0) * fm / s2);
+        ans = xnew;
+        fnew = cstab_eval_at(ans, idx, dq, qv);
+        if (std::fabs(fnew) < TOL && fnew >= 0.0) return xnew;
+        if (sign2(fm, fnew) != fm) { xl = xm; fl = fm; xh = ans; fh = fnew; }
+        else if (sign2(fl, fnew) != fl) { xh = ans; fh = fnew; }
+        else if (sign2(fh, fnew) != fh) { xl = ans; fl = fnew; }
+      }
+    } else {
+      if (fl == 0.0) return x1;
+      if (fh == 0.0) return x2;
+    }
+    return 0.0;
+  }
+  bool cstab_update_q(const double* dq, double* qv) {                                            // CStab:1056-1216 (no implicit joints: C is empty)
+    std::vector<double> uC, uC_old;
+    cstab_eval(uC_old);
+    for (int k = 0; k < nj; k++) { double v = dq[k]; v = v + qv[k]; q[k] = v; }
+    cstab_eval(uC);
+    std::vector<char> br(uC.size(), 0);
+    for (size_t i = 0; i < uC.size(); i++) br[i] = ((uC_old[i] < 0.0 && uC[i] > 0.0) || (uC_old[i] > 0.0 && uC[i] < 0.0)) ? 1 : 0;
+    double t = 1.0;
+    for (size_t i = 0; i < br.size(); i++) {
+      if (!br[i]) continue;
+      const double root = cstab_ridders(0, t, uC_old[i], uC[i], (unsigned)i, dq, qv);
+      if (root > 0.0 && root < 1.0) t = (root < t) ? root : t;
+    }
+    for (int k = 0; k < nj; k++) { double v = dq[k] * t; v = v + qv[k]; q[k] = v; }
+    cstab_eval(uC);
+    const double BETA = 0.6;
+    while (true) {
+      bool stop = true;
+      for (size_t i = 0; i < br.size(); i++) if (!br[i] && uC[i] < 0.0 && uC_old[i] > uC[i]) { stop = false; break; }
+      if (stop) break;                                             // bilateral_cvio = 0 < bilateral_eps
+      t *= BETA;
+      if (t < A_NEAR_ZERO) return false;
+      for (int k = 0; k < nj; k++) { double v = dq[k] * t; v = v + qv[k]; q[k] = v; }
+      cstab_eval(uC);
+    }
+    for (int k = 0; k < nj; k++) qv[k] = q[k];
+    return true;
+  }
+  void stabilize() {
+    if (m->cstab_max_iterations == 0) return;
+    double qd_save[NJ], qv[NJ], dq[NJ];
+    for (int i = 0; i < nj; i++) { qd_save[i] = qd[i]; qv[i] = q[i]; }
+    std::vector<double> uC;
+    double max_uvio = cstab_eval(uC);
+    unsigned iterations = 0;
+    while (max_uvio < m->cstab_eps) {
+      if (iterations == (unsigned)m->cstab_max_iterations) break;
+      if (iterations == MH_CSTAB_HARD_CAP) { aux->status |= MH_WORLD_STALLED; break; }
+      for (int i = 0; i < nj; i++) { qd[i] = 0.0; dq[i] = 0.0; }
+      // compute_problem_data: a row for every FINITE limit (CStab:257-304), upper before lower per joint; one island (one body)
+      int idx[2 * NJ]; bool upper[2 * NJ]; double viol[2 * NJ]; int nl = 0;
+      for (int i = 0; i < nj; i++) {
+        if (m->hilimit[i] < A_INF) { idx[nl] = i; upper[nl] = true; viol[nl] = (m->hilimit[i] - q[i]) - 0.0; nl++; }
+        if (m->lolimit[i] > -A_INF) { idx[nl] = i; upper[nl] = false; viol[nl] = (q[i] + 0.0) - m->lolimit[i]; nl++; }
+      }
+      if (nl > 0) {
+        if (nl > MH_LCP_MAX_N_WAVE) { aux->status |= MH_WORLD_UNSUPPORTED; break; }
+        kinematics(); crba();                                        // compute_X at the CURRENT configuration (ICH:1600-1607)
+        std::vector<double> X(H, H + nj * nj);
+        if (!inverse_spd(nj, X.data(), nj)) { aux->status |= MH_WORLD_LCP_FAILED; break; }
+        std::vector<double> MM((size_t)nl * nl), Lv(nl);
+        for (int a = 0; a < nl; a++) for (int b = a; b < nl; b++) { const double e = X[idx[a] * nj + idx[b]]; MM[a + (size_t)nl * b] = e; MM[b + (size_t)nl * a] = e; }   // ICH:1763-1771 (no signs)
+        for (int k = 0; k < nl; k++) Lv[k] = (viol[k] - std::fabs(m->cstab_eps)) - A_NEAR_ZERO;  // CStab:434-441
+        Vec z;                                                       // determine_dq's local z: size 0 -> cold lcp_fast (CStab:954)
+        oracle_rand_t rs; std::memcpy(&rs, aux->rng, sizeof(rs));
+        LCP lcp; lcp.rng = &rs;
+        Trace tr; tr.buf = trace ? trace + trace_len : nullptr; tr.cap = trace ? ((trace_cap - trace_len > 0) ? trace_cap - trace_len : 0) : 0;
+        lcp.trace = &tr;
+        unsigned piv = 0;
+        bool ok = lcp.lcp_fast(nl, MM.data(), nl, Lv.data(), z, -1.0);
+        piv += lcp.pivots;
+        if (!ok) { ok = lcp.lcp_lemke_regularized(nl, MM.data(), nl, Lv.data(), z); piv += lcp.pivots; }
+        trace_len += tr.len;
+        std::memcpy(aux->rng, &rs, sizeof(rs));
+        lcp_account(nl, piv); aux->stab_rows += (unsigned long long)nl;
+        // update_from_stacked(pd, z): l = z (whatever it holds), dv = X_LT ls, v += dv (ICH:298-397); dq = the Euler velocities
+        std::vector<double> dv(nj, 0.0);
+        for (int k = 0; k < nl; k++) { const double lk = (k < (int)z.size()) ? z[k] : 0.0; const double ls = upper[k] ? -lk : lk; for (int r = 0; r < nj; r++) dv[r] = dv[r] + ls * X[idx[k] * nj + r]; }
+        for (int r = 0; r < nj; r++) { qd[r] = qd[r] + dv[r]; dq[r] = qd[r]; }
+      }
+      if (!cstab_update_q(dq, qv)) { aux->status |= MH_WORLD_STAB_FAILED; break; }
+      max_uvio = cstab_eval(uC);
+      iterations++;
+      aux->stab_iters++;
+    }
+    for (int i = 0; i < nj; i++) { qd[i] = qd_save[i]; q[i] = qv[i]; }
+  }
+
   // TimeSteppingSimulator::step (TSS:52-111).  Without collision geometry: one mini-step of dt.
   void step(double dt) {
     if (m->nspheres > 0 || force_general) {
@@ -717,6 +839,7 @@ class Artic {
         if (m->nspheres > 0 && (aux->status & FROZEN)) break;
         if (++guard > 100000u) { aux->status |= MH_WORLD_STALLED; break; }
       }
+      if (m->nspheres == 0) stabilize();                           // TSS:97 (with spheres the stabiliser's contact rows are not built: create refuses)
       aux->steps++;
       return;
     }
@@ -725,7 +848,9 @@ class Artic {
     if (!((m->algorithm == MH_ARTIC_FSAB) ? fwd_dyn_aba(nullptr, qdd) : fwd_dyn(nullptr, qdd))) { aux->status |= MH_WORLD_LCP_FAILED; for (int i = 0; i < nj; i++) qdd[i] = 0.0; }
     for (int i = 0; i < nj; i++) qd[i] = qd[i] + qdd[i] * dt;                                      // TSS:182-192
     handle_limits();
-    aux->time += dt; aux->mini_steps++; aux->steps++;
+    aux->time += dt; aux->mini_steps++;
+    stabilize();                                                   // TSS:97
+    aux->steps++;
   }
   bool force_general = false;     // tests: run a body without spheres through do_mini_step / handle_impacts (must agree with the path above)
 };

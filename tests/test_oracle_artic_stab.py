@@ -1,0 +1,90 @@
+"""ConstraintStabilization with joint-limit rows for articulated bodies (CStab:257-304 add_limit_constraints, 434-441 L_v,
+932-970 MM = L X L', 1056-1216 update_q, 1322-1379 Ridders), as oracle/artic.hpp restates it -- on the reference's three joint-limit
+scenes (tests/scenes/{limit_pendulum,limit_double_pendulum,five_link_chain}.xml carry the numbers of example/joint-limits/*.xml).
+Ravelin's articulated-body arithmetic is not in the tree (parity unpinned): what is checked here is behaviour the code fixes."""
+import os
+
+import numpy as np
+import pytest
+
+from moby_amd import artic as A
+from moby_amd import scene as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(name):
+    m, links, joints, q0, qd0, dt = A.load_xml(os.path.join(ROOT, "tests", "scenes", name + ".xml"))
+    return m, q0, qd0, (dt or 1e-3)
+
+
+def run(oracle, m, q0, qd0, dt, nsteps):
+    q = np.array(q0, dtype=float)[None].copy(); qd = np.array(qd0, dtype=float)[None].copy(); aux = S.new_aux(1)
+    lo = np.array(list(m.lolimit)[:m.nj]); hi = np.array(list(m.hilimit)[:m.nj])
+    worst = np.zeros(m.nj)
+    for _ in range(nsteps):
+        oracle.artic_step(m, q, qd, aux, dt, 1)
+        worst = np.maximum(worst, np.maximum(q[0] - hi, lo - q[0]))
+    return q[0], qd[0], aux[0], worst
+
+
+def test_the_loader_switches_the_stabiliser_on_for_the_joint_limit_scenes():
+    for name, nj in (("limit_pendulum", 1), ("limit_double_pendulum", 2), ("five_link_chain", 5)):
+        m, q0, qd0, dt = load(name)
+        assert m.nj == nj and m.nspheres == 0
+        assert m.cstab_max_iterations == 10 and m.cstab_eps == S.NEAR_ZERO          # absent attribute: MH_CSTAB_DEFAULT_MAX_ITERATIONS (deviation 1)
+
+
+def test_a_link_thrown_past_its_limit_is_put_back_on_it(oracle):
+    """limit_pendulum: qd = 100 rad/s carries the joint 0.1 rad past its upper limit in the first step.  The impact handler only turns
+    the velocity; the stabiliser moves q back: with it the joint never ends a step beyond its limit, without it the overshoot stands."""
+    m, q0, qd0, dt = load("limit_pendulum")
+    q_on, qd_on, aux_on, worst_on = run(oracle, m, q0, qd0, dt, 60)
+    m.cstab_max_iterations = 0
+    q_off, qd_off, aux_off, worst_off = run(oracle, m, q0, qd0, dt, 60)
+    assert worst_off[0] == pytest.approx(0.1, abs=1e-12) and aux_off["stab_iters"] == 0
+    assert worst_on[0] <= 0.0 and aux_on["stab_iters"] >= 1
+    assert aux_on["stab_rows"] == 2 * aux_on["stab_iters"]                          # a row for EVERY finite limit (CStab:257-304): upper and lower
+    assert aux_on["status"] == 0
+    # velocities are saved and restored around the stabiliser (CStab:181, 246): the first step's impact gives -e qd either way
+    m2, _, _, _ = load("limit_pendulum"); q1, qd1, _, _ = run(oracle, m2, q0, qd0, dt, 1)
+    m2.cstab_max_iterations = 0; q1o, qd1o, _, _ = run(oracle, m2, q0, qd0, dt, 1)
+    assert qd1[0] == qd1o[0] and qd1[0] == pytest.approx(-50.0, abs=5e-3)            # restitution 0.5 of qd = 100 + one step of gravity
+    assert q1o[0] == pytest.approx(0.1) and q1[0] <= 0.0 and q1[0] > -1e-6          # moved back onto the limit, not past it
+
+
+def test_only_the_first_joints_slacks_open_the_stabiliser(oracle):
+    """CStab:117 reads joints[i] with i the body's index: every joint's slack in evaluate_unilateral_constraints is joint 0's.  The
+    double pendulum's SECOND joint overshoots its +-0.1 limit by 0.03 and stays there until the first joint's own limit is crossed;
+    then the LCP has a row for every finite limit of both joints (4 rows per iteration) and pulls the second joint back as well."""
+    m, q0, qd0, dt = load("limit_double_pendulum")
+    q = np.array(q0)[None].copy(); qd = np.array(qd0)[None].copy(); aux = S.new_aux(1)
+    lo = np.array(list(m.lolimit)[:2]); hi = np.array(list(m.hilimit)[:2])
+    seen_open_violation = False; first_stab = None
+    for k in range(300):
+        before = int(aux["stab_iters"][0])
+        oracle.artic_step(m, q, qd, aux, dt, 1)
+        v = np.maximum(q[0] - hi, lo - q[0])
+        if first_stab is None and int(aux["stab_iters"][0]) > before:
+            first_stab = k
+            assert v[0] <= 1e-7 and v[1] <= 1e-7                                     # the iteration that finally ran repaired both joints
+        if first_stab is None and v[1] > 1e-3:
+            seen_open_violation = True and v[0] <= 0.0                               # joint 1 violated, joint 0 fine: nothing happens
+    assert seen_open_violation and first_stab is not None
+    assert aux["stab_rows"][0] == 4 * aux["stab_iters"][0]
+    # the five-link chain never drives its first joint to a limit in 3 s: stabilisation on and off are the same trajectory
+    m5, q5, qd5, dt5 = load("five_link_chain")
+    a = run(oracle, m5, q5, qd5, dt5, 300)
+    m5.cstab_max_iterations = 0
+    b = run(oracle, m5, q5, qd5, dt5, 300)
+    assert np.array_equal(a[0], b[0]) and a[2]["stab_iters"] == 0 and a[3].max() > 1e-3
+
+
+def test_stabiliser_with_link_spheres_is_refused_by_the_loader(tmp_path):
+    src = open(os.path.join(ROOT, "tests", "scenes", "arm_on_table.xml")).read()
+    assert 'constraint-stabilization-max-iterations="0"' in src
+    p = tmp_path / "arm.xml"
+    p.write_text(src.replace(' constraint-stabilization-max-iterations="0"', ""))
+    from moby_amd import io as mio
+    with pytest.raises(mio.SceneError, match="constraint stabilisation is on"):
+        A.load_xml(str(p))
