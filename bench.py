@@ -361,8 +361,14 @@ def strong_leg(dist, mdist, S, make_batch, B_total, rank, world_size, dev, steps
 def long_horizon_leg(torch, wb, stream, B, args):
     """The same batch far from t = 0: advance to step `--long-horizon-start` (untimed), then time 200 steps.  After ~3000
     steps a few worlds per thousand cycle lcp_fast to its pivot cap on every rung of the regularisation ladder
-    ("Long horizons"); a lockstep launch lasts as long as its slowest world."""
+    ("Long horizons"); a lockstep launch lasts as long as its slowest world.  Reported besides the plain launch:
+    `idle`: from a stamped launch of the next 200 steps (mh_world_batch_profile: per-world cycle totals) the share of wave-time the
+    launch leaves idle (1 - mean / slowest) and the share of its duration with under 1 % of the waves alive ((slowest - p99) / slowest);
+    `split_streams`: the following 200 steps with the worlds that were slow in the timed interval (over twice the median pivots, or the top 2 %) in a
+    launch of their own on a second stream (mh_world_batch_step_ids): when the OTHER worlds are done -- they could start their next
+    interval then -- and when everything is."""
     try:
+        from moby_amd import _lib
         done = args.warmup + args.steps
         skip = max(0, args.long_horizon_start - done)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -373,11 +379,57 @@ def long_horizon_leg(torch, wb, stream, B, args):
         _, a1 = wb.download()
         ms = e0.elapsed_time(e1)
         rows = float(a1["lcp_rows"].astype(np.int64).sum() - a0["lcp_rows"].astype(np.int64).sum())
-        piv = float(a1["lcp_pivots"].astype(np.int64).sum() - a0["lcp_pivots"].astype(np.int64).sum())
-        return {"steps_from": max(done, args.long_horizon_start), "steps": 200, "ms_per_step": ms / 200.0,
-                "lcp_rows_per_sec": rows / (ms * 1e-3), "world_steps_per_sec": B * 200 / (ms * 1e-3),
-                "pivots_per_world_step": piv / (B * 200.0),
-                "worlds_flagged": int((a1["status"] != 0).sum())}
+        pivw = a1["lcp_pivots"].astype(np.int64) - a0["lcp_pivots"].astype(np.int64)
+        res = {"steps_from": max(done, args.long_horizon_start), "steps": 200, "ms_per_step": ms / 200.0,
+               "lcp_rows_per_sec": rows / (ms * 1e-3), "world_steps_per_sec": B * 200 / (ms * 1e-3),
+               "pivots_per_world_step": float(pivw.sum()) / (B * 200.0),
+               "worlds_flagged": int((a1["status"] != 0).sum())}
+        # where the launch's time goes: per-world stamped totals of the NEXT 200 steps
+        lib = _lib.load()
+        phc = lib.mh_world_profile_phase_count()
+        ph = np.zeros(phc + 4)
+        if phc is not None:
+            _lib.check(lib.mh_world_batch_profile(wb.handle, DT, 200, ph.ctypes.data, phc + 4))
+            mx, mn, mean, p99 = ph[phc], ph[phc + 1], ph[phc + 2], ph[phc + 3]
+            res["idle"] = {"idle_wave_time_frac": 1.0 - mean / mx, "launch_time_with_under_1pct_of_waves_alive_frac": (mx - p99) / mx,
+                           "slowest_over_mean_world": mx / mean, "slowest_over_fastest_world": mx / max(mn, 1.0),
+                           "source": "mh_world_batch_profile, steps %d..%d (s_memtime totals per world)" % (res["steps_from"] + 201, res["steps_from"] + 400)}
+        # the slow worlds of the timed interval in a launch of their own
+        thr = min(2.0 * max(1.0, float(np.median(pivw))), float(np.sort(pivw)[int(0.98 * (B - 1))]))     # over twice the median, or the top 2 %
+        slow = np.nonzero(pivw > thr)[0].astype(np.int32)
+        fast = np.setdiff1d(np.arange(B, dtype=np.int32), slow).astype(np.int32)
+        if 0 < len(slow) < B:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            t_slow = torch.from_numpy(slow).to(dev); t_fast = torch.from_numpy(fast).to(dev)
+            s2 = torch.cuda.Stream(device=dev)
+            ef, es = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            _, ab = wb.download(); piv_base = ab["lcp_pivots"].astype(np.int64)
+            e0.record()                                                     # on the current stream
+            s2.wait_event(e0)
+            wb.step_ids(DT, 200, t_slow.data_ptr(), len(slow), s2.cuda_stream)
+            es.record(s2)
+            wb.step_ids(DT, 200, t_fast.data_ptr(), len(fast), stream)
+            ef.record()
+            torch.cuda.synchronize()
+            _, a3 = wb.download()
+            # is slowness a property of a world?  the same threshold on the split interval's own pivot counts
+            res_p = None
+            try:
+                pv_before = piv_base
+                pv_now = a3["lcp_pivots"].astype(np.int64) - pv_before
+                thr2 = min(2.0 * max(1.0, float(np.median(pv_now))), float(np.sort(pv_now)[int(0.98 * (B - 1))]))
+                slow_now = set(np.nonzero(pv_now > thr2)[0].tolist())
+                res_p = len(slow_now & set(slow.tolist())) / float(len(slow))
+            except Exception:       # noqa: BLE001
+                pass
+            res["split_streams"] = {"slow_worlds": int(len(slow)), "other_worlds": int(len(fast)), "slow_again_in_this_interval_frac": res_p,
+                                    "others_done_ms_per_step": e0.elapsed_time(ef) / 200.0, "all_done_ms_per_step": e0.elapsed_time(es) / 200.0,
+                                    "others_world_steps_per_sec": len(fast) * 200 / (e0.elapsed_time(ef) * 1e-3),
+                                    "note": "worlds are independent, so the slow ones can run on a stream of their own and the rest need not wait for them at the launch "
+                                            "boundary -- IF slowness stays with a world: slow_again_in_this_interval_frac says how much of the set picked from the "
+                                            "previous interval is slow again; the rest of the tail is other worlds' episodes of lcp_fast cycling to its cap"}
+        return res
     except Exception as e:          # noqa: BLE001 -- informational leg
         return {"error": repr(e)}
 

@@ -234,13 +234,20 @@ int mh_world_batch_create(const mh_scene* scene, int B, mh_world_batch** out);
 int mh_world_batch_destroy(mh_world_batch* wb);
 int mh_world_batch_upload(mh_world_batch* wb, const double* state, const mh_world_aux* aux);
 int mh_world_batch_step(mh_world_batch* wb, void* stream, double dt, int nsteps, double* traj_dev);
+/* step of a SUBSET: nsteps x step(dt) of the worlds ids_dev[0 .. count) (a DEVICE array of world indices) on `stream`.  Worlds are
+ * independent: a batch may be split over streams, e.g. the few worlds whose solver chain runs to its pivot caps every
+ * step in a launch of their own, so that the next interval of the others does not wait for them.  Concurrent launches must not
+ * share a world. */
+int mh_world_batch_step_ids(mh_world_batch* wb, void* stream, double dt, int nsteps, const int* ids_dev, int count);
 int mh_world_batch_download(mh_world_batch* wb, double* state, mh_world_aux* aux);
 int mh_world_batch_device_ptrs(mh_world_batch* wb, double** state_dev, mh_world_aux** aux_dev);
 /* diagnostic build of the same launch with in-kernel s_memtime stamps: mean cycles per world spent in
  * each phase (order: broad phase + CA, position integration, forward dynamics, contact generation,
- * islands, problem data, LCP matrix build, LCP solve, impulse application, stabilisation) */
+ * islands, problem data, LCP matrix build, LCP solve, impulse application, stabilisation); after the per-phase entries: the slowest
+ * and the fastest world's total, the mean world's total and the total of the world at the 99th percentile (if nphase leaves room) */
 int mh_world_batch_occupancy(mh_world_batch* wb);   /* diagnostic: resident workgroups per CU (runtime query) */
 int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* phase_cycles, int nphase);
+int mh_world_profile_phase_count(void);            /* entries per world of the stamped launch (the four totals follow them) */
 
 /* Host convenience: create + upload + step + download (+ trajectory) + destroy. */
 int mh_world_step_batch(const mh_scene* scene, int B, double dt, int nsteps,

@@ -52,9 +52,11 @@ SYMBOLS = {
     "mh_world_batch_destroy": (_i, [_vp]),
     "mh_world_batch_upload": (_i, [_vp, _vp, _vp]),
     "mh_world_batch_step": (_i, [_vp, _vp, _d, _i, _vp]),
+    "mh_world_batch_step_ids": (_i, [_vp, _vp, _d, _i, _vp, _i]),
     "mh_world_batch_download": (_i, [_vp, _vp, _vp]),
     "mh_world_batch_occupancy": (_i, [_vp]),
     "mh_world_batch_profile": (_i, [_vp, _d, _i, _vp, _i]),
+    "mh_world_profile_phase_count": (_i, []),
     "mh_world_batch_device_ptrs": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "mh_world_step_batch": (_i, [_vp, _i, _d, _i, _vp, _vp, _vp]),
     # include/moby_hip_impact.h

@@ -42,7 +42,7 @@ MH_HIDDEN hipError_t mh_launch_lcp_blk(MH_LCP_BLOCK_LAUNCH_ARGS);
 MH_HIDDEN hipError_t mh_launch_lcp_blkw(MH_LCP_BLOCK_LAUNCH_ARGS);
 
 // the three size variants of the many-worlds kernel, one translation unit each (mh_world_{small,wheel,large}.hip)
-typedef void (*mh_world_kernel)(const mh_scene*, int, double, int, double*, mh_world_aux*, double*, int, double*, int, unsigned long long*);
+typedef void (*mh_world_kernel)(const mh_scene*, int, double, int, double*, mh_world_aux*, double*, int, double*, int, unsigned long long*, const int*);
 struct mh_world_variant {
   mh_world_kernel kernel;
   int ph_count;                                        // per-phase cycle accumulators of the profiling launch

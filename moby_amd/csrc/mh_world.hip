@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 #include "../../include/moby_hip.h"
 #include "mh_host.h"
 
@@ -191,10 +192,28 @@ int mh_world_batch_step(mh_world_batch* wb, void* stream, double dt, int nsteps,
   if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
   hipLaunchKernelGGL(wb->kernel, dim3(wb->B), dim3(64), 0, (hipStream_t)stream,
                      (const mh_scene*)wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, traj_dev, wb->nmax, wb->d_lu_ws, mh_g_debug_ka,
-                     (unsigned long long*)nullptr);
+                     (unsigned long long*)nullptr, (const int*)nullptr);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
+
+// nsteps x step(dt) of the worlds ids[0 .. count) only (device pointer), on the given stream: worlds are independent, so a batch can be
+// split over streams -- e.g. the few worlds whose solver chain runs to its pivot caps in their own launch, so that the next interval of
+// the others does not wait for them (bench.py's long_horizon leg).  Launches on different streams must not share a world.
+int mh_world_batch_step_ids(mh_world_batch* wb, void* stream, double dt, int nsteps, const int* ids_dev, int count)
+{
+  if (!wb || !ids_dev) return fail(MH_ERR_INVALID_ARG, "null batch / id list");
+  if (nsteps < 0 || count < 0 || count > wb->B) return fail(MH_ERR_INVALID_ARG, "bad step count (%d) or id count (%d of %d)", nsteps, count, wb->B);
+  if (nsteps == 0 || count == 0) return MH_OK;
+  if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
+  hipLaunchKernelGGL(wb->kernel, dim3(count), dim3(64), 0, (hipStream_t)stream,
+                     (const mh_scene*)wb->d_scene, count, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, wb->d_lu_ws, mh_g_debug_ka,
+                     (unsigned long long*)nullptr, ids_dev);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+int mh_world_profile_phase_count(void) { return mh_world_variant_large()->ph_count; }
 
 // diagnostic: one launch with per-phase cycle accumulators (mh::PH_*), averaged over worlds on the host
 int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* phase_cycles, int nphase)
@@ -206,7 +225,7 @@ int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* ph
   MH_HIP(hipMalloc(&dprof, sz));
   MH_HIP(hipMemset(dprof, 0, sz));
   hipLaunchKernelGGL(wb->kernel, dim3(wb->B), dim3(64), 0, (hipStream_t)nullptr,
-                     (const mh_scene*)wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, wb->d_lu_ws, mh_g_debug_ka, dprof);
+                     (const mh_scene*)wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, wb->d_lu_ws, mh_g_debug_ka, dprof, (const int*)nullptr);
   hipError_t e = hipDeviceSynchronize();
   std::vector<unsigned long long> h((size_t)wb->B * PHC);
   if (e == hipSuccess) e = hipMemcpy(h.data(), dprof, sz, hipMemcpyDeviceToHost);
@@ -227,6 +246,16 @@ int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* ph
       mx = t > mx ? t : mx; mn = t < mn ? t : mn;
     }
     phase_cycles[PHC] = mx; phase_cycles[PHC + 1] = mn;
+    // PH_COUNT + 2, + 3 (if asked for): the mean world's total, and the total of the world at the 99th percentile (1 % of the
+    // worlds take longer): with the launch lasting `mx`, (mx - p99) / mx of it runs with under 1 % of the waves alive
+    if (nphase >= PHC + 4) {
+      std::vector<double> tt((size_t)wb->B);
+      double sum = 0.0;
+      for (int b = 0; b < wb->B; b++) { double t = 0.0; for (int p = 0; p < 10; p++) t += (double)h[(size_t)b * PHC + p]; tt[b] = t; sum += t; }
+      std::sort(tt.begin(), tt.end());
+      phase_cycles[PHC + 2] = sum / wb->B;
+      phase_cycles[PHC + 3] = tt[(size_t)((wb->B - 1) * 0.99)];
+    }
   }
   return MH_OK;
 }

@@ -55,6 +55,10 @@ class WorldBatchDevice:
     def step(self, dt, nsteps=1, stream=None, traj_ptr=None):
         _lib.check(_lib.load().mh_world_batch_step(self.handle, stream, float(dt), int(nsteps), traj_ptr))
 
+    def step_ids(self, dt, nsteps, ids_dev_ptr, count, stream=None):
+        """nsteps of the worlds listed in a DEVICE int32 array (e.g. a torch tensor's data_ptr()) on `stream` (mh_world_batch_step_ids)."""
+        _lib.check(_lib.load().mh_world_batch_step_ids(self.handle, stream, float(dt), int(nsteps), ctypes.c_void_p(int(ids_dev_ptr)), int(count)))
+
     def download(self):
         st = np.zeros((self.B, self.scene.nb * S.MH_BODY_STATE))
         aux = np.zeros(self.B, dtype=S.AUX_DTYPE)

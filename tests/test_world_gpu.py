@@ -412,3 +412,24 @@ def test_checkpoint_resume_is_bit_exact(tmp_path):
     assert np.array_equal(st_d, straight.state) and np.array_equal(aux_d["rng"], straight.aux["rng"])
     bodies_only = WorldBatch(sc, first.state.copy()); bodies_only.step(1e-3, 60)
     assert not np.array_equal(bodies_only.aux["lcp_pivots"], straight.aux["lcp_pivots"] - first.aux["lcp_pivots"])
+
+
+def test_a_batch_split_over_two_launches_by_world_ids_equals_the_single_launch():
+    """mh_world_batch_step_ids: worlds are independent, so stepping two disjoint id lists (on two streams) is the plain launch."""
+    import torch
+    from moby_amd.world import WorldBatchDevice
+    B = 96
+    sc = S.sphere_stack_scene()
+    st0 = S.sphere_stack_state(B)
+    ref = WorldBatchDevice(sc, st0); ref.step(1e-3, 30); torch.cuda.synchronize(); st_r, aux_r = ref.download(); ref.close()
+    wb = WorldBatchDevice(sc, st0)
+    ids_a = torch.tensor([i for i in range(B) if i % 7 == 0], dtype=torch.int32, device="cuda")
+    ids_b = torch.tensor([i for i in range(B) if i % 7 != 0], dtype=torch.int32, device="cuda")
+    s2 = torch.cuda.Stream()
+    wb.step_ids(1e-3, 30, ids_a.data_ptr(), ids_a.numel(), s2.cuda_stream)
+    wb.step_ids(1e-3, 30, ids_b.data_ptr(), ids_b.numel(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st, aux = wb.download(); wb.close()
+    assert np.array_equal(st, st_r)
+    for f in ("rng", "lcp_rows", "lcp_pivots", "mini_steps", "status", "steps"):
+        assert np.array_equal(aux[f], aux_r[f]), f
