@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <mutex>
 #include "../../include/moby_hip_artic.h"
 #include "mh_host.h"
 #include "mh_lcp_wave.h"
@@ -796,11 +797,15 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
   }
   if (mh_device_count() <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
   {
-    static bool once = false;
-    if (!once) {
+    // the regularisation ladder's powers of ten, once per DEVICE (a second GPU of the process has its own copy of the symbol), under a lock
+    static std::mutex mu; static std::vector<char> done;
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0; MH_HIP(hipGetDevice(&dev));
+    if ((int)done.size() <= dev) done.resize(dev + 1, 0);
+    if (!done[dev]) {
       mh::Pow10Table p10; for (int i = 0; i < 64; i++) p10.v[i] = std::pow(10.0, (double)(i - 32));   // LCP.cpp:285
       MH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ar::c_pow10a), &p10, sizeof(p10)));
-      once = true;
+      done[dev] = 1;
     }
   }
   mh_artic_batch* ab = new mh_artic_batch();
@@ -826,6 +831,7 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
 int mh_artic_batch_upload(mh_artic_batch* ab, const double* q, const double* qd, const mh_world_aux* aux)
 {
   if (!ab) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_HIP(hipDeviceSynchronize());                              // a step may be in flight on a caller's non-blocking stream
   const size_t n = (size_t)ab->B * ab->nj * 8;
   if (q) MH_HIP(hipMemcpy(ab->d_q, q, n, hipMemcpyHostToDevice));
   if (qd) MH_HIP(hipMemcpy(ab->d_qd, qd, n, hipMemcpyHostToDevice));
@@ -863,6 +869,7 @@ int mh_artic_batch_fwd_dyn(mh_artic_batch* ab, const double* tau, double* qdd_ou
 {
   namespace ar = mh::artic;
   if (!ab) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_HIP(hipDeviceSynchronize());                              // a step may be in flight on a caller's non-blocking stream
   const size_t B = (size_t)ab->B, nj = (size_t)ab->nj;
   double *d_tau = nullptr, *d_qdd = nullptr, *d_H = nullptr; int* d_ok = nullptr;
   auto cleanup = [&]() { void* ps[] = { d_tau, d_qdd, d_H, d_ok }; for (void* p : ps) if (p) (void)hipFree(p); };
@@ -887,6 +894,7 @@ int mh_artic_batch_link_poses(mh_artic_batch* ab, double* poses)
 {
   namespace ar = mh::artic;
   if (!ab || !poses) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  MH_HIP(hipDeviceSynchronize());                              // a step may be in flight on a caller's non-blocking stream
   const size_t bytes = (size_t)ab->B * ab->nj * 12 * 8;
   double* d_p = nullptr;
   MH_HIP(hipMalloc((void**)&d_p, bytes));
@@ -903,6 +911,7 @@ int mh_artic_batch_jacobian(mh_artic_batch* ab, int link, const double* points, 
 {
   namespace ar = mh::artic;
   if (!ab || !points || !J_out) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  MH_HIP(hipDeviceSynchronize());                              // a step may be in flight on a caller's non-blocking stream
   if (link < 0 || link >= ab->nj) return fail(MH_ERR_INVALID_ARG, "link %d outside [0, %d)", link, ab->nj);
   const size_t pb = (size_t)ab->B * 3 * 8, jb = (size_t)ab->B * 6 * ab->nj * 8;
   double* d_p = nullptr; double* d_J = nullptr;

@@ -69,16 +69,12 @@ MH_DEV double dpp_move(double v) {
     o_ = dpp_move<0x140, 0xf>(v); v = PICK(o_, v);  /* row_mirror         */ \
     o_ = dpp_move<0x142, 0xa>(v); v = PICK(o_, v);  /* row_bcast15        */ \
     o_ = dpp_move<0x143, 0xc>(v); v = PICK(o_, v);  /* row_bcast31        */ }
-// v_min_f64 / v_max_f64 (one instruction) instead of compare + two selects.  Same results wherever these reductions are
-// used: the operands are never NaN (invalid lanes carry +-inf), and a -0 / +0 tie only decides the sign of a zero that is
-// then compared (ballot on equality, < tol tests), never stored.  -DMH_WAVE_PICK_SELECT restores the select form.
-#ifdef MH_WAVE_PICK_SELECT
-#define MH_PICK_MIN(o, v) (((o) < (v)) ? (o) : (v))
-#define MH_PICK_MAX(o, v) (((o) > (v)) ? (o) : (v))
-#else
+// v_min_f64 / v_max_f64 (one instruction) instead of compare + two selects.  Their treatment of NaN is part of the contract: fmin / fmax
+// return the OTHER operand when one is NaN, so a reduction skips NaNs the way std::min_element's `<` scan skips one that is not first
+// -- lcp_lemke's ratio test feeds NaN ratios into wave_min (mh_lcp_wave.h) and relies on exactly that (the case "the FIRST ratio is
+// NaN" is handled there separately).  A -0 / +0 tie only decides the sign of a zero that is then compared, never stored.
 #define MH_PICK_MIN(o, v) __builtin_fmin((o), (v))
 #define MH_PICK_MAX(o, v) __builtin_fmax((o), (v))
-#endif
 
 MH_DEV double wave_max(double v) { MH_DPP_REDUCE(v, MH_PICK_MAX); return read_lane(v, 63); }
 MH_DEV double wave_min(double v) { MH_DPP_REDUCE(v, MH_PICK_MIN); return read_lane(v, 63); }

@@ -180,6 +180,14 @@ extern "C" int mh_io_load_sdf(const char* path, const double gravity[3], mh_io_a
         if (xmlNode* l = child_named(lim, "lower")) J.lo = std::atof(text_of(l).c_str());
         if (xmlNode* u = child_named(lim, "upper")) J.hi = std::atof(text_of(u).c_str());
       }
+      // SDFReader::read_joint keeps <dynamics><damping> / <friction> as Joint::mu_fv / mu_fc (SDFReader.cpp:575-588); joint friction is not
+      // part of this build's forward dynamics, so a model that asks for it is refused rather than simulated without it
+      if (xmlNode* dyn = child_named(ax, "dynamics")) {
+        for (const char* tag : { "damping", "friction" })
+          if (xmlNode* d = child_named(dyn, tag)) if (std::atof(text_of(d).c_str()) != 0.0)
+            return fail("joint %s: <dynamics><%s> = %s: joint friction / damping is not supported", J.name.c_str(), tag, text_of(d).c_str());
+      }
+      if (child_named(c, "axis2")) return fail("joint %s: a second axis (<axis2>) is not supported", J.name.c_str());
       joints.push_back(J);
     }
   }
