@@ -43,16 +43,27 @@ DT = 1e-3
 
 
 def pmc_traffic(B, steps):
-    """HBM bytes of one launch of B worlds x `steps` steps, from the committed rocprofv3 PMC passes of this same
-    command (profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE of the timed launch, separate passes, normalised per
-    world-step -- the kernel's traffic is per-world scratch + state, so it scales with worlds x steps).  Counters cannot
-    be read in-process; None when no profile of this kernel is committed."""
+    """HBM bytes of one launch of B worlds x `steps` steps from the committed rocprofv3 PMC passes of this same command
+    (profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE of the timed launch, separate passes).  Counters cannot be read
+    in-process, so this is a PROFILE of the build named in the file's `commit`, reported only when this run has the profile's
+    batch size and step count (None otherwise: no extrapolation)."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        per_world_step = (t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0 / (t["worlds"] * t["steps"])
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        if int(t["worlds"]) != int(B) or int(t["steps"]) != int(steps):
+            return None
+        return (t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
+    except (OSError, KeyError, ValueError):
         return None
-    return per_world_step * B * steps
+
+
+def pmc_profile_tag():
+    """Which build the committed counter profiles (roofline.traffic / roofline.issue) were cut from."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return {"commit": t.get("commit"), "worlds": t.get("worlds"), "steps": t.get("steps"), "source": t.get("source"),
+                "fetch_bytes": t["fetch_size_kb"] * 1024.0, "write_bytes": t["write_size_kb"] * 1024.0}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def pmc_issue():
@@ -551,7 +562,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(B, args.steps),
                      "kernel": "mh_k_world_step", "kernel_avg_us": kern_s * 1e6, "launches": 1,
-                     "algorithmic_bytes_per_launch": alg_bytes, "issue": pmc_issue(),
+                     "algorithmic_bytes_per_launch": alg_bytes, "issue": pmc_issue(), "counter_profile": pmc_profile_tag(),
                      "model": "LCP-entry bytes 8(n^2+2n) per solved LCP (SURVEY 8d); the fused kernel itself only moves %d B of state per launch" % int(fused_bytes)},
     }
 
