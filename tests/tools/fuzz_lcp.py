@@ -10,7 +10,8 @@ o = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 80):
-    n = int(rng.integers(1, 65)) if rng.random() < 0.7 else int(rng.integers(65, 180))
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"        # "big": the block solver's sizes up to 420 (the structure-exploiting LU of Lemke's bases)
+    n = (int(rng.integers(65, 420)) if big else (int(rng.integers(1, 65)) if rng.random() < 0.7 else int(rng.integers(65, 180))))
     fam = str(rng.choice(["pd", "psd", "copos"])); kind = int(rng.integers(0, 4)); seed = int(rng.integers(0, 10**6))
     if fam == "copos" and n < 2: fam = "pd"
     M, q = synth.random_lcp(2, n, fam, seed=seed)
