@@ -171,6 +171,11 @@ def config4_leg(torch, nboxes=4, B=1024):
             res[tag] = {"ms": ms, "lcp_rows_per_sec": ib.n * float(r["solves"].sum()) / (ms * 1e-3),
                         "pivots_mean": float(r["pivots"].mean()), "pivots_max": int(r["pivots"].max()),
                         "worlds_with_errors": int(((r["status"] & ~2) != 0).sum())}
+            w = ib.lu_work(reset=True).sum(axis=0)
+            res[tag]["roofline"] = {"bound": "mfma", "achieved": w[0] / (ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": w[0] / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
+                                    "hbm": {"achieved": w[1] / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": w[1] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                    "model": "one dgesv per pivot: 2/3 k^3 flops, 8 k^2 bytes (SURVEY 8d), counted on the device"}
             s2 = r["state"].reshape(B, nboxes, 13); s2[:, :, 8] += -9.81e-3      # gravity acts for another dt
             ib.upload(s2.reshape(B, -1), cs)
         ib.close()
@@ -259,6 +264,24 @@ def config4_full_step_leg(torch, nboxes, B, steps, cpu_proc=None):
         return {"error": repr(e)}
 
 
+def artic_roofline(tflops, ms):
+    """The articulated kernel against its real bound, FP64 issue: ~21 kflop per world-step (CRBA + RNEA + Cholesky + the limit LCP of the
+    ur10) over the launch time, against the FP64 vector peak; `issue` = the committed SQ_* counter passes of this kernel
+    (profiles/r02_f_artic_issue.json -- the kernel has not changed since)."""
+    issue = None
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r02_f_artic_issue.json")))
+        k = t["k_artic_step_w4"]
+        issue = {"valu_busy_frac": k["valu_busy_frac"], "wave_cycles": k["wave_cycles"], "per_world_step": k["per_world_step"],
+                 "source": "profiles/r02_f_artic_issue.json (worlds %d, steps %d)" % (t["worlds"], t["steps"])}
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS, "traffic": None,
+            "kernel": "mh::artic::k_artic_step_w4", "kernel_avg_us": ms * 1e3, "launches": 1, "issue": issue,
+            "model": "21 kflop per world-step (estimate) / launch time against the FP64 vector = matrix peak; the kernel is bound by LDS round trips "
+                     "per wave (6-36 of 64 lanes busy, half of the wave cycles on s_waitcnt), not by arithmetic or HBM"}
+
+
 def config5_leg(torch, B=8192, steps=200, cpu=True):
     """BASELINE config 5: the ur10 arm (tests/scenes/ten_joint_arm.sdf = the numbers of example/ur10/model.sdf) x B random
     states, dt = 5e-4 (ur10.xml:2), `steps` steps in one launch: CRBA + RNEA + Cholesky forward dynamics and the joint-limit
@@ -324,6 +347,7 @@ def config5_leg(torch, B=8192, steps=200, cpu=True):
                 "world_steps_per_sec": B * steps / (ms * 1e-3), "lcp_rows_per_sec": rows / (ms * 1e-3),
                 "worlds_with_errors": int(((a1["status"] & ~2) != 0).sum()),
                 "flops_per_world_step_est": 21000, "gflops_est": 21000.0 * B * steps / (ms * 1e-3) / 1e9,
+                "roofline": artic_roofline(21000.0 * B * steps / (ms * 1e-3) / 1e12, ms),
                 "cpu_baseline": cpu_part}
     except Exception as e:          # noqa: BLE001 -- informational leg
         return {"error": repr(e)}
