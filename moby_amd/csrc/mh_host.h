@@ -31,13 +31,16 @@ MH_HIDDEN int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
                                       int32_t* trace, int trace_cap, int* trace_len,
                                       const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i,
                                       const int* n_arr,    // n_arr: per-problem sizes (<= n, M compact with ld = its n) or NULL
-                                      double* work = nullptr);   // B x 2 doubles or NULL: += the 2/3 k^3 flops / 8 k^2 bytes of every factorisation (n > 64)
+                                      double* work = nullptr,    // B x 2 doubles or NULL: += the 2/3 k^3 flops / 8 k^2 bytes of every factorisation (n > 64)
+                                      int wave_only = 0);        // != 0: only the problems of at most 64 rows (n_arr) -- the caller runs the others itself
+extern MH_HIDDEN int mh_g_debug_compact;             // mh_debug_set(3, v)
+extern MH_HIDDEN int mh_g_debug_tasks;               // mh_debug_set(4, v): the Lemke ladder of the island pipeline as (world, attempt) tasks (1, default) or in sequence (0)
 
 // the workgroup-per-problem LCP solver, one translation unit per thread geometry (mh_lcp_blk.hip: 256 threads, mh_lcp_blkw.hip: 1024)
 namespace mh { struct LcpParams; struct Pow10Table; }
 #define MH_LCP_BLOCK_LAUNCH_ARGS void* stream, int kind, int B, int n, const double* M, int ld, long strideM, const double* q, double* z, \
   const int* zsz_in, int* zsz_out, uint32_t* rng, int* status, unsigned* pivots, int32_t* trace, int trace_cap, int* trace_len, \
-  const mh::LcpParams* P, const mh::Pow10Table* p10, double* wsd, int* wsi, const int* run_if, const int* n_arr, int flags, double* work
+  const mh::LcpParams* P, const mh::Pow10Table* p10, double* wsd, int* wsi, const int* run_if, const int* n_arr, int flags, double* work, int task_worlds, int* solved_at
 MH_HIDDEN hipError_t mh_launch_lcp_blk(MH_LCP_BLOCK_LAUNCH_ARGS);
 MH_HIDDEN hipError_t mh_launch_lcp_blkw(MH_LCP_BLOCK_LAUNCH_ARGS);
 

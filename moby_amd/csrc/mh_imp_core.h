@@ -49,6 +49,9 @@ struct mh_imp_core {
   double* bXCn;                                     // B x ncmax x 96
   double* bJiM; double* blam; int* bact; int* bk;   // B x 48 x 96, B x 48, B x 48, B
   double* ws_d; int* ws_i;                          // block-solver workspace (nmax > 64)
+  // task mode of the Lemke ladder (one workgroup per (world, attempt), mh_lcp_block.h): per-task workspace, z, status, pivots, sizes,
+  // rand() scratch, model work; solved_at per world.  Allocated on first use for t_cap tasks.
+  double* t_wsd; int* t_wsi; double* t_z; int* t_st; unsigned* t_piv; int* t_zsz; uint32_t* t_rng; double* t_work; int* solved_at; long t_cap;
   double* work;                                     // B x 2: SURVEY 8(d)'s model work of the block solver's factorisations (2/3 k^3 flops, 8 k^2 bytes), accumulated
   int* hmax;                                        // pinned host copy of maxisl
   void* allocs[64]; int nallocs;

@@ -1171,6 +1171,9 @@ void mh_imp_core_destroy(mh_imp_core* c)
   if (!c) return;
   for (int i = 0; i < c->nallocs; i++) if (c->allocs[i]) (void)hipFree(c->allocs[i]);
   c->nallocs = 0;
+  { void* ps[] = { c->t_wsd, c->t_wsi, c->t_z, c->t_st, c->t_piv, c->t_zsz, c->t_rng, c->t_work, c->solved_at };
+    for (void* q : ps) if (q) (void)hipFree(q);
+    c->t_wsd = nullptr; c->t_wsi = nullptr; c->t_z = nullptr; c->t_st = nullptr; c->t_piv = nullptr; c->t_zsz = nullptr; c->t_rng = nullptr; c->t_work = nullptr; c->solved_at = nullptr; c->t_cap = 0; }
   if (c->hmax) { (void)hipHostFree(c->hmax); c->hmax = nullptr; }
 }
 
@@ -1264,6 +1267,105 @@ int mh_imp_core_enable_joints(mh_imp_core* c, int nj, const int* jtype, const in
   return MH_OK;
 }
 
+// ---- the Lemke ladder as (world, attempt) tasks ------------------------------------------------------------------------------
+// lcp_lemke_regularized tries lambda = 0, then 10^min_exp ... one after the other until an attempt succeeds and verifies (LCP.cpp:353-487).
+// The attempts are independent of one another (mh_lcp_block.h, LadderTask), so they run as B x R workgroups dispatched attempt-major:
+// every world's lower attempts first, higher ones as slots free up, none above an attempt already known to have succeeded.  The slowest
+// world of a batch then no longer runs its 8-12 attempts one after the other while the rest of the chip idles.  k_ladder_select takes,
+// per world, the first successful attempt in ladder order and reproduces what the sequence would have left behind: z, its size, the
+// summed pivot count, and the rand() stream (lcp_lemke draws n values whenever it is entered with z.size() != n, LCP.cpp:618-621).
+namespace mh { namespace imp {
+__global__ __launch_bounds__(T)
+void k_ladder_select(Dev d, const int* __restrict__ need, int R, int* __restrict__ lst, unsigned* __restrict__ piv)
+{
+  const int w = blockIdx.x, t = threadIdx.x, B = d.B;
+  if (!need[w]) return;
+  const int n = d.ncur[w];
+  if (n <= MH_LCP_MAX_N_WAVE) return;                            // (the wave solver ran this one's ladder)
+  __shared__ int s_sel;
+  if (t == 0) {
+    int zs = d.zsz[w], chosen = -1, last = 0;
+    unsigned total = 0u; long draws = 0; double wf = 0.0, wb = 0.0;
+    for (int r = 0; r < R; r++) {
+      const size_t i = (size_t)r * B + w;
+      const int st = d.t_st[i];
+      if (st < 0) break;                                         // not run: only above a successful attempt, never reached (defensive)
+      if (zs != n) draws += n;
+      total += d.t_piv[i]; zs = d.t_zsz[i]; last = r;
+      wf += d.t_work[2 * i]; wb += d.t_work[2 * i + 1];
+      if (st == 1) { chosen = r; break; }
+    }
+    lst[w] = (chosen >= 0) ? 1 : 0; piv[w] = total; d.zsz[w] = zs;
+    d.work[2 * (size_t)w] += wf; d.work[2 * (size_t)w + 1] += wb;
+    uint32_t* rg = d.rng + (size_t)w * MH_RAND_WORDS;            // glibc TYPE_3, as mh_rand_next
+    unsigned idx = rg[31];
+    for (long k = 0; k < draws; k++) { rg[idx] = rg[idx] + rg[(idx + 28) % 31]; idx = (idx + 1) % 31; }
+    rg[31] = idx;
+    s_sel = (chosen >= 0) ? chosen : last;
+  }
+  __syncthreads();
+  const size_t i = (size_t)s_sel * B + w;
+  for (int k = t; k < n; k += T) d.z[(size_t)w * d.nmax + k] = d.t_z[i * d.nmax + k];
+}
+}}
+
+static int core_ladder_alloc(mh_imp_core* c, long ntasks)
+{
+  if (c->t_cap >= ntasks) return MH_OK;
+  void* ps[] = { c->t_wsd, c->t_wsi, c->t_z, c->t_st, c->t_piv, c->t_zsz, c->t_rng, c->t_work };
+  for (void* q : ps) if (q) (void)hipFree(q);
+  c->t_cap = 0;
+  const size_t n = (size_t)c->nmax, nt = (size_t)ntasks;
+  bool ok = hipMalloc((void**)&c->t_wsd, nt * (n * n + 5 * n) * 8) == hipSuccess && hipMalloc((void**)&c->t_wsi, nt * 4 * n * 4) == hipSuccess
+         && hipMalloc((void**)&c->t_z, nt * n * 8) == hipSuccess && hipMalloc((void**)&c->t_st, nt * 4) == hipSuccess
+         && hipMalloc((void**)&c->t_piv, nt * 4) == hipSuccess && hipMalloc((void**)&c->t_zsz, nt * 4) == hipSuccess
+         && hipMalloc((void**)&c->t_rng, nt * MH_RAND_WORDS * 4) == hipSuccess && hipMalloc((void**)&c->t_work, nt * 2 * 8) == hipSuccess;
+  if (ok && !c->solved_at) ok = hipMalloc((void**)&c->solved_at, (size_t)c->B * 4) == hipSuccess;
+  if (ok) ok = hipMemset(c->t_rng, 0, nt * MH_RAND_WORDS * 4) == hipSuccess;
+  if (!ok) {                                                      // no room: the caller runs the ladder in sequence
+    void* qs[] = { c->t_wsd, c->t_wsi, c->t_z, c->t_st, c->t_piv, c->t_zsz, c->t_rng, c->t_work };
+    for (void* q : qs) if (q) (void)hipFree(q);
+    c->t_wsd = nullptr; c->t_wsi = nullptr; c->t_z = nullptr; c->t_st = nullptr; c->t_piv = nullptr; c->t_zsz = nullptr; c->t_rng = nullptr; c->t_work = nullptr;
+    (void)hipGetLastError();
+    return MH_ERR_HIP;
+  }
+  c->t_cap = ntasks;
+  return MH_OK;
+}
+
+// lcp_lemke_regularized(_MM, _qq, z, o) on the worlds with need[b] set: lst / piv receive the result flags and pivot counts
+static int core_lemke_stage(mh_imp_core* c, hipStream_t s, const mh_lcp_opts* o, const int* need, int* lst, unsigned* piv)
+{
+  namespace im = mh::imp;
+  const int B = c->B, n = c->nmax;
+  const int min_exp = o ? o->min_exp : -20, max_exp = o ? o->max_exp : 1; const unsigned step = o ? o->step_exp : 1u;
+  int R = 1; for (int rf = min_exp; rf < max_exp; rf += (int)step) R++;
+  const long ntasks = (long)B * R;
+  const double bytes = (double)ntasks * (((double)n * n + 5.0 * n) * 8.0 + 16.0 * n + 8.0 * n + 200.0);
+  bool tasks = mh_g_debug_tasks != 0 && n > MH_LCP_MAX_N_WAVE && step > 0 && bytes < 96e9;
+  if (tasks && core_ladder_alloc(c, ntasks) != MH_OK) tasks = false;
+  if (!tasks)
+    return mh_lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, lst, piv,
+                                   nullptr, 0, nullptr, o, need, c->ws_d, c->ws_i, c->ncur, c->work);
+  // the problems of at most 64 rows of this batch: the wave solver, whole ladder
+  int rc = mh_lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, lst, piv,
+                                   nullptr, 0, nullptr, o, need, c->ws_d, c->ws_i, c->ncur, c->work, 1);
+  if (rc != MH_OK) return rc;
+  MH_HIP(hipMemsetAsync(c->solved_at, 0x7f, (size_t)B * 4, s));
+  MH_HIP(hipMemsetAsync(c->t_work, 0, (size_t)ntasks * 16, s));
+  mh::LcpParams P; P.kind = MH_LCP_LEMKE_REG; P.min_exp = min_exp; P.step_exp = step; P.max_exp = max_exp;
+  P.piv_tol = o ? o->piv_tol : -1.0; P.zero_tol = o ? o->zero_tol : -1.0;
+  static const mh::Pow10Table p10 = [] { mh::Pow10Table t; for (int i = 0; i < 64; i++) t.v[i] = std::pow(10.0, (double)(i - 32)); return t; }();
+  // the ladder offers B x (8-12) useful workgroups at once: the narrow geometry (four problems per CU) unless its compact path does not take n
+  const bool wide = n > 512;
+  const hipError_t le = (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(s, MH_LCP_LEMKE_REG, (int)ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
+      c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, need, c->ncur, mh_g_debug_compact, c->t_work, B, c->solved_at);
+  MH_HIP(le);
+  hipLaunchKernelGGL(im::k_ladder_select, dim3(B), dim3(im::T), 0, s, *c, need, R, lst, piv);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 // the solver chain of one round over the worlds with run_if set
 static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, int mode)
 {
@@ -1273,8 +1375,7 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   if (mode == MH_CORE_IMPACT && c->ap) {
     // every island the mask selects takes the Anitescu-Potra model: lcp_lemke_regularized(_MM, _qq, z, -20, 1, -2) alone (ICH-AP:333)
     mh_lcp_opts oa; oa.min_exp = -20; oa.step_exp = 1u; oa.max_exp = -2; oa.piv_tol = -1.0; oa.zero_tol = -1.0;
-    return mh_lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, c->lst1, c->piv1,
-                                   nullptr, 0, nullptr, &oa, run_if, c->ws_d, c->ws_i, c->ncur, c->work);
+    return core_lemke_stage(c, s, &oa, run_if, c->lst1, c->piv1);
   }
   if (mode == MH_CORE_IMPACT) {
     mh_lcp_opts o1; o1.min_exp = -20; o1.step_exp = 4u; o1.max_exp = -8; o1.piv_tol = -1.0; o1.zero_tol = -1.0;   // ICH-QP:219
@@ -1287,8 +1388,7 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   if (rc != MH_OK) return rc;
   hipLaunchKernelGGL(im::k_lemke_prep, dim3(B), dim3(im::T), 0, s, *c, run_if, mode);
   MH_HIP(hipGetLastError());
-  return mh_lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, c->lst2, c->piv2,
-                                 nullptr, 0, nullptr, nullptr, c->need2, c->ws_d, c->ws_i, c->ncur, c->work);             // ICH-QP:224, CStab:955
+  return core_lemke_stage(c, s, nullptr, c->need2, c->lst2, c->piv2);                                                // ICH-QP:224, CStab:955
 }
 
 int mh_imp_core_process(mh_imp_core* c, void* stream, int mode)

@@ -594,6 +594,14 @@ MH_DEV bool verify(const Mat& M, double lam, const Ws& W, const double* q, const
 }
 
 // LCP.cpp:545-1003 (dense)
+// Task mode of the lcp_lemke kinds: the attempts of lcp_lemke_regularized's ladder do not depend on one another (each starts from z = 0,
+// LCP.cpp:564, and lcp_lemke never USES the rand() values it draws), so one workgroup can run ONE attempt of ONE problem and a
+// selection pass afterwards takes the first attempt, in ladder order, that succeeded.  solved_at[w] = the lowest attempt known to have
+// succeeded: attempts above it are not started, and a running one gives up when it learns of a lower success (its result could never
+// be the one selected).  rung < 0: not in task mode.
+struct LadderTask { int* solved_at; int rung;
+  MH_DEV bool pointless() const { return rung >= 0 && *(volatile int*)solved_at < rung; } };
+
 // the basis of lcp_lemke by columns, for lu_compact: position p holds the slack -e_{id-n}, the artificial column, or column id of M
 struct LemkeCol { const Mat* M; const int* bv; const double* art; double lam; int n, tt;
   MH_DEV int unit_row(int p) const { const int id = bv[p]; return (id >= n && id != tt) ? id - n : -1; }
@@ -601,7 +609,7 @@ struct LemkeCol { const Mat* M; const int* bv; const double* art; double lam; in
   MH_DEV double load_id(int id, int i) const { return (id == tt) ? art[i] : M->at(i, id, lam); } };
 
 MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, double* z, int& zsize, double piv_tol, double zero_tol,
-                      double nrm_lam, unsigned& pivots, Trace2& tr, bool compact)
+                      double nrm_lam, unsigned& pivots, Trace2& tr, bool compact, const LadderTask& task)
 {
   const int n = M.n, t = tid();
   const unsigned MAXITER = (50u * (unsigned)n < 1000u) ? 50u * (unsigned)n : 1000u;
@@ -635,6 +643,7 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
   if (t == 0) { W.x[lvindex] = tval; W.bv[lvindex] = tt; }
   sync();
   for (pivots = 0; pivots < MAXITER; pivots++) {
+    if (task.rung >= 0 && (pivots & 15u) == 15u && bcast_i(task.pointless() ? 1 : 0)) { zsize = n; return false; }   // (a lower attempt has succeeded)
     if (leaving == tt) {
       for (int p = t; p < n; p += T) { const int id = W.bv[p]; if (id < n) z[id] = W.x[p]; }   // (:804-806)
       sync();
@@ -706,7 +715,7 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
 // the four public solvers (lcp_solve_wave's attempt loop)
 template <int FAM>      // 0: the lcp_fast kinds, 1: the lcp_lemke kinds -- one kernel each, so that neither carries the other's registers
 MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, const Ws& W, const double* q, double* z, int& zsize,
-                      unsigned& pivots, Trace2& tr, bool compact)
+                      unsigned& pivots, Trace2& tr, bool compact, int att_first, int att_count, const LadderTask& task)
 {
   const int n = M.n, t = tid();
   const bool reg = (P.kind == MH_LCP_FAST_REG) || (P.kind == MH_LCP_LEMKE_REG);
@@ -717,12 +726,16 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
   const double ZERO_TOL = (P.zero_tol > 0.0) ? P.zero_tol : (double)n * nrm0 * MH_NEAR_ZERO;
   unsigned total = 0;
   double offmax = 0.0;
-  int rf = P.min_exp;
-  for (int attempt = 0; ; attempt++) {
+  bool have_off = false;
+  // attempt a >= 1 of the ladder regularises with 10^rf, rf = min_exp + (a - 1) step_exp (LCP.cpp:252-262, 404-414); a launch may run a
+  // window [att_first, att_first + att_count) of it -- the whole ladder by default, ONE attempt per workgroup in task mode
+  for (int attempt = att_first; attempt - att_first < att_count; attempt++) {
     double lam = 0.0, nrm = nrm0;
+    const int rf = P.min_exp + (attempt - 1) * (int)P.step_exp;
     if (attempt > 0) {
       if (!reg || !(rf < P.max_exp)) break;
-      if (attempt == 1) {
+      if (!have_off) {
+        have_off = true;
         double mo = 0.0;
         for (long e = t; e < nn; e += T) { const int r = (int)(e % n), c = (int)(e / n); if (r != c) { const double a = fabs(M.M[r + (size_t)M.ld * c]); mo = (a > mo) ? a : mo; } }
         offmax = red_max(mo);
@@ -736,11 +749,11 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
     if (reg) tr.push(0x40000000 | attempt);
     bool ok;
     if constexpr (FAM == 0) ok = lcp_fast(M, lam, W, q, z, zsize, P.zero_tol, nrm, pivots, tr);
-    else ok = lcp_lemke(M, lam, W, q, z, zsize, P.piv_tol, P.zero_tol, nrm, pivots, tr, compact);
+    else ok = lcp_lemke(M, lam, W, q, z, zsize, P.piv_tol, P.zero_tol, nrm, pivots, tr, compact, task);
     if (!reg) return ok;
     const bool good = ok && verify(M, lam, W, q, z, ZERO_TOL, attempt > 0);
     if (attempt == 0) { if (good) return true; total += pivots; }
-    else { total += pivots; if (good) { pivots = total; return true; } rf += (int)P.step_exp; }
+    else { total += pivots; if (good) { pivots = total; return true; } }
   }
   pivots = total;
   return false;
@@ -755,25 +768,32 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
                     uint32_t* __restrict__ rngg, int* __restrict__ status, unsigned* __restrict__ pivots_out,
                     int32_t* __restrict__ trace, int trace_cap, int* __restrict__ trace_len,
                     LcpParams P, Pow10Table p10, double* __restrict__ wsd, int* __restrict__ wsi,
-                    const int* __restrict__ run_if, const int* __restrict__ n_arr, int flags, double* __restrict__ work)
+                    const int* __restrict__ run_if, const int* __restrict__ n_arr, int flags, double* __restrict__ work,
+                    int task_worlds, int* __restrict__ solved_at)
 {
+  // b: the index of everything this workgroup OWNS (z, sizes, rand() state, status, pivots, workspace, work counters); bw: the problem it
+  // reads (M, q, its size, the mask).  They differ in task mode only (task_worlds > 0: task b = attempt b / task_worlds of problem
+  // b % task_worlds, attempt-major so that the lower attempts of every problem are dispatched first)
   const int b = blockIdx.x;
   if (b >= B) return;
-  if (run_if && run_if[b] == 0) return;
+  const int bw = (task_worlds > 0) ? b % task_worlds : b;
+  LadderTask task; task.solved_at = (task_worlds > 0) ? solved_at + bw : nullptr; task.rung = (task_worlds > 0) ? b / task_worlds : -1;
   const int t = tid();
+  if (run_if && run_if[bw] == 0) { if (task_worlds > 0 && t == 0) status[b] = -1; return; }
+  if (task_worlds > 0 && task.pointless()) { if (t == 0) status[b] = -1; return; }     // -1: not run
   Ws W;
   double* wd = wsd + (size_t)b * ws_doubles(n);
   int* wi = wsi + (size_t)b * ws_ints(n);
   // per-problem sizes: strides of q / z / M / the workspace stay those of the largest problem (the launch's n), M is
   // compact (ld = its own n); problems of at most 64 rows belong to the wave solver of the same call
   const int nstride = n;
-  if (n_arr) { n = n_arr[b]; ld = n; if (n <= MH_LCP_MAX_N_WAVE) return; }
+  if (n_arr) { n = n_arr[bw]; ld = n; if (n <= MH_LCP_MAX_N_WAVE) { if (task_worlds > 0 && t == 0) status[b] = -1; return; } }
   W.A = wd; W.b = wd + (size_t)n * n; W.w = W.b + n; W.x = W.w + n; W.d = W.x + n; W.art = W.d + n;
   W.list = wi; W.flag = wi + n; W.pos = wi + 2 * (size_t)n; W.bv = wi + 3 * (size_t)n;
   if (t < 32) s_rng[t] = rngg[(size_t)b * MH_RAND_WORDS + t];
   if (t == 0) { s_luc_bug = 0; s_work[0] = 0.0; s_work[1] = 0.0; }
-  Mat M; M.M = Mg + (size_t)b * strideM; M.ld = ld; M.n = n;
-  const double* q = qg + (size_t)b * nstride;
+  Mat M; M.M = Mg + (size_t)bw * strideM; M.ld = ld; M.n = n;
+  const double* q = qg + (size_t)bw * nstride;
   double* z = zg + (size_t)b * nstride;
   int zsize = zsz_in ? zsz_in[b] : n;
   if (zsize != n) for (int i = t; i < n; i += T) z[i] = 0.0;
@@ -785,7 +805,8 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   sync();
   const unsigned long long t_kernel = bp_tick();
 #endif
-  const bool ok = lcp_solve<FAM>(P, p10, M, W, q, z, zsize, piv, tr, (flags & 1) != 0);
+  const bool ok = lcp_solve<FAM>(P, p10, M, W, q, z, zsize, piv, tr, (flags & 1) != 0, (task.rung >= 0) ? task.rung : 0, (task.rung >= 0) ? 1 : 0x3fffffff, task);
+  if (task.rung >= 0 && ok && t == 0) atomicMin(task.solved_at, task.rung);
   sync();
 #ifdef MH_BLK_PROF
   if (t == 0 && (b == 0 || b == 5)) printf("blk prof (cycles, block %d, %u pivots, %llu ticks in all): list %llu gather %llu panel %llu swap %llu trail %llu solve %llu gemv %llu randmin %llu compact %llu [setup %llu panel %llu u12 %llu trail %llu back %llu; dense steps %llu panels %llu]\n", b, piv, bp_tick() - t_kernel,
@@ -808,14 +829,14 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
 extern "C" MH_HIDDEN hipError_t MH_BLK_LAUNCHER(void* stream, int kind, int B, int n, const double* M, int ld, long strideM, const double* q, double* z,
                                      const int* zsz_in, int* zsz_out, uint32_t* rng, int* status, unsigned* pivots,
                                      int32_t* trace, int trace_cap, int* trace_len, const mh::LcpParams* P, const mh::Pow10Table* p10,
-                                     double* wsd, int* wsi, const int* run_if, const int* n_arr, int flags, double* work)
+                                     double* wsd, int* wsi, const int* run_if, const int* n_arr, int flags, double* work, int task_worlds, int* solved_at)
 {
   namespace ns = mh::MH_BLK_NS;
   if (kind == MH_LCP_FAST || kind == MH_LCP_FAST_REG)
     hipLaunchKernelGGL(ns::k_lcp_block<0>, dim3(B), dim3(ns::T), 0, (hipStream_t)stream, B, n, M, ld, strideM, q, z, zsz_in, zsz_out, rng, status, pivots,
-                       trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags, work);
+                       trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags, work, task_worlds, solved_at);
   else
     hipLaunchKernelGGL(ns::k_lcp_block<1>, dim3(B), dim3(ns::T), 0, (hipStream_t)stream, B, n, M, ld, strideM, q, z, zsz_in, zsz_out, rng, status, pivots,
-                       trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags, work);
+                       trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags, work, task_worlds, solved_at);
   return hipGetLastError();
 }

@@ -8,4 +8,4 @@ python tests/tools/fuzz_big.py 7200 40 > gpurun_out/soak3/fuzz_big.txt 2>&1; tai
 python tests/tools/fuzz_artic_stab.py 7300 120 > gpurun_out/soak3/fuzz_artic_stab.txt 2>&1; tail -1 gpurun_out/soak3/fuzz_artic_stab.txt
 python tests/tools/fuzz_artic.py 7400 40 > gpurun_out/soak3/fuzz_artic.txt 2>&1; tail -1 gpurun_out/soak3/fuzz_artic.txt
 python tests/tools/fuzz_joints.py 7500 40 > gpurun_out/soak3/fuzz_joints.txt 2>&1; tail -1 gpurun_out/soak3/fuzz_joints.txt
-python tests/tools/fuzz_parity.py 7600 > gpurun_out/soak3/fuzz_parity.txt 2>&1; tail -1 gpurun_out/soak3/fuzz_parity.txt
+python tests/tools/fuzz_parity.py 7600 7640 200 > gpurun_out/soak3/fuzz_parity.txt 2>&1; tail -1 gpurun_out/soak3/fuzz_parity.txt
