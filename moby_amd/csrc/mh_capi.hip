@@ -158,7 +158,7 @@ int mh_rand_next(uint32_t* st)
   return (int)(v >> 1);
 }
 
-int mh_g_debug_tasks = 1;
+int mh_g_debug_tasks = 2;      // mh_debug_set(4, v): 0 = the Lemke ladder in sequence, 1 = as (world, attempt) tasks, 2 = tasks + speculation beside lcp_fast
 int mh_g_debug_compact = 1;  // mh_debug_set(3, v): 1 = Lemke's bases through the structure-exploiting LU (mh_lu_compact.inc), 0 = dense LU only
 int mh_g_debug_blk = 0;      // mh_debug_set(2, v): 0 = choose, 1 = 256-thread block solver, 2 = 1024-thread block solver
 int mh_g_debug_ka = 64;          // LDS LU block edge of the world kernel (clamped to the variant MHW_KA_V); mh_debug_set(1, 0) forces the HBM workspace path
@@ -317,7 +317,7 @@ extern "C" int mh_debug_set(int key, int value)
 {
   if (key == 1) { if (value < 0 || value > 64) return fail(MH_ERR_INVALID_ARG, "LU block edge outside [0, 64]"); mh_g_debug_ka = value; return MH_OK; }
   if (key == 2) { if (value < 0 || value > 2) return fail(MH_ERR_INVALID_ARG, "block solver geometry outside {0, 1, 2}"); mh_g_debug_blk = value; return MH_OK; }
-  if (key == 4) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "ladder-task switch outside {0, 1}"); mh_g_debug_tasks = value; return MH_OK; }
+  if (key == 4) { if (value < 0 || value > 2) return fail(MH_ERR_INVALID_ARG, "ladder-task switch outside {0, 1, 2}"); mh_g_debug_tasks = value; return MH_OK; }
   if (key == 3) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "compact-LU switch outside {0, 1}"); mh_g_debug_compact = value; return MH_OK; }
   return fail(MH_ERR_INVALID_ARG, "unknown debug key %d", key);
 }

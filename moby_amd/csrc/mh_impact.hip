@@ -1171,6 +1171,7 @@ void mh_imp_core_destroy(mh_imp_core* c)
   if (!c) return;
   for (int i = 0; i < c->nallocs; i++) if (c->allocs[i]) (void)hipFree(c->allocs[i]);
   c->nallocs = 0;
+  if (c->s2) { (void)hipStreamSynchronize((hipStream_t)c->s2); (void)hipStreamDestroy((hipStream_t)c->s2); (void)hipEventDestroy((hipEvent_t)c->ev0); (void)hipEventDestroy((hipEvent_t)c->ev1); c->s2 = nullptr; }
   { void* ps[] = { c->t_wsd, c->t_wsi, c->t_z, c->t_st, c->t_piv, c->t_zsz, c->t_rng, c->t_work, c->solved_at };
     for (void* q : ps) if (q) (void)hipFree(q);
     c->t_wsd = nullptr; c->t_wsi = nullptr; c->t_z = nullptr; c->t_st = nullptr; c->t_piv = nullptr; c->t_zsz = nullptr; c->t_rng = nullptr; c->t_work = nullptr; c->solved_at = nullptr; c->t_cap = 0; }
@@ -1333,37 +1334,58 @@ static int core_ladder_alloc(mh_imp_core* c, long ntasks)
   return MH_OK;
 }
 
-// lcp_lemke_regularized(_MM, _qq, z, o) on the worlds with need[b] set: lst / piv receive the result flags and pivot counts
-static int core_lemke_stage(mh_imp_core* c, hipStream_t s, const mh_lcp_opts* o, const int* need, int* lst, unsigned* piv)
+// lcp_lemke_regularized(_MM, _qq, z, o) as tasks, in two halves so that the first can run on another stream while lcp_fast is still
+// at work: ladder_launch starts the B x R attempts for the worlds `mask` selects (it reads _MM, _qq, the sizes -- nothing lcp_fast
+// writes); ladder_finish, on the pipeline's stream and after lcp_fast, runs the wave solver's whole ladder for the problems of at most
+// 64 rows and the selection for the worlds need[b] selects (a subset of `mask`): lst / piv receive result flags and pivot counts.
+struct LadderPlan { int R; long ntasks; bool ok; mh_lcp_opts o; bool has_o; };
+static LadderPlan core_ladder_plan(mh_imp_core* c, const mh_lcp_opts* o)
 {
-  namespace im = mh::imp;
-  const int B = c->B, n = c->nmax;
+  LadderPlan L; L.has_o = o != nullptr; if (o) L.o = *o;
+  const int n = c->nmax;
   const int min_exp = o ? o->min_exp : -20, max_exp = o ? o->max_exp : 1; const unsigned step = o ? o->step_exp : 1u;
-  int R = 1; for (int rf = min_exp; rf < max_exp; rf += (int)step) R++;
-  const long ntasks = (long)B * R;
-  const double bytes = (double)ntasks * (((double)n * n + 5.0 * n) * 8.0 + 16.0 * n + 8.0 * n + 200.0);
-  bool tasks = mh_g_debug_tasks != 0 && n > MH_LCP_MAX_N_WAVE && step > 0 && bytes < 96e9;
-  if (tasks && core_ladder_alloc(c, ntasks) != MH_OK) tasks = false;
-  if (!tasks)
-    return mh_lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, lst, piv,
-                                   nullptr, 0, nullptr, o, need, c->ws_d, c->ws_i, c->ncur, c->work);
-  // the problems of at most 64 rows of this batch: the wave solver, whole ladder
-  int rc = mh_lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, lst, piv,
-                                   nullptr, 0, nullptr, o, need, c->ws_d, c->ws_i, c->ncur, c->work, 1);
-  if (rc != MH_OK) return rc;
-  MH_HIP(hipMemsetAsync(c->solved_at, 0x7f, (size_t)B * 4, s));
-  MH_HIP(hipMemsetAsync(c->t_work, 0, (size_t)ntasks * 16, s));
-  mh::LcpParams P; P.kind = MH_LCP_LEMKE_REG; P.min_exp = min_exp; P.step_exp = step; P.max_exp = max_exp;
+  L.R = 1; if (step > 0) for (int rf = min_exp; rf < max_exp; rf += (int)step) L.R++;
+  L.ntasks = (long)c->B * L.R;
+  const double bytes = (double)L.ntasks * (((double)n * n + 5.0 * n) * 8.0 + 16.0 * n + 8.0 * n + 200.0);
+  L.ok = mh_g_debug_tasks != 0 && n > MH_LCP_MAX_N_WAVE && step > 0 && bytes < 96e9 && core_ladder_alloc(c, L.ntasks) == MH_OK;
+  return L;
+}
+static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& L, const int* mask)
+{
+  const int B = c->B, n = c->nmax;
+  const mh_lcp_opts* o = L.has_o ? &L.o : nullptr;
+  MH_HIP(hipMemsetAsync(c->solved_at, 0x7f, (size_t)B * 4, st));
+  MH_HIP(hipMemsetAsync(c->t_work, 0, (size_t)L.ntasks * 16, st));
+  mh::LcpParams P; P.kind = MH_LCP_LEMKE_REG; P.min_exp = o ? o->min_exp : -20; P.step_exp = o ? o->step_exp : 1u; P.max_exp = o ? o->max_exp : 1;
   P.piv_tol = o ? o->piv_tol : -1.0; P.zero_tol = o ? o->zero_tol : -1.0;
   static const mh::Pow10Table p10 = [] { mh::Pow10Table t; for (int i = 0; i < 64; i++) t.v[i] = std::pow(10.0, (double)(i - 32)); return t; }();
   // the ladder offers B x (8-12) useful workgroups at once: the narrow geometry (four problems per CU) unless its compact path does not take n
   const bool wide = n > 512;
-  const hipError_t le = (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(s, MH_LCP_LEMKE_REG, (int)ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
-      c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, need, c->ncur, mh_g_debug_compact, c->t_work, B, c->solved_at);
+  const hipError_t le = (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
+      c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact, c->t_work, B, c->solved_at);
   MH_HIP(le);
-  hipLaunchKernelGGL(im::k_ladder_select, dim3(B), dim3(im::T), 0, s, *c, need, R, lst, piv);
+  return MH_OK;
+}
+static int core_ladder_finish(mh_imp_core* c, hipStream_t s, const LadderPlan& L, const int* need, int* lst, unsigned* piv)
+{
+  namespace im = mh::imp;
+  const int B = c->B, n = c->nmax;
+  int rc = mh_lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, lst, piv,
+                                   nullptr, 0, nullptr, L.has_o ? &L.o : nullptr, need, c->ws_d, c->ws_i, c->ncur, c->work, 1);
+  if (rc != MH_OK) return rc;
+  hipLaunchKernelGGL(im::k_ladder_select, dim3(B), dim3(im::T), 0, s, *c, need, L.R, lst, piv);
   MH_HIP(hipGetLastError());
   return MH_OK;
+}
+static int core_lemke_stage(mh_imp_core* c, hipStream_t s, const mh_lcp_opts* o, const int* need, int* lst, unsigned* piv)
+{
+  const int B = c->B, n = c->nmax;
+  const LadderPlan L = core_ladder_plan(c, o);
+  if (!L.ok)
+    return mh_lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, lst, piv,
+                                   nullptr, 0, nullptr, o, need, c->ws_d, c->ws_i, c->ncur, c->work);
+  const int rc = core_ladder_launch(c, s, L, need);
+  return rc != MH_OK ? rc : core_ladder_finish(c, s, L, need, lst, piv);
 }
 
 // the solver chain of one round over the worlds with run_if set
@@ -1377,6 +1399,26 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
     mh_lcp_opts oa; oa.min_exp = -20; oa.step_exp = 1u; oa.max_exp = -2; oa.piv_tol = -1.0; oa.zero_tol = -1.0;
     return core_lemke_stage(c, s, &oa, run_if, c->lst1, c->piv1);
   }
+  // Speculation: on LCPs of 256 rows and more lcp_fast[_regularized] almost never succeeds (box stacks: 19 % at n = 256, 0 % at n = 512), so
+  // the Lemke ladder that will be needed anyway starts at once, on a second stream, for every world of the round; its tasks read nothing
+  // lcp_fast writes, and the selection afterwards only looks at the worlds whose lcp_fast did fail.  mh_debug_set(4, 1) turns it off.
+  LadderPlan L; L.ok = false;
+  const bool spec_wanted = mh_g_debug_tasks >= 2 && n >= 256;
+  if (spec_wanted) L = core_ladder_plan(c, nullptr);
+  bool spec = spec_wanted && L.ok;
+  if (spec && !c->s2) {
+    hipStream_t s2; hipEvent_t e0, e1;
+    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess
+        && hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess) { c->s2 = s2; c->ev0 = e0; c->ev1 = e1; }
+    else { (void)hipGetLastError(); spec = false; }
+  }
+  if (spec) {
+    MH_HIP(hipEventRecord((hipEvent_t)c->ev0, s));
+    MH_HIP(hipStreamWaitEvent((hipStream_t)c->s2, (hipEvent_t)c->ev0, 0));
+    rc = core_ladder_launch(c, (hipStream_t)c->s2, L, run_if);
+    if (rc != MH_OK) return rc;
+    MH_HIP(hipEventRecord((hipEvent_t)c->ev1, (hipStream_t)c->s2));
+  }
   if (mode == MH_CORE_IMPACT) {
     mh_lcp_opts o1; o1.min_exp = -20; o1.step_exp = 4u; o1.max_exp = -8; o1.piv_tol = -1.0; o1.zero_tol = -1.0;   // ICH-QP:219
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, nullptr, c->rng, c->lst1, c->piv1,
@@ -1388,6 +1430,10 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   if (rc != MH_OK) return rc;
   hipLaunchKernelGGL(im::k_lemke_prep, dim3(B), dim3(im::T), 0, s, *c, run_if, mode);
   MH_HIP(hipGetLastError());
+  if (spec) {                                                     // the tasks have been running beside lcp_fast: wait for them, then select
+    MH_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->ev1, 0));
+    return core_ladder_finish(c, s, L, c->need2, c->lst2, c->piv2);
+  }
   return core_lemke_stage(c, s, nullptr, c->need2, c->lst2, c->piv2);                                                // ICH-QP:224, CStab:955
 }
 

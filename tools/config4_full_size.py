@@ -7,6 +7,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from moby_amd import scene as S, stack as K
 
+from moby_amd import _lib
+if os.environ.get("MH_BLK_GEOM"):          # 1 = 256-thread block solver, 2 = 1024-thread (mh_debug_set key 2)
+    _lib.check(_lib.load().mh_debug_set(2, int(os.environ["MH_BLK_GEOM"])))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 sc = K.box_stack_scene(N)
