@@ -155,7 +155,7 @@ def test_config4_stated_size_properties():
 
 def test_config4_stated_size_full_batch():
     """BASELINE config 4 at the stated size AND the batch size the configuration names: 16 boxes (impact LCP n = 512) x 1024
-    worlds, one full TimeSteppingSimulator::step (the size bench.py's `config4_full_step` leg runs; about a minute and a half).
+    worlds, one full TimeSteppingSimulator::step (the size bench.py's `config4_full_step` leg runs; about 75 s).
     No world fails, identical worlds give identical results wherever they sit in the batch, the stacks stay put, momentum
     is what gravity put in, and the solver chain did the work the CPU oracle does on such worlds (thousands of pivots each)."""
     N, B = CONFIG4_BOXES, 1024
