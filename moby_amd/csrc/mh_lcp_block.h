@@ -452,7 +452,7 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
 // LCP.cpp:199-209 over the variables i with member(i) (list order = index order); val(i) reads
 // the candidate.  Consumes exactly one rand().  Returns the chosen variable (uniform).
 template <class Val, class Mem>
-MH_DEV int rand_min(int n, Val val, Mem member, double tol, double& vsel) {
+MH_DEV int rand_min(int n, Val val, Mem member, double tol, double& vsel, bool& tie) {
   const int t = tid();
   double best = inf(); int bi = 0x7fffffff;
   for (int i = t; i < n; i += T) if (member(i)) { const double v = val(i); if (v < best) { best = v; bi = i; } }
@@ -460,6 +460,7 @@ MH_DEV int rand_min(int n, Val val, Mem member, double tol, double& vsel) {
   int c = 0;
   for (int i = t; i < n; i += T) if (member(i) && i != imin && val(i) < vmin + tol) c++;
   const int cnt = 1 + red_sum_int(c);
+  tie = tie || cnt > 1;
   const int r = rand_next() % cnt;
   int chosen = imin;
   if (r != 0) {
@@ -471,8 +472,30 @@ MH_DEV int rand_min(int n, Val val, Mem member, double tol, double& vsel) {
 }
 
 // LCP.cpp:41-196.  z (n, in/out) and zsize as in lcp_fast_wave.
+// Repeating pivot sequences.  One iteration of the loop below is a function of the index set alone (the matrices are rebuilt from it;
+// the rand() VALUE matters only when rand_min finds several minima), so once the set at the top of an iteration equals the set h
+// iterations earlier and none of those h iterations saw a tie, the remaining iterations repeat them for ever -- and this is how
+// lcp_fast fails on the contact LCPs of resting stacks: LCP.cpp:176-187 takes the position found in the old _z as an index into the
+// NEW _nonbas, moves the variable that has just entered straight out again, and the loop spins on one basis until MAX_PIV (period 1
+// in all but a few percent of the failing calls, 2-4 in the rest; 85-95 % of the iterations of such a call).  What the reference
+// leaves behind after r repetitions is known without running them: z untouched, pivots advanced, 1-2 rand() calls and 0-2 trace entries
+// per iteration.  So the repetitions are skipped (whole periods only; the < h iterations left over are run).  FH_P: the longest period
+// recognised; the sets of the last FH_P iterations are kept as bit words in LDS.
+constexpr int FH_P = 8;
+constexpr int FH_N = 2048, FH_W = FH_N / 32 + 2;    // larger problems run every iteration
+__shared__ unsigned s_fh[FH_P][FH_W], s_fcur[FH_W];
+__shared__ int s_fm[FH_P], s_frc[FH_P], s_ftc[FH_P], s_ftr[FH_P][2];
+MH_DEV void rand_skip(unsigned m) {      // m rand() calls whose values nobody looks at
+  if (tid() == 0) {
+    unsigned idx = s_rng[31];
+    for (unsigned i = 0; i < m; i++) { unsigned j = idx + 28; if (j >= 31) j -= 31; s_rng[idx] = s_rng[idx] + s_rng[j]; idx = (idx + 1 == 31) ? 0 : idx + 1; }
+    s_rng[31] = idx;
+  }
+  sync();
+}
+
 MH_DEV bool lcp_fast(const Mat& M, double lam, const Ws& W, const double* q, double* z, int& zsize, double zero_tol,
-                     double nrm_lam, unsigned& pivots, Trace2& tr)
+                     double nrm_lam, unsigned& pivots, Trace2& tr, bool skip_repeats)
 {
   const int n = M.n, t = tid();
   if (zero_tol < 0.0) zero_tol = (double)n * nrm_lam * MH_DBL_EPS;
@@ -487,7 +510,45 @@ MH_DEV bool lcp_fast(const Mat& M, double lam, const Ws& W, const double* q, dou
   }
   sync();
   const unsigned MAX_PIV = 2u * (unsigned)n;
-  for (pivots = 0; pivots < MAX_PIV; pivots++) {
+  const int nwords = (n + 31) >> 5;
+  int it = 0;                      // iterations RUN (the ring of index sets is addressed by it, pivots counts the skipped ones too)
+  int last_tie = -1, ncalls = 0, npush = 0;
+  bool skipped = !skip_repeats || n > FH_N;
+  for (pivots = 0; pivots < MAX_PIV; pivots++, it++) {
+    if (!skipped) {
+      if (it > 0 && t == 0) { s_frc[(it - 1) % FH_P] = ncalls; s_ftc[(it - 1) % FH_P] = npush; }
+      ncalls = 0; npush = 0;
+      for (int i0 = 0; i0 < n; i0 += T) {
+        const int i = i0 + t;
+        const unsigned long long m = __ballot(i < n && W.flag[i] != 0);
+        if ((t & 63) == 0 && i < n) { s_fcur[i >> 5] = (unsigned)m; s_fcur[(i >> 5) + 1] = (unsigned)(m >> 32); }
+      }
+      if (t < FH_P) s_fm[t] = 1;
+      sync();
+      const int depth = (it < FH_P) ? it : FH_P;
+      for (int e = t; e < FH_P * nwords; e += T) { const int h = e / nwords, wd = e - h * nwords; if (s_fh[h][wd] != s_fcur[wd]) s_fm[h] = 0; }
+      sync();
+      int lag = 0;
+      for (int h = 1; h <= depth; h++) if (lag == 0 && s_fm[(it - h) % FH_P] != 0 && last_tie < it - h) lag = h;
+      const unsigned reps = lag ? (MAX_PIV - pivots) / (unsigned)lag : 0u;
+      if (reps > 0) {
+        unsigned calls = 0, pushes = 0;
+        for (int h = lag; h >= 1; h--) { calls += (unsigned)s_frc[(it - h) % FH_P]; pushes += (unsigned)s_ftc[(it - h) % FH_P]; }
+        rand_skip(calls * reps);
+        for (unsigned r = 0; r < reps; r++) {
+          if (!tr.buf || tr.len >= tr.cap) { tr.len += (int)(pushes * (reps - r)); break; }
+          for (int h = lag; h >= 1; h--) { const int sl = (it - h) % FH_P; for (int e = 0; e < s_ftc[sl]; e++) tr.push(s_ftr[sl][e]); }
+        }
+        pivots += reps * (unsigned)lag;
+        skipped = true;
+        if (pivots >= MAX_PIV) { pivots = MAX_PIV; break; }
+      } else {
+        for (int wd = t; wd < nwords; wd += T) s_fh[it % FH_P][wd] = s_fcur[wd];
+      }
+      sync();
+    }
+    auto push = [&](int32_t v) { tr.push(v); if (t == 0 && npush < 2) s_ftr[it % FH_P][npush] = v; npush++; };
+    bool tie = false;
     unsigned long long tq = bp_tick();
     const int k = build_list(n, W);
     bp_tock(BP_LIST, tq); tq = bp_tick();
@@ -528,14 +589,14 @@ MH_DEV bool lcp_fast(const Mat& M, double lam, const Ws& W, const double* q, dou
     auto zval = [&](int i) { return W.b[W.pos[i]]; };
     auto isnb = [&](int i) { return W.flag[i] != 0; };
     double wsel = 0.0; int minw = -1;
-    if (k < n) minw = rand_min(n, wval, isb, zero_tol, wsel);
+    if (k < n) minw = (ncalls++, rand_min(n, wval, isb, zero_tol, wsel, tie));
     if (minw < 0 || wsel > -zero_tol) {
       double zsel = 0.0; int minz = -1;
-      if (k > 0) minz = rand_min(n, zval, isnb, zero_tol, zsel);
+      if (k > 0) minz = (ncalls++, rand_min(n, zval, isnb, zero_tol, zsel, tie));
       bp_tock(BP_RANDMIN, tq);
       if (minz >= 0 && zsel < -zero_tol) {
         if (t == 0) W.flag[minz] = 0;
-        tr.push(-(int32_t)(minz + 1));
+        push(-(int32_t)(minz + 1));
         sync();
       } else {
         for (int i = t; i < n; i += T) z[i] = W.flag[i] ? W.b[W.pos[i]] : 0.0;
@@ -544,9 +605,9 @@ MH_DEV bool lcp_fast(const Mat& M, double lam, const Ws& W, const double* q, dou
         return true;
       }
     } else {
-      tr.push((int32_t)(minw + 1));
+      push((int32_t)(minw + 1));
       double zsel = 0.0; int minzv = -1;
-      if (k > 0) minzv = rand_min(n, zval, isnb, zero_tol, zsel);
+      if (k > 0) minzv = (ncalls++, rand_min(n, zval, isnb, zero_tol, zsel, tie));
       bp_tock(BP_RANDMIN, tq);
       int idx2 = -1;
       if (minzv >= 0 && zsel < -zero_tol) {
@@ -560,9 +621,10 @@ MH_DEV bool lcp_fast(const Mat& M, double lam, const Ws& W, const double* q, dou
         sync(); idx2 = s_bi[3]; sync();
       }
       if (t == 0) { W.flag[minw] = 1; if (idx2 >= 0) W.flag[idx2] = 0; }
-      if (idx2 >= 0) tr.push(-(int32_t)(idx2 + 1));
+      if (idx2 >= 0) push(-(int32_t)(idx2 + 1));
       sync();
     }
+    if (tie) last_tie = it;
   }
   return false;
 }
@@ -715,7 +777,7 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
 // the four public solvers (lcp_solve_wave's attempt loop)
 template <int FAM>      // 0: the lcp_fast kinds, 1: the lcp_lemke kinds -- one kernel each, so that neither carries the other's registers
 MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, const Ws& W, const double* q, double* z, int& zsize,
-                      unsigned& pivots, Trace2& tr, bool compact, int att_first, int att_count, const LadderTask& task)
+                      unsigned& pivots, Trace2& tr, bool compact, bool skip_repeats, int att_first, int att_count, const LadderTask& task)
 {
   const int n = M.n, t = tid();
   const bool reg = (P.kind == MH_LCP_FAST_REG) || (P.kind == MH_LCP_LEMKE_REG);
@@ -748,7 +810,7 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
     }
     if (reg) tr.push(0x40000000 | attempt);
     bool ok;
-    if constexpr (FAM == 0) ok = lcp_fast(M, lam, W, q, z, zsize, P.zero_tol, nrm, pivots, tr);
+    if constexpr (FAM == 0) ok = lcp_fast(M, lam, W, q, z, zsize, P.zero_tol, nrm, pivots, tr, skip_repeats);
     else ok = lcp_lemke(M, lam, W, q, z, zsize, P.piv_tol, P.zero_tol, nrm, pivots, tr, compact, task);
     if (!reg) return ok;
     const bool good = ok && verify(M, lam, W, q, z, ZERO_TOL, attempt > 0);
@@ -805,7 +867,7 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   sync();
   const unsigned long long t_kernel = bp_tick();
 #endif
-  const bool ok = lcp_solve<FAM>(P, p10, M, W, q, z, zsize, piv, tr, (flags & 1) != 0, (task.rung >= 0) ? task.rung : 0, (task.rung >= 0) ? 1 : 0x3fffffff, task);
+  const bool ok = lcp_solve<FAM>(P, p10, M, W, q, z, zsize, piv, tr, (flags & 1) != 0, (flags & 2) != 0, (task.rung >= 0) ? task.rung : 0, (task.rung >= 0) ? 1 : 0x3fffffff, task);
   if (task.rung >= 0 && ok && t == 0) atomicMin(task.solved_at, task.rung);
   sync();
 #ifdef MH_BLK_PROF
