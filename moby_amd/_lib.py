@@ -123,6 +123,11 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # test hook: MOBY_HIP_DEBUG="key=value,..." applies mh_debug_set switches (A/B runs of tools/ and bench legs in one process tree)
+    for kv in filter(None, os.environ.get("MOBY_HIP_DEBUG", "").split(",")):
+        k, v = kv.split("=")
+        if lib.mh_debug_set(int(k), int(v)) != MH_OK:
+            raise MobyHipError(MH_ERR_INVALID_ARG, "MOBY_HIP_DEBUG: mh_debug_set(%s) refused" % kv)
     return lib
 
 

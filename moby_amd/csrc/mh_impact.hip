@@ -1375,6 +1375,22 @@ static int core_ladder_finish(mh_imp_core* c, hipStream_t s, const LadderPlan& L
   if (rc != MH_OK) return rc;
   hipLaunchKernelGGL(im::k_ladder_select, dim3(B), dim3(im::T), 0, s, *c, need, L.R, lst, piv);
   MH_HIP(hipGetLastError());
+  static const bool stats = getenv("MH_LADDER_STATS") != nullptr;       // diagnostic: how much of the tasks' work the selection used
+  if (stats) {
+    MH_HIP(hipStreamSynchronize(s));
+    std::vector<int> st((size_t)L.ntasks), nd((size_t)B), sa((size_t)B); std::vector<unsigned> pv((size_t)L.ntasks);
+    MH_HIP(hipMemcpy(st.data(), c->t_st, st.size() * 4, hipMemcpyDeviceToHost)); MH_HIP(hipMemcpy(pv.data(), c->t_piv, pv.size() * 4, hipMemcpyDeviceToHost));
+    MH_HIP(hipMemcpy(nd.data(), need, nd.size() * 4, hipMemcpyDeviceToHost)); MH_HIP(hipMemcpy(sa.data(), c->solved_at, sa.size() * 4, hipMemcpyDeviceToHost));
+    double used = 0, all = 0, longest = 0; long run = 0, worlds = 0;
+    for (int w = 0; w < B; w++) {
+      if (!nd[w]) continue;
+      worlds++;
+      double mine = 0;
+      for (int r = 0; r < L.R; r++) { const size_t i = (size_t)r * B + w; if (st[i] < 0) continue; run++; all += pv[i]; if (r <= sa[w]) { used += pv[i]; mine += pv[i]; } }
+      if (mine > longest) longest = mine;
+    }
+    fprintf(stderr, "ladder tasks: %ld worlds, %ld tasks run, pivots used %.0f of %.0f run (%.1f %%), longest world %.0f, mean world %.0f\n", worlds, run, used, all, all > 0 ? 100.0 * used / all : 0.0, longest, worlds ? used / worlds : 0.0);
+  }
   return MH_OK;
 }
 static int core_lemke_stage(mh_imp_core* c, hipStream_t s, const mh_lcp_opts* o, const int* need, int* lst, unsigned* piv)

@@ -218,7 +218,7 @@ MH_DEV int lu_solve_wave_hbm(int k, double* A, double& b)
 
 // LCP.cpp:199-209: v is defined on the lanes of `mask` (list order = lane
 // order).  Consumes exactly one rand().  Returns the chosen lane.
-MH_DEV int rand_min_wave(double v, uint64_t mask, double tol, WaveRand& rng, double& val)
+MH_DEV int rand_min_wave(double v, uint64_t mask, double tol, WaveRand& rng, double& val, bool& tie)
 {
   const int lane = lane_id();
   const bool in = (mask >> lane) & 1ull;
@@ -232,6 +232,7 @@ MH_DEV int rand_min_wave(double v, uint64_t mask, double tol, WaveRand& rng, dou
   } else argmin_first(v, in, vmin, imin);
   const uint64_t qm = ballot(in && lane != imin && v < vmin + tol);
   const int cnt = 1 + popc(qm);
+  tie = tie || cnt > 1;                          // the draw decides something
   const int rv = rng.next();                    // always consumed (LCP.cpp:208)
   const int r = (cnt == 1) ? 0 : rv % cnt;
   const int chosen = (r == 0) ? imin : nth_set_bit(qm, r - 1);
@@ -432,9 +433,10 @@ MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, LuScratch S,
     // both draws of the iteration (LCP.cpp:147 then :153/:172): every path takes the w draw when a basic
     // variable exists and then the z draw when a nonbasic one does, in that order
     double wsel = 0.0; int minw = -1;
-    if (bmask != 0ull) minw = rand_min_wave(w, bmask, zero_tol, rng, wsel);
+    bool tie = false;
+    if (bmask != 0ull) minw = rand_min_wave(w, bmask, zero_tol, rng, wsel, tie);
     double zsel = 0.0; int minz = -1;
-    if (k > 0) minz = rand_min_wave(zv, nbmask, zero_tol, rng, zsel);
+    if (k > 0) minz = rand_min_wave(zv, nbmask, zero_tol, rng, zsel, tie);
     lp_tock(LP_RANDMIN, tg);
     if (minw < 0 || wsel > -zero_tol) {
       if (minz >= 0 && zsel < -zero_tol) {
@@ -456,6 +458,24 @@ MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, LuScratch S,
         const int idx2 = nth_set_bit(nb_new, posz);
         nbmask &= ~bit(idx2);
         tr.push(-(int32_t)(idx2 + 1));
+#ifndef MH_NO_REPEAT_SKIP
+        // Repeating pivot sequences.  The position rule above can send the variable that has just entered straight out again.  The set
+        // is then what it was at the top of this iteration, and an iteration is a function of the set alone unless a draw decided
+        // something (rand_min with several minima): every remaining iteration repeats this one, and the loop spins on one basis until
+        // MAX_PIV.  That is how lcp_fast fails on resting stacks, and what the slow worlds of a long run spend their time on (80 % of
+        // their lcp_fast iterations at step 4200 of the sphere-stack batch, tools/slow_world_diag.py).  What the repetitions leave
+        // behind is known without running them: two draws and two trace entries each, z untouched.  Period 1 only here -- the ring of
+        // sets that periods 2-3 need (a fifth of the repeats in box stacks, none in the sphere stacks) cost the headline kernel 6 %;
+        // mh_lcp_block.h, for n > 64, recognises periods up to 8.
+        if (idx2 == minw && !tie) {
+          const unsigned rest = MAX_PIV - (pivots + 1u);
+          rng.skip(2u * rest);
+          if (tr.buf && tr.len < tr.cap) for (unsigned r = 0; r < rest; r++) { tr.push((int32_t)(minw + 1)); tr.push(-(int32_t)(idx2 + 1)); }
+          else tr.len += (int)(2u * rest);
+          pivots = MAX_PIV;
+          return false;
+        }
+#endif
       }
     }
   }

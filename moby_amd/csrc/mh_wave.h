@@ -146,6 +146,7 @@ struct WaveRand {
     idx = (idx + 1 == 31) ? 0 : idx + 1;
     return (int)(v >> 1);
   }
+  MH_DEV void skip(unsigned m) { for (unsigned i = 0; i < m; i++) (void)next(); }     // m draws whose values nobody looks at
 };
 
 } // namespace mh

@@ -43,6 +43,12 @@
 #include "compact_lu.hpp"
 
 namespace oracle {
+// diagnostic (oracle_dbg_fast_repeats): how lcp_fast spends its iterations.  [0] iterations run, [1] of them with the index set of
+// the iteration before (LCP.cpp:176-187 moved the entering variable straight out again: the loop spins on one basis), [2] with the set
+// of one of the 2..8 iterations before that, [3] draws that decided something (rand_min with more than one minimum), [4] calls that ran
+// into MAX_PIV.  Off (g_fast_diag = 0) it costs one test per iteration.
+static int g_fast_diag = 0;
+static unsigned long long g_fast_stats[13] = {0};   // [5 + h]: iterations on the set of h + 1 iterations before (h = 0..7)
 static unsigned long long g_lu_hist[130] = {0};   // diagnostic: LU sizes (lcp_fast: [k], Lemke: [65 + n])
 
 
@@ -111,6 +117,7 @@ class LCP {
     _minima.push_back(minv);
     for (unsigned i = 0; i < v.size(); i++)
       if (i != minv && v[i] < v[minv] + zero_tol) _minima.push_back(i);
+    if (g_fast_diag && _minima.size() > 1) g_fast_stats[3]++;
     return _minima[(unsigned)oracle_rand(rng) % _minima.size()];
   }
 
@@ -140,7 +147,15 @@ class LCP {
       for (unsigned i = 0; i < N; i++) if (i != minw) _bas.push_back(i);
     }
     const unsigned MAX_PIV = 2*N;
+    std::vector<std::vector<unsigned>> seen;                                   // diagnostic: the index sets of the last 8 iterations
     for (pivots = 0; pivots < MAX_PIV; pivots++) {
+      if (g_fast_diag) {
+        g_fast_stats[0]++;
+        for (size_t h = 0; h < seen.size(); h++) if (seen[seen.size() - 1 - h] == _nonbas) { g_fast_stats[h == 0 ? 1 : 2]++; g_fast_stats[5 + h]++; break; }
+        if (seen.size() == 8) seen.erase(seen.begin());
+        seen.push_back(_nonbas);
+        if (pivots + 1 == MAX_PIV) g_fast_stats[4]++;
+      }
       const unsigned k = _nonbas.size(), nb = _bas.size();
       _Msub.assign((size_t)k*k, 0.0);
       for (unsigned c = 0; c < k; c++) for (unsigned r = 0; r < k; r++) _Msub[r + k*c] = Mat(_nonbas[r], _nonbas[c]);

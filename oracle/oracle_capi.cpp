@@ -119,6 +119,8 @@ double oracle_world_step(const mh_scene* sc, double dt, int nsteps, double* stat
 
 unsigned long long oracle_dbg_ca_iters(void) { return g_ca_iters; }
 int oracle_dbg_lemke_exit(void) { return g_lemke_exit; }
+// lcp_fast's iteration statistics (lcp.hpp, g_fast_stats): on != 0 switches the counting on and clears the counters; out (13 values) may be null
+void oracle_dbg_fast_repeats(int on, unsigned long long* out) { if (out) for (int i = 0; i < 13; i++) out[i] = g_fast_stats[i]; g_fast_diag = on; if (on) for (int i = 0; i < 13; i++) g_fast_stats[i] = 0; }
 // diagnostic: write every impact LCP solve_impact_lcp sees (inputs, rand() state, pivot counts) to `path`; NULL stops
 void oracle_dbg_lcp_dump(const char* path) { if (g_lcp_dump) { std::fclose(g_lcp_dump); g_lcp_dump = nullptr; } if (path) g_lcp_dump = std::fopen(path, "wb"); }
 // the model of the device's structure-exploiting LU (compact_lu.hpp): nb = panel width of the check (0 = off)
