@@ -256,6 +256,17 @@ def config4_full_step_leg(torch, nboxes, B, steps, cpu_proc=None):
                            "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
                            "model": "every factorisation (one per pivot) as a dense dgesv: 2/3 k^3 flops, 8 k^2 bytes (SURVEY 8d); FP64 vector = matrix peak, "
                                     "the kernels run unfused (half of it) and skip the exact zeros of Lemke's bases, so executed flops are far fewer"}
+        # HBM bytes of the block solver's kernels in one such step, from the committed counter passes (not a measurement of this run)
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "r03_c_config4_step_pmc.json")))
+            if ("%d-box" % nboxes) in t["workload"] and ("x %d worlds" % B) in t["workload"] and steps == 1:
+                ks = [v for k, v in t["kernels"].items() if "k_lcp_block" in k]
+                res["roofline"]["traffic"] = 1e9 * sum(v.get("fetch_GB", 0.0) + v.get("write_GB", 0.0) for v in ks)
+                res["roofline"]["counter_profile"] = {"commit": t["commit"], "source": "profiles/r03_c_config4_step_pmc.json", "seconds_under_profiler": sum(v["seconds"] for v in ks),
+                                                      "note": "FETCH_SIZE + WRITE_SIZE of mh::blk / mh::blkw::k_lcp_block over one step; against model_bytes: the panels of every "
+                                                              "factorisation stream the columns to their right through HBM"}
+        except (OSError, KeyError, ValueError):
+            pass
         bb.close()
         if cpu_proc is not None:
             res["cpu_baseline"] = config4_cpu_sample_collect(cpu_proc, nboxes)
@@ -463,7 +474,7 @@ def long_horizon_leg(torch, wb, stream, B, args):
                                     "others_world_steps_per_sec": len(fast) * 200 / (e0.elapsed_time(ef) * 1e-3),
                                     "note": "worlds are independent, so the slow ones can run on a stream of their own and the rest need not wait for them at the launch "
                                             "boundary -- IF slowness stays with a world: slow_again_in_this_interval_frac says how much of the set picked from the "
-                                            "previous interval is slow again; the rest of the tail is other worlds' episodes of lcp_fast cycling to its cap"}
+                                            "previous interval is slow again; the rest of the tail is other worlds' episodes of lcp_fast failing (its repetitions are skipped, the Lemke ladder that follows is not)"}
         return res
     except Exception as e:          # noqa: BLE001 -- informational leg
         return {"error": repr(e)}

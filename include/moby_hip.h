@@ -210,7 +210,12 @@ typedef struct mh_world_aux {
 /* test hooks: key 1 = edge of the LDS-resident LU block of the world kernel (0..64, clamped to what the
  * kernel variant holds: 12 or 16; 0 sends every LU factorisation through the HBM workspace path) */
 int  mh_debug_set(int key, int value);   /* key 2: block LCP solver (n > 64) thread geometry -- 0 choose by n and B,
-                                            1 = 256 threads per problem, 2 = 1024 threads per problem */
+                                            1 = 256 threads per problem, 2 = 1024 threads per problem;
+                                            key 3: lcp_lemke's bases (n > 64) through the structure-exploiting LU (1, default) or the dense one (0);
+                                            key 4: the Lemke ladder of the island pipeline in sequence (0), as (world, attempt) tasks (1),
+                                                   tasks started beside lcp_fast when n >= 256 (2, default);
+                                            key 5: lcp_fast (n > 64) skips the repetitions of a repeating pivot sequence (1, default) or
+                                                   runs every iteration (0).  None of the switches changes a result */
 void mh_scene_defaults(mh_scene* s);   /* zero + the reference's default tolerances */
 void mh_world_aux_init(mh_world_aux* a, uint32_t seed);
 
