@@ -463,7 +463,7 @@ MH_DEV bool lcp_fast_wave(int n, const MatT& M, double lam, LuScratch S,
         // is then what it was at the top of this iteration, and an iteration is a function of the set alone unless a draw decided
         // something (rand_min with several minima): every remaining iteration repeats this one, and the loop spins on one basis until
         // MAX_PIV.  That is how lcp_fast fails on resting stacks, and what the slow worlds of a long run spend their time on (80 % of
-        // their lcp_fast iterations at step 4200 of the sphere-stack batch, tools/slow_world_diag.py).  What the repetitions leave
+        // their lcp_fast iterations at step 4200 of the sphere-stack batch, tests/tools/slow_world_diag.py).  What the repetitions leave
         // behind is known without running them: two draws and two trace entries each, z untouched.  Period 1 only here -- the ring of
         // sets that periods 2-3 need (a fifth of the repeats in box stacks, none in the sphere stacks) cost the headline kernel 6 %;
         // mh_lcp_block.h, for n > 64, recognises periods up to 8.

@@ -2,10 +2,10 @@
 with the most pivots over the next 200 steps, and steps THOSE on the CPU oracle for 50 steps with lcp_fast's iteration statistics
 switched on (oracle_dbg_fast_repeats): iterations run, iterations spent on the index set of the iteration before, on one of the 2..8
 before that, draws that decided something, calls that ran into MAX_PIV.
-python tools/slow_world_diag.py [start = 4200] [B = 4096] [worlds = 6]"""
+python tests/tools/slow_world_diag.py [start = 4200] [B = 4096] [worlds = 6]"""
 import ctypes, json, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from moby_amd import scene as S
