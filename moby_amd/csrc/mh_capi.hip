@@ -160,6 +160,7 @@ int mh_rand_next(uint32_t* st)
 
 int mh_g_debug_tasks = 2;      // mh_debug_set(4, v): 0 = the Lemke ladder in sequence, 1 = as (world, attempt) tasks, 2 = tasks + speculation beside lcp_fast
 int mh_g_debug_repeats = 1;  // mh_debug_set(5, v): 1 = lcp_fast (n > 64) skips the repetitions of a repeating pivot sequence (mh_lcp_block.h), 0 = runs them
+int mh_g_debug_reuse = 1;    // mh_debug_set(6, v): 1 = the structure-exploiting LU keeps the factors of the columns before the one a Lemke pivot changed, 0 = factorises from scratch
 int mh_g_debug_compact = 1;  // mh_debug_set(3, v): 1 = Lemke's bases through the structure-exploiting LU (mh_lu_compact.inc), 0 = dense LU only
 int mh_g_debug_blk = 0;      // mh_debug_set(2, v): 0 = choose, 1 = 256-thread block solver, 2 = 1024-thread block solver
 int mh_g_debug_ka = 64;          // LDS LU block edge of the world kernel (clamped to the variant MHW_KA_V); mh_debug_set(1, 0) forces the HBM workspace path
@@ -232,7 +233,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     if (mh_g_debug_blk == 1) wide = false; else if (mh_g_debug_blk == 2) wide = true;
     if (wsd && wsi) {
       const hipError_t le = wave_only ? hipSuccess : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1), work, 0, nullptr);
+                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2), work, 0, nullptr);
       MH_HIP(le);
       if (n_arr) {          // the problems of this call that fit one wavefront (n_arr[b] <= 64) take the wave solver
         const size_t ldsw = (size_t)(2 * MH_LCP_MAX_N_WAVE * MH_LCP_MAX_N_WAVE + MH_LCP_MAX_N_WAVE) * sizeof(double);
@@ -249,7 +250,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     hipError_t e = hipMallocAsync((void**)&wsi, ni * sizeof(int), (hipStream_t)stream);
     if (e != hipSuccess) { (void)hipFreeAsync(wsd, (hipStream_t)stream); return fail(MH_ERR_HIP, "workspace allocation failed: %s", hipGetErrorString(e)); }
     const hipError_t le = (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1), work, 0, nullptr);
+                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2), work, 0, nullptr);
     e = le;
     (void)hipFreeAsync(wsd, (hipStream_t)stream); (void)hipFreeAsync(wsi, (hipStream_t)stream);
     if (e != hipSuccess) return fail(MH_ERR_HIP, "block LCP launch failed: %s", hipGetErrorString(e));
@@ -319,6 +320,7 @@ extern "C" int mh_debug_set(int key, int value)
   if (key == 1) { if (value < 0 || value > 64) return fail(MH_ERR_INVALID_ARG, "LU block edge outside [0, 64]"); mh_g_debug_ka = value; return MH_OK; }
   if (key == 2) { if (value < 0 || value > 2) return fail(MH_ERR_INVALID_ARG, "block solver geometry outside {0, 1, 2}"); mh_g_debug_blk = value; return MH_OK; }
   if (key == 4) { if (value < 0 || value > 2) return fail(MH_ERR_INVALID_ARG, "ladder-task switch outside {0, 1, 2}"); mh_g_debug_tasks = value; return MH_OK; }
+  if (key == 6) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "factor-reuse switch outside {0, 1}"); mh_g_debug_reuse = value; return MH_OK; }
   if (key == 5) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "repeat-skipping switch outside {0, 1}"); mh_g_debug_repeats = value; return MH_OK; }
   if (key == 3) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "compact-LU switch outside {0, 1}"); mh_g_debug_compact = value; return MH_OK; }
   return fail(MH_ERR_INVALID_ARG, "unknown debug key %d", key);

@@ -1362,7 +1362,7 @@ static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& 
   // the ladder offers B x (8-12) useful workgroups at once: the narrow geometry (four problems per CU) unless its compact path does not take n
   const bool wide = mh_g_debug_blk ? mh_g_debug_blk == 2 && n >= 192 : n > 512;
   const hipError_t le = (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
-      c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact, c->t_work, B, c->solved_at);
+      c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2), c->t_work, B, c->solved_at);
   MH_HIP(le);
   return MH_OK;
 }

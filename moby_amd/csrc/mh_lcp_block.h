@@ -671,7 +671,7 @@ struct LemkeCol { const Mat* M; const int* bv; const double* art; double lam; in
   MH_DEV double load_id(int id, int i) const { return (id == tt) ? art[i] : M->at(i, id, lam); } };
 
 MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, double* z, int& zsize, double piv_tol, double zero_tol,
-                      double nrm_lam, unsigned& pivots, Trace2& tr, bool compact, const LadderTask& task)
+                      double nrm_lam, unsigned& pivots, Trace2& tr, bool compact, bool reuse, const LadderTask& task)
 {
   const int n = M.n, t = tid();
   const unsigned MAXITER = (50u * (unsigned)n < 1000u) ? 50u * (unsigned)n : 1000u;
@@ -704,6 +704,7 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
   sync();
   if (t == 0) { W.x[lvindex] = tval; W.bv[lvindex] = tt; }
   sync();
+  int prev_nd = -1;                                                 // lu_compact's records of the last basis (it differs from the next one at lvindex only)
   for (pivots = 0; pivots < MAXITER; pivots++) {
     if (task.rung >= 0 && (pivots & 15u) == 15u && bcast_i(task.pointless() ? 1 : 0)) { zsize = n; return false; }   // (a lower attempt has succeeded)
     if (leaving == tt) {
@@ -722,7 +723,8 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
     if (compact && n <= CN) {
       const unsigned long long tc = bp_tick();
       LemkeCol colv; colv.M = &M; colv.bv = W.bv; colv.art = W.art; colv.lam = lam; colv.n = n; colv.tt = tt;
-      info = lu_compact(n, colv, W.A, W.d, W.w);   // W.w: unused by lcp_lemke, the trash column of the update lists
+      if (!reuse) prev_nd = -1;
+      info = lu_compact(n, colv, W.A, W.d, W.w, W.list, prev_nd, lvindex);   // W.w: unused by lcp_lemke, the trash column of the update lists; W.list .. W.pos: 3 n ints, idle here
       bp_tock(BP_COMPACT, tc);
     }
     if (info == LUC_FALLBACK) {
@@ -741,6 +743,7 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
       } }
     sync();
     bp_tock(BP_GATHER, tq);
+    prev_nd = -1;                                                   // (the dense route overwrites the workspace)
     info = lu_solve(n, W.A, W.d);
     }
     if (info != 0) return false;                                    // singular basis (:840-850), size stays 2n
@@ -777,7 +780,7 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
 // the four public solvers (lcp_solve_wave's attempt loop)
 template <int FAM>      // 0: the lcp_fast kinds, 1: the lcp_lemke kinds -- one kernel each, so that neither carries the other's registers
 MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, const Ws& W, const double* q, double* z, int& zsize,
-                      unsigned& pivots, Trace2& tr, bool compact, bool skip_repeats, int att_first, int att_count, const LadderTask& task)
+                      unsigned& pivots, Trace2& tr, bool compact, bool skip_repeats, bool reuse, int att_first, int att_count, const LadderTask& task)
 {
   const int n = M.n, t = tid();
   const bool reg = (P.kind == MH_LCP_FAST_REG) || (P.kind == MH_LCP_LEMKE_REG);
@@ -811,7 +814,7 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
     if (reg) tr.push(0x40000000 | attempt);
     bool ok;
     if constexpr (FAM == 0) ok = lcp_fast(M, lam, W, q, z, zsize, P.zero_tol, nrm, pivots, tr, skip_repeats);
-    else ok = lcp_lemke(M, lam, W, q, z, zsize, P.piv_tol, P.zero_tol, nrm, pivots, tr, compact, task);
+    else ok = lcp_lemke(M, lam, W, q, z, zsize, P.piv_tol, P.zero_tol, nrm, pivots, tr, compact, reuse, task);
     if (!reg) return ok;
     const bool good = ok && verify(M, lam, W, q, z, ZERO_TOL, attempt > 0);
     if (attempt == 0) { if (good) return true; total += pivots; }
@@ -867,7 +870,7 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   sync();
   const unsigned long long t_kernel = bp_tick();
 #endif
-  const bool ok = lcp_solve<FAM>(P, p10, M, W, q, z, zsize, piv, tr, (flags & 1) != 0, (flags & 2) != 0, (task.rung >= 0) ? task.rung : 0, (task.rung >= 0) ? 1 : 0x3fffffff, task);
+  const bool ok = lcp_solve<FAM>(P, p10, M, W, q, z, zsize, piv, tr, (flags & 1) != 0, (flags & 2) != 0, (flags & 4) != 0, (task.rung >= 0) ? task.rung : 0, (task.rung >= 0) ? 1 : 0x3fffffff, task);
   if (task.rung >= 0 && ok && t == 0) atomicMin(task.solved_at, task.rung);
   sync();
 #ifdef MH_BLK_PROF
