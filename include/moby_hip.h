@@ -215,7 +215,10 @@ int  mh_debug_set(int key, int value);   /* key 2: block LCP solver (n > 64) thr
                                             key 4: the Lemke ladder of the island pipeline in sequence (0), as (world, attempt) tasks (1),
                                                    tasks started beside lcp_fast when n >= 256 (2, default);
                                             key 5: lcp_fast (n > 64) skips the repetitions of a repeating pivot sequence (1, default) or
-                                                   runs every iteration (0).  None of the switches changes a result */
+                                                   runs every iteration (0);
+                                            key 6: the structure-exploiting LU reuses the factors of the unchanged leading columns from one Lemke
+                                                   pivot to the next (1, default) or factorises every basis from scratch (0).
+                                            None of the switches changes a result */
 void mh_scene_defaults(mh_scene* s);   /* zero + the reference's default tolerances */
 void mh_world_aux_init(mh_world_aux* a, uint32_t seed);
 
