@@ -34,6 +34,7 @@ MH_HIDDEN int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
                                       double* work = nullptr,    // B x 2 doubles or NULL: += the 2/3 k^3 flops / 8 k^2 bytes of every factorisation (n > 64)
                                       int wave_only = 0);        // != 0: only the problems of at most 64 rows (n_arr) -- the caller runs the others itself
 extern MH_HIDDEN int mh_g_debug_repeats;             // mh_debug_set(5, v)
+extern MH_HIDDEN int mh_g_debug_sched;               // mh_debug_set(7, v)
 extern MH_HIDDEN int mh_g_debug_reuse;               // mh_debug_set(6, v)
 extern MH_HIDDEN int mh_g_debug_compact;             // mh_debug_set(3, v)
 extern MH_HIDDEN int mh_g_debug_tasks;               // mh_debug_set(4, v): the Lemke ladder of the island pipeline as (world, attempt) tasks (1, default) or in sequence (0)

@@ -1321,7 +1321,7 @@ static int core_ladder_alloc(mh_imp_core* c, long ntasks)
          && hipMalloc((void**)&c->t_z, nt * n * 8) == hipSuccess && hipMalloc((void**)&c->t_st, nt * 4) == hipSuccess
          && hipMalloc((void**)&c->t_piv, nt * 4) == hipSuccess && hipMalloc((void**)&c->t_zsz, nt * 4) == hipSuccess
          && hipMalloc((void**)&c->t_rng, nt * MH_RAND_WORDS * 4) == hipSuccess && hipMalloc((void**)&c->t_work, nt * 2 * 8) == hipSuccess;
-  if (ok && !c->solved_at) ok = hipMalloc((void**)&c->solved_at, (size_t)c->B * 4) == hipSuccess;
+  if (ok && !c->solved_at) ok = hipMalloc((void**)&c->solved_at, 3 * (size_t)c->B * 4) == hipSuccess;   // + next attempt, attempts over (mh_lcp_block.h pick_task)
   if (ok) ok = hipMemset(c->t_rng, 0, nt * MH_RAND_WORDS * 4) == hipSuccess;
   if (!ok) {                                                      // no room: the caller runs the ladder in sequence
     void* qs[] = { c->t_wsd, c->t_wsi, c->t_z, c->t_st, c->t_piv, c->t_zsz, c->t_rng, c->t_work };
@@ -1350,11 +1350,15 @@ static LadderPlan core_ladder_plan(mh_imp_core* c, const mh_lcp_opts* o)
   L.ok = mh_g_debug_tasks != 0 && n > MH_LCP_MAX_N_WAVE && step > 0 && bytes < 96e9 && core_ladder_alloc(c, L.ntasks) == MH_OK;
   return L;
 }
-static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& L, const int* mask)
+// sched: the tasks are handed out by need (mh_lcp_block.h pick_task: as many workgroups as the chip holds, each taking tasks until none is
+// left) instead of by block index.  Not beside lcp_fast: workgroups that stay would keep its kernel off the CUs they occupy.
+static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& L, const int* mask, bool sched)
 {
   const int B = c->B, n = c->nmax;
   const mh_lcp_opts* o = L.has_o ? &L.o : nullptr;
   MH_HIP(hipMemsetAsync(c->solved_at, 0x7f, (size_t)B * 4, st));
+  MH_HIP(hipMemsetAsync(c->solved_at + B, 0, 2 * (size_t)B * 4, st));
+  if (sched) MH_HIP(hipMemsetAsync(c->t_st, 0xff, (size_t)L.ntasks * 4, st));                     // -1: never handed out
   MH_HIP(hipMemsetAsync(c->t_work, 0, (size_t)L.ntasks * 16, st));
   mh::LcpParams P; P.kind = MH_LCP_LEMKE_REG; P.min_exp = o ? o->min_exp : -20; P.step_exp = o ? o->step_exp : 1u; P.max_exp = o ? o->max_exp : 1;
   P.piv_tol = o ? o->piv_tol : -1.0; P.zero_tol = o ? o->zero_tol : -1.0;
@@ -1362,7 +1366,7 @@ static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& 
   // the ladder offers B x (8-12) useful workgroups at once: the narrow geometry (four problems per CU) unless its compact path does not take n
   const bool wide = mh_g_debug_blk ? mh_g_debug_blk == 2 && n >= 192 : n > 512;
   const hipError_t le = (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
-      c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2), c->t_work, B, c->solved_at);
+      c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2) | (sched ? 8 : 0), c->t_work, B, c->solved_at);
   MH_HIP(le);
   return MH_OK;
 }
@@ -1400,7 +1404,7 @@ static int core_lemke_stage(mh_imp_core* c, hipStream_t s, const mh_lcp_opts* o,
   if (!L.ok)
     return mh_lcp_solve_dev_masked(s, MH_LCP_LEMKE_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, lst, piv,
                                    nullptr, 0, nullptr, o, need, c->ws_d, c->ws_i, c->ncur, c->work);
-  const int rc = core_ladder_launch(c, s, L, need);
+  const int rc = core_ladder_launch(c, s, L, need, mh_g_debug_sched != 0);
   return rc != MH_OK ? rc : core_ladder_finish(c, s, L, need, lst, piv);
 }
 
@@ -1419,7 +1423,10 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   // the Lemke ladder that will be needed anyway starts at once, on a second stream, for every world of the round; its tasks read nothing
   // lcp_fast writes, and the selection afterwards only looks at the worlds whose lcp_fast did fail.  mh_debug_set(4, 1) turns it off.
   LadderPlan L; L.ok = false;
-  const bool spec_wanted = mh_g_debug_tasks >= 2 && n >= 256;
+  // ... unless the batch fills the chip with LCPs on which lcp_fast practically never succeeds (16-box stacks, n = 512, x 1024): running ahead
+  // buys nothing there, and the tasks are better handed out by need afterwards (31.7 s instead of 35.7 s per full step)
+  const bool full_chip = mh_g_debug_sched != 0 && n >= 384 && B >= 4 * mh_cu_count();
+  const bool spec_wanted = mh_g_debug_tasks >= 2 && n >= 256 && !full_chip;
   if (spec_wanted) L = core_ladder_plan(c, nullptr);
   bool spec = spec_wanted && L.ok;
   if (spec && !c->s2) {
@@ -1431,7 +1438,7 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   if (spec) {
     MH_HIP(hipEventRecord((hipEvent_t)c->ev0, s));
     MH_HIP(hipStreamWaitEvent((hipStream_t)c->s2, (hipEvent_t)c->ev0, 0));
-    rc = core_ladder_launch(c, (hipStream_t)c->s2, L, run_if);
+    rc = core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, false);
     if (rc != MH_OK) return rc;
     MH_HIP(hipEventRecord((hipEvent_t)c->ev1, (hipStream_t)c->s2));
   }

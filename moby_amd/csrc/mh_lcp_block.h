@@ -824,6 +824,43 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
   return false;
 }
 
+// The ladder's tasks handed out by need.  Per problem w (3 ints at solved_at[w], [Bw + w], [2 Bw + w]): the lowest attempt known to
+// have succeeded, the next attempt to hand out, the number of attempts over.  While at least as many problems are unsolved as there
+// are workgroups, a free workgroup takes the next attempt of the problem with the FEWEST attempts running (ties: the lowest index):
+// every ladder then runs in sequence and nothing is started above an attempt that will succeed (by block index 11-18 % of the pivots
+// of a full batch were spent there).  With fewer problems than workgroups it takes the LOWEST attempt not yet handed out (ties: the
+// lowest index) -- the attempt-major order of the block-index launch, which spends the spare workgroups on the attempts most likely
+// to be the one selected (fewest-running first ran 19 % more pivots there).
+// Returns the task index attempt * Bw + w, or -1 when nothing is left to hand out (block-uniform).
+MH_DEV int pick_task(int Bw, int R, int* st, const int* __restrict__ run_if, const int* __restrict__ n_arr)
+{
+  const int t = tid();
+  volatile int* solved = st; volatile int* next = st + Bw; volatile int* done = st + 2 * Bw;
+  for (;;) {                                       // (a lost compare-and-swap means another workgroup took a task: the whole makes progress)
+    double best = inf(), lowest = inf(); int bw = 0x7fffffff, lw = 0x7fffffff, open_ = 0;
+    for (int w = t; w < Bw; w += T) {
+      if (run_if && run_if[w] == 0) continue;
+      if (n_arr && n_arr[w] <= MH_LCP_MAX_N_WAVE) continue;
+      const int nr = next[w];
+      if (nr >= R || solved[w] < nr) continue;
+      open_++;
+      const double d = (double)(nr - done[w]);
+      if (d < best) { best = d; bw = w; }
+      if ((double)nr < lowest) { lowest = (double)nr; lw = w; }
+    }
+    double dmin; int w, w2; red_min_first(best, bw, dmin, w); red_min_first(lowest, lw, dmin, w2);
+    if (w == 0x7fffffff) return -1;
+    if (red_sum_int(open_) < (int)gridDim.x) w = w2;
+    int got = -2;
+    if (t == 0) {
+      const int nr = next[w];
+      if (nr < R && !(solved[w] < nr) && atomicCAS(st + Bw + w, nr, nr + 1) == nr) got = nr * Bw + w;
+    }
+    got = bcast_i(got);
+    if (got >= 0) return got;
+  }
+}
+
 // n > 64: one T-thread workgroup per LCP, M read in place from HBM, everything else in a per-problem HBM workspace.
 template <int FAM>
 __global__ __launch_bounds__(T) MH_BLK_KATTR
@@ -838,21 +875,27 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
 {
   // b: the index of everything this workgroup OWNS (z, sizes, rand() state, status, pivots, workspace, work counters); bw: the problem it
   // reads (M, q, its size, the mask).  They differ in task mode only (task_worlds > 0: task b = attempt b / task_worlds of problem
-  // b % task_worlds, attempt-major so that the lower attempts of every problem are dispatched first)
-  const int b = blockIdx.x;
-  if (b >= B) return;
+  // b % task_worlds).  Two ways of handing tasks out: by block index, attempt-major, so that the lower attempts of every problem are
+  // dispatched first (one task per workgroup); or, flags & 8, by pick_task below (a workgroup takes tasks until none is left).
+  const int t = tid();
+  const int n_launch = n, ld_launch = ld;
+  const bool queue = (FAM == 1) && task_worlds > 0 && (flags & 8) != 0;     // (the lcp_fast kinds have no tasks: their kernel keeps the single pass)
+  for (int round = 0; FAM == 1 || round < 1; round++) {
+  int b;
+  if (queue) { b = pick_task(task_worlds, B / task_worlds, solved_at, run_if, n_arr); if (b < 0) return; }
+  else { if (round > 0) return; b = blockIdx.x; if (b >= B) return; }
+  n = n_launch; ld = ld_launch;
   const int bw = (task_worlds > 0) ? b % task_worlds : b;
   LadderTask task; task.solved_at = (task_worlds > 0) ? solved_at + bw : nullptr; task.rung = (task_worlds > 0) ? b / task_worlds : -1;
-  const int t = tid();
-  if (run_if && run_if[bw] == 0) { if (task_worlds > 0 && t == 0) status[b] = -1; return; }
-  if (task_worlds > 0 && task.pointless()) { if (t == 0) status[b] = -1; return; }     // -1: not run
+  if (run_if && run_if[bw] == 0) { if (task_worlds > 0 && t == 0) status[b] = -1; continue; }
+  if (task_worlds > 0 && task.pointless()) { if (t == 0) status[b] = -1; if (queue && t == 0) atomicAdd(solved_at + 2 * task_worlds + bw, 1); continue; }     // -1: not run
   Ws W;
   double* wd = wsd + (size_t)b * ws_doubles(n);
   int* wi = wsi + (size_t)b * ws_ints(n);
   // per-problem sizes: strides of q / z / M / the workspace stay those of the largest problem (the launch's n), M is
   // compact (ld = its own n); problems of at most 64 rows belong to the wave solver of the same call
   const int nstride = n;
-  if (n_arr) { n = n_arr[bw]; ld = n; if (n <= MH_LCP_MAX_N_WAVE) { if (task_worlds > 0 && t == 0) status[b] = -1; return; } }
+  if (n_arr) { n = n_arr[bw]; ld = n; if (n <= MH_LCP_MAX_N_WAVE) { if (task_worlds > 0 && t == 0) status[b] = -1; continue; } }
   W.A = wd; W.b = wd + (size_t)n * n; W.w = W.b + n; W.x = W.w + n; W.d = W.x + n; W.art = W.d + n;
   W.list = wi; W.flag = wi + n; W.pos = wi + 2 * (size_t)n; W.bv = wi + 3 * (size_t)n;
   if (t < 32) s_rng[t] = rngg[(size_t)b * MH_RAND_WORDS + t];
@@ -885,7 +928,10 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
     if (pivots_out) pivots_out[b] = piv;
     if (zsz_out) zsz_out[b] = zsize;
     if (trace_len) trace_len[b] = tr.len;
+    if (queue) atomicAdd(solved_at + 2 * task_worlds + bw, 1);          // one more attempt of this problem is over
   }
+  sync();
+  }   // (the next task of this workgroup)
 }
 
 } } // namespace mh::MH_BLK_NS
@@ -900,8 +946,15 @@ extern "C" MH_HIDDEN hipError_t MH_BLK_LAUNCHER(void* stream, int kind, int B, i
   if (kind == MH_LCP_FAST || kind == MH_LCP_FAST_REG)
     hipLaunchKernelGGL(ns::k_lcp_block<0>, dim3(B), dim3(ns::T), 0, (hipStream_t)stream, B, n, M, ld, strideM, q, z, zsz_in, zsz_out, rng, status, pivots,
                        trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags, work, task_worlds, solved_at);
-  else
-    hipLaunchKernelGGL(ns::k_lcp_block<1>, dim3(B), dim3(ns::T), 0, (hipStream_t)stream, B, n, M, ld, strideM, q, z, zsz_in, zsz_out, rng, status, pivots,
+  else {
+    int grid = B;
+    if (task_worlds > 0 && (flags & 8)) {                               // as many workgroups as the chip holds at once; each takes tasks until none is left
+      static int per_cu = 0;
+      if (per_cu == 0) { int v = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, ns::k_lcp_block<1>, ns::T, 0) != hipSuccess || v < 1) v = 1; per_cu = v; }
+      const int cap = per_cu * mh_cu_count(); grid = (B < cap) ? B : cap;
+    }
+    hipLaunchKernelGGL(ns::k_lcp_block<1>, dim3(grid), dim3(ns::T), 0, (hipStream_t)stream, B, n, M, ld, strideM, q, z, zsz_in, zsz_out, rng, status, pivots,
                        trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags, work, task_worlds, solved_at);
+  }
   return hipGetLastError();
 }

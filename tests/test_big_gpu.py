@@ -208,7 +208,8 @@ def test_structure_exploiting_lu_route_equals_the_dense_route_in_full_steps():
 def test_factor_reuse_across_lemke_pivots_changes_nothing():
     """mh_lu_compact.inc keeps, from one Lemke pivot to the next, the factors of the columns before the one the pivot changed
     (mh_debug_set key 6; 0 = every basis factorised from scratch).  Same 16-box worlds, one full step, both ways: states, rand()
-    streams, pivot counts and flags equal bit for bit -- with the ladder as tasks and in sequence (key 4)."""
+    streams, pivot counts and flags equal bit for bit -- with the ladder as tasks beside lcp_fast, as tasks after it (handed out by need,
+    key 7, or by block index) and in sequence (key 4)."""
     from moby_amd import _lib
     N, B = CONFIG4_BOXES, 12
     sc = K.box_stack_scene(N)
@@ -216,16 +217,16 @@ def test_factor_reuse_across_lemke_pivots_changes_nothing():
     res = {}
     lib = _lib.load()
     try:
-        for tasks, reuse in ((2, 1), (2, 0), (0, 1)):
-            _lib.check(lib.mh_debug_set(4, tasks)); _lib.check(lib.mh_debug_set(6, reuse))
+        for tasks, reuse, sched in ((2, 1, 1), (2, 0, 1), (0, 1, 1), (1, 1, 1), (1, 1, 0)):
+            _lib.check(lib.mh_debug_set(4, tasks)); _lib.check(lib.mh_debug_set(6, reuse)); _lib.check(lib.mh_debug_set(7, sched))
             bb = K.BigBatch(sc, st0)
             bb.step(1e-3, 1)
-            res[(tasks, reuse)] = bb.download()
+            res[(tasks, reuse, sched)] = bb.download()
             bb.close()
     finally:
-        _lib.check(lib.mh_debug_set(4, 2)); _lib.check(lib.mh_debug_set(6, 1))
-    ref = res[(2, 0)]
-    for k in ((2, 1), (0, 1)):
+        _lib.check(lib.mh_debug_set(4, 2)); _lib.check(lib.mh_debug_set(6, 1)); _lib.check(lib.mh_debug_set(7, 1))
+    ref = res[(2, 0, 1)]
+    for k in ((2, 1, 1), (0, 1, 1), (1, 1, 1), (1, 1, 0)):
         assert np.array_equal(res[k][0], ref[0]), k
         for f in FIELDS:
             assert np.array_equal(res[k][1][f], ref[1][f]), (k, f)
