@@ -22,6 +22,13 @@ echo "sq done" >> $OUT/progress.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4ks -- python3 tools/impact_bench.py 16:256:0 > $OUT/c4_impact_bench.jsonl 2> $OUT/c4ks.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/c4fetch -- python3 tools/impact_bench.py 8:256:0 > /dev/null 2> $OUT/c4fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/c4write -- python3 tools/impact_bench.py 8:256:0 > $OUT/c4_impact_bench_8.jsonl 2> $OUT/c4write.err
+echo "config 4 impact done" >> $OUT/progress.txt
+# config 4 at full size: ONE full step of 16 boxes x 1024 worlds -- where its time goes (kernel trace) and what it moves through HBM
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4step_ks -- python3 tools/config4_full_size.py 16 1024 > $OUT/c4step.json 2> $OUT/c4step_ks.err
+echo "config 4 step trace done" >> $OUT/progress.txt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/c4step_fetch -- python3 tools/config4_full_size.py 16 1024 > /dev/null 2> $OUT/c4step_fetch.err
+echo "config 4 step fetch done" >> $OUT/progress.txt
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/c4step_write -- python3 tools/config4_full_size.py 16 1024 > /dev/null 2> $OUT/c4step_write.err
 echo "config 4 done" >> $OUT/progress.txt
 # keep what is merged back small: drop everything but the csv summaries
 find $OUT -name "*.db" -delete 2>/dev/null || true

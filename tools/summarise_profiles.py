@@ -72,3 +72,57 @@ if rows:
     json.dump(out, open(os.path.join(P, "pmc_issue.json"), "w"), indent=1)
     print("valu busy %.3f; per world-step: %s" % (out["valu_busy_frac"], out["per_world_step"]))
 print("value %.4g %s, kernel %.1f us, frac %.4f" % (bench["value"], bench["unit"], bench["roofline"]["kernel_avg_us"], bench["roofline"]["frac"]))
+
+
+# ---- config 4: the block solver's kernels in a cold impact-handler call and in one full step at 16 boxes x 1024 worlds ----
+import collections
+
+
+def per_kernel(csvfile, col):
+    tot = collections.defaultdict(float); n = collections.defaultdict(int)
+    for r in csv.DictReader(open(csvfile)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        tot[k] += float(r[col]) if col != "dur" else (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e9
+        n[k] += 1
+    return tot, n
+
+
+if os.path.exists(os.path.join(src, "c4_impact_bench.jsonl")):
+    shutil.copy(os.path.join(src, "c4_impact_bench.jsonl"), os.path.join(P, tag + "_config4_impact_bench.jsonl"))
+ks4 = one("c4ks/*/*_kernel_stats.csv")
+if ks4:
+    csv.writer(open(os.path.join(P, tag + "_config4_impact_kernel_stats.csv"), "w")).writerows(list(csv.reader(open(ks4)))[:8])
+if os.path.exists(os.path.join(src, "c4step.json")):
+    line = [l for l in open(os.path.join(src, "c4step.json")) if l.startswith("{")]
+    if line:
+        open(os.path.join(P, tag + "_config4_16x1024.json"), "w").write(line[-1])
+kt4 = one("c4step_ks/*/*_kernel_trace.csv")
+if kt4:
+    rd = csv.reader(open(kt4)); h = next(rd)
+    rows = [(r[h.index("Kernel_Name")].split("(")[0].replace("void ", ""), int(r[h.index("Start_Timestamp")]), int(r[h.index("End_Timestamp")])) for r in rd if "k_lcp_block" in r[h.index("Kernel_Name")]]
+    if rows:
+        t0 = rows[0][1]; tot = collections.defaultdict(float)
+        out = ["# rocprofv3 --kernel-trace --stats -- python3 tools/config4_full_size.py 16 1024 (commit %s): the block solver's launches of ONE full step" % COMMIT,
+               "# kernel, start [s], duration [s]   (k_lcp_block<0>: the lcp_fast kinds; <1>: the Lemke ladder's (world, attempt) tasks)"]
+        for k, a, b in rows:
+            out.append("%-32s %8.3f %8.3f" % (k, (a - t0) / 1e9, (b - a) / 1e9)); tot[k] += (b - a) / 1e9
+        out.append("# totals: " + ", ".join("%s %.1f s" % kv for kv in tot.items()))
+        open(os.path.join(P, tag + "_config4_step_kernel_trace.txt"), "w").write("\n".join(out) + "\n")
+        print(out[-1])
+f4, w4 = one("c4step_fetch/*/*_counter_collection.csv"), one("c4step_write/*/*_counter_collection.csv")
+if f4 and w4:
+    res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (then WRITE_SIZE, separate passes) --output-format csv -- python3 tools/config4_full_size.py 16 1024",
+           "workload": "ONE full step of 16-box stacks (impact LCP n = 512) x 1024 worlds", "commit": COMMIT,
+           "units": "counter value x 1 KiB, summed over the kernel's launches of the step", "kernels": {}}
+    for kind, f in (("fetch", f4), ("write", w4)):
+        tot, n = per_kernel(f, "Counter_Value")
+        for k, v in tot.items():
+            if v * 1024 / 1e9 > 0.05:
+                res["kernels"].setdefault(k, {"launches": n[k]})[kind + "_GB"] = round(v * 1024 / 1e9, 2)
+    dur, _ = per_kernel(one("c4step_fetch/*/*_kernel_trace.csv"), "dur")
+    for k in res["kernels"]:
+        res["kernels"][k]["seconds"] = round(dur.get(k, 0.0), 3)
+    json.dump(res, open(os.path.join(P, tag + "_config4_step_pmc.json"), "w"), indent=1)
+    for k, v in res["kernels"].items():
+        if "k_lcp_block" in k:
+            print(k, v)
