@@ -228,7 +228,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     // (n = 256: 1.34x at 256 problems, 1.07x at 512, 0.80x at 1024; n = 128 x 1024: 0.85x)
     bool wide = n >= 384 || (n >= 192 && B <= 2 * mh_cu_count());
     // the lcp_lemke kinds run the structure-exploiting LU (mh_lu_compact.inc), which is bound by its chain of round trips, not
-    // by arithmetic: four narrow problems per CU overlap theirs (8-box stacks x 1024: 5.7 s narrow, 10.8 s wide); the wide geometry
+    // by arithmetic: several narrow problems per CU (three now, four when this was measured) overlap theirs (8-box stacks x 1024: 5.7 s narrow, 10.8 s wide); the wide geometry
     // keeps the sizes the narrow one's compact path does not take (n > 512) and batches of at most one problem per CU
     if (kind == MH_LCP_LEMKE || kind == MH_LCP_LEMKE_REG) wide = n > 512 || (n >= 192 && B <= mh_cu_count());
     if (mh_g_debug_blk == 1) wide = false; else if (mh_g_debug_blk == 2) wide = true;

@@ -1363,7 +1363,7 @@ static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& 
   mh::LcpParams P; P.kind = MH_LCP_LEMKE_REG; P.min_exp = o ? o->min_exp : -20; P.step_exp = o ? o->step_exp : 1u; P.max_exp = o ? o->max_exp : 1;
   P.piv_tol = o ? o->piv_tol : -1.0; P.zero_tol = o ? o->zero_tol : -1.0;
   static const mh::Pow10Table p10 = [] { mh::Pow10Table t; for (int i = 0; i < 64; i++) t.v[i] = std::pow(10.0, (double)(i - 32)); return t; }();
-  // the ladder offers B x (8-12) useful workgroups at once: the narrow geometry (four problems per CU) unless its compact path does not take n
+  // the ladder offers B x (8-12) useful workgroups at once: the narrow geometry (three problems per CU) unless its compact path does not take n
   const bool wide = mh_g_debug_blk ? mh_g_debug_blk == 2 && n >= 192 : n > 512;
   const hipError_t le = (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
       c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2) | (sched ? 8 : 0), c->t_work, B, c->solved_at);
@@ -1425,7 +1425,7 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   LadderPlan L; L.ok = false;
   // ... unless the batch fills the chip with LCPs on which lcp_fast practically never succeeds (16-box stacks, n = 512, x 1024): running ahead
   // buys nothing there, and the tasks are better handed out by need afterwards (31.7 s instead of 35.7 s per full step)
-  const bool full_chip = mh_g_debug_sched != 0 && n >= 384 && B >= 4 * mh_cu_count();
+  const bool full_chip = mh_g_debug_sched != 0 && n >= 384 && B >= 3 * mh_cu_count();
   const bool spec_wanted = mh_g_debug_tasks >= 2 && n >= 256 && !full_chip;
   if (spec_wanted) L = core_ladder_plan(c, nullptr);
   bool spec = spec_wanted && L.ok;
