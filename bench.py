@@ -258,11 +258,13 @@ def config4_full_step_leg(torch, nboxes, B, steps, cpu_proc=None):
                                     "the kernels run unfused (half of it) and skip the exact zeros of Lemke's bases, so executed flops are far fewer"}
         # HBM bytes of the block solver's kernels in one such step, from the committed counter passes (not a measurement of this run)
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "r03_c_config4_step_pmc.json")))
+            import glob
+            src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_[a-z]_config4_step_pmc.json")))[-1]     # the latest session's cut
+            t = json.load(open(src))
             if ("%d-box" % nboxes) in t["workload"] and ("x %d worlds" % B) in t["workload"] and steps == 1:
                 ks = [v for k, v in t["kernels"].items() if "k_lcp_block" in k]
                 res["roofline"]["traffic"] = 1e9 * sum(v.get("fetch_GB", 0.0) + v.get("write_GB", 0.0) for v in ks)
-                res["roofline"]["counter_profile"] = {"commit": t["commit"], "source": "profiles/r03_c_config4_step_pmc.json", "seconds_under_profiler": sum(v["seconds"] for v in ks),
+                res["roofline"]["counter_profile"] = {"commit": t["commit"], "source": "profiles/" + os.path.basename(src), "seconds_under_profiler": sum(v["seconds"] for v in ks),
                                                       "note": "FETCH_SIZE + WRITE_SIZE of mh::blk / mh::blkw::k_lcp_block over one step; against model_bytes: the panels of every "
                                                               "factorisation stream the columns to their right through HBM"}
         except (OSError, KeyError, ValueError):
