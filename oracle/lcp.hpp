@@ -360,8 +360,12 @@ class LCP {
         if (g_lemke_compact) {
           std::vector<int> kd(n), ix(n);
           for (unsigned p = 0; p < n; p++) { const unsigned id = _bas[p]; if (id >= n && id != t) { kd[p] = CL_UNIT; ix[p] = (int)(id - n); } else { kd[p] = CL_DENSE; ix[p] = (int)p; } }
-          info = lu_solve_compact((int)n, kd.data(), ix.data(), _Bl.data(), (int)n, _dl.data(), g_lemke_compact);
-          if (info == CL_FALLBACK) _dl = _Be;
+          if (g_lemke_compact & 0x100) {               // the model WITH reuse across pivots: the basis differs from the last one at lvindex only
+            if (pivots == 0) _keep.valid = false;
+            info = lu_solve_compact_keep(_keep, (int)n, kd.data(), ix.data(), _Bl.data(), (int)n, _dl.data(), g_lemke_compact & 0xff, (int)lvindex);
+            g_compact_stats[7] += (unsigned long long)_keep.reused_steps * (_keep.valid ? 1 : 0);
+          } else info = lu_solve_compact((int)n, kd.data(), ix.data(), _Bl.data(), (int)n, _dl.data(), g_lemke_compact);
+          if (info == CL_FALLBACK) { _dl = _Be; _keep.valid = false; }
         }
         if (info == CL_FALLBACK) info = lu_solve(n, _Al.data(), n, _dl.data());
         if (g_compact_check) {
@@ -410,6 +414,7 @@ class LCP {
 
  private:
   std::vector<unsigned> _bas, _nonbas, _minima, _j, _jkeep;
+  CompactLuKeep _keep;                                  // (g_lemke_compact & 0x100: the reuse model of compact_lu.hpp)
   std::vector<double> _Msub, _z, _w, _wx, _Bl, _Al, _x, _u, _Be, _dl;
   double _norm = 0.0;
 };

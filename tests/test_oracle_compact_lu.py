@@ -95,6 +95,32 @@ def test_every_lemke_basis_of_a_box_stack_matches(oracle):
         assert stt[3] < 0.5 * n * stt[0]            # the structure is there: well under n/2 dense steps per factorisation
 
 
+def test_reuse_across_lemke_pivots_gives_the_same_ladder(oracle):
+    """The reuse model (oracle/compact_lu.hpp, lu_solve_compact_keep: the factors of the columns before the one a pivot changed are
+    kept, the kept steps replayed and applied to the rebuilt columns only) inside the oracle's own lcp_lemke_regularized, on box-stack
+    impact LCPs: the same result, pivot count, pivot trace and z as with every basis solved by the dense dgesv -- and most dense
+    steps of a factorisation do come from the one before."""
+    from moby_amd import impact as I
+    for nbx, w, nb in ((4, 1, 8), (6, 2, 8), (5, 0, 3)):
+        mass, J, st, cs = I.box_stack(nbx, B=3)
+        n = I.lcp_size(4 * nbx, 4)
+        nn, MM, qq = oracle.impact_lcp(nbx, mass, J, st[w], cs[w], n)
+        ref = oracle.lcp(LEMKE_REG, MM, qq, z=np.zeros(n), z_size=n, trace_cap=1 << 16)
+        oracle.lib.oracle_dbg_compact_check(0)                       # clears the counters
+        oracle.lib.oracle_dbg_lemke_compact(nb | 0x100)
+        try:
+            r = oracle.lcp(LEMKE_REG, MM, qq, z=np.zeros(n), z_size=n, trace_cap=1 << 16)
+            stt = np.zeros(8, dtype=np.uint64); oracle.lib.oracle_dbg_compact_stats(stt.ctypes.data_as(ctypes.c_void_p))
+        finally:
+            oracle.lib.oracle_dbg_lemke_compact(0)
+        assert r["ok"] and ref["ok"]
+        assert r["pivots"] == ref["pivots"] and r["trace_len"] == ref["trace_len"]
+        assert np.array_equal(r["trace"], ref["trace"])
+        assert np.array_equal(r["z"], ref["z"])
+        assert np.array_equal(r["rng"], ref["rng"])
+        assert stt[7] > 4 * r["pivots"], (stt[7], r["pivots"])          # kept steps per factorisation (dozens on the longer ladders)
+
+
 def test_sixty_four_box_stack_defeats_the_first_rung_of_the_lemke_ladder(oracle):
     """BASELINE config 4 names 64 boxes per world (impact LCP n = 2048).  DESIGN 4 states that the reference's own solver chain does
     not solve that LCP; the device evidence is profiles/r01_k (255 of 256 worlds MH_WORLD_LCP_FAILED after 24 minutes).  This is
