@@ -231,9 +231,10 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     // by arithmetic: several narrow problems per CU (three now, four when this was measured) overlap theirs (8-box stacks x 1024: 5.7 s narrow, 10.8 s wide); the wide geometry
     // keeps the sizes the narrow one's compact path does not take (n > 512) and batches of at most one problem per CU
     if (kind == MH_LCP_LEMKE || kind == MH_LCP_LEMKE_REG) wide = n > 512 || (n >= 192 && B <= mh_cu_count());
+    if (wave_only == 2) wide = false;
     if (mh_g_debug_blk == 1) wide = false; else if (mh_g_debug_blk == 2) wide = true;
     if (wsd && wsi) {
-      const hipError_t le = wave_only ? hipSuccess : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
+      const hipError_t le = (wave_only == 1) ? hipSuccess : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
                                    trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2), work, 0, nullptr);
       MH_HIP(le);
       if (n_arr) {          // the problems of this call that fit one wavefront (n_arr[b] <= 64) take the wave solver

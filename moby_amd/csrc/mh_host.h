@@ -32,7 +32,8 @@ MH_HIDDEN int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
                                       const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i,
                                       const int* n_arr,    // n_arr: per-problem sizes (<= n, M compact with ld = its n) or NULL
                                       double* work = nullptr,    // B x 2 doubles or NULL: += the 2/3 k^3 flops / 8 k^2 bytes of every factorisation (n > 64)
-                                      int wave_only = 0);        // != 0: only the problems of at most 64 rows (n_arr) -- the caller runs the others itself
+                                      int wave_only = 0);        // 1: only the problems of at most 64 rows (n_arr) -- the caller runs the others itself; 2: the block solver in its
+                                                                 // narrow geometry (the caller has other workgroups on the chip for it to share the CUs with)
 extern MH_HIDDEN int mh_g_debug_repeats;             // mh_debug_set(5, v)
 extern MH_HIDDEN int mh_g_debug_sched;               // mh_debug_set(7, v)
 extern MH_HIDDEN int mh_g_debug_reuse;               // mh_debug_set(6, v)

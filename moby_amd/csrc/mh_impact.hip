@@ -1435,6 +1435,8 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
         && hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess) { c->s2 = s2; c->ev0 = e0; c->ev1 = e1; }
     else { (void)hipGetLastError(); spec = false; }
   }
+  // (lcp_fast then runs in the narrow geometry: a 1024-thread workgroup needs a whole CU and would wait for the tasks' workgroups to leave
+  //  it -- 16 boxes x 256 worlds: 4.05 -> 3.55 s per cold call)
   if (spec) {
     MH_HIP(hipEventRecord((hipEvent_t)c->ev0, s));
     MH_HIP(hipStreamWaitEvent((hipStream_t)c->s2, (hipEvent_t)c->ev0, 0));
@@ -1445,10 +1447,10 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   if (mode == MH_CORE_IMPACT) {
     mh_lcp_opts o1; o1.min_exp = -20; o1.step_exp = 4u; o1.max_exp = -8; o1.piv_tol = -1.0; o1.zero_tol = -1.0;   // ICH-QP:219
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, nullptr, c->rng, c->lst1, c->piv1,
-                                 nullptr, 0, nullptr, &o1, run_if, c->ws_d, c->ws_i, c->ncur, c->work);
+                                 nullptr, 0, nullptr, &o1, run_if, c->ws_d, c->ws_i, c->ncur, c->work, spec ? 2 : 0);
   } else {
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, c->lst1, c->piv1,
-                                 nullptr, 0, nullptr, nullptr, run_if, c->ws_d, c->ws_i, c->ncur, c->work);               // CStab:954
+                                 nullptr, 0, nullptr, nullptr, run_if, c->ws_d, c->ws_i, c->ncur, c->work, spec ? 2 : 0);   // CStab:954
   }
   if (rc != MH_OK) return rc;
   hipLaunchKernelGGL(im::k_lemke_prep, dim3(B), dim3(im::T), 0, s, *c, run_if, mode);
