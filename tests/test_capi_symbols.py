@@ -108,6 +108,23 @@ def test_argument_validation_without_gpu():
     assert rc == _lib.MH_ERR_INVALID_ARG
 
 
+def test_scheduling_switches_validate_their_values_without_gpu():
+    """mh_debug_set: every documented key takes its documented values and refuses others; defaults restored."""
+    from moby_amd import _lib
+    lib = _lib.load()
+    ranges = {2: (0, 2), 3: (0, 1), 4: (0, 2), 5: (0, 1), 6: (0, 1), 7: (0, 1)}
+    defaults = {2: 0, 3: 1, 4: 2, 5: 1, 6: 1, 7: 1}
+    try:
+        for key, (lo, hi) in ranges.items():
+            for v in range(lo, hi + 1):
+                assert lib.mh_debug_set(key, v) == _lib.MH_OK, (key, v)
+            assert lib.mh_debug_set(key, hi + 1) == _lib.MH_ERR_INVALID_ARG and lib.mh_debug_set(key, lo - 1) == _lib.MH_ERR_INVALID_ARG, key
+        assert lib.mh_debug_set(99, 0) != _lib.MH_OK
+    finally:
+        for key, v in defaults.items():
+            assert lib.mh_debug_set(key, v) == _lib.MH_OK
+
+
 def test_product_never_imports_oracle():
     """The product package must not reference oracle/ (no CPU fallback); neither do the measurement scripts under tools/
     (checkers that run next to the oracle live in tests/tools/)."""
