@@ -180,7 +180,10 @@ MH_DEV int build_list(int n, const Ws& W) {
 //   * the trailing matrix is read and written once per PANEL, with the NB multipliers of a row in
 //     registers and the NB pivot rows staged through LDS (s_u), instead of once per column;
 //   * row swaps outside the panel are plain global-memory swaps off the critical path.
-constexpr int NB = 8;
+#ifndef MH_BLK_NB
+#define MH_BLK_NB 8
+#endif
+constexpr int NB = MH_BLK_NB;           // panel width.  8 everywhere today; what a wider panel would still have to change is asserted where it is assumed
 constexpr int UCH = MH_BLK_UCH;          // columns of the pivot-row block staged in LDS at a time
 #ifndef MH_BLK_TCOLS
 #define MH_BLK_TCOLS 8
