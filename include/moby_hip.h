@@ -65,6 +65,18 @@ typedef struct mh_lcp_opts {
 int         mh_version(void);
 const char* mh_last_error(void);
 int         mh_device_count(void);
+/* Devices.  One process may drive every GPU of a node: worlds are independent, so a batch of B worlds is split
+ * into one batch per device and nothing but per-interval counters crosses devices (moby_amd/cpp/example_multi_gpu.cpp: one
+ * batch + stream per device, the counters reduced with RCCL's ncclAllReduce).
+ *   - a batch (mh_world_batch, mh_big_batch, mh_impact_batch, mh_artic_batch) lives on the device that is CURRENT in the calling
+ *     thread when its `create` runs (mh_device_set, or hipSetDevice in a HIP program); `mh_*_batch_device` returns it;
+ *   - every later entry point that takes the batch runs on THAT device, whatever device the calling thread has current at the
+ *     time: the library switches to the batch's device for the call and restores the caller's before it returns;
+ *   - a `stream` argument must belong to the batch's device (HIP refuses the launch otherwise: MH_ERR_HIP); device pointers
+ *     handed to a batch's entry points (traj_dev, ids_dev, `device_ptrs` results) are that device's;
+ *   - the stateless entries (mh_lcp_solve_batch[_dev], mh_world_step_batch, mh_impact_process_batch) run on the current device. */
+int         mh_device_get(void);        /* the calling thread's current device, or MH_ERR_NO_DEVICE */
+int         mh_device_set(int device);  /* 0 <= device < mh_device_count(); MH_ERR_INVALID_ARG otherwise, MH_ERR_NO_DEVICE without a GPU */
 
 /* glibc srand(seed) state for one world (host helper, no GPU needed) */
 void        mh_rand_seed(uint32_t* state32, uint32_t seed);
@@ -241,12 +253,21 @@ void mh_world_aux_init(mh_world_aux* a, uint32_t seed);
 typedef struct mh_world_batch mh_world_batch;
 int mh_world_batch_create(const mh_scene* scene, int B, mh_world_batch** out);
 int mh_world_batch_destroy(mh_world_batch* wb);
+/* The per-interval reduction of a multi-GPU run, device side.  Enqueues on `stream` a pass over the batch's solver records
+ * that leaves, in DEVICE memory, the MH_COUNTERS-element vectors a collective then reduces over the devices of the node (RCCL:
+ * ncclAllReduce(sums, ncclUint64, ncclSum) and (maxs, ncclUint64, ncclMax); moby_amd/cpp/example_multi_gpu.cpp):
+ *   [0] steps  [1] lcp_rows  [2] lcp_pivots  [3] worlds with an error bit (MH_WORLD_IMPACT_TOL, a warning, not counted)
+ *   [4] lcp_solves  [5] mini_steps  [6] stab_iters  [7] lcp_alg_bytes
+ * sums = the totals over this batch's worlds, maxs = the largest value any one world holds (the slowest world of the interval). */
+#define MH_COUNTERS 8
+int mh_world_batch_counters_dev(mh_world_batch* wb, void* stream, unsigned long long* sums_dev, unsigned long long* maxs_dev);
+int mh_world_batch_device(const mh_world_batch* wb);   /* the device the batch lives on (see Devices above) */
 int mh_world_batch_upload(mh_world_batch* wb, const double* state, const mh_world_aux* aux);
 int mh_world_batch_step(mh_world_batch* wb, void* stream, double dt, int nsteps, double* traj_dev);
 /* step of a SUBSET: nsteps x step(dt) of the worlds ids_dev[0 .. count) (a DEVICE array of world indices) on `stream`.  Worlds are
  * independent: a batch may be split over streams, e.g. the few worlds whose solver chain runs to its pivot caps every
  * step in a launch of their own, so that the next interval of the others does not wait for them.  Concurrent launches must not
- * share a world. */
+ * share a world, and the ids of ONE launch must be unique (two wavefronts on one world race); an id outside [0, B) is ignored. */
 int mh_world_batch_step_ids(mh_world_batch* wb, void* stream, double dt, int nsteps, const int* ids_dev, int count);
 int mh_world_batch_download(mh_world_batch* wb, double* state, mh_world_aux* aux);
 int mh_world_batch_device_ptrs(mh_world_batch* wb, double** state_dev, mh_world_aux** aux_dev);

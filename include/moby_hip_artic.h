@@ -100,6 +100,7 @@ typedef struct mh_artic_model {
 typedef struct mh_artic_batch mh_artic_batch;
 int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** out);
 int mh_artic_batch_destroy(mh_artic_batch* ab);
+int mh_artic_batch_device(const mh_artic_batch* ab);   /* the device the batch lives on (moby_hip.h, Devices) */
 int mh_artic_batch_upload(mh_artic_batch* ab, const double* q, const double* qd, const mh_world_aux* aux);
 int mh_artic_batch_step(mh_artic_batch* ab, void* stream, double dt, int nsteps);
 int mh_artic_batch_fwd_dyn(mh_artic_batch* ab, const double* tau, double* qdd_out, double* H_out);

@@ -55,6 +55,7 @@ typedef struct mh_impact_batch mh_impact_batch;
 int mh_impact_batch_create(int B, int nb, int nc, int nk, const double* mass, const double* inertia,
                            mh_impact_batch** out);
 int mh_impact_batch_destroy(mh_impact_batch* ib);
+int mh_impact_batch_device(const mh_impact_batch* ib);   /* the device the batch lives on (moby_hip.h, Devices) */
 int mh_impact_batch_upload(mh_impact_batch* ib, const double* state, const mh_contact* contacts);
 int mh_impact_batch_process(mh_impact_batch* ib, void* stream);
 int mh_impact_batch_download(mh_impact_batch* ib, double* state, double* impulses, int* status,

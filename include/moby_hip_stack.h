@@ -115,6 +115,7 @@ typedef struct mh_big_scene {
 typedef struct mh_big_batch mh_big_batch;
 int mh_big_batch_create(const mh_big_scene* scene, int B, mh_big_batch** out);
 int mh_big_batch_destroy(mh_big_batch* bb);
+int mh_big_batch_device(const mh_big_batch* bb);   /* the device the batch lives on (moby_hip.h, Devices) */
 /* upload: state (B x nb x 13) and / or aux (B records; NULL leaves them).  aux carries the rand() state, clocks, counters, flags and
  * the handler's warm-start SIZES (zlast_size, zbuf_size, zbuf_cap): a zeroed aux makes the next solve cold.  The vectors behind those
  * sizes are load_solver_state's: a resume is download + save_solver_state, then upload + load_solver_state. */

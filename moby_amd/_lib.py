@@ -41,6 +41,13 @@ SYMBOLS = {
     "mh_version": (_i, []),
     "mh_last_error": (ctypes.c_char_p, []),
     "mh_device_count": (_i, []),
+    "mh_device_get": (_i, []),
+    "mh_device_set": (_i, [_i]),
+    "mh_world_batch_device": (_i, [_vp]),
+    "mh_world_batch_counters_dev": (_i, [_vp, _vp, _vp, _vp]),
+    "mh_big_batch_device": (_i, [_vp]),
+    "mh_artic_batch_device": (_i, [_vp]),
+    "mh_impact_batch_device": (_i, [_vp]),
     "mh_rand_seed": (None, [_vp, ctypes.c_uint32]),
     "mh_rand_next": (_i, [_vp]),
     "mh_lcp_solve_batch_dev": (_i, [_vp, _i] + _LCP_TAIL),

@@ -735,6 +735,7 @@ void k_artic_jacobian(const Model* __restrict__ Mg, int B, const double* __restr
 }} // namespace mh::artic
 
 struct mh_artic_batch {
+  int device;                // the HIP device the batch lives on (current at create); every entry point runs there (MH_ON_DEVICE)
   int B, nj, nspheres, cstab;
   mh::artic::Model* d_model;
   double* d_q; double* d_qd; mh_world_aux* d_aux;
@@ -743,9 +744,12 @@ struct mh_artic_batch {
 
 extern "C" {
 
+int mh_artic_batch_device(const mh_artic_batch* ab) { return ab ? ab->device : fail(MH_ERR_INVALID_ARG, "null batch"); }
+
 int mh_artic_batch_destroy(mh_artic_batch* ab)
 {
   if (!ab) return MH_OK;
+  MH_ON_DEVICE(ab);
   (void)hipDeviceSynchronize();
   void* ps[] = { ab->d_model, ab->d_q, ab->d_qd, ab->d_aux, ab->d_ws };
   for (void* p : ps) if (p) (void)hipFree(p);
@@ -809,6 +813,7 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
     }
   }
   mh_artic_batch* ab = new mh_artic_batch();
+  if (hipGetDevice(&ab->device) != hipSuccess) { delete ab; return fail(MH_ERR_HIP, "hipGetDevice failed"); }
   ab->B = B; ab->nj = nj; ab->nspheres = model->nspheres; ab->cstab = model->cstab_max_iterations != 0 ? 1 : 0; ab->d_model = nullptr; ab->d_q = nullptr; ab->d_qd = nullptr; ab->d_aux = nullptr; ab->d_ws = nullptr;
   const size_t sB = (size_t)B;
   bool ok = hipMalloc((void**)&ab->d_model, sizeof(ar::Model)) == hipSuccess && hipMalloc((void**)&ab->d_q, sB * nj * 8) == hipSuccess
@@ -831,6 +836,7 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
 int mh_artic_batch_upload(mh_artic_batch* ab, const double* q, const double* qd, const mh_world_aux* aux)
 {
   if (!ab) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(ab);
   MH_HIP(hipDeviceSynchronize());                              // a step may be in flight on a caller's non-blocking stream
   const size_t n = (size_t)ab->B * ab->nj * 8;
   if (q) MH_HIP(hipMemcpy(ab->d_q, q, n, hipMemcpyHostToDevice));
@@ -843,6 +849,7 @@ int mh_artic_batch_step(mh_artic_batch* ab, void* stream, double dt, int nsteps)
 {
   namespace ar = mh::artic;
   if (!ab) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(ab);
   if (nsteps < 0) return fail(MH_ERR_INVALID_ARG, "negative step count");
   if (nsteps == 0) return MH_OK;
   if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
@@ -869,6 +876,7 @@ int mh_artic_batch_fwd_dyn(mh_artic_batch* ab, const double* tau, double* qdd_ou
 {
   namespace ar = mh::artic;
   if (!ab) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(ab);
   MH_HIP(hipDeviceSynchronize());                              // a step may be in flight on a caller's non-blocking stream
   const size_t B = (size_t)ab->B, nj = (size_t)ab->nj;
   double *d_tau = nullptr, *d_qdd = nullptr, *d_H = nullptr; int* d_ok = nullptr;
@@ -894,6 +902,7 @@ int mh_artic_batch_link_poses(mh_artic_batch* ab, double* poses)
 {
   namespace ar = mh::artic;
   if (!ab || !poses) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  MH_ON_DEVICE(ab);
   MH_HIP(hipDeviceSynchronize());                              // a step may be in flight on a caller's non-blocking stream
   const size_t bytes = (size_t)ab->B * ab->nj * 12 * 8;
   double* d_p = nullptr;
@@ -911,6 +920,7 @@ int mh_artic_batch_jacobian(mh_artic_batch* ab, int link, const double* points, 
 {
   namespace ar = mh::artic;
   if (!ab || !points || !J_out) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  MH_ON_DEVICE(ab);
   MH_HIP(hipDeviceSynchronize());                              // a step may be in flight on a caller's non-blocking stream
   if (link < 0 || link >= ab->nj) return fail(MH_ERR_INVALID_ARG, "link %d outside [0, %d)", link, ab->nj);
   const size_t pb = (size_t)ab->B * 3 * 8, jb = (size_t)ab->B * 6 * ab->nj * 8;
@@ -932,6 +942,7 @@ int mh_artic_batch_jacobian(mh_artic_batch* ab, int link, const double* points, 
 int mh_artic_batch_download(mh_artic_batch* ab, double* q, double* qd, mh_world_aux* aux)
 {
   if (!ab) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(ab);
   MH_HIP(hipDeviceSynchronize());
   const size_t n = (size_t)ab->B * ab->nj * 8;
   if (q) MH_HIP(hipMemcpy(q, ab->d_q, n, hipMemcpyDeviceToHost));

@@ -1098,6 +1098,7 @@ void k_pairs_now(Dev d)
 
 // ---------------------------------------------------------------------------------------------------------
 struct mh_big_batch {
+  int device;                // the HIP device the batch lives on (current at create); every entry point runs there (MH_ON_DEVICE)
   mh::big::Dev d;
   mh_imp_core core;
   int B, nb, cap;
@@ -1146,9 +1147,12 @@ int run_stabilize(mh_big_batch* bb, hipStream_t s, int count_step)
 
 extern "C" {
 
+int mh_big_batch_device(const mh_big_batch* bb) { return bb ? bb->device : fail(MH_ERR_INVALID_ARG, "null batch"); }
+
 int mh_big_batch_destroy(mh_big_batch* bb)
 {
   if (!bb) return MH_OK;
+  MH_ON_DEVICE(bb);
   (void)hipDeviceSynchronize();
   mh_imp_core_destroy(&bb->core);
   for (void* p : bb->allocs) if (p) (void)hipFree(p);
@@ -1162,6 +1166,7 @@ int mh_big_batch_lcp_capacity(const mh_big_batch* bb) { return bb ? bb->cap : 0;
 int mh_big_batch_lu_work(mh_big_batch* bb, double* work, int reset)
 {
   if (!bb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(bb);
   return mh_imp_core_lu_work(&bb->core, work, reset);
 }
 
@@ -1249,6 +1254,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
   if (cap < 1 || cap > MH_LCP_MAX_N_BLOCK) return fail(MH_ERR_UNSUPPORTED_N, "lcp_n_max = %ld outside [1, %d]", cap, MH_LCP_MAX_N_BLOCK);
   if (mh_device_count() <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
   mh_big_batch* bb = new mh_big_batch();
+  if (hipGetDevice(&bb->device) != hipSuccess) { delete bb; return fail(MH_ERR_HIP, "hipGetDevice failed"); }
   bb->B = B; bb->nb = nb; bb->cap = (int)cap; bb->d_rng = nullptr; bb->h_flag = nullptr;
   std::memset(&bb->d, 0, sizeof(bb->d)); std::memset(&bb->core, 0, sizeof(bb->core));
   int rc = mh_imp_core_create(&bb->core, B, nb, ncmax, sc->nk, (int)cap);
@@ -1332,6 +1338,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
 int mh_big_batch_upload(mh_big_batch* bb, const double* state, const mh_world_aux* aux)
 {
   if (!bb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(bb);
   const size_t B = (size_t)bb->B;
   MH_HIP(hipDeviceSynchronize());
   if (state) MH_HIP(hipMemcpy(bb->d.state, state, B * bb->nb * 13 * 8, hipMemcpyHostToDevice));
@@ -1371,6 +1378,7 @@ int mh_big_batch_upload(mh_big_batch* bb, const double* state, const mh_world_au
 int mh_big_batch_download(mh_big_batch* bb, double* state, mh_world_aux* aux)
 {
   if (!bb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(bb);
   const size_t B = (size_t)bb->B;
   MH_HIP(hipDeviceSynchronize());
   if (state) MH_HIP(hipMemcpy(state, bb->d.state, B * bb->nb * 13 * 8, hipMemcpyDeviceToHost));
@@ -1406,6 +1414,7 @@ int mh_big_batch_step(mh_big_batch* bb, void* stream, double dt, int nsteps)
 {
   namespace bg = mh::big;
   if (!bb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(bb);
   if (nsteps < 0) return fail(MH_ERR_INVALID_ARG, "negative step count");
   if (nsteps > 0 && !(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
   hipStream_t s = (hipStream_t)stream;
@@ -1435,6 +1444,7 @@ int mh_big_batch_stabilize(mh_big_batch* bb, void* stream)
 {
   namespace bg = mh::big;
   if (!bb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(bb);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bg::k_pairs_now, dim3(bb->B), dim3(bg::T), 0, s, bb->d);
   MH_HIP(hipGetLastError());
@@ -1444,6 +1454,7 @@ int mh_big_batch_stabilize(mh_big_batch* bb, void* stream)
 int mh_big_batch_save_solver_state(mh_big_batch* bb, double* zlast, double* zbuf, int* sizes3)
 {
   if (!bb || !zlast || !zbuf || !sizes3) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  MH_ON_DEVICE(bb);
   MH_HIP(hipDeviceSynchronize());
   const size_t B = (size_t)bb->B, n = (size_t)bb->cap;
   std::vector<int> a(B), b2(B), c(B);
@@ -1459,6 +1470,7 @@ int mh_big_batch_save_solver_state(mh_big_batch* bb, double* zlast, double* zbuf
 int mh_big_batch_load_solver_state(mh_big_batch* bb, const double* zlast, const double* zbuf, const int* sizes3)
 {
   if (!bb || !zlast || !zbuf || !sizes3) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  MH_ON_DEVICE(bb);
   const size_t B = (size_t)bb->B, n = (size_t)bb->cap;
   std::vector<int> a(B), b2(B), c(B);
   for (size_t i = 0; i < B; i++) {

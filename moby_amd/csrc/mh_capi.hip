@@ -127,6 +127,22 @@ int mh_device_count(void)
   return n;
 }
 
+int mh_device_get(void)
+{
+  int d = -1;
+  if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return fail(MH_ERR_NO_DEVICE, "no HIP device visible"); }
+  return d;
+}
+
+int mh_device_set(int device)
+{
+  const int n = mh_device_count();
+  if (n <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n) return fail(MH_ERR_INVALID_ARG, "device %d of %d", device, n);
+  MH_HIP(hipSetDevice(device));
+  return MH_OK;
+}
+
 void mh_rand_seed(uint32_t* st, uint32_t seed)
 {
   // glibc srandom_r, TYPE_3: r[i] = 16807*r[i-1] mod (2^31-1), then 310 draws

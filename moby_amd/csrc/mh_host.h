@@ -20,6 +20,22 @@ MH_HIDDEN int mh_fail(int code, const char* fmt, ...);
 
 MH_HIDDEN int mh_cu_count();
 
+}  // extern "C"
+// Device affinity (include/moby_hip.h "Devices"): a batch lives on the device that was current when it was created, and every entry
+// point that takes it runs THERE whatever device the calling thread has current -- the guard switches and restores on the way out.
+struct mh_dev_guard {
+  int prev = -1, want = -1; hipError_t err = hipSuccess;
+  explicit mh_dev_guard(int dev) : want(dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != want) err = hipSetDevice(want); else prev = -1;
+  }
+  ~mh_dev_guard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+  mh_dev_guard(const mh_dev_guard&) = delete; mh_dev_guard& operator=(const mh_dev_guard&) = delete;
+};
+#define MH_ON_DEVICE(h_) mh_dev_guard dev_guard_((h_)->device); \
+  if (dev_guard_.err != hipSuccess) return mh_fail(MH_ERR_HIP, "cannot switch to device %d, the batch's: %s", (h_)->device, hipGetErrorString(dev_guard_.err))
+extern "C" {
+
 // the LCP entry with a per-problem mask (run_if[b] == 0: problem b is skipped, outputs untouched) and an optional
 // caller-owned block-solver workspace (ws_d: B (n^2 + 5n) doubles, ws_i: B 4n ints); the exported entry
 // mh_lcp_solve_batch_dev is the unmasked case
@@ -42,6 +58,9 @@ extern MH_HIDDEN int mh_g_debug_tasks;               // mh_debug_set(4, v): the 
 
 // the workgroup-per-problem LCP solver, one translation unit per thread geometry (mh_lcp_blk.hip: 256 threads, mh_lcp_blkw.hip: 1024)
 namespace mh { struct LcpParams; struct Pow10Table; }
+// task mode of the block solver's lcp_lemke kinds: bit 30 of a task's z_size_out = the attempt left through lcp_lemke's trivial exit
+// (LCP.cpp:578) and would not have drawn from rand() whatever z.size() it was entered with (k_ladder_select)
+#define MH_TASK_NODRAW 0x40000000
 #define MH_LCP_BLOCK_LAUNCH_ARGS void* stream, int kind, int B, int n, const double* M, int ld, long strideM, const double* q, double* z, \
   const int* zsz_in, int* zsz_out, uint32_t* rng, int* status, unsigned* pivots, int32_t* trace, int trace_cap, int* trace_len, \
   const mh::LcpParams* P, const mh::Pow10Table* p10, double* wsd, int* wsi, const int* run_if, const int* n_arr, int flags, double* work, int task_worlds, int* solved_at

@@ -1291,8 +1291,9 @@ void k_ladder_select(Dev d, const int* __restrict__ need, int R, int* __restrict
       const size_t i = (size_t)r * B + w;
       const int st = d.t_st[i];
       if (st < 0) break;                                         // not run: only above a successful attempt, never reached (defensive)
-      if (zs != n) draws += n;
-      total += d.t_piv[i]; zs = d.t_zsz[i]; last = r;
+      const int zo = d.t_zsz[i];
+      if (zs != n && !(zo & MH_TASK_NODRAW)) draws += n;       // (lcp_lemke's trivial exit, LCP.cpp:578, returns before the draws of :618-620)
+      total += d.t_piv[i]; zs = zo & ~MH_TASK_NODRAW; last = r;
       wf += d.t_work[2 * i]; wb += d.t_work[2 * i + 1];
       if (st == 1) { chosen = r; break; }
     }
@@ -1518,6 +1519,7 @@ int mh_imp_core_process(mh_imp_core* c, void* stream, int mode)
 // ---------------------------------------------------------------------------------------------------------
 // seam B2: include/moby_hip_impact.h
 struct mh_impact_batch {
+  int device;                // the HIP device the batch lives on (current at create); every entry point runs there (MH_ON_DEVICE)
   int B, nb, nc, nk, n;
   mh_imp_core c;
   double* d_mass; double* d_inertia; double* d_state; mh_contact* d_contacts; uint32_t* d_rng; int* d_status;
@@ -1525,9 +1527,12 @@ struct mh_impact_batch {
 
 extern "C" {
 
+int mh_impact_batch_device(const mh_impact_batch* ib) { return ib ? ib->device : fail(MH_ERR_INVALID_ARG, "null batch"); }
+
 int mh_impact_batch_destroy(mh_impact_batch* ib)
 {
   if (!ib) return MH_OK;
+  MH_ON_DEVICE(ib);
   (void)hipDeviceSynchronize();
   mh_imp_core_destroy(&ib->c);
   void* ps[] = { ib->d_mass, ib->d_inertia, ib->d_state, ib->d_contacts, ib->d_rng, ib->d_status };
@@ -1553,6 +1558,7 @@ int mh_impact_batch_create(int B, int nb, int nc, int nk, const double* mass, co
   }
   if (mh_device_count() <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
   mh_impact_batch* ib = new mh_impact_batch();
+  if (hipGetDevice(&ib->device) != hipSuccess) { delete ib; return fail(MH_ERR_HIP, "hipGetDevice failed"); }
   std::memset(ib, 0, sizeof(*ib));
   ib->B = B; ib->nb = nb; ib->nc = nc; ib->nk = nk; ib->n = (int)n;
   int rc = mh_imp_core_create(&ib->c, B, nb, nc, nk, (int)n);
@@ -1583,6 +1589,7 @@ int mh_impact_batch_lcp_size(const mh_impact_batch* ib) { return ib ? ib->n : 0;
 int mh_impact_batch_set_model(mh_impact_batch* ib, int model)
 {
   if (!ib) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(ib);
   if (model != MH_IMPACT_MODEL_DS && model != MH_IMPACT_MODEL_AP) return fail(MH_ERR_INVALID_ARG, "impact model %d (MH_IMPACT_MODEL_DS / _AP)", model);
   ib->c.ap = (model == MH_IMPACT_MODEL_AP) ? 1 : 0;
   return MH_OK;
@@ -1591,6 +1598,7 @@ int mh_impact_batch_set_model(mh_impact_batch* ib, int model)
 int mh_impact_batch_upload(mh_impact_batch* ib, const double* state, const mh_contact* contacts)
 {
   if (!ib || !state || !contacts) return fail(MH_ERR_INVALID_ARG, "null batch/state/contacts");
+  MH_ON_DEVICE(ib);
   const size_t ncon = (size_t)ib->B * ib->nc;
   for (size_t i = 0; i < ncon; i++) {
     const mh_contact& c = contacts[i];
@@ -1609,6 +1617,7 @@ int mh_impact_batch_upload(mh_impact_batch* ib, const double* state, const mh_co
 int mh_impact_batch_process(mh_impact_batch* ib, void* stream)
 {
   if (!ib) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(ib);
   MH_HIP(hipMemsetAsync(ib->c.cnt, 0, (size_t)ib->B * 5 * 8, (hipStream_t)stream));     // pivots / solves are per call
   return mh_imp_core_process(&ib->c, stream, MH_CORE_IMPACT);
 }
@@ -1616,6 +1625,7 @@ int mh_impact_batch_process(mh_impact_batch* ib, void* stream)
 int mh_impact_batch_download(mh_impact_batch* ib, double* state, double* impulses, int* status, unsigned* pivots, int* solves)
 {
   if (!ib) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(ib);
   MH_HIP(hipDeviceSynchronize());
   const size_t B = (size_t)ib->B;
   if (state) MH_HIP(hipMemcpy(state, ib->d_state, B * ib->nb * 13 * 8, hipMemcpyDeviceToHost));
@@ -1640,12 +1650,14 @@ int mh_imp_core_lu_work(mh_imp_core* c, double* work, int reset)
 int mh_impact_batch_lu_work(mh_impact_batch* ib, double* work, int reset)
 {
   if (!ib) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(ib);
   return mh_imp_core_lu_work(&ib->c, work, reset);
 }
 
 int mh_impact_batch_debug_lcp(mh_impact_batch* ib, double* MM, double* qq)
 {
   if (!ib) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(ib);
   MH_HIP(hipDeviceSynchronize());
   const size_t B = (size_t)ib->B, n = (size_t)ib->n;
   if (MM) MH_HIP(hipMemcpy(MM, ib->c.MM, B * n * n * 8, hipMemcpyDeviceToHost));
@@ -1656,6 +1668,7 @@ int mh_impact_batch_debug_lcp(mh_impact_batch* ib, double* MM, double* qq)
 int mh_impact_batch_save_solver_state(mh_impact_batch* ib, double* zlast, int* zlast_size, uint32_t* rng, int* status)
 {
   if (!ib || !zlast || !zlast_size || !rng || !status) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  MH_ON_DEVICE(ib);
   MH_HIP(hipDeviceSynchronize());
   const size_t B = (size_t)ib->B;
   MH_HIP(hipMemcpy(zlast, ib->c.zlast, B * ib->n * 8, hipMemcpyDeviceToHost));
@@ -1669,6 +1682,7 @@ int mh_impact_batch_load_solver_state(mh_impact_batch* ib, const double* zlast, 
                                       const int* status)
 {
   if (!ib || !zlast || !zlast_size || !rng || !status) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  MH_ON_DEVICE(ib);
   for (int b = 0; b < ib->B; b++)
     if (zlast_size[b] < 0 || zlast_size[b] > ib->n) return fail(MH_ERR_INVALID_ARG, "world %d: _zlast of size %d in a batch of capacity n = %d", b, zlast_size[b], ib->n);
   MH_HIP(hipDeviceSynchronize());
@@ -1687,6 +1701,7 @@ int mh_impact_batch_load_solver_state(mh_impact_batch* ib, const double* zlast, 
 int mh_impact_batch_save_noslip_state(mh_impact_batch* ib, double* v, int* v_size)
 {
   if (!ib || !v || !v_size) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  MH_ON_DEVICE(ib);
   MH_HIP(hipDeviceSynchronize());
   MH_HIP(hipMemcpy(v, ib->c.vns, (size_t)ib->B * MH_NOSLIP_MAX * 8, hipMemcpyDeviceToHost));
   MH_HIP(hipMemcpy(v_size, ib->c.vns_size, (size_t)ib->B * 4, hipMemcpyDeviceToHost));
@@ -1696,6 +1711,7 @@ int mh_impact_batch_save_noslip_state(mh_impact_batch* ib, double* v, int* v_siz
 int mh_impact_batch_load_noslip_state(mh_impact_batch* ib, const double* v, const int* v_size)
 {
   if (!ib || !v || !v_size) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  MH_ON_DEVICE(ib);
   for (int b = 0; b < ib->B; b++)
     if (v_size[b] < 0 || v_size[b] > MH_NOSLIP_MAX) return fail(MH_ERR_INVALID_ARG, "world %d: _v of size %d (0 .. %d)", b, v_size[b], MH_NOSLIP_MAX);
   MH_HIP(hipDeviceSynchronize());
@@ -1707,6 +1723,7 @@ int mh_impact_batch_load_noslip_state(mh_impact_batch* ib, const double* v, cons
 int mh_impact_batch_device_ptrs(mh_impact_batch* ib, double** state_dev, mh_contact** contacts_dev)
 {
   if (!ib) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(ib);
   if (state_dev) *state_dev = ib->d_state;
   if (contacts_dev) *contacts_dev = ib->d_contacts;
   return MH_OK;

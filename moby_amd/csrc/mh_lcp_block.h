@@ -664,6 +664,7 @@ MH_DEV bool verify(const Mat& M, double lam, const Ws& W, const double* q, const
 // selection pass afterwards takes the first attempt, in ladder order, that succeeded.  solved_at[w] = the lowest attempt known to have
 // succeeded: attempts above it are not started, and a running one gives up when it learns of a lower success (its result could never
 // be the one selected).  rung < 0: not in task mode.
+__shared__ int s_nodraw;   // lcp_lemke left through its trivial exit (LCP.cpp:578), before the n rand() draws of :618-620
 struct LadderTask { int* solved_at; int rung;
   MH_DEV bool pointless() const { return rung >= 0 && *(volatile int*)solved_at < rung; } };
 
@@ -686,7 +687,7 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
   double best = inf(); int bi = 0x7fffffff;
   for (int i = t; i < n; i += T) { const double v = q[i]; if (v < best) { best = v; bi = i; } }
   double xmin; int lvindex; red_min_first(best, bi, xmin, lvindex);
-  if (xmin > -zero_tol) { zsize = n; return true; }
+  if (xmin > -zero_tol) { if (t == 0) s_nodraw = 1; zsize = n; return true; }   // (:578: returns BEFORE _restart_z0's draws -- a task reports it, see k_ladder_select)
   zsize = 2 * n;                                                    // z.set_zero(2n) (:596)
   const int tt = 2 * n;
   if (z0size != n) for (int i = 0; i < n; i++) (void)rand_next();   // _restart_z0 (:618-620)
@@ -891,7 +892,8 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   const int bw = (task_worlds > 0) ? b % task_worlds : b;
   LadderTask task; task.solved_at = (task_worlds > 0) ? solved_at + bw : nullptr; task.rung = (task_worlds > 0) ? b / task_worlds : -1;
   if (run_if && run_if[bw] == 0) { if (task_worlds > 0 && t == 0) status[b] = -1; continue; }
-  if (task_worlds > 0 && task.pointless()) { if (t == 0) status[b] = -1; if (queue && t == 0) atomicAdd(solved_at + 2 * task_worlds + bw, 1); continue; }     // -1: not run
+  // (block-uniform: thread 0 reads solved_at once and broadcasts -- another workgroup's atomicMin may land between the loads of two waves)
+  if (task_worlds > 0 && bcast_i(task.pointless() ? 1 : 0)) { if (t == 0) status[b] = -1; if (queue && t == 0) atomicAdd(solved_at + 2 * task_worlds + bw, 1); continue; }     // -1: not run
   Ws W;
   double* wd = wsd + (size_t)b * ws_doubles(n);
   int* wi = wsi + (size_t)b * ws_ints(n);
@@ -902,7 +904,7 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   W.A = wd; W.b = wd + (size_t)n * n; W.w = W.b + n; W.x = W.w + n; W.d = W.x + n; W.art = W.d + n;
   W.list = wi; W.flag = wi + n; W.pos = wi + 2 * (size_t)n; W.bv = wi + 3 * (size_t)n;
   if (t < 32) s_rng[t] = rngg[(size_t)b * MH_RAND_WORDS + t];
-  if (t == 0) { s_luc_bug = 0; s_work[0] = 0.0; s_work[1] = 0.0; }
+  if (t == 0) { s_luc_bug = 0; s_work[0] = 0.0; s_work[1] = 0.0; s_nodraw = 0; }
   Mat M; M.M = Mg + (size_t)bw * strideM; M.ld = ld; M.n = n;
   const double* q = qg + (size_t)bw * nstride;
   double* z = zg + (size_t)b * nstride;
@@ -929,7 +931,7 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
     if (s_luc_bug) printf("mh_lcp_block: index invariant %d of the compact LU violated (problem %d, n %d)\n", s_luc_bug & 15, b, s_luc_bug >> 4);
     status[b] = s_luc_bug ? -7 : (ok ? 1 : 0);
     if (pivots_out) pivots_out[b] = piv;
-    if (zsz_out) zsz_out[b] = zsize;
+    if (zsz_out) zsz_out[b] = zsize | ((task.rung >= 0 && s_nodraw) ? MH_TASK_NODRAW : 0);   // (task mode only: bit 30 = this attempt would not have drawn)
     if (trace_len) trace_len[b] = tr.len;
     if (queue) atomicAdd(solved_at + 2 * task_worlds + bw, 1);          // one more attempt of this problem is over
   }

@@ -88,6 +88,7 @@ void mh_world_aux_init(mh_world_aux* a, uint32_t seed)
 
 
 struct mh_world_batch {
+  int device;                // the HIP device the batch lives on (current at create); every entry point runs there (MH_ON_DEVICE)
   mh_scene scene;
   int B;
   int nmax;
@@ -105,6 +106,7 @@ int mh_world_batch_occupancy(mh_world_batch* wb);
 int mh_world_batch_occupancy(mh_world_batch* wb)
 {
   if (!wb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(wb);
   int n = 0;
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wb->kernel, 64, 0);
   if (e != hipSuccess) return fail(MH_ERR_HIP, "occupancy query failed: %s", hipGetErrorString(e));
@@ -122,6 +124,7 @@ int mh_world_batch_create(const mh_scene* scene, int B, mh_world_batch** out)
   std::call_once(g_tables_once, init_tables);
   if (g_tables_err != hipSuccess) return fail(MH_ERR_HIP, "constant table upload failed: %s", hipGetErrorString(g_tables_err));
   mh_world_batch* wb = new mh_world_batch();
+  if (hipGetDevice(&wb->device) != hipSuccess) { delete wb; return fail(MH_ERR_HIP, "hipGetDevice failed"); }
   wb->scene = *scene; wb->B = B;
   wb->nmax = scene->lcp_n_max ? scene->lcp_n_max : MH_LCP_MAX_N_WAVE;
   {
@@ -165,9 +168,12 @@ int mh_world_batch_create(const mh_scene* scene, int B, mh_world_batch** out)
   return MH_OK;
 }
 
+int mh_world_batch_device(const mh_world_batch* wb) { return wb ? wb->device : fail(MH_ERR_INVALID_ARG, "null batch"); }
+
 int mh_world_batch_destroy(mh_world_batch* wb)
 {
   if (!wb) return MH_OK;
+  MH_ON_DEVICE(wb);
   if (wb->d_scene) (void)hipFree(wb->d_scene);
   if (wb->d_state) (void)hipFree(wb->d_state);
   if (wb->d_aux) (void)hipFree(wb->d_aux);
@@ -179,6 +185,7 @@ int mh_world_batch_destroy(mh_world_batch* wb)
 int mh_world_batch_upload(mh_world_batch* wb, const double* state, const mh_world_aux* aux)
 {
   if (!wb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(wb);
   if (state) MH_HIP(hipMemcpy(wb->d_state, state, (size_t)wb->B * wb->scene.nb * MH_BODY_STATE * sizeof(double), hipMemcpyHostToDevice));
   if (aux) MH_HIP(hipMemcpy(wb->d_aux, aux, (size_t)wb->B * sizeof(mh_world_aux), hipMemcpyHostToDevice));
   return MH_OK;
@@ -187,6 +194,7 @@ int mh_world_batch_upload(mh_world_batch* wb, const double* state, const mh_worl
 int mh_world_batch_step(mh_world_batch* wb, void* stream, double dt, int nsteps, double* traj_dev)
 {
   if (!wb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(wb);
   if (nsteps < 0) return fail(MH_ERR_INVALID_ARG, "negative step count");
   if (nsteps == 0) return MH_OK;
   if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
@@ -203,11 +211,12 @@ int mh_world_batch_step(mh_world_batch* wb, void* stream, double dt, int nsteps,
 int mh_world_batch_step_ids(mh_world_batch* wb, void* stream, double dt, int nsteps, const int* ids_dev, int count)
 {
   if (!wb || !ids_dev) return fail(MH_ERR_INVALID_ARG, "null batch / id list");
+  MH_ON_DEVICE(wb);
   if (nsteps < 0 || count < 0 || count > wb->B) return fail(MH_ERR_INVALID_ARG, "bad step count (%d) or id count (%d of %d)", nsteps, count, wb->B);
   if (nsteps == 0 || count == 0) return MH_OK;
   if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
   hipLaunchKernelGGL(wb->kernel, dim3(count), dim3(64), 0, (hipStream_t)stream,
-                     (const mh_scene*)wb->d_scene, count, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, wb->d_lu_ws, mh_g_debug_ka,
+                     (const mh_scene*)wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, wb->d_lu_ws, mh_g_debug_ka,
                      (unsigned long long*)nullptr, ids_dev);
   MH_HIP(hipGetLastError());
   return MH_OK;
@@ -219,6 +228,7 @@ int mh_world_profile_phase_count(void) { return mh_world_variant_large()->ph_cou
 int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* phase_cycles, int nphase)
 {
   if (!wb || !phase_cycles) return fail(MH_ERR_INVALID_ARG, "null argument");
+  MH_ON_DEVICE(wb);
   unsigned long long* dprof = nullptr;
   const int PHC = mh_world_variant_large()->ph_count;   // the same enum in every variant
   const size_t sz = (size_t)wb->B * PHC * sizeof(unsigned long long);
@@ -263,15 +273,59 @@ int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* ph
 int mh_world_batch_download(mh_world_batch* wb, double* state, mh_world_aux* aux)
 {
   if (!wb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(wb);
   MH_HIP(hipDeviceSynchronize());
   if (state) MH_HIP(hipMemcpy(state, wb->d_state, (size_t)wb->B * wb->scene.nb * MH_BODY_STATE * sizeof(double), hipMemcpyDeviceToHost));
   if (aux) MH_HIP(hipMemcpy(aux, wb->d_aux, (size_t)wb->B * sizeof(mh_world_aux), hipMemcpyDeviceToHost));
   return MH_OK;
 }
 
+// The per-interval reduction of SURVEY 8(e), device side: what one device contributes to the node's SUM and MAX vectors, left in
+// device memory for a collective (RCCL's ncclAllReduce) -- no host round trip, nothing per step.
+namespace mh { namespace world_red {
+__global__ __launch_bounds__(256)
+void k_counters(const mh_world_aux* __restrict__ aux, int B, unsigned long long* __restrict__ sums, unsigned long long* __restrict__ maxs)
+{
+  __shared__ unsigned long long s_s[MH_COUNTERS][4], s_m[MH_COUNTERS][4];
+  unsigned long long v[MH_COUNTERS] = { 0, 0, 0, 0, 0, 0, 0, 0 }, m[MH_COUNTERS] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  for (int w = blockIdx.x * 256 + threadIdx.x; w < B; w += gridDim.x * 256) {
+    const mh_world_aux& a = aux[w];
+    const unsigned long long c[MH_COUNTERS] = { a.steps, a.lcp_rows, a.lcp_pivots, (unsigned long long)((a.status & ~MH_WORLD_IMPACT_TOL) != 0),
+                                                a.lcp_solves, a.mini_steps, a.stab_iters, a.lcp_alg_bytes };
+#pragma unroll
+    for (int k = 0; k < MH_COUNTERS; k++) { v[k] += c[k]; m[k] = (c[k] > m[k]) ? c[k] : m[k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < MH_COUNTERS; k++) {
+    for (int off = 32; off > 0; off >>= 1) { v[k] += __shfl_xor(v[k], off); const unsigned long long o = __shfl_xor(m[k], off); m[k] = (o > m[k]) ? o : m[k]; }
+    if ((threadIdx.x & 63) == 0) { s_s[k][threadIdx.x >> 6] = v[k]; s_m[k][threadIdx.x >> 6] = m[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < MH_COUNTERS) {
+    const int k = threadIdx.x;
+    unsigned long long a = 0, b = 0;
+    for (int q = 0; q < 4; q++) { a += s_s[k][q]; b = (s_m[k][q] > b) ? s_m[k][q] : b; }
+    atomicAdd(sums + k, a); atomicMax(maxs + k, b);
+  }
+}
+}}
+
+int mh_world_batch_counters_dev(mh_world_batch* wb, void* stream, unsigned long long* sums_dev, unsigned long long* maxs_dev)
+{
+  if (!wb || !sums_dev || !maxs_dev) return fail(MH_ERR_INVALID_ARG, "null batch / buffer");
+  MH_ON_DEVICE(wb);
+  MH_HIP(hipMemsetAsync(sums_dev, 0, MH_COUNTERS * sizeof(unsigned long long), (hipStream_t)stream));
+  MH_HIP(hipMemsetAsync(maxs_dev, 0, MH_COUNTERS * sizeof(unsigned long long), (hipStream_t)stream));
+  const int grid = std::min((wb->B + 255) / 256, 1024);
+  hipLaunchKernelGGL(mh::world_red::k_counters, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const mh_world_aux*)wb->d_aux, wb->B, sums_dev, maxs_dev);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 int mh_world_batch_device_ptrs(mh_world_batch* wb, double** state_dev, mh_world_aux** aux_dev)
 {
   if (!wb) return fail(MH_ERR_INVALID_ARG, "null batch");
+  MH_ON_DEVICE(wb);
   if (state_dev) *state_dev = wb->d_state;
   if (aux_dev) *aux_dev = wb->d_aux;
   return MH_OK;

@@ -65,6 +65,33 @@ def test_ctypes_mirrors_have_the_c_struct_sizes(tmp_path):
     assert got == want, (got, want)
 
 
+def test_device_selection_is_validated_without_a_gpu():
+    """Device affinity behind the C ABI (moby_hip.h, Devices): a batch lives on the device current at create and every entry
+    point switches to it.  Without a GPU the selection entry points must refuse instead of crashing; with one, an index
+    outside [0, mh_device_count()) is MH_ERR_INVALID_ARG and a null handle has no device."""
+    from moby_amd import _lib
+    lib = _lib.load()
+    n = lib.mh_device_count()
+    assert n >= 0
+    if n == 0:
+        assert lib.mh_device_set(0) == _lib.MH_ERR_NO_DEVICE and lib.mh_device_get() == _lib.MH_ERR_NO_DEVICE
+        assert b"no HIP device" in lib.mh_last_error()
+    else:
+        assert lib.mh_device_set(n) == _lib.MH_ERR_INVALID_ARG and lib.mh_device_set(-1) == _lib.MH_ERR_INVALID_ARG
+        assert lib.mh_device_set(0) == _lib.MH_OK and lib.mh_device_get() == 0
+    for f in (lib.mh_world_batch_device, lib.mh_big_batch_device, lib.mh_artic_batch_device, lib.mh_impact_batch_device):
+        assert f(None) == _lib.MH_ERR_INVALID_ARG
+
+
+def test_multi_gpu_adapter_compiles_against_rccl(tmp_path):
+    """moby_amd/cpp/example_multi_gpu.cpp (one process, one batch + stream per device, RCCL ncclAllReduce of the counters) builds
+    in the CPU container; it runs inside `-m gpu` (tests/test_world_gpu.py::test_cpp_multi_gpu_example)."""
+    import subprocess
+    cpp = os.path.join(ROOT, "moby_amd", "cpp")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", os.path.join(cpp, "example_multi_gpu.cpp"), "-L" + os.path.join(ROOT, "moby_amd"),
+                           "-lmoby_hip", "-lmoby_hip_io", "-lrccl", "-Wl,-rpath," + os.path.join(ROOT, "moby_amd"), "-o", str(tmp_path / "example_multi_gpu")])
+
+
 def test_rand_seed_matches_libc():
     from moby_amd import _lib
     lib = _lib.load()

@@ -385,6 +385,37 @@ def test_ap_random_multi_island_graphs_match_oracle(ap_oracle, seed, nb, nc, nk)
     ib.close()
 
 
+@pytest.mark.parametrize("tasks", [0, 1, 2])
+def test_ap_ladder_trivial_exit_draws_nothing(ap_oracle, tasks):
+    """lcp_lemke's trivial exit (LCP.cpp:578, min(q) > -zero_tol) returns BEFORE _restart_z0's n rand() draws (:618-620).  Under the
+    A-P model the ladder is entered cold (z.size() = 0 != n), so a separating island must leave its world's rand() stream where it
+    was -- in sequence (mh_debug_set(4, 0)) and as (world, attempt) tasks (1, 2) alike.  n = 72 (block solver); worlds 0-1
+    separate (q >= 0), world 2 falls; rand() streams compared word for word with the oracle's."""
+    lib = _lib.load()
+    nbx, B, nk = 3, 3, 4
+    mass, J, st, cs = I.box_stack(nbx, B=B, epsilon=0.0, mu=0.3, nk=nk)
+    st.reshape(B, nbx, 13)[:2, :, 8] = 0.25 + 0.25 * np.arange(nbx)      # separating: every relative normal velocity positive
+    nc = 4 * nbx; n = I.lcp_size(nc, nk)
+    assert I.ap_lcp_size(nc, nk) > 64
+    try:
+        _lib.check(lib.mh_debug_set(4, tasks))
+        ib = I.ImpactBatch(B, nbx, nc, nk, mass, J, model=I.MH_IMPACT_MODEL_AP)
+        aux = S.new_aux(B); zl = np.zeros((B, n)); zb = np.zeros((B, n))
+        rng0 = aux["rng"].copy()
+        st_o = st.copy()
+        for call in range(2):
+            r = ib.process(st_o.copy(), cs)
+            imp_o, piv_o, sol_o = oracle_batch(ap_oracle, nbx, mass, J, st_o, cs, n, aux, zl, zb)
+            assert_same(r, st_o, imp_o, piv_o, sol_o, aux)
+            ss = ib.solver_state()
+            assert np.array_equal(ss["rng"], aux["rng"])
+            assert np.array_equal(aux["rng"][:2], rng0[:2]) and (piv_o[:2] == 0).all()      # the trivial exit: no pivots, no draws
+            assert not np.array_equal(aux["rng"][2], rng0[2])
+        ib.close()
+    finally:
+        _lib.check(lib.mh_debug_set(4, 2))
+
+
 def test_ap_model_argument_check():
     mass, J, st, cs = I.box_stack(1, B=1)
     ib = I.ImpactBatch(1, 1, 4, 4, mass, J)

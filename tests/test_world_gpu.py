@@ -366,6 +366,21 @@ def test_cpp_simulator_adapter_example():
     assert abs(z - 5.0) < 1e-6
 
 
+def test_cpp_multi_gpu_example():
+    """moby_amd/cpp/MobyHipMultiGpu.h: one process, one batch + stream per visible device, the counters reduced through RCCL's C API
+    (ncclAllReduce SUM + MAX); batches follow their device whatever device the calling thread has current.  On this box: 1 device."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = os.path.join(root, "moby_amd", "cpp")
+    exe = os.path.join(cpp, "example_multi_gpu")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", os.path.join(cpp, "example_multi_gpu.cpp"), "-L" + os.path.join(root, "moby_amd"),
+                           "-lmoby_hip", "-lmoby_hip_io", "-lrccl", "-Wl,-rpath," + os.path.join(root, "moby_amd"), "-o", exe])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.check_output([exe, os.path.join(root, "tests", "scenes", "three_spheres_on_a_plane.xml"), "64", "100"], env=env).decode()
+    assert "placed=1 affinity=1 same=1 reduced=1" in out and "worlds=64 steps=100" in out, out
+    assert "world_steps=6400" in out
+
+
 def test_full_batch_2048_wheels_properties():
     """BASELINE config 3 at full size (2048 worlds): size-independent properties -- every world stays in its
     plane, no spoke tip sinks below the slope, the wheels only lose energy (the slope's potential included),
