@@ -451,6 +451,7 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
 }
 
 #include "mh_lu_compact.inc"
+#include "mh_lu_left.inc"
 
 // LCP.cpp:199-209 over the variables i with member(i) (list order = index order); val(i) reads
 // the candidate.  Consumes exactly one rand().  Returns the chosen variable (uniform).
@@ -728,7 +729,11 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
       const unsigned long long tc = bp_tick();
       LemkeCol colv; colv.M = &M; colv.bv = W.bv; colv.art = W.art; colv.lam = lam; colv.n = n; colv.tt = tt;
       if (!reuse) prev_nd = -1;
+#ifdef MH_BLK_RIGHT_LOOKING      /* the round-3 schedule (mh_lu_compact.inc), kept for A/B builds */
       info = lu_compact(n, colv, W.A, W.d, W.w, W.list, prev_nd, lvindex);   // W.w: unused by lcp_lemke, the trash column of the update lists; W.list .. W.pos: 3 n ints, idle here
+#else
+      info = lu_left(n, colv, W.A, W.d, W.list, prev_nd, lvindex);           // W.list .. W.pos: 3 n ints, idle here (the step records between calls)
+#endif
       bp_tock(BP_COMPACT, tc);
     }
     if (info == LUC_FALLBACK) {

@@ -82,6 +82,44 @@ class BigScene:
         c.joint_vec_in, c.joint_vec_out = P(self.joint_vec_in, _dp), P(self.joint_vec_out, _dp)
         self.c = c
 
+    @classmethod
+    def from_scene(cls, sc, state, lcp_n_max=0):
+        """The large-world scene that says what an ``mh_scene`` (moby_amd/io.py: ``load_xml``, i.e. XMLReader::read,
+        /root/reference/src/XMLReader.cpp:151-204) says, for worlds the one-wavefront stepper does not take: stacked boxes such as
+        example/stacks/stack.xml.  Every enabled pair becomes a candidate pair in the canonical order; a box-box pair is modelled as
+        MH_PAIR_VERTEX_FACE (moby_hip_stack.h: the higher-id box on the +Y face of the lower-id one) when the two bounding spheres
+        of the INITIAL state (``state``: nb x 13) reach each other -- the pairs CCD::broad_phase (src/CCD.cpp:702-988) could ever
+        report for a resting stack -- and is left out otherwise (a box two storeys up never meets the box below).  Box-sphere pairs
+        are refused: their contact generation is not built."""
+        nb = sc.nb; ntot = nb + (1 if sc.has_ground else 0)
+        st = np.asarray(state, dtype=np.float64).reshape(-1)[:nb * S.MH_BODY_STATE].reshape(nb, S.MH_BODY_STATE)
+        gt = [int(sc.geom_type[b]) for b in range(nb)]
+        dims = np.array([[sc.geom_dim[b][k] for k in range(3)] for b in range(nb)])
+        rad = [0.5 * float(np.linalg.norm(dims[b])) if gt[b] == S.MH_GEOM_BOX else float(dims[b][0]) for b in range(nb)]
+        pairs, idx = [], []
+        for i in range(ntot):
+            for j in range(i + 1, ntot):
+                pi = S.pair_index(i, j, ntot)
+                if not sc.pair_enabled[pi]:
+                    continue
+                model = MH_PAIR_CLOSED_FORM
+                if j < nb and (gt[i] == S.MH_GEOM_BOX or gt[j] == S.MH_GEOM_BOX):
+                    if gt[i] != gt[j]:
+                        raise ValueError("bodies %d, %d: box-sphere contact is not built (disable the pair)" % (i, j))
+                    if float(np.linalg.norm(st[i, :3] - st[j, :3])) > rad[i] + rad[j]:
+                        continue
+                    model = MH_PAIR_VERTEX_FACE
+                pairs.append((i, j, model)); idx.append(pi)
+        nks = set(int(sc.cp_nk[p]) for p in idx)
+        if len(nks) > 1:
+            raise ValueError("the large-world stepper takes ONE friction-cone-edges value per scene, got %r" % sorted(nks))
+        col = lambda a: [float(a[p]) for p in idx]
+        return cls(gt, dims, [sc.mass[b] for b in range(nb)], [[sc.inertia[b][k] for k in range(3)] for b in range(nb)], pairs,
+                   gravity=[sc.gravity[k] for k in range(3)], plane_R=[sc.plane_R[k] for k in range(9)], plane_o=[sc.plane_o[k] for k in range(3)],
+                   has_ground=bool(sc.has_ground), nk=(nks.pop() if nks else 4), epsilon=col(sc.cp_epsilon), mu_coulomb=col(sc.cp_mu_coulomb),
+                   mu_viscous=col(sc.cp_mu_viscous), compliance=col(sc.cp_compliance), cstab_max_iterations=sc.cstab_max_iterations,
+                   lcp_n_max=lcp_n_max)
+
     @property
     def npairs(self):
         return len(self.pair_a)

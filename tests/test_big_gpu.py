@@ -121,6 +121,22 @@ def test_stabilize_alone_is_the_b3_seam(oracle):
     assert (gaps > -1e-9).all() and (r[1]["stab_iters"] >= 1).all()
 
 
+def test_box_tower_scene_file_steps_like_the_oracle(oracle):
+    """tests/scenes/three_box_tower.xml (what example/stacks/stack.xml's simulator holds; tests/test_io.py compares the two) through
+    mh_io_load_xml -> BigScene.from_scene -> mh_big_batch: n = 96 impact LCPs (block solver), perturbed copies, 12 steps."""
+    import os
+    from moby_amd import io as mio
+    sc1, st1, _, _ = mio.load_xml(os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes", "three_box_tower.xml"))
+    sc = K.BigScene.from_scene(sc1, st1)
+    B = 4
+    st0 = np.tile(st1.reshape(1, -1), (B, 1)).reshape(B, 3, 13)
+    rng = np.random.default_rng(11)
+    st0[1:, :, 7:13] += 1e-3 * rng.standard_normal((B - 1, 3, 6))
+    r = run_both(oracle, sc, st0.reshape(B, -1), 1e-3, 6, chunks=2)
+    assert_parity(*r)
+    assert (r[1]["lcp_rows"] >= 12 * 96).all() and (r[1]["status"] & ~S.MH_WORLD_IMPACT_TOL == 0).all()
+
+
 def test_sixteen_box_stack_one_step_matches_oracle(oracle):
     """n = 512 impact LCP (the wide block solver, Lemke fallback) inside a full step."""
     N, B = 16, 2
@@ -129,6 +145,22 @@ def test_sixteen_box_stack_one_step_matches_oracle(oracle):
     r = run_both(oracle, sc, st0, 1e-3, 1)
     assert_parity(*r)
     assert (r[1]["lcp_rows"] >= 512).all()
+
+
+@pytest.mark.parametrize("nboxes,B,nsteps", [(8, 3, 3), (12, 2, 2)])
+def test_tall_stacks_several_steps_match_the_oracle(oracle, nboxes, B, nsteps):
+    """The block solver (n = 256 / 384) against the ORACLE over several steps with every scheduling switch at its default: the
+    structure-exploiting LU with factor reuse across Lemke pivots, the ladder as tasks handed out by need, lcp_fast's repetitions
+    skipped.  Step 2 on enters lcp_fast warm-started from _zlast (ICH-QP:158-162, 233), fails, and walks the ladder again: states,
+    rand() streams, every counter and the warm-start vectors themselves equal oracle.big_step bit for bit."""
+    sc = K.box_stack_scene(nboxes)
+    st0 = K.box_stack_state(nboxes, B)
+    r = run_both(oracle, sc, st0, 1e-3, 1, chunks=nsteps)          # one step per launch: the warm start crosses launches too
+    assert_parity(*r)
+    aux = r[1]
+    assert (aux["steps"] == nsteps).all() and (aux["zlast_size"] == 32 * nboxes).all()
+    assert (aux["lcp_pivots"][1:] > 2000).all()                     # the perturbed worlds went through the Lemke ladder
+    assert (aux["lcp_solves"] >= nsteps).all()
 
 
 CONFIG4_BOXES = 16        # the size bench.py's config-4 leg names (n = 512 impact LCP per world); see DESIGN.md 4

@@ -79,6 +79,31 @@ def test_reference_example_files_load_to_the_same_scenes():
     np.testing.assert_array_equal(st, S.box_state(w=(0.0, 10.0, 0.0)))
 
 
+def test_box_tower_file_becomes_a_large_world_scene(oracle):
+    """example/stacks/stack.xml (three of its boxes and the ground are in the simulator, stack.xml:84-97) through mh_io_load_xml and
+    BigScene.from_scene into the large-world stepper's scene: ground-box pairs as closed forms, the two touching box pairs as
+    vertex-face pairs, box1-box3 (never in reach) left out, the file's ContactParameters on their pairs.  The reference's own file,
+    read in place when the tree is present, says the same as the fixture written for this repository; 50 steps of the oracle keep
+    the tower where it stands."""
+    from moby_amd import stack as K
+    sc, st, ids, _ = mio.load_xml(os.path.join(SCENES, "three_box_tower.xml"))
+    assert ids == ["box1", "box2", "box3", "ground"]
+    if os.path.isdir(REF):
+        sc_r, st_r, ids_r, _ = mio.load_xml(os.path.join(REF, "stacks", "stack.xml"))
+        assert ids_r == ids and bytes(sc_r) == bytes(sc) and np.array_equal(st_r, st)
+    big = K.BigScene.from_scene(sc, st)
+    assert list(zip(big.pair_a, big.pair_b, big.pair_model)) == [(0, 1, K.MH_PAIR_VERTEX_FACE), (0, 3, 0), (1, 2, K.MH_PAIR_VERTEX_FACE), (1, 3, 0), (2, 3, 0)]
+    assert list(big.cp_mu_coulomb) == [1e-4, 1e-4, 1e-4, 0.0, 0.0] and big.c.nk == 4
+    np.testing.assert_allclose(big.mass, [10.0, 9.025, 8.1], rtol=1e-15)
+    cap = big.lcp_capacity()
+    w = st.reshape(-1).copy(); aux = S.new_aux(1)
+    oracle.big_step(big, w, aux, 1e-3, 50, zlast=np.zeros(cap), zbuf=np.zeros(cap), cap=cap)
+    b = w.reshape(3, 13)
+    assert aux["status"][0] == 0 and aux["lcp_rows"][0] >= 50 * 96          # three interfaces x 4 corners x 8 rows per step
+    np.testing.assert_allclose(b[:, 1], [0.5, 1.5, 2.5], atol=1e-6)
+    assert np.abs(b[:, [0, 2]]).max() < 1e-12 and np.abs(b[:, 7:13]).max() < 1e-2
+
+
 def test_axis_angle_orientation(tmp_path):
     p = tmp_path / "tilted.xml"
     p.write_text('<XML><MOBY><Sphere id="s" radius="1" mass="1"/><Plane id="p"/><RigidBody id="b" position="0 2 0" aangle="0 0 2 1.5707963267948966">'
