@@ -172,10 +172,12 @@ def config4_leg(torch, nboxes=4, B=1024):
                         "pivots_mean": float(r["pivots"].mean()), "pivots_max": int(r["pivots"].max()),
                         "worlds_with_errors": int(((r["status"] & ~2) != 0).sum())}
             w = ib.lu_work(reset=True).sum(axis=0)
-            res[tag]["roofline"] = {"bound": "mfma", "achieved": w[0] / (ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            res[tag]["roofline"] = {"bound": "fp64_valu", "achieved": w[0] / (ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": w[0] / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
+                                    "model_flops": float(w[0]), "executed_flops": float(w[2]), "executed_tflops": w[2] / (ms * 1e-3) / 1e12,
                                     "hbm": {"achieved": w[1] / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": w[1] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                                    "model": "one dgesv per pivot: 2/3 k^3 flops, 8 k^2 bytes (SURVEY 8d), counted on the device"}
+                                    "model": "achieved = MODEL flops (one dense dgesv per pivot: 2/3 k^3 flops, 8 k^2 bytes, SURVEY 8d) over time; executed_flops = what the "
+                                             "factorisation routines issue (no MFMA: FP64 vector ALU, unfused), both counted on the device"}
             s2 = r["state"].reshape(B, nboxes, 13); s2[:, :, 8] += -9.81e-3      # gravity acts for another dt
             ib.upload(s2.reshape(B, -1), cs)
         ib.close()
@@ -224,8 +226,8 @@ def config4_cpu_sample_collect(proc, nboxes, timeout=400):
 
 
 def config4_full_step_leg(torch, nboxes, B, steps, cpu_proc=None):
-    """BASELINE config 4 as FULL simulator steps (include/moby_hip_stack.h) at the size this build states and tests
-    (tests/test_big_gpu.py::test_config4_stated_size_full_batch): B stacks of `nboxes` boxes, each step = conservative advancement
+    """BASELINE config 4 as FULL simulator steps (include/moby_hip_stack.h) at the bench size (16 boxes, n = 512;
+    tests/test_big_gpu.py::test_config4_bench_size_full_batch): B stacks of `nboxes` boxes, each step = conservative advancement
     + contact generation + process_constraints over every island + stabilisation, all on the device.  The first step is cold.
     `roofline`: the solver chain's factorisations priced as SURVEY 8(d) does -- one dgesv per pivot (LCP.cpp:120, :837-838),
     2/3 k^3 flops over 8 k^2 bytes, counted on the device (mh_big_batch_lu_work) -- over the wall time of the step (the block
@@ -244,29 +246,37 @@ def config4_full_step_leg(torch, nboxes, B, steps, cpu_proc=None):
             rows = float(aux["lcp_rows"].astype(np.int64).sum()) - (prev if prev is not None else 0.0)
             prev = float(aux["lcp_rows"].astype(np.int64).sum())
             res["steps"].append({"s": dt_s, "world_steps_per_sec": B / dt_s, "lcp_rows_per_sec": rows / dt_s})
-        work = bb.lu_work().sum(axis=0)
+        wk = bb.lu_work()
+        work = wk.sum(axis=0)
         res["worlds_with_errors"] = int(((aux["status"] & ~2) != 0).sum())
+        # how busy the solver kept the chip: seconds workgroups spent on problems (every ladder attempt) over slots x wall time.  Slots: the
+        # Lemke kinds' kernel holds 3 workgroups per CU (256 threads each), the lcp_fast kinds' one per CU -- priced against the larger number
+        slots = 3 * torch.cuda.get_device_properties(0).multi_processor_count
+        res["idle"] = {"solver_workgroup_seconds": float(work[3]), "wall_seconds": total_s, "mean_busy_workgroups": float(work[3]) / total_s, "slots": slots,
+                       "idle_frac": 1.0 - float(work[3]) / (total_s * slots),
+                       "slowest_world_solver_seconds": float(wk[:, 3].max()), "mean_world_solver_seconds": float(wk[:, 3].mean())}
         res["pivots_per_world_step"] = float(aux["lcp_pivots"].astype(np.int64).mean()) / steps
         res["world_steps_per_sec"] = B * steps / total_s
         res["lcp_rows_per_sec"] = prev / total_s
         tf = work[0] / total_s / 1e12; gbs = work[1] / total_s / 1e9
-        res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+        res["roofline"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
                            "traffic": None, "kernel": "mh::blk::k_lcp_block<1> / <0> (the workgroup-per-problem LCP solver: lcp_lemke / lcp_fast kinds)",
                            "seconds": total_s, "model_flops": float(work[0]), "model_bytes": float(work[1]),
+                           "executed_flops": float(work[2]), "executed_tflops": float(work[2]) / total_s / 1e12, "executed_frac_of_unfused_peak": float(work[2]) / total_s / 1e12 / (FP64_PEAK_TFLOPS / 2),
                            "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
-                           "model": "every factorisation (one per pivot) as a dense dgesv: 2/3 k^3 flops, 8 k^2 bytes (SURVEY 8d); FP64 vector = matrix peak, "
-                                    "the kernels run unfused (half of it) and skip the exact zeros of Lemke's bases, so executed flops are far fewer"}
+                           "model": "achieved = MODEL flops: every factorisation (one per pivot) as a dense dgesv, 2/3 k^3 flops, 8 k^2 bytes (SURVEY 8d); the kernels "
+                                    "execute no MFMA (FP64 matrix peak = FP64 vector peak on gfx950), run unfused (half of the peak) and perform only the part of a dgesv "
+                                    "that Lemke's mostly-slack bases need: executed_flops"}
         # HBM bytes of the block solver's kernels in one such step, from the committed counter passes (not a measurement of this run)
         try:
             import glob
             src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_[a-z]_config4_step_pmc.json")))[-1]     # the latest session's cut
             t = json.load(open(src))
-            if ("%d-box" % nboxes) in t["workload"] and ("x %d worlds" % B) in t["workload"] and steps == 1:
+            if ("%d-box" % nboxes) in t["workload"] and ("x %d worlds" % B) in t["workload"]:
                 ks = [v for k, v in t["kernels"].items() if "k_lcp_block" in k]
                 res["roofline"]["traffic"] = 1e9 * sum(v.get("fetch_GB", 0.0) + v.get("write_GB", 0.0) for v in ks)
                 res["roofline"]["counter_profile"] = {"commit": t["commit"], "source": "profiles/" + os.path.basename(src), "seconds_under_profiler": sum(v["seconds"] for v in ks),
-                                                      "note": "FETCH_SIZE + WRITE_SIZE of mh::blk / mh::blkw::k_lcp_block over one step; against model_bytes: the panels of every "
-                                                              "factorisation stream the columns to their right through HBM"}
+                                                      "note": "FETCH_SIZE + WRITE_SIZE of mh::blk / mh::blkw::k_lcp_block over ONE cold step (the first of this leg's)"}
         except (OSError, KeyError, ValueError):
             pass
         bb.close()
@@ -289,7 +299,7 @@ def artic_roofline(tflops, ms):
                  "source": "profiles/r02_f_artic_issue.json (worlds %d, steps %d)" % (t["worlds"], t["steps"])}
     except (OSError, KeyError, ValueError):
         pass
-    return {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS, "traffic": None,
+    return {"bound": "fp64_valu", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS, "traffic": None,
             "kernel": "mh::artic::k_artic_step_w4", "kernel_avg_us": ms * 1e3, "launches": 1, "issue": issue,
             "model": "21 kflop per world-step (estimate) / launch time against the FP64 vector = matrix peak; the kernel is bound by LDS round trips "
                      "per wave (6-36 of 64 lanes busy, half of the wave cycles on s_waitcnt), not by arithmetic or HBM"}
@@ -491,7 +501,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--no-config5", action="store_true")
-    ap.add_argument("--config4-boxes", type=int, default=16, help="box stack height of the config-4 full-step leg (n = 32 x boxes; 16 = the stated size)")
+    ap.add_argument("--config4-boxes", type=int, default=16, help="box stack height of the config-4 full-step leg (n = 32 x boxes; 16 = the bench size, n = 512: BASELINE names 64 boxes, which the reference's own solver chain cannot solve -- DESIGN 4.2)")
     ap.add_argument("--config4-worlds", type=int, default=1024)
     ap.add_argument("--config4-steps", type=int, default=1)
     ap.add_argument("--no-long-horizon", action="store_true")

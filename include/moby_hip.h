@@ -222,7 +222,8 @@ typedef struct mh_world_aux {
 /* test hooks: key 1 = edge of the LDS-resident LU block of the world kernel (0..64, clamped to what the
  * kernel variant holds: 12 or 16; 0 sends every LU factorisation through the HBM workspace path) */
 int  mh_debug_set(int key, int value);   /* key 2: block LCP solver (n > 64) thread geometry -- 0 choose by n and B,
-                                            1 = 256 threads per problem, 2 = 1024 threads per problem;
+                                            1 = 256 threads per problem, 2 = 1024 threads per problem, 3 / 4 = 64 / 128 threads per problem
+                                            (the lcp_lemke kinds with n <= 512 only; the lcp_fast kinds keep the choice of 0);
                                             key 3: lcp_lemke's bases (n > 64) through the structure-exploiting LU (1, default) or the dense one (0);
                                             key 4: the Lemke ladder of the island pipeline in sequence (0), as (world, attempt) tasks (1),
                                                    tasks started beside lcp_fast when n >= 256 (2, default);

@@ -66,8 +66,11 @@ int mh_impact_batch_lcp_size(const mh_impact_batch* ib);
 int mh_impact_batch_debug_lcp(mh_impact_batch* ib, double* MM, double* qq);
 /* Measurement aid: per world, the work SURVEY 8(d) prices the solver chain at -- every factorisation of the workgroup-per-problem
  * solver (one per pivot: src/LCP.cpp:120 for lcp_fast's k x k nonbasic block, :837-838 for lcp_lemke's n x n basis) counted as a
- * dense dgesv, 2/3 k^3 flops over 8 k^2 bytes, whatever the kernels skip of it.  work: B x 2 doubles (flops, bytes), accumulated
- * since the batch was created or last reset (reset != 0 zeroes the counters after the copy).  LCPs of at most 64 rows are not counted. */
+ * dense dgesv, 2/3 k^3 flops over 8 k^2 bytes, whatever the kernels skip of it.  work: B x 4 doubles, accumulated since the batch
+ * was created or last reset (reset != 0 zeroes the counters after the copy): [0] those model flops, [1] those model bytes, [2] the
+ * flops the factorisation routines really issue (the structure-exploiting LU of Lemke's bases performs a small part of a dgesv), [3] the
+ * seconds workgroups spent on the world's problems, every attempt of the Lemke ladder included (summed over a batch and divided by
+ * resident workgroups x wall time: how busy the solver kept the chip).  LCPs of at most 64 rows are not counted. */
 int mh_impact_batch_lu_work(mh_impact_batch* ib, double* work, int reset);
 /* checkpoint / resume: what the handler keeps between calls -- _zlast (B*n), its size (B), the rand()
  * streams (B*MH_RAND_WORDS) and the sticky status bits (B).  The reference's XML pickle drops _zlast, so a resumed run

@@ -124,7 +124,7 @@ int mh_big_batch_step(mh_big_batch* bb, void* stream, double dt, int nsteps);
 int mh_big_batch_stabilize(mh_big_batch* bb, void* stream);
 int mh_big_batch_download(mh_big_batch* bb, double* state, mh_world_aux* aux);
 int mh_big_batch_lcp_capacity(const mh_big_batch* bb);
-/* the handlers' solver chain priced as SURVEY 8(d) does (see mh_impact_batch_lu_work): B x 2 doubles (flops, bytes) */
+/* the handlers' solver chain priced as SURVEY 8(d) does (see mh_impact_batch_lu_work): B x 4 doubles */
 int mh_big_batch_lu_work(mh_big_batch* bb, double* work, int reset);
 /* checkpoint / resume: _zlast, _z (B x capacity each) and their sizes (B each: zlast_size, zbuf_size, zbuf_cap) */
 int mh_big_batch_save_solver_state(mh_big_batch* bb, double* zlast, double* zbuf, int* sizes3);

@@ -179,7 +179,7 @@ int mh_g_debug_repeats = 1;  // mh_debug_set(5, v): 1 = lcp_fast (n > 64) skips 
 int mh_g_debug_sched = 1;    // mh_debug_set(7, v): 1 = the ladder's tasks are handed out by need (pick_task), 0 = by block index, attempt-major
 int mh_g_debug_reuse = 1;    // mh_debug_set(6, v): 1 = the structure-exploiting LU keeps the factors of the columns before the one a Lemke pivot changed, 0 = factorises from scratch
 int mh_g_debug_compact = 1;  // mh_debug_set(3, v): 1 = Lemke's bases through the structure-exploiting LU (mh_lu_compact.inc), 0 = dense LU only
-int mh_g_debug_blk = 0;      // mh_debug_set(2, v): 0 = choose, 1 = 256-thread block solver, 2 = 1024-thread block solver
+int mh_g_debug_blk = 0;      // mh_debug_set(2, v): 0 = choose, 1 = 256-thread block solver, 2 = 1024-thread block solver, 3 = one wavefront per problem (lcp_lemke kinds, n <= 512)
 int mh_g_debug_ka = 64;          // LDS LU block edge of the world kernel (clamped to the variant MHW_KA_V); mh_debug_set(1, 0) forces the HBM workspace path
 int mh_cu_count()
 {
@@ -249,8 +249,13 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     if (kind == MH_LCP_LEMKE || kind == MH_LCP_LEMKE_REG) wide = n > 512 || (n >= 192 && B <= mh_cu_count());
     if (wave_only == 2) wide = false;
     if (mh_g_debug_blk == 1) wide = false; else if (mh_g_debug_blk == 2) wide = true;
+    // the lcp_lemke kinds, n <= 512, far more problems than CUs: one wavefront per problem (mh_lcp_blk1.hip)
+    const bool lemke_kind = kind == MH_LCP_LEMKE || kind == MH_LCP_LEMKE_REG;
+    const bool one_wave = lemke_kind && n <= 512 && (mh_g_debug_blk == 3 || (mh_g_debug_blk == 0 && B >= MH_BLK1_MIN_PER_CU * mh_cu_count()));
+    const bool two_waves = lemke_kind && n <= 512 && (mh_g_debug_blk == 4 || (mh_g_debug_blk == 0 && B >= MH_BLK2_MIN_PER_CU * mh_cu_count()));
+    auto launcher = two_waves ? mh_launch_lcp_blk2 : one_wave ? mh_launch_lcp_blk1 : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk);
     if (wsd && wsi) {
-      const hipError_t le = (wave_only == 1) ? hipSuccess : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
+      const hipError_t le = (wave_only == 1) ? hipSuccess : launcher(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
                                    trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2), work, 0, nullptr);
       MH_HIP(le);
       if (n_arr) {          // the problems of this call that fit one wavefront (n_arr[b] <= 64) take the wave solver
@@ -267,7 +272,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     MH_HIP(hipMallocAsync((void**)&wsd, nd * sizeof(double), (hipStream_t)stream));
     hipError_t e = hipMallocAsync((void**)&wsi, ni * sizeof(int), (hipStream_t)stream);
     if (e != hipSuccess) { (void)hipFreeAsync(wsd, (hipStream_t)stream); return fail(MH_ERR_HIP, "workspace allocation failed: %s", hipGetErrorString(e)); }
-    const hipError_t le = (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
+    const hipError_t le = launcher(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
                                    trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2), work, 0, nullptr);
     e = le;
     (void)hipFreeAsync(wsd, (hipStream_t)stream); (void)hipFreeAsync(wsi, (hipStream_t)stream);
@@ -336,7 +341,7 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 extern "C" int mh_debug_set(int key, int value)
 {
   if (key == 1) { if (value < 0 || value > 64) return fail(MH_ERR_INVALID_ARG, "LU block edge outside [0, 64]"); mh_g_debug_ka = value; return MH_OK; }
-  if (key == 2) { if (value < 0 || value > 2) return fail(MH_ERR_INVALID_ARG, "block solver geometry outside {0, 1, 2}"); mh_g_debug_blk = value; return MH_OK; }
+  if (key == 2) { if (value < 0 || value > 4) return fail(MH_ERR_INVALID_ARG, "block solver geometry outside {0, 1, 2, 3, 4}"); mh_g_debug_blk = value; return MH_OK; }
   if (key == 4) { if (value < 0 || value > 2) return fail(MH_ERR_INVALID_ARG, "ladder-task switch outside {0, 1, 2}"); mh_g_debug_tasks = value; return MH_OK; }
   if (key == 7) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "task-scheduling switch outside {0, 1}"); mh_g_debug_sched = value; return MH_OK; }
   if (key == 6) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "factor-reuse switch outside {0, 1}"); mh_g_debug_reuse = value; return MH_OK; }

@@ -47,7 +47,7 @@ MH_HIDDEN int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
                                       int32_t* trace, int trace_cap, int* trace_len,
                                       const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i,
                                       const int* n_arr,    // n_arr: per-problem sizes (<= n, M compact with ld = its n) or NULL
-                                      double* work = nullptr,    // B x 2 doubles or NULL: += the 2/3 k^3 flops / 8 k^2 bytes of every factorisation (n > 64)
+                                      double* work = nullptr,    // B x MH_WORK doubles or NULL: += the 2/3 k^3 flops / 8 k^2 bytes of every factorisation (n > 64), issued flops, ticks
                                       int wave_only = 0);        // 1: only the problems of at most 64 rows (n_arr) -- the caller runs the others itself; 2: the block solver in its
                                                                  // narrow geometry (the caller has other workgroups on the chip for it to share the CUs with)
 extern MH_HIDDEN int mh_g_debug_repeats;             // mh_debug_set(5, v)
@@ -58,6 +58,9 @@ extern MH_HIDDEN int mh_g_debug_tasks;               // mh_debug_set(4, v): the 
 
 // the workgroup-per-problem LCP solver, one translation unit per thread geometry (mh_lcp_blk.hip: 256 threads, mh_lcp_blkw.hip: 1024)
 namespace mh { struct LcpParams; struct Pow10Table; }
+// per-problem work counters of the block solver (mh_*_batch_lu_work): [0] model flops, [1] model bytes (one dgesv per pivot),
+// [2] flops the factorisation routines issue, [3] wall-clock ticks (device) / seconds (as returned to the caller) spent on the problem
+#define MH_WORK 4
 // task mode of the block solver's lcp_lemke kinds: bit 30 of a task's z_size_out = the attempt left through lcp_lemke's trivial exit
 // (LCP.cpp:578) and would not have drawn from rand() whatever z.size() it was entered with (k_ladder_select)
 #define MH_TASK_NODRAW 0x40000000
@@ -66,6 +69,12 @@ namespace mh { struct LcpParams; struct Pow10Table; }
   const mh::LcpParams* P, const mh::Pow10Table* p10, double* wsd, int* wsi, const int* run_if, const int* n_arr, int flags, double* work, int task_worlds, int* solved_at
 MH_HIDDEN hipError_t mh_launch_lcp_blk(MH_LCP_BLOCK_LAUNCH_ARGS);
 MH_HIDDEN hipError_t mh_launch_lcp_blkw(MH_LCP_BLOCK_LAUNCH_ARGS);
+#define MH_BLK2_MIN_PER_CU 4      /* problems (worlds of a ladder launch) per CU from which the lcp_lemke kinds take the 128-thread geometry: four problems share
+                                     a CU there (measured, 16-box stacks: 363 k pivots/s on a full chip against 262 k with 256 threads at two per CU and 323 k
+                                     with the round-3 right-looking LU at three; below that the 256-thread geometry finishes a problem sooner) */
+#define MH_BLK1_MIN_PER_CU 1000000   /* problems per CU from which the one-wave geometry is chosen by itself (tuned by measurement; off until then) */
+MH_HIDDEN hipError_t mh_launch_lcp_blk1(MH_LCP_BLOCK_LAUNCH_ARGS);
+MH_HIDDEN hipError_t mh_launch_lcp_blk2(MH_LCP_BLOCK_LAUNCH_ARGS);   // two wavefronts per problem (lcp_lemke kinds, n <= 512, large batches)   // one wavefront per problem (lcp_lemke kinds, n <= 512, large batches)
 
 // the three size variants of the many-worlds kernel, one translation unit each (mh_world_{small,wheel,large}.hip)
 typedef void (*mh_world_kernel)(const mh_scene*, int, double, int, double*, mh_world_aux*, double*, int, double*, int, unsigned long long*, const int*);

@@ -53,7 +53,7 @@ struct mh_imp_core {
   // rand() scratch, model work; solved_at per world.  Allocated on first use for t_cap tasks.
   void* s2; void* ev0; void* ev1;                   // second stream + events: the ladder's tasks beside lcp_fast (speculation, core_solve_round)
   double* t_wsd; int* t_wsi; double* t_z; int* t_st; unsigned* t_piv; int* t_zsz; uint32_t* t_rng; double* t_work; int* solved_at; long t_cap;
-  double* work;                                     // B x 2: SURVEY 8(d)'s model work of the block solver's factorisations (2/3 k^3 flops, 8 k^2 bytes), accumulated
+  double* work;                                     // B x MH_WORK (mh_host.h): SURVEY 8(d)'s model work of the block solver's factorisations (2/3 k^3 flops, 8 k^2 bytes), accumulated
   int* hmax;                                        // pinned host copy of maxisl
   void* allocs[64]; int nallocs;
 };

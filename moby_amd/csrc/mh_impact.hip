@@ -1215,7 +1215,7 @@ int mh_imp_core_create(mh_imp_core* c, int B, int nb, int ncmax, int nk, int nma
   c->piv1 = (unsigned*)A(sB * 4, true); c->piv2 = (unsigned*)A(sB * 4, true);
   c->imp = (double*)A(sB * snc * 3 * 8, true);
   c->cnt = (unsigned long long*)A(sB * 5 * 8, true);
-  c->work = (double*)A(sB * 2 * 8, true);
+  c->work = (double*)A(sB * MH_WORK * 8, true);
   double* dcos = (double*)A(c->kh * 8, false); double* dsin = (double*)A(c->kh * 8, false);
   c->nk4 = (nk > 4) ? (nk + 4) / 4 : 1;                                     // ICH-AP:113-118
   double* acos_ = (double*)A(c->nk4 * 8, false); double* asin_ = (double*)A(c->nk4 * 8, false);
@@ -1294,11 +1294,16 @@ void k_ladder_select(Dev d, const int* __restrict__ need, int R, int* __restrict
       const int zo = d.t_zsz[i];
       if (zs != n && !(zo & MH_TASK_NODRAW)) draws += n;       // (lcp_lemke's trivial exit, LCP.cpp:578, returns before the draws of :618-620)
       total += d.t_piv[i]; zs = zo & ~MH_TASK_NODRAW; last = r;
-      wf += d.t_work[2 * i]; wb += d.t_work[2 * i + 1];
+      wf += d.t_work[MH_WORK * i]; wb += d.t_work[MH_WORK * i + 1];
       if (st == 1) { chosen = r; break; }
     }
     lst[w] = (chosen >= 0) ? 1 : 0; piv[w] = total; d.zsz[w] = zs;
-    d.work[2 * (size_t)w] += wf; d.work[2 * (size_t)w + 1] += wb;
+    d.work[MH_WORK * (size_t)w] += wf; d.work[MH_WORK * (size_t)w + 1] += wb;
+    for (int r = 0; r < R; r++) {                                  // issued flops and time: every attempt that ran, selected or not
+      const size_t i = (size_t)r * B + w;
+      if (d.t_st[i] == -1) continue;
+      d.work[MH_WORK * (size_t)w + 2] += d.t_work[MH_WORK * i + 2]; d.work[MH_WORK * (size_t)w + 3] += d.t_work[MH_WORK * i + 3];
+    }
     uint32_t* rg = d.rng + (size_t)w * MH_RAND_WORDS;            // glibc TYPE_3, as mh_rand_next
     unsigned idx = rg[31];
     for (long k = 0; k < draws; k++) { rg[idx] = rg[idx] + rg[(idx + 28) % 31]; idx = (idx + 1) % 31; }
@@ -1321,7 +1326,7 @@ static int core_ladder_alloc(mh_imp_core* c, long ntasks)
   bool ok = hipMalloc((void**)&c->t_wsd, nt * (n * n + 5 * n) * 8) == hipSuccess && hipMalloc((void**)&c->t_wsi, nt * 4 * n * 4) == hipSuccess
          && hipMalloc((void**)&c->t_z, nt * n * 8) == hipSuccess && hipMalloc((void**)&c->t_st, nt * 4) == hipSuccess
          && hipMalloc((void**)&c->t_piv, nt * 4) == hipSuccess && hipMalloc((void**)&c->t_zsz, nt * 4) == hipSuccess
-         && hipMalloc((void**)&c->t_rng, nt * MH_RAND_WORDS * 4) == hipSuccess && hipMalloc((void**)&c->t_work, nt * 2 * 8) == hipSuccess;
+         && hipMalloc((void**)&c->t_rng, nt * MH_RAND_WORDS * 4) == hipSuccess && hipMalloc((void**)&c->t_work, nt * MH_WORK * 8) == hipSuccess;
   if (ok && !c->solved_at) ok = hipMalloc((void**)&c->solved_at, 3 * (size_t)c->B * 4) == hipSuccess;   // + next attempt, attempts over (mh_lcp_block.h pick_task)
   if (ok) ok = hipMemset(c->t_rng, 0, nt * MH_RAND_WORDS * 4) == hipSuccess;
   if (!ok) {                                                      // no room: the caller runs the ladder in sequence
@@ -1360,13 +1365,15 @@ static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& 
   MH_HIP(hipMemsetAsync(c->solved_at, 0x7f, (size_t)B * 4, st));
   MH_HIP(hipMemsetAsync(c->solved_at + B, 0, 2 * (size_t)B * 4, st));
   if (sched) MH_HIP(hipMemsetAsync(c->t_st, 0xff, (size_t)L.ntasks * 4, st));                     // -1: never handed out
-  MH_HIP(hipMemsetAsync(c->t_work, 0, (size_t)L.ntasks * 16, st));
+  MH_HIP(hipMemsetAsync(c->t_work, 0, (size_t)L.ntasks * MH_WORK * 8, st));
   mh::LcpParams P; P.kind = MH_LCP_LEMKE_REG; P.min_exp = o ? o->min_exp : -20; P.step_exp = o ? o->step_exp : 1u; P.max_exp = o ? o->max_exp : 1;
   P.piv_tol = o ? o->piv_tol : -1.0; P.zero_tol = o ? o->zero_tol : -1.0;
   static const mh::Pow10Table p10 = [] { mh::Pow10Table t; for (int i = 0; i < 64; i++) t.v[i] = std::pow(10.0, (double)(i - 32)); return t; }();
   // the ladder offers B x (8-12) useful workgroups at once: the narrow geometry (three problems per CU) unless its compact path does not take n
   const bool wide = mh_g_debug_blk ? mh_g_debug_blk == 2 && n >= 192 : n > 512;
-  const hipError_t le = (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk)(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
+  const bool one_wave = n <= 512 && (mh_g_debug_blk == 3 || (mh_g_debug_blk == 0 && L.ntasks >= (long)MH_BLK1_MIN_PER_CU * mh_cu_count()));
+  const bool two_waves = n <= 512 && (mh_g_debug_blk == 4 || (mh_g_debug_blk == 0 && B >= MH_BLK2_MIN_PER_CU * mh_cu_count()));   // (B worlds: the ladder then runs in sequence per world, paced by throughput)
+  const hipError_t le = (two_waves ? mh_launch_lcp_blk2 : one_wave ? mh_launch_lcp_blk1 : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk))(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
       c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2) | (sched ? 8 : 0), c->t_work, B, c->solved_at);
   MH_HIP(le);
   return MH_OK;
@@ -1642,8 +1649,13 @@ int mh_impact_batch_download(mh_impact_batch* ib, double* state, double* impulse
 int mh_imp_core_lu_work(mh_imp_core* c, double* work, int reset)
 {
   MH_HIP(hipDeviceSynchronize());
-  if (work) MH_HIP(hipMemcpy(work, c->work, (size_t)c->B * 2 * 8, hipMemcpyDeviceToHost));
-  if (reset) MH_HIP(hipMemset(c->work, 0, (size_t)c->B * 2 * 8));
+  if (work) {
+    MH_HIP(hipMemcpy(work, c->work, (size_t)c->B * MH_WORK * 8, hipMemcpyDeviceToHost));
+    int dev = 0, khz = 0;                                          // [3]: ticks of the constant-rate wall clock -> seconds
+    MH_HIP(hipGetDevice(&dev)); MH_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    for (int b = 0; b < c->B; b++) work[MH_WORK * (size_t)b + 3] = (khz > 0) ? work[MH_WORK * (size_t)b + 3] / (1e3 * (double)khz) : 0.0;
+  }
+  if (reset) MH_HIP(hipMemset(c->work, 0, (size_t)c->B * MH_WORK * 8));
   return MH_OK;
 }
 

@@ -11,7 +11,7 @@
 #define MH_BLK_PANEL_CAP 1792
 #define MH_BLK_CN 512
 #ifndef MH_BLK_WAVES
-#define MH_BLK_WAVES 3
+#define MH_BLK_WAVES 2
 #endif
 #define MH_BLK_KATTR __attribute__((amdgpu_waves_per_eu(MH_BLK_WAVES, MH_BLK_WAVES)))
 #define MH_BLK_LAUNCHER mh_launch_lcp_blk

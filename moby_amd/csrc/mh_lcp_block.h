@@ -25,6 +25,7 @@
 // -DMH_BLK_PROF: panel 30 %, trailing update 27 %, solves 12 %.
 // No include guard: one translation unit per thread geometry (mh_lcp_blk.hip, mh_lcp_blkw.hip) defines MH_BLK_NS / MH_BLK_T / ...
 // and MH_BLK_LAUNCHER and includes this file; each compiles two kernels (the lcp_fast kinds, the lcp_lemke kinds).
+#include <type_traits>
 #include "mh_lcp_wave.h"
 #include "mh_host.h"
 
@@ -53,8 +54,11 @@ MH_DEV size_t ws_ints(int n) { return 4 * (size_t)n; }
 
 // SURVEY 8(d)'s model of one factorisation (LCP.cpp:120, :837-838): dgesv of a k x k matrix = 2/3 k^3 flops over 8 k^2 bytes,
 // whatever this build skips of it; summed per problem for the roofline figures of bench.py (thread 0 only)
-__shared__ double s_work[2];
+// [2]: the flops the factorisation routines really ISSUE (every lane-operation of their update loops, masked rows included; the exact
+// zeros they skip are not in it), [3]: ticks of the constant-rate wall clock this workgroup spent on the problem
+__shared__ double s_work[MH_WORK];
 MH_DEV void account_lu(int k) { if (threadIdx.x == 0) { const double kk = (double)k; s_work[0] += (2.0 / 3.0) * kk * kk * kk; s_work[1] += 8.0 * kk * kk; } }
+MH_DEV void account_issued(double flops) { if (threadIdx.x == 0) s_work[2] += flops; }
 __shared__ double s_bd[4];
 __shared__ int s_bi[4];
 __shared__ unsigned s_rng[32];
@@ -192,10 +196,16 @@ constexpr int TCOLS = MH_BLK_TCOLS;      // trailing-update columns a thread has
 constexpr int PANEL_CAP = MH_BLK_PANEL_CAP;   // doubles (14 / 28 KB): rows x NB of the panel held in LDS
 __shared__ double s_u[NB][UCH + 8];          // (+ 8: the padding group of the compact LU's update lists)
 __shared__ int s_li[UCH + 16];
-constexpr int LIST_CAP = 1024;
+#ifndef MH_BLK_LIST_CAP
+#define MH_BLK_LIST_CAP 1024
+#endif
+constexpr int LIST_CAP = MH_BLK_LIST_CAP;
 __shared__ int s_list[LIST_CAP];
 __shared__ double s_panel[PANEL_CAP];
-constexpr int RHS_CAP = 1024;            // the right-hand side stays in LDS for the whole factorisation when k fits
+#ifndef MH_BLK_RHS_CAP
+#define MH_BLK_RHS_CAP 1024
+#endif
+constexpr int RHS_CAP = MH_BLK_RHS_CAP;  // the right-hand side stays in LDS for the whole factorisation when k fits
 __shared__ double s_b[RHS_CAP];
 __shared__ int s_ipiv[NB];
 // Exact skips of the trailing update.  a <- a - l*u leaves a as it is (up to the sign of a zero) when l == 0 or
@@ -349,6 +359,7 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
     bp_tock(BP_SWAP, tp); tp = bp_tick();
     const int c0 = j0 + nbk;                               // first trailing column
     if (c0 >= k) break;
+    account_issued(2.0 * (double)nbk * (double)(k - c0) * (double)(k - c0) + (double)nbk * (double)nbk * (double)(k - j0));
     if (t == 0) { s_sk[0] = 1; s_sk[1] = 1; s_sk[2] = 1; s_sk[3] = 1; }
     sync();
     { bool z = true, f = true;
@@ -909,7 +920,8 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   W.A = wd; W.b = wd + (size_t)n * n; W.w = W.b + n; W.x = W.w + n; W.d = W.x + n; W.art = W.d + n;
   W.list = wi; W.flag = wi + n; W.pos = wi + 2 * (size_t)n; W.bv = wi + 3 * (size_t)n;
   if (t < 32) s_rng[t] = rngg[(size_t)b * MH_RAND_WORDS + t];
-  if (t == 0) { s_luc_bug = 0; s_work[0] = 0.0; s_work[1] = 0.0; s_nodraw = 0; }
+  if (t == 0) { s_luc_bug = 0; s_work[0] = 0.0; s_work[1] = 0.0; s_work[2] = 0.0; s_work[3] = 0.0; s_nodraw = 0; }
+  const unsigned long long t_task = wall_clock64();
   Mat M; M.M = Mg + (size_t)bw * strideM; M.ld = ld; M.n = n;
   const double* q = qg + (size_t)bw * nstride;
   double* z = zg + (size_t)b * nstride;
@@ -927,11 +939,11 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   if (task.rung >= 0 && ok && t == 0) atomicMin(task.solved_at, task.rung);
   sync();
 #ifdef MH_BLK_PROF
-  if (t == 0 && (b == 0 || b == 5)) printf("blk prof (cycles, block %d, %u pivots, %llu ticks in all): list %llu gather %llu panel %llu swap %llu trail %llu solve %llu gemv %llu randmin %llu compact %llu [setup %llu panel %llu u12 %llu trail %llu back %llu; dense steps %llu panels %llu]\n", b, piv, bp_tick() - t_kernel,
+  if (t == 0 && (b == 0 || b == 5)) printf("blk prof (cycles, block %d, %u pivots, %.3f ms wall, %llu ticks in all): list %llu gather %llu panel %llu swap %llu trail %llu solve %llu gemv %llu randmin %llu compact %llu [setup %llu panel %llu u12 %llu trail %llu back %llu; dense steps %llu panels %llu]\n", b, piv, (double)(wall_clock64() - t_task) * 1e-5, bp_tick() - t_kernel,
                                s_prof[0], s_prof[1], s_prof[2], s_prof[3], s_prof[4], s_prof[5], s_prof[6], s_prof[7], s_prof[8], s_prof[9], s_prof[10], s_prof[11], s_prof[12], s_prof[13], s_prof[14], s_prof[15]);
 #endif
   if (t < 32) rngg[(size_t)b * MH_RAND_WORDS + t] = s_rng[t];
-  if (t == 0 && work) { work[2 * (size_t)b] += s_work[0]; work[2 * (size_t)b + 1] += s_work[1]; }
+  if (t == 0 && work) { double* wk = work + MH_WORK * (size_t)b; wk[0] += s_work[0]; wk[1] += s_work[1]; wk[2] += s_work[2]; wk[3] += (double)(wall_clock64() - t_task); }
   if (t == 0) {
     if (s_luc_bug) printf("mh_lcp_block: index invariant %d of the compact LU violated (problem %d, n %d)\n", s_luc_bug & 15, b, s_luc_bug >> 4);
     status[b] = s_luc_bug ? -7 : (ok ? 1 : 0);

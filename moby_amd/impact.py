@@ -119,8 +119,9 @@ class ImpactBatch:
             _lib.check(_lib.load().mh_impact_batch_load_noslip_state(self.handle, v.ctypes.data, vs.ctypes.data))
 
     def lu_work(self, reset=False):
-        """(B, 2): flops and bytes of the block solver's factorisations priced as dense dgesv calls (mh_impact_batch_lu_work)."""
-        w = np.zeros((self.B, 2))
+        """(B, 4): model flops and model bytes of the block solver's factorisations priced as dense dgesv calls, the flops its
+        routines really issue, and the seconds its workgroups spent on the world's problems (mh_impact_batch_lu_work)."""
+        w = np.zeros((self.B, 4))
         _lib.check(_lib.load().mh_impact_batch_lu_work(self.handle, w.ctypes.data, int(bool(reset))))
         return w
 

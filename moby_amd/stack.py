@@ -288,8 +288,9 @@ class BigBatch:
         _lib.check(_lib.load().mh_big_batch_load_solver_state(self.handle, zl.ctypes.data, zb.ctypes.data, sz.ctypes.data))
 
     def lu_work(self, reset=False):
-        """(B, 2): flops and bytes of the block solver's factorisations priced as dense dgesv calls (mh_big_batch_lu_work)."""
-        w = np.zeros((self.B, 2))
+        """(B, 4): model flops and model bytes of the block solver's factorisations priced as dense dgesv calls, the flops its
+        routines really issue, and the seconds its workgroups spent on the world's problems (mh_big_batch_lu_work)."""
+        w = np.zeros((self.B, 4))
         _lib.check(_lib.load().mh_big_batch_lu_work(self.handle, w.ctypes.data, int(bool(reset))))
         return w
 

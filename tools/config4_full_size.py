@@ -1,5 +1,5 @@
-"""BASELINE config 4 at the size this build states (16 boxes per world, n = 512 impact LCPs) x 1024 worlds, ONE full
-TimeSteppingSimulator::step: the property test of tests/test_big_gpu.py::test_config4_stated_size_properties at the
+"""BASELINE config 4 at the bench size (16 boxes per world, n = 512 impact LCPs; BASELINE names 64, the reference's chain solves up to 32)
+x 1024 worlds, full TimeSteppingSimulator::step calls: the property test of tests/test_big_gpu.py::test_config4_bench_size_properties at the
 batch size the configuration names.  Prints one JSON line (kept under profiles/).
 python tools/config4_full_size.py [boxes] [worlds]"""
 import json, os, sys, time
