@@ -24,7 +24,8 @@ Prints ONE JSON line on rank 0 with `roofline` (dominant kernel) and
 Informational legs (rank 0, N = 1, outside the timed region): `config4_impact_handler` -- 4-box stacks x1024 through the
 impact-handler entry (include/moby_hip_impact.h), one cold and one warm call; `config4_full_step` -- box stacks as full
 simulator steps (include/moby_hip_stack.h); `config5_ur10` -- the ur10 arm x8192 (include/moby_hip_artic.h);
-`long_horizon` -- the headline batch at steps 4000-4200.
+`config2_full_run` -- the headline batch's whole
+1000-step run from t = 0; `long_horizon` -- the headline batch at steps 4000-4200.
 """
 import argparse
 import json
@@ -416,6 +417,36 @@ def strong_leg(dist, mdist, S, make_batch, B_total, rank, world_size, dev, steps
                     % (count, count / 256.0)}
 
 
+def config2_full_run_leg(torch, S, WorldBatchDevice, B, launches=5, total_steps=1000):
+    """BASELINE config 2 as BASELINE.md states it: sphere-stack x B, the whole 1000-step run from t = 0 (regress/sphere-stack.dat is
+    1000 rows), in `launches` launches of total_steps / launches steps; rows/s and world-steps/s over the WHOLE run, per-launch
+    milliseconds beside them (the run slows down as worlds leave the easy regime: `long_horizon`)."""
+    try:
+        sc = S.sphere_stack_scene()
+        wb = WorldBatchDevice(sc, S.sphere_stack_state_range(0, B))
+        stream = torch.cuda.current_stream().cuda_stream
+        per = total_steps // launches
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
+        torch.cuda.synchronize()
+        evs[0].record()
+        for k in range(launches):
+            wb.step(DT, per, stream); evs[k + 1].record()
+        torch.cuda.synchronize()
+        _, aux = wb.download()
+        ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(launches)]
+        tot = evs[0].elapsed_time(evs[launches]) * 1e-3
+        rows = float(aux["lcp_rows"].astype(np.int64).sum())
+        w0 = wb.download()[0].reshape(B, sc.nb, 13)[0]
+        wb.close()
+        return {"workload": "sphere-stack x%d, steps 0..%d from t = 0 in %d launches (BASELINE.md 4, config 2)" % (B, per * launches, launches),
+                "seconds": tot, "ms_per_launch": ms, "ms_per_step": tot / (per * launches) * 1e3,
+                "lcp_rows_per_sec": rows / tot, "world_steps_per_sec": B * per * launches / tot,
+                "worlds_with_errors": int(((aux["status"] & ~S.MH_WORLD_IMPACT_TOL) != 0).sum()),
+                "world0_heights": [float(w0[b, 2]) for b in range(sc.nb)]}     # regress/sphere-stack.dat:1000: 1, 3, 5
+    except Exception as e:          # noqa: BLE001 -- informational leg
+        return {"error": repr(e)}
+
+
 def long_horizon_leg(torch, wb, stream, B, args):
     """The same batch far from t = 0: advance to step `--long-horizon-start` (untimed), then time 200 steps.  After ~3000
     steps a few worlds per thousand cycle lcp_fast to its pivot cap on every rung of the regularisation ladder
@@ -622,6 +653,7 @@ def main():
     if cpu is not None:
         out["cpu_baseline"] = cpu
     if rank == 0 and world_size == 1 and not args.no_long_horizon:
+        out["config2_full_run"] = config2_full_run_leg(torch, S, WorldBatchDevice, B)   # after the timed region; informational
         out["long_horizon"] = long_horizon_leg(torch, wb, stream, B, args)   # after the timed region; informational
     if rank == 0 and world_size == 1 and not args.no_config4:
         out["config4_impact_handler"] = config4_leg(torch)             # after the timed region; informational

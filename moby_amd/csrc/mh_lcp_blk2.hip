@@ -18,7 +18,7 @@
 #define MH_LL_W 12
 #endif
 #ifndef MH_LL_SPARE
-#define MH_LL_SPARE 3
+#define MH_LL_SPARE 2
 #endif
 #ifndef MH_LL_G
 #define MH_LL_G 8

@@ -26,6 +26,7 @@
 // No include guard: one translation unit per thread geometry (mh_lcp_blk.hip, mh_lcp_blkw.hip) defines MH_BLK_NS / MH_BLK_T / ...
 // and MH_BLK_LAUNCHER and includes this file; each compiles two kernels (the lcp_fast kinds, the lcp_lemke kinds).
 #include <type_traits>
+#include <utility>
 #include "mh_lcp_wave.h"
 #include "mh_host.h"
 

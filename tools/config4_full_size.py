@@ -1,39 +1,80 @@
-"""BASELINE config 4 at the bench size (16 boxes per world, n = 512 impact LCPs; BASELINE names 64, the reference's chain solves up to 32)
-x 1024 worlds, full TimeSteppingSimulator::step calls: the property test of tests/test_big_gpu.py::test_config4_bench_size_properties at the
-batch size the configuration names.  Prints one JSON line (kept under profiles/).
-python tools/config4_full_size.py [boxes] [worlds]"""
+"""BASELINE config 4 through the large-world stepper at a size given on the command line: B stacks of N boxes (impact LCP n = 32 N),
+`steps` full TimeSteppingSimulator::step calls (the first cold, the others warm-started from _zlast).  16 boxes (n = 512) is the bench size;
+BASELINE names 64, which the reference's own solver chain does not solve; 32 is the largest it does.  Prints one JSON line
+(kept under profiles/): per-step seconds, properties of the final state, and -- with --oracle-world W -- the CPU oracle's step of
+world W beside it (flags, pivot counts, state: equal bit for bit or reported as different).
+python tools/config4_full_size.py [boxes] [worlds] [steps] [--oracle-world W]"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from moby_amd import scene as S, stack as K
 
 from moby_amd import _lib
-if os.environ.get("MH_BLK_GEOM"):          # 1 = 256-thread block solver, 2 = 1024-thread (mh_debug_set key 2)
+if os.environ.get("MH_BLK_GEOM"):          # mh_debug_set key 2 (the block solver's thread geometry)
     _lib.check(_lib.load().mh_debug_set(2, int(os.environ["MH_BLK_GEOM"])))
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+N = int(args[0]) if len(args) > 0 else 16
+B = int(args[1]) if len(args) > 1 else 1024
+steps = int(args[2]) if len(args) > 2 else 1
+ow = int(sys.argv[sys.argv.index("--oracle-world") + 1]) if "--oracle-world" in sys.argv else None
 sc = K.box_stack_scene(N)
 st0 = K.box_stack_state(N, B)
-st0[B // 2:] = st0[:B // 2]                                   # second half = copy of the first: batch-order independence
+if B >= 2:
+    st0[B // 2:] = st0[:B // 2]                               # second half = copy of the first: batch-order independence
 bb = K.BigBatch(sc, st0)
-t0 = time.perf_counter()
-bb.step(1e-3, 1)
-st, aux = bb.download()
-secs = time.perf_counter() - t0
+# a step of a large batch can take many minutes without a line of output: keep a heartbeat file growing (gpurun takes silence for a hang)
+import threading
+_stop = threading.Event()
+def _beat():
+    hb = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "config4_heartbeat.txt")
+    try:
+        os.makedirs(os.path.dirname(hb), exist_ok=True)
+        while not _stop.wait(60.0):
+            with open(hb, "a") as f:
+                f.write("%s boxes %d worlds %d alive\n" % (time.strftime("%H:%M:%S"), N, B))
+    except OSError:
+        pass
+threading.Thread(target=_beat, daemon=True).start()
+secs = []
+for k in range(steps):
+    t0 = time.perf_counter()
+    bb.step(1e-3, 1)
+    st, aux = bb.download()
+    secs.append(time.perf_counter() - t0)
+    print("step %d: %.2f s, worlds with errors %d" % (k, secs[-1], int(((aux["status"] & ~S.MH_WORLD_IMPACT_TOL) != 0).sum())), file=sys.stderr, flush=True)
+wk = bb.lu_work()
+cap = bb.cap
 bb.close()
-b = st.reshape(B, N, 13); b0 = st0.reshape(B, N, 13)
+_stop.set()
+b = st.reshape(B, N, 13)
 mass = sc.mass
+h = B // 2 if B >= 2 else B
 out = {
-    "workload": "box stack of %d (impact LCP n = %d) x %d worlds, one full step, dt = 1e-3" % (N, 32 * N, B),
-    "seconds": secs, "world_steps_per_sec": B / secs,
+    "workload": "box stack of %d (impact LCP n = %d) x %d worlds, %d full step%s, dt = 1e-3" % (N, 32 * N, B, steps, "" if steps == 1 else "s (cold, then warm-started)"),
+    "seconds": float(sum(secs)), "seconds_per_step": secs, "world_steps_per_sec": B * steps / float(sum(secs)),
     "worlds_with_errors": int(((aux["status"] & ~S.MH_WORLD_IMPACT_TOL) != 0).sum()),
+    "worlds_lcp_failed": int(((aux["status"] & S.MH_WORLD_LCP_FAILED) != 0).sum()),
+    "status_flags_per_world": [int(x) for x in aux["status"][:min(B, 16)]],
     "worlds_impact_tolerance_warnings": int(((aux["status"] & S.MH_WORLD_IMPACT_TOL) != 0).sum()),
-    "batch_order_independent": bool(np.array_equal(st[B // 2:], st[:B // 2]) and np.array_equal(aux["lcp_pivots"][B // 2:], aux["lcp_pivots"][:B // 2])),
+    "batch_order_independent": bool(B < 2 or (np.array_equal(st[h:2 * h], st[:h]) and np.array_equal(aux["lcp_pivots"][h:2 * h], aux["lcp_pivots"][:h]))),
     "max_height_error": float(np.abs(b[:, :, 1] - 0.5 - np.arange(N)).max()),
-    "max_speed_after_step": float(np.abs(b[:, :, 7:13]).max()),
-    # momentum: gravity adds -m g dt per body per step; what is left of it after the impact is carried by the ground
-    "max_abs_vertical_momentum_after_step": float(np.abs((mass[None, :] * b[:, :, 8]).sum(axis=1)).max()),
+    "max_speed_after_last_step": float(np.abs(b[:, :, 7:13]).max()),
     "lcp_rows_mean": float(aux["lcp_rows"].mean()), "lcp_pivots_mean": float(aux["lcp_pivots"].mean()), "lcp_pivots_max": int(aux["lcp_pivots"].max()),
     "lcp_solves_mean": float(aux["lcp_solves"].mean()), "stab_rows_mean": float(aux["stab_rows"].mean()), "stab_iters_mean": float(aux["stab_iters"].mean()),
+    "solver_workgroup_seconds": float(wk[:, 3].sum()), "slowest_world_solver_seconds": float(wk[:, 3].max()), "mean_world_solver_seconds": float(wk[:, 3].mean()),
+    "model_flops": float(wk[:, 0].sum()), "issued_flops": float(wk[:, 2].sum()),
 }
+if ow is not None:
+    from tests.oracle_api import Oracle
+    o = Oracle(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle.so"))
+    o.lib.oracle_dbg_lemke_compact(8)          # lcp_lemke's bases through the bit-equal structure-exploiting model (a dense dgesv of a 2048 x 2048 basis per pivot takes an hour)
+    so = st0[ow].copy(); ao = S.new_aux(1); zl = np.zeros(cap); zb = np.zeros(cap)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        o.big_step(sc, so, ao, 1e-3, 1, zlast=zl, zbuf=zb, cap=cap)
+    out["oracle"] = {"world": ow, "seconds": time.perf_counter() - t0, "status": int(ao["status"][0]), "lcp_pivots": int(ao["lcp_pivots"][0]),
+                     "lcp_solves": int(ao["lcp_solves"][0]), "gpu_status": int(aux["status"][ow]), "gpu_lcp_pivots": int(aux["lcp_pivots"][ow]),
+                     "status_equal": bool(int(ao["status"][0]) == int(aux["status"][ow])),
+                     "state_equal": bool(np.array_equal(so, st[ow])), "rng_equal": bool(np.array_equal(ao["rng"][0], aux["rng"][ow])),
+                     "pivots_equal": bool(int(ao["lcp_pivots"][0]) == int(aux["lcp_pivots"][ow]))}
 print(json.dumps(out))
