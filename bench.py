@@ -250,9 +250,10 @@ def config4_full_step_leg(torch, nboxes, B, steps, cpu_proc=None):
         wk = bb.lu_work()
         work = wk.sum(axis=0)
         res["worlds_with_errors"] = int(((aux["status"] & ~2) != 0).sum())
-        # how busy the solver kept the chip: seconds workgroups spent on problems (every ladder attempt) over slots x wall time.  Slots: the
-        # Lemke kinds' kernel holds 3 workgroups per CU (256 threads each), the lcp_fast kinds' one per CU -- priced against the larger number
-        slots = 3 * torch.cuda.get_device_properties(0).multi_processor_count
+        # how busy the solver kept the chip: seconds workgroups spent on problems (every ladder attempt) over slots x wall time.  Slots: what the
+        # Lemke kinds' kernel holds at once (the lcp_fast kinds' kernel holds one 1024-thread problem per CU: priced against the larger number)
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        slots = (4 if B >= 4 * cus else 2) * cus        # the ladder's tasks: four 128-thread problems per CU from 4 worlds per CU up, else two 256-thread ones (mh_host.h MH_BLK2_MIN_PER_CU)
         res["idle"] = {"solver_workgroup_seconds": float(work[3]), "wall_seconds": total_s, "mean_busy_workgroups": float(work[3]) / total_s, "slots": slots,
                        "idle_frac": 1.0 - float(work[3]) / (total_s * slots),
                        "slowest_world_solver_seconds": float(wk[:, 3].max()), "mean_world_solver_seconds": float(wk[:, 3].mean())}
@@ -534,7 +535,7 @@ def main():
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--config4-boxes", type=int, default=16, help="box stack height of the config-4 full-step leg (n = 32 x boxes; 16 = the bench size, n = 512: BASELINE names 64 boxes, which the reference's own solver chain cannot solve -- DESIGN 4.2)")
     ap.add_argument("--config4-worlds", type=int, default=1024)
-    ap.add_argument("--config4-steps", type=int, default=1)
+    ap.add_argument("--config4-steps", type=int, default=3, help="full steps of the config-4 leg: the first cold, the others warm-started from _zlast")
     ap.add_argument("--no-long-horizon", action="store_true")
     ap.add_argument("--long-horizon-start", type=int, default=4000)
     args = ap.parse_args()

@@ -19,8 +19,8 @@
  *
  * Scope: config 5 is the robot alone (self-collision disabled as in ur10.xml:12: no contact rows, one mini-step per step);
  * optionally sphere primitives on links against a static plane (mh_artic_model.nspheres, no-slip contacts), no actuator torques (controller plugins stay on the host side of the seam: add them
- * through qdd = H^-1 (tau - C) by passing tau).  Constraint stabilisation with joint-limit rows: mh_artic_model.cstab_max_iterations
- * (ur10.xml:11 sets constraint-stabilization-max-iterations = 0 = off).
+ * through qdd = H^-1 (tau - C) by passing tau).  Constraint stabilisation with joint-limit rows and, for bodies with link spheres, contact
+ * rows: mh_artic_model.cstab_max_iterations (ur10.xml:11 sets constraint-stabilization-max-iterations = 0 = off).
  */
 #ifndef MOBY_HIP_ARTIC_H
 #define MOBY_HIP_ARTIC_H
@@ -85,8 +85,10 @@ typedef struct mh_artic_model {
                                                       sets 0 = off; the reference's own default is UINT_MAX, see MH_CSTAB_DEFAULT_MAX_ITERATIONS) */
   /* ConstraintStabilization::stabilize after every step (TSS:97) with the body's JOINT LIMITS as rows (CStab:257-304 add_limit_constraints:
    * one row per finite limit, signed_violation = its distance; L_v = violation - |eps| - NEAR_ZERO, CStab:434-441; MM = L X L',
-   * CStab:932-970; the line search of update_q over the limit slacks, CStab:1056-1216, 1322-1379).  Bodies WITH sphere primitives are
-   * stepped with stabilisation off only (mh_artic_batch_create refuses the combination): the contact rows of the stabiliser are not built. */
+   * CStab:932-970; the line search of update_q over the limit slacks, CStab:1056-1216, 1322-1379).  Bodies WITH sphere primitives add a
+   * contact row per (sphere, plane) pair (CStab:306-345: the synthetic contact "between separated bodies" when the signed distance is
+   * at least NEAR_ZERO, find_contacts' otherwise; Cn_v = distance - |eps| - NEAR_ZERO, CStab:431) and the mixed LCP
+   * MM = [Cn X Cn'  Cn X L'; .  L X L'] (CStab:705-904, 932-970); update_q's line search then evaluates the sphere distances too. */
   double cstab_eps;                                /* ConstraintStabilization::eps ("unilateral-stabilization-tol"), default NEAR_ZERO (CStab:59) */
 } mh_artic_model;
 

@@ -783,9 +783,6 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
     if (!(model->sphere_radius[s] > 0.0)) return fail(MH_ERR_INVALID_ARG, "sphere %d: radius must be > 0", s);
   }
   if (model->cstab_max_iterations < 0) return fail(MH_ERR_INVALID_ARG, "cstab_max_iterations = %d < 0", model->cstab_max_iterations);
-  if (model->cstab_max_iterations != 0 && model->nspheres > 0)
-    return fail(MH_ERR_INVALID_ARG, "constraint stabilisation with link spheres: the stabiliser's contact rows are not built for articulated bodies; "
-                                   "set cstab_max_iterations = 0 (as example/ur10/ur10.xml:11 does)");
   if (model->nspheres > 0) {
     const double* Rp = model->plane_R; const double nn = Rp[1]*Rp[1] + Rp[4]*Rp[4] + Rp[7]*Rp[7];
     if (!(nn > 0.999999 && nn < 1.000001)) return fail(MH_ERR_INVALID_ARG, "plane_R is not a rotation (its +Y column is the plane normal)");
@@ -818,7 +815,7 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
   const size_t sB = (size_t)B;
   bool ok = hipMalloc((void**)&ab->d_model, sizeof(ar::Model)) == hipSuccess && hipMalloc((void**)&ab->d_q, sB * nj * 8) == hipSuccess
          && hipMalloc((void**)&ab->d_qd, sB * nj * 8) == hipSuccess && hipMalloc((void**)&ab->d_aux, sB * sizeof(mh_world_aux)) == hipSuccess;
-  if (ok && model->nspheres > 0 && !(model->cp_mu_coulomb >= 1e2))
+  if (ok && model->nspheres > 0 && (!(model->cp_mu_coulomb >= 1e2) || model->cstab_max_iterations != 0))   // (the stabiliser's LCP with contact AND limit rows lives there too)
     ok = hipMalloc((void**)&ab->d_ws, sB * 2 * MH_LCP_MAX_N_WAVE * MH_LCP_MAX_N_WAVE * sizeof(double)) == hipSuccess;
   if (ok) {
     std::vector<mh_world_aux> a(sB);

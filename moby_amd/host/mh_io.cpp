@@ -680,16 +680,11 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
     m.min_step_size = std::sqrt(2.220446049250313e-16); m.contact_dist_thresh = 1e-6;
     { const Attrs sa = attrs_of(sim); if (sa.has("min-step-size")) m.min_step_size = std::atof(sa.str("min-step-size").c_str()); }
   }
-  // constraint stabilisation (ConstraintSimulator.cpp:574-590): joint-limit rows only -- a body whose link spheres can meet the plane must
-  // switch it off explicitly, as ur10.xml:11 does (the contact rows of the stabiliser are not built: never silently dropped)
+  // constraint stabilisation (ConstraintSimulator.cpp:574-590): joint-limit rows, and contact rows for the link spheres that can meet the plane
   { const Attrs sa = attrs_of(sim);
     m.cstab_eps = std::sqrt(2.220446049250313e-16);
     if (sa.has("unilateral-stabilization-tol")) m.cstab_eps = std::atof(sa.str("unilateral-stabilization-tol").c_str());
-    const bool given = sa.has("constraint-stabilization-max-iterations");
-    const unsigned long mi = given ? std::strtoul(sa.str("constraint-stabilization-max-iterations").c_str(), nullptr, 10) : (unsigned long)MH_CSTAB_DEFAULT_MAX_ITERATIONS;
-    if (m.nspheres > 0 && mi != 0)
-      return fail("%s: link spheres can meet the plane and constraint stabilisation is on (%s): its contact rows are not supported for articulated bodies; "
-                  "set constraint-stabilization-max-iterations=\"0\" (as example/ur10/ur10.xml does)", path, given ? "as written" : "the default");
+    const unsigned long mi = sa.has("constraint-stabilization-max-iterations") ? std::strtoul(sa.str("constraint-stabilization-max-iterations").c_str(), nullptr, 10) : (unsigned long)MH_CSTAB_DEFAULT_MAX_ITERATIONS;
     m.cstab_max_iterations = (int)((mi > 0x7fffffffUL) ? 0x7fffffffUL : mi); }
   if (step_size) { *step_size = 0.0; if (xmlNode* drv = first(root, "DRIVER")) { const Attrs a = attrs_of(drv); if (a.has("step-size")) *step_size = std::atof(a.str("step-size").c_str()); } }
   return 0;

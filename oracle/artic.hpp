@@ -703,13 +703,24 @@ class Artic {
     return h;
   }
 
-  // ---- ConstraintStabilization::stabilize for this body: joint-limit rows (CStab:167-254, 257-304, 434-441, 932-970, 1056-1216) ----
+  // ---- ConstraintStabilization::stabilize for this body: contact rows of the link spheres and joint-limit rows (CStab:167-254, 257-304,
+  // 306-345, 431-441, 705-904, 932-970, 1056-1216) ----
   // evaluate_unilateral_constraints (CStab:88-131): the pairwise distances (none without collision geometry), then for every
   // joint j of body i the limit slacks of joints[i] -- the body's index in the simulator's list, not j (CStab:117, kept): with one
   // articulated body per world that is joint 0, nj times
-  double cstab_eval(std::vector<double>& uC) const {
+  // With sphere primitives on the links the pairwise distances come first (sim->calc_pairwise_distances over the simulator's pair list:
+  // every (sphere, plane) pair, the plane's bounding volume being infinite), each the sphere's signed distance to the plane at the
+  // CURRENT q (SpherePrimitive.cpp:104-136 / PlanePrimitive.cpp:385-411, as CA_step reads it).
+  double cstab_eval(std::vector<double>& uC) {
     double vio = A_INF;
     uC.clear();
+    if (m->nspheres > 0) {
+      kinematics();
+      for (int s = 0; s < m->nspheres; s++) {
+        double ctr[3], cp[3]; sphere_center(s, ctr); to_plane(ctr, cp);
+        uC.push_back(cp[1] + (-1.0 * m->sphere_radius[s])); vio = (uC.back() < vio) ? uC.back() : vio;
+      }
+    }
     for (int j = 0; j < nj; j++) {
       uC.push_back((m->hilimit[0] - q[0]) - 0.0); vio = (uC.back() < vio) ? uC.back() : vio;      // hilimit - q - tare, tare = 0
       uC.push_back((q[0] + 0.0) - m->lolimit[0]); vio = (uC.back() < vio) ? uC.back() : vio;
@@ -786,35 +797,89 @@ class Artic {
       if (iterations == (unsigned)m->cstab_max_iterations) break;
       if (iterations == MH_CSTAB_HARD_CAP) { aux->status |= MH_WORLD_STALLED; break; }
       for (int i = 0; i < nj; i++) { qd[i] = 0.0; dq[i] = 0.0; }
-      // compute_problem_data: a row for every FINITE limit (CStab:257-304), upper before lower per joint; one island (one body)
+      // compute_problem_data (CStab:347-492): one contact per (sphere, plane) pair of the broad phase -- a synthetic one "between
+      // separated bodies" when the signed distance is at least NEAR_ZERO (add_contact_constraints, CStab:306-331: point = the closest
+      // point on the sphere, normal = from it towards the closest point on the plane, as the reference computes p2 - p1), the contact
+      // of find_contacts otherwise (:337); then a row for every FINITE limit (CStab:257-304), upper before lower per joint; one
+      // island (every constraint touches the one body)
+      std::vector<AContact> cs;
+      if (m->nspheres > 0) {
+        kinematics();
+        for (int s = 0; s < m->nspheres; s++) {
+          double ctr[3], cp[3]; sphere_center(s, ctr); to_plane(ctr, cp);
+          const double low = cp[1] + (-1.0 * m->sphere_radius[s]);
+          AContact c;
+          if (low >= A_NEAR_ZERO) {
+            double on_plane[3]; from_plane(cp[0], 0.0, cp[2], on_plane); from_plane(cp[0], low, cp[2], c.p);
+            const double d[3] = { on_plane[0] - c.p[0], on_plane[1] - c.p[1], on_plane[2] - c.p[2] };
+            const double len = std::sqrt((d[0]*d[0] + d[1]*d[1]) + d[2]*d[2]);
+            for (int k = 0; k < 3; k++) c.n[k] = d[k] / len;
+            c.s = s; c.link = m->sphere_link[s]; c.dist = low;
+            orthonormal_basis(c.n, c.sv, c.tv);
+            cs.push_back(c);
+          } else if (find_contact(s, A_NEAR_ZERO, c)) cs.push_back(c);
+        }
+      }
+      const int nc = (int)cs.size();
       int idx[2 * NJ]; bool upper[2 * NJ]; double viol[2 * NJ]; int nl = 0;
       for (int i = 0; i < nj; i++) {
         if (m->hilimit[i] < A_INF) { idx[nl] = i; upper[nl] = true; viol[nl] = (m->hilimit[i] - q[i]) - 0.0; nl++; }
         if (m->lolimit[i] > -A_INF) { idx[nl] = i; upper[nl] = false; viol[nl] = (q[i] + 0.0) - m->lolimit[i]; nl++; }
       }
-      if (nl > 0) {
-        if (nl > MH_LCP_MAX_N_WAVE) { aux->status |= MH_WORLD_UNSUPPORTED; break; }
+      if (nc + nl > 0) {
+        const int n = nc + nl;
+        if (n > MH_LCP_MAX_N_WAVE) { aux->status |= MH_WORLD_UNSUPPORTED; break; }
         kinematics(); crba();                                        // compute_X at the CURRENT configuration (ICH:1600-1607)
         std::vector<double> X(H, H + nj * nj);
         if (!inverse_spd(nj, X.data(), nj)) { aux->status |= MH_WORLD_LCP_FAILED; break; }
-        std::vector<double> MM((size_t)nl * nl), Lv(nl);
-        for (int a = 0; a < nl; a++) for (int b = a; b < nl; b++) { const double e = X[idx[a] * nj + idx[b]]; MM[a + (size_t)nl * b] = e; MM[b + (size_t)nl * a] = e; }   // ICH:1763-1771 (no signs)
-        for (int k = 0; k < nl; k++) Lv[k] = (viol[k] - std::fabs(m->cstab_eps)) - A_NEAR_ZERO;  // CStab:434-441
+        // set_unilateral_constraint_data (CStab:705-904): Cn rows [n, r x n] . calc_jacobian(link) at the link's COM (add_contact_to_Jacobian,
+        // CStab:906-929: the plane's body is disabled and adds nothing), X_CnT = (Cn X)', Cn_X_CnT = Cn X_CnT, Cn_X_LT = Cn X_LT with
+        // X_LT's columns the UNSIGNED rows of X (compute_limit_components, ICH:1755-1781) -- the products of handle_impacts' normal rows
+        std::vector<double> C((size_t)nc * nj, 0.0), XC((size_t)nc * nj, 0.0);
+        for (int i = 0; i < nc; i++) {
+          const int l = cs[i].link;
+          double rc[3], com[3], r[3], J[6 * NJ], w[6];
+          artic::mat3vec(R[l], m->com[l], rc);
+          for (int k = 0; k < 3; k++) { com[k] = x[l][k] + rc[k]; r[k] = cs[i].p[k] - com[k]; }
+          jacobian(l, com, J);
+          artic::cross3(r, cs[i].n, w + 3);
+          for (int k = 0; k < 3; k++) w[k] = cs[i].n[k];
+          for (int j = 0; j < nj; j++) { double acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + w[k] * J[k * nj + j]; C[(size_t)i * nj + j] = acc; }
+        }
+        for (int i = 0; i < nc; i++) for (int c = 0; c < nj; c++) {
+          double acc = 0.0; for (int k = 0; k < nj; k++) acc = acc + C[(size_t)i * nj + k] * X[k * nj + c];
+          XC[(size_t)i * nj + c] = acc;
+        }
+        // determine_dq (CStab:932-970): MM = [Cn_X_CnT  Cn_X_LT; Cn_X_LT'  L_X_LT], qq = [Cn_v; L_v]
+        std::vector<double> MM((size_t)n * n), Lv(n);
+        for (int i = 0; i < nc; i++) for (int j = 0; j < nc; j++) { double acc = 0.0; for (int k = 0; k < nj; k++) acc = acc + C[(size_t)i * nj + k] * XC[(size_t)j * nj + k]; MM[i + (size_t)n * j] = acc; }
+        for (int i = 0; i < nc; i++) for (int k2 = 0; k2 < nl; k2++) {
+          double acc = 0.0; for (int k = 0; k < nj; k++) acc = acc + C[(size_t)i * nj + k] * X[idx[k2] * nj + k];
+          MM[i + (size_t)n * (nc + k2)] = acc; MM[(nc + k2) + (size_t)n * i] = acc;
+        }
+        for (int a = 0; a < nl; a++) for (int b = a; b < nl; b++) { const double e = X[idx[a] * nj + idx[b]]; MM[(nc + a) + (size_t)n * (nc + b)] = e; MM[(nc + b) + (size_t)n * (nc + a)] = e; }   // ICH:1763-1771 (no signs)
+        for (int i = 0; i < nc; i++) Lv[i] = (cs[i].dist - std::fabs(m->cstab_eps)) - A_NEAR_ZERO;      // CStab:431
+        for (int k = 0; k < nl; k++) Lv[nc + k] = (viol[k] - std::fabs(m->cstab_eps)) - A_NEAR_ZERO;  // CStab:434-441
+        const int nl_only = nl; (void)nl_only;
         Vec z;                                                       // determine_dq's local z: size 0 -> cold lcp_fast (CStab:954)
         oracle_rand_t rs; std::memcpy(&rs, aux->rng, sizeof(rs));
         LCP lcp; lcp.rng = &rs;
         Trace tr; tr.buf = trace ? trace + trace_len : nullptr; tr.cap = trace ? ((trace_cap - trace_len > 0) ? trace_cap - trace_len : 0) : 0;
         lcp.trace = &tr;
         unsigned piv = 0;
-        bool ok = lcp.lcp_fast(nl, MM.data(), nl, Lv.data(), z, -1.0);
+        bool ok = lcp.lcp_fast(n, MM.data(), n, Lv.data(), z, -1.0);
         piv += lcp.pivots;
-        if (!ok) { ok = lcp.lcp_lemke_regularized(nl, MM.data(), nl, Lv.data(), z); piv += lcp.pivots; }
+        if (!ok) { ok = lcp.lcp_lemke_regularized(n, MM.data(), n, Lv.data(), z); piv += lcp.pivots; }
         trace_len += tr.len;
         std::memcpy(aux->rng, &rs, sizeof(rs));
-        lcp_account(nl, piv); aux->stab_rows += (unsigned long long)nl;
-        // update_from_stacked(pd, z): l = z (whatever it holds), dv = X_LT ls, v += dv (ICH:298-397); dq = the Euler velocities
+        lcp_account(n, piv); aux->stab_rows += (unsigned long long)n;
+        // update_from_stacked(pd, z): cn, l = z (whatever it holds), dv = X_CnT cn + X_LT ls, v += dv (ICH:298-397; the tangential
+        // products have no columns here); dq = the Euler velocities
         std::vector<double> dv(nj, 0.0);
-        for (int k = 0; k < nl; k++) { const double lk = (k < (int)z.size()) ? z[k] : 0.0; const double ls = upper[k] ? -lk : lk; for (int r = 0; r < nj; r++) dv[r] = dv[r] + ls * X[idx[k] * nj + r]; }
+        if (nc > 0) for (int r = 0; r < nj; r++) { double acc = 0.0; for (int i = 0; i < nc; i++) { const double ci = (i < (int)z.size()) ? z[i] : 0.0; acc = acc + XC[(size_t)i * nj + r] * ci; } dv[r] = acc; }
+        { std::vector<double> t2(nj, 0.0);
+          for (int k = 0; k < nl; k++) { const double lk = (nc + k < (int)z.size()) ? z[nc + k] : 0.0; const double ls = upper[k] ? -lk : lk; for (int r = 0; r < nj; r++) t2[r] = t2[r] + ls * X[idx[k] * nj + r]; }
+          for (int r = 0; r < nj; r++) dv[r] = (nc > 0) ? dv[r] + t2[r] : t2[r]; }
         for (int r = 0; r < nj; r++) { qd[r] = qd[r] + dv[r]; dq[r] = qd[r]; }
       }
       if (!cstab_update_q(dq, qv)) { aux->status |= MH_WORLD_STAB_FAILED; break; }
@@ -839,7 +904,7 @@ class Artic {
         if (m->nspheres > 0 && (aux->status & FROZEN)) break;
         if (++guard > 100000u) { aux->status |= MH_WORLD_STALLED; break; }
       }
-      if (m->nspheres == 0) stabilize();                           // TSS:97 (with spheres the stabiliser's contact rows are not built: create refuses)
+      stabilize();                                                   // TSS:97
       aux->steps++;
       return;
     }

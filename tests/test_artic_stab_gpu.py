@@ -79,3 +79,25 @@ def test_stabiliser_with_link_spheres_is_refused(oracle):
     m.cstab_max_iterations = 3
     with pytest.raises(Exception, match="stabilis"):
         A.ArticBatch(m, np.zeros((1, 2)), np.zeros((1, 2)))
+
+
+@pytest.mark.parametrize("mu", ["100", "0.4"])
+def test_arm_on_table_with_the_stabilisers_contact_rows_matches_the_oracle(oracle, tmp_path, mu):
+    """Bodies with link spheres AND the stabiliser on (mh_artic_contacts.inc: stabilize_contacts -- the mixed LCP
+    [Cn X Cn'  Cn X L'; .  L X L'] of CStab:705-904, 932-970, update_q's line search over the sphere distances): tests/scenes/
+    arm_on_table.xml with constraint-stabilization-max-iterations = 10, perturbed arms falling onto the table and resting there, with the
+    no-slip model (mu = 100) and the Drumwright-Shell model (mu = 0.4, whose LCP shares the HBM workspace with the stabiliser's):
+    joint positions, velocities, rand() streams, flags and counters bit for bit."""
+    src = open(os.path.join(ROOT, "tests", "scenes", "arm_on_table.xml")).read()
+    p = tmp_path / "arm.xml"
+    p.write_text(src.replace('constraint-stabilization-max-iterations="0"', 'constraint-stabilization-max-iterations="10"').replace('mu-coulomb="100"', 'mu-coulomb="%s"' % mu))
+    m, links, joints, q0, qd0, dt = A.load_xml(str(p))
+    assert m.nspheres == 2 and m.cstab_max_iterations == 10
+    B = 8
+    rng = np.random.default_rng(3)
+    q = np.tile(q0, (B, 1)); qd = np.tile(qd0, (B, 1))
+    q[1:, 0] += rng.uniform(-0.3, 0.3, B - 1); q[1:, 1] += rng.uniform(-0.2, 0.2, B - 1); qd[1:] += rng.uniform(-0.5, 0.5, (B - 1, m.nj))
+    _, _, aux = both(oracle, m, q, qd, dt, 300, chunks=4)
+    assert (aux["stab_iters"] > 0).sum() >= B // 2                              # the stabiliser really ran
+    assert (aux["stab_rows"][aux["stab_iters"] > 0] % 8 == 0).all()             # two sphere rows + six limit rows per iteration
+    assert ((aux["status"] & ~(S.MH_WORLD_IMPACT_TOL | S.MH_WORLD_UNSUPPORTED | S.MH_WORLD_STALLED)) == 0).all()

@@ -80,11 +80,51 @@ def test_only_the_first_joints_slacks_open_the_stabiliser(oracle):
     assert np.array_equal(a[0], b[0]) and a[2]["stab_iters"] == 0 and a[3].max() > 1e-3
 
 
-def test_stabiliser_with_link_spheres_is_refused_by_the_loader(tmp_path):
+def arm_with_stabiliser(tmp_path, iterations="10"):
     src = open(os.path.join(ROOT, "tests", "scenes", "arm_on_table.xml")).read()
     assert 'constraint-stabilization-max-iterations="0"' in src
     p = tmp_path / "arm.xml"
-    p.write_text(src.replace(' constraint-stabilization-max-iterations="0"', ""))
-    from moby_amd import io as mio
-    with pytest.raises(mio.SceneError, match="constraint stabilisation is on"):
-        A.load_xml(str(p))
+    p.write_text(src.replace('constraint-stabilization-max-iterations="0"', 'constraint-stabilization-max-iterations="%s"' % iterations))
+    m, links, joints, q0, qd0, dt = A.load_xml(str(p))
+    return m, q0, qd0, dt
+
+
+def test_stabiliser_with_link_spheres_adds_contact_rows(oracle, tmp_path):
+    """Bodies with sphere primitives: the stabiliser's LCP has a row per (sphere, plane) pair before the limit rows
+    (CStab:306-345, 431, 705-904, 932-970: MM = [Cn X Cn'  Cn X L'; .  L X L']) and update_q's line search watches the sphere
+    distances.  tests/scenes/arm_on_table.xml with the stabiliser ON (the loader used to refuse it): the arm comes to rest on the table;
+    every stabilisation LCP has 2 + 6 rows, the spheres end every step no deeper than the stabiliser's tolerance allows, velocities are
+    those of the run without it to round-off of the different configurations, and nothing but the warned tolerance flag is raised."""
+    m, q0, qd0, dt = arm_with_stabiliser(tmp_path)
+    assert m.cstab_max_iterations == 10 and m.nspheres == 2
+    def run(mm, nsteps):
+        q = np.array(q0, dtype=float)[None].copy(); qd = np.array(qd0, dtype=float)[None].copy(); aux = S.new_aux(1)
+        oracle.artic_step(mm, q, qd, aux, dt, nsteps)
+        return q[0], qd[0], aux[0]
+    q_on, qd_on, a_on = run(m, 1500)
+    off = type(m).from_buffer_copy(m); off.cstab_max_iterations = 0
+    q_off, qd_off, a_off = run(off, 1500)
+    assert a_on["stab_iters"] > 0 and a_on["stab_rows"] == 8 * a_on["stab_iters"]          # two spheres + six finite limits per iteration
+    assert a_off["stab_iters"] == 0
+    assert (int(a_on["status"]) & ~S.MH_WORLD_IMPACT_TOL) == 0
+    assert np.abs(q_on - q_off).max() < 5e-3 and np.abs(q_on - q_off).max() > 0.0           # it moved the configuration, a little
+    assert np.abs(qd_on).max() < 1e-9 and np.abs(qd_off).max() < 1e-9                       # both at rest on the table
+
+
+def test_stabiliser_lifts_a_sunken_sphere_and_keeps_the_velocities(oracle, tmp_path):
+    """One step from a configuration whose tip sphere sits 2 mm inside the table, at rest: the stabiliser moves q until the deepest
+    sphere is within its tolerance of the surface and leaves the velocities exactly as the step computed them (CStab:181, 246)."""
+    m, q0, qd0, dt = arm_with_stabiliser(tmp_path, "50")
+    off = type(m).from_buffer_copy(m); off.cstab_max_iterations = 0
+    # settle on the table without the stabiliser, then push the slider 2 mm further out (its axis points down at the table)
+    q = np.array(q0, dtype=float)[None].copy(); qd = np.array(qd0, dtype=float)[None].copy(); aux = S.new_aux(1)
+    oracle.artic_step(off, q, qd, aux, dt, 1500)
+    q[0, 2] += 2e-3; qd[:] = 0.0
+    qa, qda, aa = q.copy(), qd.copy(), S.new_aux(1)
+    qb, qdb, ab = q.copy(), qd.copy(), S.new_aux(1)
+    oracle.artic_step(m, qa, qda, aa, dt, 1)
+    oracle.artic_step(off, qb, qdb, ab, dt, 1)
+    assert aa["stab_iters"][0] >= 1 and ab["stab_iters"][0] == 0
+    assert np.array_equal(qda, qdb)                                                          # velocities: untouched by the stabiliser
+    assert np.abs(qa - qb).max() > 1e-4                                                      # the configuration: moved back out
+    assert (int(aa["status"][0]) & ~S.MH_WORLD_IMPACT_TOL) == 0

@@ -1,9 +1,9 @@
 """BASELINE config 4 through the large-world stepper at a size given on the command line: B stacks of N boxes (impact LCP n = 32 N),
 `steps` full TimeSteppingSimulator::step calls (the first cold, the others warm-started from _zlast).  16 boxes (n = 512) is the bench size;
 BASELINE names 64, which the reference's own solver chain does not solve; 32 is the largest it does.  Prints one JSON line
-(kept under profiles/): per-step seconds, properties of the final state, and -- with --oracle-world W -- the CPU oracle's step of
-world W beside it (flags, pivot counts, state: equal bit for bit or reported as different).
-python tools/config4_full_size.py [boxes] [worlds] [steps] [--oracle-world W]"""
+(kept under profiles/): per-step seconds, properties of the final state; with --dump-world W FILE.npz the start and end state and the
+solver record of world W are saved for tests/tools/config4_oracle_world.py, which runs the CPU oracle on the same world and compares.
+python tools/config4_full_size.py [boxes] [worlds] [steps] [--dump-world W FILE.npz]"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,11 +12,14 @@ from moby_amd import scene as S, stack as K
 from moby_amd import _lib
 if os.environ.get("MH_BLK_GEOM"):          # mh_debug_set key 2 (the block solver's thread geometry)
     _lib.check(_lib.load().mh_debug_set(2, int(os.environ["MH_BLK_GEOM"])))
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for a in sys.argv[1:] if not a.startswith("--") and not a.endswith(".npz")]
+if "--dump-world" in sys.argv:
+    args = [a for k, a in enumerate(sys.argv[1:]) if not a.startswith("--") and not a.endswith(".npz") and sys.argv[k] != "--dump-world"]
 N = int(args[0]) if len(args) > 0 else 16
 B = int(args[1]) if len(args) > 1 else 1024
 steps = int(args[2]) if len(args) > 2 else 1
-ow = int(sys.argv[sys.argv.index("--oracle-world") + 1]) if "--oracle-world" in sys.argv else None
+ow = int(sys.argv[sys.argv.index("--dump-world") + 1]) if "--dump-world" in sys.argv else None
+dump = sys.argv[sys.argv.index("--dump-world") + 2] if ow is not None else None
 sc = K.box_stack_scene(N)
 st0 = K.box_stack_state(N, B)
 if B >= 2:
@@ -64,17 +67,7 @@ out = {
     "solver_workgroup_seconds": float(wk[:, 3].sum()), "slowest_world_solver_seconds": float(wk[:, 3].max()), "mean_world_solver_seconds": float(wk[:, 3].mean()),
     "model_flops": float(wk[:, 0].sum()), "issued_flops": float(wk[:, 2].sum()),
 }
-if ow is not None:
-    from tests.oracle_api import Oracle
-    o = Oracle(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle.so"))
-    o.lib.oracle_dbg_lemke_compact(8)          # lcp_lemke's bases through the bit-equal structure-exploiting model (a dense dgesv of a 2048 x 2048 basis per pivot takes an hour)
-    so = st0[ow].copy(); ao = S.new_aux(1); zl = np.zeros(cap); zb = np.zeros(cap)
-    t0 = time.perf_counter()
-    for k in range(steps):
-        o.big_step(sc, so, ao, 1e-3, 1, zlast=zl, zbuf=zb, cap=cap)
-    out["oracle"] = {"world": ow, "seconds": time.perf_counter() - t0, "status": int(ao["status"][0]), "lcp_pivots": int(ao["lcp_pivots"][0]),
-                     "lcp_solves": int(ao["lcp_solves"][0]), "gpu_status": int(aux["status"][ow]), "gpu_lcp_pivots": int(aux["lcp_pivots"][ow]),
-                     "status_equal": bool(int(ao["status"][0]) == int(aux["status"][ow])),
-                     "state_equal": bool(np.array_equal(so, st[ow])), "rng_equal": bool(np.array_equal(ao["rng"][0], aux["rng"][ow])),
-                     "pivots_equal": bool(int(ao["lcp_pivots"][0]) == int(aux["lcp_pivots"][ow]))}
+if ow is not None:          # the GPU side of world `ow` for tests/tools/config4_oracle_world.py (the checker that runs the CPU oracle on the same world)
+    np.savez(dump, boxes=N, steps=steps, world=ow, cap=cap, st0=st0[ow], st=st[ow], aux=aux[ow:ow + 1])
+    out["dumped_world"] = {"world": ow, "file": dump}
 print(json.dumps(out))

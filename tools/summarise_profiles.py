@@ -8,6 +8,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMIT = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None   # the build the session ran (commit before profiling)
 P = os.path.join(ROOT, "profiles")
+CMDTXT = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "python3 bench.py --no-cpu-baseline --no-config4 --no-long-horizon --no-config5"
 one = lambda pat: (glob.glob(os.path.join(src, pat)) or [None])[0]
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(P, tag + "_bench.json"))
 if os.path.exists(os.path.join(src, "bench_under_rocprof.json")):
@@ -49,7 +50,7 @@ hdr, rows = counters(["fetch", "write"])
 if rows:
     w = csv.writer(open(os.path.join(P, tag + "_world_step_pmc.csv"), "w")); w.writerow(hdr); w.writerows(rows)
     t = {"source": "profiles/%s_world_step_pmc.csv" % tag, "commit": COMMIT,
-         "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline --no-config4 --no-long-horizon --no-config5 (separate passes)",
+         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE --output-format csv -- %s (separate passes)" % CMDTXT,
          "kernel": "mh::small::mh_k_world_step", "worlds": B, "steps": steps,
          "fetch_size_kb": value(hdr, rows, "FETCH_SIZE")[0], "write_size_kb": value(hdr, rows, "WRITE_SIZE")[0],
          "note": "the timed launch of each pass; dword-per-lane scratch accesses, uncalibrated width (guide: FETCH_SIZE may under-report up to 2x); bench.py normalises per world-step"}
@@ -61,7 +62,7 @@ if rows:
     c = {n: value(hdr, rows, n)[0] for n in set(r[hdr.index("Counter_Name")] for r in rows)}
     dur = value(hdr, rows, "SQ_ACTIVE_INST_VALU")[1]
     simds, clk = 256 * 4, 2.4e9
-    out = {"commit": COMMIT, "source": "profiles/%s_world_step_sq_pmc.csv (two rocprofv3 --pmc passes of `python3 bench.py --no-cpu-baseline --no-config4 --no-long-horizon --no-config5`, the timed launch)" % tag,
+    out = {"commit": COMMIT, "source": "profiles/%s_world_step_sq_pmc.csv (two rocprofv3 --pmc passes of `%s`, the timed launch)" % (tag, CMDTXT),
            "kernel": "mh::small::mh_k_world_step", "worlds": B, "steps": steps, "kernel_seconds": dur,
            "per_world_step": {"valu_insts": c["SQ_INSTS_VALU"] / (B * steps), "salu_insts": c["SQ_INSTS_SALU"] / (B * steps),
                               "lds_insts": c["SQ_INSTS_LDS"] / (B * steps), "vmem_insts": c["SQ_INSTS_VMEM"] / (B * steps)},
