@@ -1353,7 +1353,11 @@ static LadderPlan core_ladder_plan(mh_imp_core* c, const mh_lcp_opts* o)
   L.R = 1; if (step > 0) for (int rf = min_exp; rf < max_exp; rf += (int)step) L.R++;
   L.ntasks = (long)c->B * L.R;
   const double bytes = (double)L.ntasks * (((double)n * n + 5.0 * n) * 8.0 + 16.0 * n + 8.0 * n + 200.0);
-  L.ok = mh_g_debug_tasks != 0 && n > MH_LCP_MAX_N_WAVE && step > 0 && bytes < 96e9 && core_ladder_alloc(c, L.ntasks) == MH_OK;
+  // the tasks' workspaces (one per (world, attempt): n^2 + 5 n doubles each -- 48 GB for 16-box stacks x 1024 worlds) are kept until
+  // the batch is destroyed; they may take at most 70 % of what the device has free when they are first allocated, otherwise the ladder runs in sequence
+  bool fits = c->t_cap >= L.ntasks;
+  if (!fits) { size_t fr = 0, tot = 0; fits = hipMemGetInfo(&fr, &tot) == hipSuccess && bytes < 0.7 * (double)fr; (void)hipGetLastError(); }
+  L.ok = mh_g_debug_tasks != 0 && n > MH_LCP_MAX_N_WAVE && step > 0 && fits && core_ladder_alloc(c, L.ntasks) == MH_OK;
   return L;
 }
 // sched: the tasks are handed out by need (mh_lcp_block.h pick_task: as many workgroups as the chip holds, each taking tasks until none is
@@ -1460,9 +1464,10 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, c->lst1, c->piv1,
                                  nullptr, 0, nullptr, nullptr, run_if, c->ws_d, c->ws_i, c->ncur, c->work, spec ? 2 : 0);   // CStab:954
   }
-  if (rc != MH_OK) return rc;
+  if (rc != MH_OK) { if (spec) (void)hipStreamWaitEvent(s, (hipEvent_t)c->ev1, 0); return rc; }     // (the tasks' stream joins this one on every way out)
   hipLaunchKernelGGL(im::k_lemke_prep, dim3(B), dim3(im::T), 0, s, *c, run_if, mode);
-  MH_HIP(hipGetLastError());
+  { const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { if (spec) (void)hipStreamWaitEvent(s, (hipEvent_t)c->ev1, 0); return fail(MH_ERR_HIP, "k_lemke_prep failed: %s", hipGetErrorString(e)); } }
   if (spec) {                                                     // the tasks have been running beside lcp_fast: wait for them, then select
     MH_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->ev1, 0));
     return core_ladder_finish(c, s, L, c->need2, c->lst2, c->piv2);

@@ -73,12 +73,16 @@ def test_ur10_with_constraint_stabilisation_on_matches_the_oracle(oracle):
     assert nfin > 16 and (aux["stab_rows"][aux["stab_iters"] > 0] % nfin == 0).all()                 # beyond the 16-row limit LCP of the impact handler
 
 
-def test_stabiliser_with_link_spheres_is_refused(oracle):
-    from moby_amd import _lib
+def test_two_link_chain_with_a_sphere_and_the_stabiliser_matches_the_oracle(oracle):
+    """A sphere on the second link of a chain swinging into a plane, stabiliser on (3 iterations; the combination used to be refused):
+    a contact row and four limit rows per stabilisation LCP, GPU = oracle."""
     m = A.add_spheres(A.chain_model(2, lo=-3.0, hi=3.0), [(1, (0.0, 0.0, -0.5), 0.05)], plane_point=(0.0, 0.0, -0.9))
     m.cstab_max_iterations = 3
-    with pytest.raises(Exception, match="stabilis"):
-        A.ArticBatch(m, np.zeros((1, 2)), np.zeros((1, 2)))
+    B = 6
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-0.4, 0.4, (B, 2)); qd = rng.uniform(-2.0, 2.0, (B, 2))
+    _, _, aux = both(oracle, m, q, qd, 1e-3, 200, chunks=3)
+    assert (aux["stab_rows"][aux["stab_iters"] > 0] % 5 == 0).all()
 
 
 @pytest.mark.parametrize("mu", ["100", "0.4"])
