@@ -292,13 +292,13 @@ def config4_full_step_leg(torch, nboxes, B, steps, cpu_proc=None):
 def artic_roofline(tflops, ms):
     """The articulated kernel against its real bound, FP64 issue: ~21 kflop per world-step (CRBA + RNEA + Cholesky + the limit LCP of the
     ur10) over the launch time, against the FP64 vector peak; `issue` = the committed SQ_* counter passes of this kernel
-    (profiles/r02_f_artic_issue.json -- the kernel has not changed since)."""
+    (profiles/r04_a_artic_issue.json)."""
     issue = None
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r02_f_artic_issue.json")))
-        k = t["k_artic_step_w4"]
+        t = json.load(open(os.path.join(ROOT, "profiles", "r04_a_artic_issue.json")))
+        k = t["kernels"]["k_artic_step_w4"]
         issue = {"valu_busy_frac": k["valu_busy_frac"], "wave_cycles": k["wave_cycles"], "per_world_step": k["per_world_step"],
-                 "source": "profiles/r02_f_artic_issue.json (worlds %d, steps %d)" % (t["worlds"], t["steps"])}
+                 "source": "profiles/r04_a_artic_issue.json (ur10 x 8192, 200 steps)"}
     except (OSError, KeyError, ValueError):
         pass
     return {"bound": "fp64_valu", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS, "traffic": None,

@@ -97,10 +97,13 @@ static size_t lds_bytes(int nj, int nlcap = NLMAX) {
 }
 
 // link frames, motion subspaces and spatial inertias about the world origin for the q in LDS (oracle Artic::kinematics)
+// PACK worlds per wavefront: PACK = 1 -- the whole wave works on the image at g; PACK = 2 -- lanes 0-31 and 32-63 each work on THEIR
+// world's image (g is then a per-lane pointer, `lane` the lane's index within its half): the same instruction stream steps two worlds
+template <int PACK = 1>
 MH_DEV void kin_inertia(const Model& M, const Lay& Y, double* g)
 {
   const mh_artic_model& m = M.m;
-  const int nj = Y.nj, lane = lane_id();
+  const int nj = Y.nj, lane = lane_id() & (64 / PACK - 1);
   // local transforms: lane = link
   if (lane < nj) {
     const int i = lane;
@@ -175,11 +178,13 @@ MH_DEV void kin_inertia(const Model& M, const Lay& Y, double* g)
 }
 
 // kinematics + spatial inertias + bias + H + Cholesky + qdd for the q / qd in LDS.  Returns false if H is not PD.
+template <int PACK = 1>
 MH_DEV bool dynamics(const Model& M, const Lay& Y, double* g, const double* tau_w)
 {
   const mh_artic_model& m = M.m;
-  const int nj = Y.nj, lane = lane_id();
-  kin_inertia(M, Y, g);
+  constexpr int STR = 64 / PACK;
+  const int nj = Y.nj, lane = lane_id() & (STR - 1);
+  kin_inertia<PACK>(M, Y, g);
   // recursive Newton-Euler with qdd = 0 (the links' OWN inertias): lanes 0..5 = spatial components
   for (int i = 0; i < nj; i++) {
     const int p = m.parent[i];
@@ -216,11 +221,11 @@ MH_DEV bool dynamics(const Model& M, const Lay& Y, double* g, const double* tau_
   // composite inertias, in place: lanes 0..35 = entries
   for (int i = nj - 1; i >= 0; i--) {
     const int p = m.parent[i];
-    if (p >= 0 && lane < 36) g[Y.I6 + 36 * p + lane] = g[Y.I6 + 36 * p + lane] + g[Y.I6 + 36 * i + lane];
+    if (p >= 0) for (int e = lane; e < 36; e += STR) g[Y.I6 + 36 * p + e] = g[Y.I6 + 36 * p + e] + g[Y.I6 + 36 * i + e];
     wave_sync();
   }
   // F_i = Ic_i S_i: lanes (i, r)
-  for (int e = lane; e < 6 * nj; e += 64) {
+  for (int e = lane; e < 6 * nj; e += STR) {
     const int i = e / 6, r = e - 6 * i;
     const double* I6 = g + Y.I6 + 36 * i + 6 * r; const double* S = g + Y.S + 6 * i;
     double acc = 0.0; for (int k = 0; k < 6; k++) acc = acc + I6[k] * S[k];
@@ -228,7 +233,7 @@ MH_DEV bool dynamics(const Model& M, const Lay& Y, double* g, const double* tau_
   }
   wave_sync();
   // H(i, j) = S_j' F_i for j on i's path to the base (and its mirror); 0 elsewhere: lanes = entries
-  for (int e = lane; e < nj * nj; e += 64) {
+  for (int e = lane; e < nj * nj; e += STR) {
     const int i = e / nj, j = e - nj * i;
     double h = 0.0;
     if ((M.anc[i] >> j) & 1u) h = dot6(g + Y.S + 6 * j, g + Y.F + 6 * i);
@@ -237,7 +242,7 @@ MH_DEV bool dynamics(const Model& M, const Lay& Y, double* g, const double* tau_
   }
   wave_sync();
   // dpotf2('L') on a copy: lane = row
-  for (int e = lane; e < nj * nj; e += 64) g[Y.L + e] = g[Y.H + e];
+  for (int e = lane; e < nj * nj; e += STR) g[Y.L + e] = g[Y.H + e];
   wave_sync();
   double* L = g + Y.L;                             // symmetric: row-major == column-major; L(i, k) at L[i + nj k]
   bool pd = true;
@@ -249,7 +254,7 @@ MH_DEV bool dynamics(const Model& M, const Lay& Y, double* g, const double* tau_
     }
     wave_sync();
     const double ajj0 = g[Y.Iv];
-    if (!(ajj0 > 0.0)) { pd = false; break; }
+    if (!(ajj0 > 0.0)) { pd = false; if (PACK == 1) break; }      // (packed: the other world of the wave goes on; this one computes on, its result is dropped)
     const double ajj = sqrt(ajj0);
     if (lane == j) L[j + nj * j] = ajj;
     if (lane > j && lane < nj) {
@@ -259,7 +264,7 @@ MH_DEV bool dynamics(const Model& M, const Lay& Y, double* g, const double* tau_
     }
     wave_sync();
   }
-  if (!pd) return false;
+  if (PACK == 1 && !pd) return false;
   // dpotrs: lane = row for the column sweeps
   double* b = g + Y.qdd;
   if (lane < nj) b[lane] = (tau_w ? tau_w[lane] : 0.0) - g[Y.C + lane];
@@ -275,7 +280,7 @@ MH_DEV bool dynamics(const Model& M, const Lay& Y, double* g, const double* tau_
     if (lane == k) { double s = b[k]; for (int i = k + 1; i < nj; i++) s = s - L[i + nj * k] * b[i]; b[k] = s / L[k + nj * k]; }
     wave_sync();
   }
-  return true;
+  return pd;
 }
 
 // calc_fwd_dyn, eFeatherstone (RCArticulatedBody::algorithm_type): the articulated-body recursion, every spatial quantity at the
@@ -667,6 +672,60 @@ __global__ __launch_bounds__(64)
 void k_artic_step_w2(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
                      mh_world_aux* __restrict__ auxg) { artic_step_body<false>(Mg, B, dt, nsteps, qg, qdg, auxg); }
 
+// TWO worlds per wavefront (round 4): lanes 0-31 step world 2b, lanes 32-63 world 2b + 1, out of two LDS images, through ONE instruction
+// stream -- the kernel is bound by instruction issue and LDS round trips with 6-36 of 64 lanes at work, so the second world rides on
+// instructions the first one pays for.  The forward dynamics (kinematics, RNEA, CRBA, Cholesky: no data-dependent control flow) run
+// packed; the joint-limit handler, whose pivoting loops are wave-uniform per WORLD, runs on each world in turn with the whole wave (it
+// leaves at once when no limit is hit).  16 worlds per CU as before (8 waves x 2 images of 10 KB) at 256 registers per lane: no spills.
+// CRB bodies without spheres and without the stabiliser (config 5).  Selected by MH_ARTIC_PACK=1 (see mh_artic_batch_step for what it measured).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_artic_step_p2(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
+                     mh_world_aux* __restrict__ auxg)
+{
+  extern __shared__ double g[];
+  const int b0 = 2 * (int)blockIdx.x;
+  if (b0 >= B) return;
+  const Model& M = *Mg;
+  const int nj = M.m.nj, lane = lane_id(), wl = lane >> 5, hl = lane & 31;
+  const Lay Y(nj);
+  const bool two = b0 + 1 < B;                                       // (an odd batch: the last wave's second half idles on an image nobody reads)
+  const int b = b0 + wl;
+  double* gw = g + (size_t)wl * Y.total;                             // this lane's world
+  const bool mine = hl < nj && (wl == 0 || two);
+  if (hl < nj) { gw[Y.q + hl] = mine ? qg[(size_t)b * nj + hl] : 0.0; gw[Y.qd + hl] = mine ? qdg[(size_t)b * nj + hl] : 0.0; }
+  WaveRand rng0, rng1; rng0.load(auxg[b0].rng); rng1.load(auxg[two ? b0 + 1 : b0].rng);
+  if (lane == 0) g_lcp_prof_on = 0;
+  int status0 = uni(auxg[b0].status), status1 = two ? uni(auxg[b0 + 1].status) : 0;
+  unsigned long long solves0 = 0, rows0 = 0, pivs0 = 0, bytes0 = 0, solves1 = 0, rows1 = 0, pivs1 = 0, bytes1 = 0;
+  wave_sync();
+  for (int s = 0; s < nsteps; s++) {
+    if (hl < nj) { double qn = gw[Y.qd + hl] * dt; qn = qn + gw[Y.q + hl]; gw[Y.q + hl] = qn; }      // positions with the OLD velocity (TSS:156-164)
+    wave_sync();
+    const bool okl = dynamics<2>(M, Y, gw, nullptr);
+    const bool ok0 = (ballot(okl) & 1ull) != 0ull, ok1 = ((ballot(okl) >> 32) & 1ull) != 0ull;
+    if (!ok0) status0 |= MH_WORLD_LCP_FAILED;
+    if (two && !ok1) status1 |= MH_WORLD_LCP_FAILED;
+    if (hl < nj) { const double qdd = okl ? gw[Y.qdd + hl] : 0.0; gw[Y.qd + hl] = gw[Y.qd + hl] + qdd * dt; }   // TSS:182-192
+    wave_sync();
+    if (ok0) handle_limits(M, Y, g, auxg + b0, rng0, status0, solves0, rows0, pivs0, bytes0);
+    wave_sync();
+    if (two && ok1) handle_limits(M, Y, g + Y.total, auxg + b0 + 1, rng1, status1, solves1, rows1, pivs1, bytes1);
+    wave_sync();
+  }
+  if (mine) { qg[(size_t)b * nj + hl] = gw[Y.q + hl]; qdg[(size_t)b * nj + hl] = gw[Y.qd + hl]; }
+  rng0.store(auxg[b0].rng);
+  if (two) rng1.store(auxg[b0 + 1].rng);
+  if (lane == 0) {
+    for (int w = 0; w < (two ? 2 : 1); w++) {
+      mh_world_aux* aux = auxg + b0 + w;
+      double tm = aux->time; for (int s = 0; s < nsteps; s++) tm += dt;
+      aux->time = tm; aux->status = w ? status1 : status0;
+      aux->steps += (unsigned long long)nsteps; aux->mini_steps += (unsigned long long)nsteps;
+      aux->lcp_solves += w ? solves1 : solves0; aux->lcp_rows += w ? rows1 : rows0; aux->lcp_pivots += w ? pivs1 : pivs0; aux->lcp_alg_bytes += w ? bytes1 : bytes0;
+    }
+  }
+}
+
 // the same step followed by ConstraintStabilization::stabilize (joint-limit rows): its own kernel, so that bodies stepped with
 // stabilisation off (ur10.xml:11) carry neither its registers nor its 20 KB LDS image (a row for every finite limit: 2 nj)
 __global__ __launch_bounds__(64)
@@ -736,7 +795,7 @@ void k_artic_jacobian(const Model* __restrict__ Mg, int B, const double* __restr
 
 struct mh_artic_batch {
   int device;                // the HIP device the batch lives on (current at create); every entry point runs there (MH_ON_DEVICE)
-  int B, nj, nspheres, cstab;
+  int B, nj, nspheres, cstab, algorithm;
   mh::artic::Model* d_model;
   double* d_q; double* d_qd; mh_world_aux* d_aux;
   double* d_ws;           // link contacts with the Drumwright-Shell model: _MM + LU workspace, 2 x 64 x 64 doubles per world
@@ -811,7 +870,7 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
   }
   mh_artic_batch* ab = new mh_artic_batch();
   if (hipGetDevice(&ab->device) != hipSuccess) { delete ab; return fail(MH_ERR_HIP, "hipGetDevice failed"); }
-  ab->B = B; ab->nj = nj; ab->nspheres = model->nspheres; ab->cstab = model->cstab_max_iterations != 0 ? 1 : 0; ab->d_model = nullptr; ab->d_q = nullptr; ab->d_qd = nullptr; ab->d_aux = nullptr; ab->d_ws = nullptr;
+  ab->B = B; ab->nj = nj; ab->algorithm = model->algorithm; ab->nspheres = model->nspheres; ab->cstab = model->cstab_max_iterations != 0 ? 1 : 0; ab->d_model = nullptr; ab->d_q = nullptr; ab->d_qd = nullptr; ab->d_aux = nullptr; ab->d_ws = nullptr;
   const size_t sB = (size_t)B;
   bool ok = hipMalloc((void**)&ab->d_model, sizeof(ar::Model)) == hipSuccess && hipMalloc((void**)&ab->d_q, sB * nj * 8) == hipSuccess
          && hipMalloc((void**)&ab->d_qd, sB * nj * 8) == hipSuccess && hipMalloc((void**)&ab->d_aux, sB * sizeof(mh_world_aux)) == hipSuccess;
@@ -858,6 +917,15 @@ int mh_artic_batch_step(mh_artic_batch* ab, void* stream, double dt, int nsteps)
   }
   if (ab->cstab) {
     hipLaunchKernelGGL(ar::k_artic_step_stab, dim3(ab->B), dim3(64), ar::lds_bytes(ab->nj, ar::NLSTAB), (hipStream_t)stream,
+                       (const ar::Model*)ab->d_model, ab->B, dt, nsteps, ab->d_q, ab->d_qd, ab->d_aux);
+    MH_HIP(hipGetLastError());
+    return MH_OK;
+  }
+  // (off by default: measured on ur10 x 8192 x 200 steps it retires a world-step in 27 % fewer vector and 40 % fewer LDS instructions and takes
+  //  27.4 ms against 26.2 -- two images per wave halve the resident waves, and with them what hides the LDS round trips; profiles/r04_a_artic_issue.json)
+  static const int pack = [] { const char* e = std::getenv("MH_ARTIC_PACK"); return e ? std::atoi(e) : 0; }();
+  if (pack != 0 && ab->algorithm == MH_ARTIC_CRB && !std::getenv("MH_ARTIC_WAVES")) {          // two worlds per wavefront (k_artic_step_p2)
+    hipLaunchKernelGGL(ar::k_artic_step_p2, dim3((ab->B + 1) / 2), dim3(64), 2 * ar::lds_bytes(ab->nj), (hipStream_t)stream,
                        (const ar::Model*)ab->d_model, ab->B, dt, nsteps, ab->d_q, ab->d_qd, ab->d_aux);
     MH_HIP(hipGetLastError());
     return MH_OK;

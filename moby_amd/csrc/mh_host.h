@@ -90,5 +90,6 @@ MH_HIDDEN const mh_world_variant* mh_world_variant_large();
 // mh_debug_set keys 1 / 2 (test hooks; defined in mh_capi.hip)
 extern MH_HIDDEN int mh_g_debug_ka;
 extern MH_HIDDEN int mh_g_debug_blk;
+extern MH_HIDDEN int mh_g_debug_fastgeom;
 
 }  // extern "C"
