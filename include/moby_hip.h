@@ -232,6 +232,9 @@ int  mh_debug_set(int key, int value);   /* key 2: block LCP solver (n > 64) thr
                                             key 6: the structure-exploiting LU reuses the factors of the unchanged leading columns from one Lemke
                                                    pivot to the next (1, default) or factorises every basis from scratch (0).
                                             key 7: ladder tasks started after lcp_fast are handed out by need (1, default) or by block index (0).
+                                            key 8: thread geometry of the lcp_fast kinds alone for n <= 512 (0 choose, 1-4 as key 2);
+                                            key 9: fixed-base CRB articulated bodies without spheres / stabiliser stepped two worlds per wavefront (1; default 0:
+                                                   measured no faster, profiles/r04_a_artic_issue.json).
                                             None of the switches changes a result */
 void mh_scene_defaults(mh_scene* s);   /* zero + the reference's default tolerances */
 void mh_world_aux_init(mh_world_aux* a, uint32_t seed);

@@ -923,7 +923,8 @@ int mh_artic_batch_step(mh_artic_batch* ab, void* stream, double dt, int nsteps)
   }
   // (off by default: measured on ur10 x 8192 x 200 steps it retires a world-step in 27 % fewer vector and 40 % fewer LDS instructions and takes
   //  27.4 ms against 26.2 -- two images per wave halve the resident waves, and with them what hides the LDS round trips; profiles/r04_a_artic_issue.json)
-  static const int pack = [] { const char* e = std::getenv("MH_ARTIC_PACK"); return e ? std::atoi(e) : 0; }();
+  static const int pack_env = [] { const char* e = std::getenv("MH_ARTIC_PACK"); return e ? std::atoi(e) : 0; }();
+  const int pack = pack_env | mh_g_debug_artic_pack;                 // mh_debug_set(9, 1)
   if (pack != 0 && ab->algorithm == MH_ARTIC_CRB && !std::getenv("MH_ARTIC_WAVES")) {          // two worlds per wavefront (k_artic_step_p2)
     hipLaunchKernelGGL(ar::k_artic_step_p2, dim3((ab->B + 1) / 2), dim3(64), 2 * ar::lds_bytes(ab->nj), (hipStream_t)stream,
                        (const ar::Model*)ab->d_model, ab->B, dt, nsteps, ab->d_q, ab->d_qd, ab->d_aux);

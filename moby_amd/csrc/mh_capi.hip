@@ -179,6 +179,7 @@ int mh_g_debug_repeats = 1;  // mh_debug_set(5, v): 1 = lcp_fast (n > 64) skips 
 int mh_g_debug_sched = 1;    // mh_debug_set(7, v): 1 = the ladder's tasks are handed out by need (pick_task), 0 = by block index, attempt-major
 int mh_g_debug_reuse = 1;    // mh_debug_set(6, v): 1 = the structure-exploiting LU keeps the factors of the columns before the one a Lemke pivot changed, 0 = factorises from scratch
 int mh_g_debug_compact = 1;  // mh_debug_set(3, v): 1 = Lemke's bases through the structure-exploiting LU (mh_lu_compact.inc), 0 = dense LU only
+int mh_g_debug_artic_pack = 0;
 int mh_g_debug_fastgeom = 0; // mh_debug_set(8, v): the lcp_fast kinds' thread geometry for n <= 512 -- 0 choose, 1 = 256, 2 = 1024, 3 = 64, 4 = 128 threads per problem
 int mh_g_debug_blk = 0;      // mh_debug_set(2, v): 0 = choose, 1 = 256-thread block solver, 2 = 1024-thread block solver, 3 = one wavefront per problem (lcp_lemke kinds, n <= 512)
 int mh_g_debug_ka = 64;          // LDS LU block edge of the world kernel (clamped to the variant MHW_KA_V); mh_debug_set(1, 0) forces the HBM workspace path
@@ -344,6 +345,7 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 extern "C" int mh_debug_set(int key, int value)
 {
   if (key == 1) { if (value < 0 || value > 64) return fail(MH_ERR_INVALID_ARG, "LU block edge outside [0, 64]"); mh_g_debug_ka = value; return MH_OK; }
+  if (key == 9) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "articulated packing outside {0, 1}"); mh_g_debug_artic_pack = value; return MH_OK; }
   if (key == 8) { if (value < 0 || value > 4) return fail(MH_ERR_INVALID_ARG, "lcp_fast geometry outside {0 .. 4}"); mh_g_debug_fastgeom = value; return MH_OK; }
   if (key == 2) { if (value < 0 || value > 4) return fail(MH_ERR_INVALID_ARG, "block solver geometry outside {0, 1, 2, 3, 4}"); mh_g_debug_blk = value; return MH_OK; }
   if (key == 4) { if (value < 0 || value > 2) return fail(MH_ERR_INVALID_ARG, "ladder-task switch outside {0, 1, 2}"); mh_g_debug_tasks = value; return MH_OK; }

@@ -91,5 +91,6 @@ MH_HIDDEN const mh_world_variant* mh_world_variant_large();
 extern MH_HIDDEN int mh_g_debug_ka;
 extern MH_HIDDEN int mh_g_debug_blk;
 extern MH_HIDDEN int mh_g_debug_fastgeom;
+extern MH_HIDDEN int mh_g_debug_artic_pack;          // mh_debug_set(9, v): the articulated stepper with two worlds per wavefront (k_artic_step_p2)
 
 }  // extern "C"

@@ -189,3 +189,28 @@ def test_link_jacobian_seam_matches_oracle(oracle):
     with pytest.raises(Exception):
         ab.jacobian(m.nj, pts)
     ab.close()
+
+
+def test_two_worlds_per_wavefront_stepper_equals_the_default_one():
+    """mh_debug_set(9, 1): k_artic_step_p2 steps two worlds per wavefront (lanes 0-31 / 32-63 on two LDS images, the forward dynamics in one
+    instruction stream, the limit handler per world).  Same ur10 states, an ODD batch, 3 x 60 steps both ways: q, qd, rand() streams,
+    flags and counters equal bit for bit.  (The default kernel is held to the oracle above; this one is the measured experiment of
+    DESIGN 4.4 -- no faster -- kept with its profile.)"""
+    from moby_amd import _lib
+    lib = _lib.load()
+    m, _, _ = A.load_sdf(os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes", "ten_joint_arm.sdf"))
+    q0, qd0 = ur10_states(m, 129)
+    res = {}
+    try:
+        for pack in (0, 1):
+            _lib.check(lib.mh_debug_set(9, pack))
+            ab = A.ArticBatch(m, q0, qd0)
+            for _ in range(3):
+                ab.step(5e-4, 60)
+            res[pack] = ab.download(); ab.close()
+    finally:
+        _lib.check(lib.mh_debug_set(9, 0))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for f in ("rng", "time", "status", "steps", "lcp_solves", "lcp_rows", "lcp_pivots", "vns_size"):
+        assert np.array_equal(res[0][2][f], res[1][2][f]), f
+    assert (res[0][2]["lcp_solves"] > 0).any()
