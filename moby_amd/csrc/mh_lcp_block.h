@@ -480,7 +480,17 @@ MH_DEV int rand_min(int n, Val val, Mem member, double tol, double& vsel, bool& 
   const int r = rand_next() % cnt;
   int chosen = imin;
   if (r != 0) {
-    if (t == 0) { int seen = 0, pick = imin; for (int i = 0; i < n; i++) if (member(i) && i != imin && val(i) < vmin + tol) { if (seen == r - 1) { pick = i; break; } seen++; } s_bi[2] = pick; }
+    // the (r - 1)-th of the other candidates in index order: contiguous index ranges per thread, a block scan of their counts, and the one
+    // thread whose range holds it walks its own few elements (one thread walking all n: 40 % of lcp_fast's time on box stacks, whose
+    // symmetric corner contacts tie all the time)
+    const int per = (n + T - 1) / T, lo = t * per, hi = (lo + per < n) ? lo + per : n;
+    int c2 = 0;
+    for (int i = lo; i < hi; i++) if (member(i) && i != imin && val(i) < vmin + tol) c2++;
+    int tot;
+    const int base = excl_scan_int(c2, tot);
+    if (t == 0) s_bi[2] = imin;
+    sync();
+    if (r - 1 >= base && r - 1 < base + c2) { int seen = base; for (int i = lo; i < hi; i++) if (member(i) && i != imin && val(i) < vmin + tol) { if (seen == r - 1) { s_bi[2] = i; break; } seen++; } }
     sync(); chosen = s_bi[2]; sync();
   }
   vsel = val(chosen);

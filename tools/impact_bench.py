@@ -26,7 +26,8 @@ def case(nbx, B, warm_calls=5):
     out = {"case": "config 4 box stack via impact handler", "nboxes": nbx, "nc": nc, "n": ib.n, "worlds": B,
            "cold_ms": cold_ms, "cold_pivots_mean": float(r["pivots"].mean()), "cold_pivots_max": int(r["pivots"].max()),
            "cold_rows_per_s": ib.n * float(r["solves"].sum()) / (cold_ms * 1e-3),
-           "alg_bytes_per_solve": 8 * (ib.n * ib.n + 2 * ib.n), "bad_worlds": int((r["status"] & ~2 != 0).sum())}
+           "alg_bytes_per_solve": 8 * (ib.n * ib.n + 2 * ib.n), "bad_worlds": int((r["status"] & ~2 != 0).sum()),
+           "status_flags_per_world": [int(x) for x in r["status"][:64]], "pivots_per_world": [int(x) for x in r["pivots"][:64]]}
     warm = []
     piv = []
     for _ in range(warm_calls):
