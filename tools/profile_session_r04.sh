@@ -21,6 +21,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 echo "sq done" >> $OUT/progress.txt
 # config 4 at the bench size: three full steps (cold, then warm), then ONE step under the profiler: kernel trace, FETCH_SIZE, WRITE_SIZE
 python3 tools/config4_full_size.py 16 1024 3 > $OUT/c4_3steps.json 2> $OUT/c4_3steps.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_3steps_ks -- python3 tools/config4_full_size.py 16 1024 3 > /dev/null 2> $OUT/c4_3steps_ks.err
 echo "config 4 three steps done" >> $OUT/progress.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4step_ks -- python3 tools/config4_full_size.py 16 1024 > $OUT/c4step.json 2> $OUT/c4step_ks.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/c4step_fetch -- python3 tools/config4_full_size.py 16 1024 > /dev/null 2> $OUT/c4step_fetch.err

@@ -127,3 +127,30 @@ if f4 and w4:
     for k, v in res["kernels"].items():
         if "k_lcp_block" in k:
             print(k, v)
+
+kt3 = one("c4_3steps_ks/*/*_kernel_trace.csv")
+if kt3:
+    rd = csv.reader(open(kt3)); h = next(rd)
+    rows = sorted([(int(r[h.index("Start_Timestamp")]), int(r[h.index("End_Timestamp")]), r[h.index("Kernel_Name")].split("(")[0].replace("void ", "")) for r in rd])
+    blk = [r for r in rows if "k_lcp_block" in r[2]]
+    if blk:
+        # the steps: gaps of more than 0.2 s between launches of the block solver do not occur inside a step; cut at the three largest... simpler: cut where a
+        # download (no kernel at all for > 50 ms) separates steps
+        t0 = rows[0][0]; cuts = [rows[0][0]]
+        for a, b in zip(rows, rows[1:]):
+            if b[0] - a[1] > 50e6: cuts.append(b[0])
+        cuts.append(rows[-1][1])
+        out = ["# rocprofv3 --kernel-trace -- python3 tools/config4_full_size.py 16 1024 3 (commit %s): seconds per kernel family in every stretch of launches" % COMMIT,
+               "# (stretches are separated by host-side gaps > 50 ms: the downloads between steps)"]
+        for k in range(len(cuts) - 1):
+            tot = collections.defaultdict(float)
+            for a, b, nme in rows:
+                if cuts[k] <= a < cuts[k + 1]: tot[nme] += (b - a) / 1e9
+            top = sorted(tot.items(), key=lambda kv: -kv[1])[:4]
+            out.append("stretch %d: %.2f s .. %.2f s: " % (k, (cuts[k] - t0) / 1e9, (cuts[k + 1] - t0) / 1e9) + ", ".join("%s %.2f s" % kv for kv in top))
+        open(os.path.join(P, tag + "_config4_3steps_kernel_trace.txt"), "w").write("\n".join(out) + "\n")
+        print("\n".join(out[2:]))
+if os.path.exists(os.path.join(src, "c4_3steps.json")):
+    line = [l for l in open(os.path.join(src, "c4_3steps.json")) if l.startswith("{")]
+    if line:
+        open(os.path.join(P, tag + "_config4_16x1024_3steps.json"), "w").write(line[-1])
