@@ -215,6 +215,26 @@ def test_config4_bench_size_full_batch():
     assert aux["lcp_solves"].min() >= 2 and aux["stab_rows"].mean() > 100          # impact + stabilisation LCPs were solved
 
 
+def test_config4_largest_solvable_size_properties():
+    """32 boxes per stack (impact LCP n = 1024, the 1024-thread geometry with the left-looking LU): the largest stack of BASELINE config 4's family that the
+    reference's own solver chain solves (64 boxes, n = 2048, defeats it: tests/test_oracle_compact_lu.py, profiles/r04_a_config4_64_boxes_x8_impact_call.json).
+    One full step of 8 worlds (the batch of 1024: profiles/r04_a_config4_32_boxes_x1024.json): no world fails, identical worlds agree, the stacks stay put."""
+    N, B = 32, 8
+    sc = K.box_stack_scene(N)
+    st0 = K.box_stack_state(N, B)
+    st0[B // 2:] = st0[:B // 2]
+    bb = K.BigBatch(sc, st0)
+    bb.step(1e-3, 1)
+    st, aux = bb.download()
+    bb.close()
+    assert ((aux["status"] & ~S.MH_WORLD_IMPACT_TOL) == 0).all()
+    assert np.array_equal(st[B // 2:], st[:B // 2]) and np.array_equal(aux["lcp_pivots"][B // 2:], aux["lcp_pivots"][:B // 2])
+    assert (aux["steps"] == 1).all() and (aux["lcp_rows"] >= 32 * N).all()
+    b = st.reshape(B, N, 13)
+    assert np.abs(b[:, :, 1] - 0.5 - np.arange(N)).max() < 1e-4
+    assert np.abs(b[:, :, 7:13]).max() < 5e-2
+
+
 def test_every_lemke_geometry_gives_the_same_full_steps():
     """The lcp_lemke kinds' thread geometries (mh_debug_set key 2: 256 / 1024 / 64 / 128 threads per problem; panels of 16 / 16 / 8 / 12
     columns, rounds of 16 / 16 / 4 / 8 steps in the left-looking LU) through the same 16-box worlds, one full step: states, rand()
