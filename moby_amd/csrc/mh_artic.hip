@@ -103,7 +103,7 @@ template <int PACK = 1>
 MH_DEV void kin_inertia(const Model& M, const Lay& Y, double* g)
 {
   const mh_artic_model& m = M.m;
-  const int nj = Y.nj, lane = lane_id() & (64 / PACK - 1);
+  const int nj = Y.nj, lane = (PACK == 1) ? lane_id() : (lane_id() & (64 / PACK - 1));
   // local transforms: lane = link
   if (lane < nj) {
     const int i = lane;
@@ -183,7 +183,7 @@ MH_DEV bool dynamics(const Model& M, const Lay& Y, double* g, const double* tau_
 {
   const mh_artic_model& m = M.m;
   constexpr int STR = 64 / PACK;
-  const int nj = Y.nj, lane = lane_id() & (STR - 1);
+  const int nj = Y.nj, lane = (PACK == 1) ? lane_id() : (lane_id() & (STR - 1));
   kin_inertia<PACK>(M, Y, g);
   // recursive Newton-Euler with qdd = 0 (the links' OWN inertias): lanes 0..5 = spatial components
   for (int i = 0; i < nj; i++) {
