@@ -174,7 +174,7 @@ int mh_rand_next(uint32_t* st)
   return (int)(v >> 1);
 }
 
-int mh_g_debug_tasks = 2;      // mh_debug_set(4, v): 0 = the Lemke ladder in sequence, 1 = as (world, attempt) tasks, 2 = tasks + speculation beside lcp_fast
+int mh_g_debug_tasks = 2;      // mh_debug_set(4, v): 0 = the Lemke ladder in sequence, 1 = as (world, attempt) tasks, 2 = tasks + speculation beside lcp_fast, 3 = 2 + at full chip the tasks launched behind lcp_fast on a second stream
 int mh_g_debug_repeats = 1;  // mh_debug_set(5, v): 1 = lcp_fast (n > 64) skips the repetitions of a repeating pivot sequence (mh_lcp_block.h), 0 = runs them
 int mh_g_debug_sched = 1;    // mh_debug_set(7, v): 1 = the ladder's tasks are handed out by need (pick_task), 0 = by block index, attempt-major
 int mh_g_debug_reuse = 1;    // mh_debug_set(6, v): 1 = the structure-exploiting LU keeps the factors of the columns before the one a Lemke pivot changed, 0 = factorises from scratch
@@ -348,7 +348,7 @@ extern "C" int mh_debug_set(int key, int value)
   if (key == 9) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "articulated packing outside {0, 1}"); mh_g_debug_artic_pack = value; return MH_OK; }
   if (key == 8) { if (value < 0 || value > 4) return fail(MH_ERR_INVALID_ARG, "lcp_fast geometry outside {0 .. 4}"); mh_g_debug_fastgeom = value; return MH_OK; }
   if (key == 2) { if (value < 0 || value > 4) return fail(MH_ERR_INVALID_ARG, "block solver geometry outside {0, 1, 2, 3, 4}"); mh_g_debug_blk = value; return MH_OK; }
-  if (key == 4) { if (value < 0 || value > 2) return fail(MH_ERR_INVALID_ARG, "ladder-task switch outside {0, 1, 2}"); mh_g_debug_tasks = value; return MH_OK; }
+  if (key == 4) { if (value < 0 || value > 3) return fail(MH_ERR_INVALID_ARG, "ladder-task switch outside {0, 1, 2, 3}"); mh_g_debug_tasks = value; return MH_OK; }
   if (key == 7) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "task-scheduling switch outside {0, 1}"); mh_g_debug_sched = value; return MH_OK; }
   if (key == 6) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "factor-reuse switch outside {0, 1}"); mh_g_debug_reuse = value; return MH_OK; }
   if (key == 5) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "repeat-skipping switch outside {0, 1}"); mh_g_debug_repeats = value; return MH_OK; }

@@ -1438,7 +1438,12 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   // ... unless the batch fills the chip with LCPs on which lcp_fast practically never succeeds (16-box stacks, n = 512, x 1024): running ahead
   // buys nothing there, and the tasks are better handed out by need afterwards (31.7 s instead of 35.7 s per full step)
   const bool full_chip = mh_g_debug_sched != 0 && n >= 384 && B >= 3 * mh_cu_count();
-  const bool spec_wanted = mh_g_debug_tasks >= 2 && n >= 256 && !full_chip;
+  // Full chip, mh_debug_set(4, 3) (default): lcp_fast's kernel is launched FIRST, in its own (1024-thread) geometry, and the ladder's tasks -- handed
+  // out by need -- right behind it on the second stream.  That kernel's time is its slowest world's (a few worlds per thousand run all 2n
+  // iterations of every rung, seconds, while the mean world is done in tens of milliseconds): the CUs the finished worlds leave take the ladder's
+  // workgroups instead of idling until the last world is through.
+  const bool overlap = mh_g_debug_tasks >= 3 && full_chip && n >= 256;
+  const bool spec_wanted = (mh_g_debug_tasks >= 2 && n >= 256 && !full_chip) || overlap;
   if (spec_wanted) L = core_ladder_plan(c, nullptr);
   bool spec = spec_wanted && L.ok;
   if (spec && !c->s2) {
@@ -1452,19 +1457,27 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   if (spec) {
     MH_HIP(hipEventRecord((hipEvent_t)c->ev0, s));
     MH_HIP(hipStreamWaitEvent((hipStream_t)c->s2, (hipEvent_t)c->ev0, 0));
-    rc = core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, false);
-    if (rc != MH_OK) return rc;
-    MH_HIP(hipEventRecord((hipEvent_t)c->ev1, (hipStream_t)c->s2));
+    if (!overlap) {
+      rc = core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, false);
+      if (rc != MH_OK) return rc;
+      MH_HIP(hipEventRecord((hipEvent_t)c->ev1, (hipStream_t)c->s2));
+    }
   }
+  const int fast_geom = (spec && !overlap) ? 2 : 0;
   if (mode == MH_CORE_IMPACT) {
     mh_lcp_opts o1; o1.min_exp = -20; o1.step_exp = 4u; o1.max_exp = -8; o1.piv_tol = -1.0; o1.zero_tol = -1.0;   // ICH-QP:219
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, nullptr, c->rng, c->lst1, c->piv1,
-                                 nullptr, 0, nullptr, &o1, run_if, c->ws_d, c->ws_i, c->ncur, c->work, spec ? 2 : 0);
+                                 nullptr, 0, nullptr, &o1, run_if, c->ws_d, c->ws_i, c->ncur, c->work, fast_geom);
   } else {
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, c->lst1, c->piv1,
-                                 nullptr, 0, nullptr, nullptr, run_if, c->ws_d, c->ws_i, c->ncur, c->work, spec ? 2 : 0);   // CStab:954
+                                 nullptr, 0, nullptr, nullptr, run_if, c->ws_d, c->ws_i, c->ncur, c->work, fast_geom);   // CStab:954
   }
-  if (rc != MH_OK) { if (spec) (void)hipStreamWaitEvent(s, (hipEvent_t)c->ev1, 0); return rc; }     // (the tasks' stream joins this one on every way out)
+  if (rc == MH_OK && spec && overlap) {                          // the ladder's tasks, by need, behind lcp_fast's launch
+    rc = core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, true);
+    if (rc == MH_OK) { const hipError_t e = hipEventRecord((hipEvent_t)c->ev1, (hipStream_t)c->s2); if (e != hipSuccess) rc = fail(MH_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e)); }
+    if (rc != MH_OK) { (void)hipStreamSynchronize((hipStream_t)c->s2); return rc; }
+  } else
+  if (rc != MH_OK) { if (spec && !overlap) (void)hipStreamWaitEvent(s, (hipEvent_t)c->ev1, 0); return rc; }     // (the tasks' stream joins this one on every way out)
   hipLaunchKernelGGL(im::k_lemke_prep, dim3(B), dim3(im::T), 0, s, *c, run_if, mode);
   { const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (spec) (void)hipStreamWaitEvent(s, (hipEvent_t)c->ev1, 0); return fail(MH_ERR_HIP, "k_lemke_prep failed: %s", hipGetErrorString(e)); } }
