@@ -910,7 +910,7 @@ int mh_artic_batch_step(mh_artic_batch* ab, void* stream, double dt, int nsteps)
   if (nsteps == 0) return MH_OK;
   if (!(dt > 0.0)) return fail(MH_ERR_INVALID_ARG, "dt must be > 0");
   if (ab->nspheres > 0) {                                     // bodies with collision geometry: the full step with mini-steps and contact rows
-    hipLaunchKernelGGL(ar::k_artic_step_contacts, dim3(ab->B), dim3(64), ar::lds_bytes_contacts(ab->nj), (hipStream_t)stream,
+    hipLaunchKernelGGL(ab->cstab ? ar::k_artic_step_contacts_stab : ar::k_artic_step_contacts, dim3(ab->B), dim3(64), ar::lds_bytes_contacts(ab->nj), (hipStream_t)stream,
                        (const ar::Model*)ab->d_model, ab->B, dt, nsteps, ab->d_q, ab->d_qd, ab->d_aux, ab->d_ws);
     MH_HIP(hipGetLastError());
     return MH_OK;
