@@ -3,7 +3,9 @@
 BASELINE names 64, which the reference's own solver chain does not solve; 32 is the largest it does.  Prints one JSON line
 (kept under profiles/): per-step seconds, properties of the final state; with --dump-world W FILE.npz the start and end state and the
 solver record of world W are saved for tests/tools/config4_oracle_world.py, which runs the CPU oracle on the same world and compares.
-python tools/config4_full_size.py [boxes] [worlds] [steps] [--dump-world W FILE.npz]"""
+--states-of B0 takes the start states of the first `worlds` worlds of a batch of B0 (the perturbations are drawn per batch) without mirroring the second
+half; --dump-failed PREFIX saves every world that ends with MH_WORLD_LCP_FAILED as PREFIX_w<index>.npz in the same format.
+python tools/config4_full_size.py [boxes] [worlds] [steps] [--dump-world W FILE.npz] [--states-of B0] [--dump-failed PREFIX]"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,17 +14,23 @@ from moby_amd import scene as S, stack as K
 from moby_amd import _lib
 if os.environ.get("MH_BLK_GEOM"):          # mh_debug_set key 2 (the block solver's thread geometry)
     _lib.check(_lib.load().mh_debug_set(2, int(os.environ["MH_BLK_GEOM"])))
-args = [a for a in sys.argv[1:] if not a.startswith("--") and not a.endswith(".npz")]
-if "--dump-world" in sys.argv:
-    args = [a for k, a in enumerate(sys.argv[1:]) if not a.startswith("--") and not a.endswith(".npz") and sys.argv[k] != "--dump-world"]
+if os.environ.get("MH_FAST_GEOM"):         # mh_debug_set key 8 (the lcp_fast kinds' thread geometry for n <= 512)
+    _lib.check(_lib.load().mh_debug_set(8, int(os.environ["MH_FAST_GEOM"])))
+_opt = {"--dump-world": 2, "--states-of": 1, "--dump-failed": 1}
+args, _k = [], 1
+while _k < len(sys.argv):
+    if sys.argv[_k] in _opt: _k += 1 + _opt[sys.argv[_k]]
+    else: args.append(sys.argv[_k]); _k += 1
 N = int(args[0]) if len(args) > 0 else 16
 B = int(args[1]) if len(args) > 1 else 1024
 steps = int(args[2]) if len(args) > 2 else 1
 ow = int(sys.argv[sys.argv.index("--dump-world") + 1]) if "--dump-world" in sys.argv else None
 dump = sys.argv[sys.argv.index("--dump-world") + 2] if ow is not None else None
 sc = K.box_stack_scene(N)
-st0 = K.box_stack_state(N, B)
-if B >= 2:
+B0 = int(sys.argv[sys.argv.index("--states-of") + 1]) if "--states-of" in sys.argv else None
+dump_failed = sys.argv[sys.argv.index("--dump-failed") + 1] if "--dump-failed" in sys.argv else None
+st0 = K.box_stack_state(N, B) if B0 is None else np.ascontiguousarray(K.box_stack_state(N, B0)[:B])
+if B >= 2 and B0 is None:
     st0[B // 2:] = st0[:B // 2]                               # second half = copy of the first: batch-order independence
 bb = K.BigBatch(sc, st0)
 # a step of a large batch can take many minutes without a line of output: keep a heartbeat file growing (gpurun takes silence for a hang)
@@ -59,7 +67,7 @@ out = {
     "worlds_lcp_failed": int(((aux["status"] & S.MH_WORLD_LCP_FAILED) != 0).sum()),
     "status_flags_per_world": [int(x) for x in aux["status"][:min(B, 16)]],
     "worlds_impact_tolerance_warnings": int(((aux["status"] & S.MH_WORLD_IMPACT_TOL) != 0).sum()),
-    "batch_order_independent": bool(B < 2 or (np.array_equal(st[h:2 * h], st[:h]) and np.array_equal(aux["lcp_pivots"][h:2 * h], aux["lcp_pivots"][:h]))),
+    "batch_order_independent": None if B0 is not None else bool(B < 2 or (np.array_equal(st[h:2 * h], st[:h]) and np.array_equal(aux["lcp_pivots"][h:2 * h], aux["lcp_pivots"][:h]))),
     "max_height_error": float(np.abs(b[:, :, 1] - 0.5 - np.arange(N)).max()),
     "max_speed_after_last_step": float(np.abs(b[:, :, 7:13]).max()),
     "lcp_rows_mean": float(aux["lcp_rows"].mean()), "lcp_pivots_mean": float(aux["lcp_pivots"].mean()), "lcp_pivots_max": int(aux["lcp_pivots"].max()),
@@ -70,4 +78,11 @@ out = {
 if ow is not None:          # the GPU side of world `ow` for tests/tools/config4_oracle_world.py (the checker that runs the CPU oracle on the same world)
     np.savez(dump, boxes=N, steps=steps, world=ow, cap=cap, st0=st0[ow], st=st[ow], aux=aux[ow:ow + 1])
     out["dumped_world"] = {"world": ow, "file": dump}
+if dump_failed is not None:
+    bad = [int(w) for w in np.nonzero((aux["status"] & S.MH_WORLD_LCP_FAILED) != 0)[0]]
+    for w in bad:
+        np.savez("%s_w%d.npz" % (dump_failed, w), boxes=N, steps=steps, world=w, cap=cap, st0=st0[w], st=st[w], aux=aux[w:w + 1])
+    out["failed_worlds"] = bad
+if B0 is not None:
+    out["states_of_batch"] = B0
 print(json.dumps(out))
