@@ -14,6 +14,8 @@ from moby_amd import scene as S, stack as K
 from moby_amd import _lib
 if os.environ.get("MH_BLK_GEOM"):          # mh_debug_set key 2 (the block solver's thread geometry)
     _lib.check(_lib.load().mh_debug_set(2, int(os.environ["MH_BLK_GEOM"])))
+if os.environ.get("MH_COMPACT_LU"):        # mh_debug_set key 3 (0: the dense LU everywhere)
+    _lib.check(_lib.load().mh_debug_set(3, int(os.environ["MH_COMPACT_LU"])))
 if os.environ.get("MH_FAST_GEOM"):         # mh_debug_set key 8 (the lcp_fast kinds' thread geometry for n <= 512)
     _lib.check(_lib.load().mh_debug_set(8, int(os.environ["MH_FAST_GEOM"])))
 _opt = {"--dump-world": 2, "--states-of": 1, "--dump-failed": 1}
