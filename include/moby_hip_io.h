@@ -58,10 +58,25 @@ typedef struct mh_io_artic {
 } mh_io_artic;
 int mh_io_load_sdf(const char* path, const double gravity[3], mh_io_artic* out);
 
+/* URDF robots (example/urdf/pendulum.urdf): the subset of URDFReader::read (src/URDFReader.cpp:65-141, 144-203, 299-403, 456-566, 599-636,
+ * 943-1043) an articulated-body batch needs -- <robot name>, <link name> (<inertial>: origin xyz / rpy, mass value, inertia ixx..izz given in the
+ * inertial frame), <joint name type="revolute|continuous|prismatic|fixed"> (parent link, child link, origin xyz / rpy RELATIVE TO THE PARENT LINK's
+ * frame, axis xyz in the joint's frame, default (1, 0, 0); limit lower / upper).  As in the reference the child link's frame IS the joint's frame, a
+ * revolute joint without limits gets -pi/2 .. pi/2, continuous and prismatic ones -10000 .. 10000 (URDFReader.cpp:326-345), a <limit> element counts
+ * only if it carries effort, lower or upper (:549), <dynamics damping friction> land in Joint::mu_fv / mu_fc, which a reduced-coordinate body never
+ * reads (only src/MCArticulatedBody.cpp:419-420 does) and are therefore accepted and without effect, and floating / planar joints are not read.
+ * The base is the one link that is no joint's child; it is FIXED (RCArticulatedBody floating-base="false", example/urdf/pendulum-urdf.xml:23), its
+ * frame is the model frame.  The batch knows 1-DOF joints only, so a FIXED joint welds its child to the link that carries it: masses add up, the
+ * COM and the tensor about it follow the parallel-axis theorem, joints hanging from the welded link hang from the carrier -- one rigid body, which is
+ * what a zero-DOF joint is in reduced coordinates.  A moving link must end up with mass > 0 (the reference disables a link without: :613-616).
+ * Collision geometry is skipped here as in mh_io_load_sdf; mh_io_load_xml_artic (urdf-filename) keeps the <collision> spheres.  0 on success. */
+int mh_io_load_urdf(const char* path, const double gravity[3], mh_io_artic* out);
+
 /* A Moby XML file with ONE fixed-base <RCArticulatedBody> (the files of example/joint-limits, example/reduced-coords: RigidBody links
  * with InertiaFromPrimitive | mass / inertia, <RevoluteJoint> / <PrismaticJoint> with location / axis in the global frame, lower-limits,
  * upper-limits, restitution-coeff, q, qd -- RCArticulatedBody.cpp:162-260, Joint.cpp:184-345, RevoluteJoint.cpp:39-55,
- * PrismaticJoint.cpp) -> mh_artic_model at q = 0 (the link poses the file states; the base link is the link no joint carries), the
+ * PrismaticJoint.cpp; or urdf-filename="..." (ArticulatedBody.cpp:250-273: links and joints from the URDF file next to the XML file, as
+ * mh_io_load_urdf reads them, q = qd = 0, the first <collision> sphere of a link as its link sphere) -> mh_artic_model at q = 0 (the link poses the file states; the base link is the link no joint carries), the
  * joints' q / qd as the initial state (q0, qd0: MH_ARTIC_MAX_JOINTS doubles each, joint order = out->joint_id), <DRIVER step-size>,
  * the simulator's GravityForce, fdyn-algorithm crb / fsab.
  * Collision geometry: a link's <CollisionGeometry> with a <Sphere> primitive becomes a link sphere; ONE disabled <RigidBody> with a

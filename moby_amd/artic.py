@@ -56,6 +56,20 @@ def load_sdf(path, gravity=(0.0, 0.0, -9.81)):
     return m, [io.link_id[i].value.decode() for i in range(m.nj)], [io.joint_id[i].value.decode() for i in range(m.nj)]
 
 
+def load_urdf(path, gravity=(0.0, 0.0, -9.81)):
+    """A URDF robot with a fixed base (src/URDFReader.cpp; include/moby_hip_io.h: mh_io_load_urdf) -> (model, link ids, joint ids)."""
+    lib = mio.load()
+    lib.mh_io_load_urdf.restype = ctypes.c_int
+    lib.mh_io_load_urdf.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(mh_io_artic)]
+    out = mh_io_artic()
+    g = (ctypes.c_double * 3)(*gravity)
+    if lib.mh_io_load_urdf(os.fsencode(path), g, ctypes.byref(out)) != 0:
+        raise mio.SceneError(lib.mh_io_last_error().decode("utf-8", "replace"))
+    m = mh_artic_model()
+    ctypes.memmove(ctypes.addressof(m), ctypes.addressof(out.model), ctypes.sizeof(mh_artic_model))
+    return m, [out.link_id[i].value.decode() for i in range(m.nj)], [out.joint_id[i].value.decode() for i in range(m.nj)]
+
+
 def load_xml(path):
     """-> (mh_artic_model, link names, joint names, q0, qd0, step size): a Moby XML file with one fixed-base RCArticulatedBody
     (include/moby_hip_io.h: mh_io_load_xml_artic) -- the model at q = 0, the joints' q / qd attributes as the initial state."""

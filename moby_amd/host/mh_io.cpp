@@ -247,6 +247,188 @@ extern "C" int mh_io_load_sdf(const char* path, const double gravity[3], mh_io_a
 }
 
 
+// ---- URDF (src/URDFReader.cpp) ----------------------------------------------------------------------------
+namespace {
+struct UrdfLink { std::string name; bool has_inertial = false; Pose inertial; double mass = 0.0; double I[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                  int cg = 0; Pose cg_pose; double cg_radius = 0.0; std::string cg_kind; };      // cg: 0 none, 1 sphere, 2 box / cylinder
+struct UrdfJoint { std::string name, parent, child; int type = 0; Pose origin; double axis[3] = {1.0, 0.0, 0.0}; double lo = 0.0, hi = 0.0; };
+constexpr int URDF_FIXED = 2;
+// URDFReader::read_origin (URDFReader.cpp:943-972): the first <origin>, xyz and rpy attributes, Quatd::rpy
+bool urdf_origin(xmlNode* parent, Pose& p) {
+  p = identity_pose();
+  xmlNode* n = child_named(parent, "origin");
+  if (!n) return true;
+  const Attrs a = attrs_of(n);
+  if (a.has("xyz")) { const std::vector<double> v = numbers(a.str("xyz")); if (v.size() != 3) return false; for (int i = 0; i < 3; i++) p.x[i] = v[i]; }
+  if (a.has("rpy")) { const std::vector<double> v = numbers(a.str("rpy")); if (v.size() != 3) return false; rpy_to_R(v[0], v[1], v[2], p.R); }
+  return true;
+}
+// the robot as a fixed-base tree of 1-DOF joints; a FixedJoint's outboard link rides on the link that carries it
+struct UrdfGeom { int link; std::string id; bool sphere; double center[3]; double radius; std::string kind; };   // link -1: the base
+struct UrdfRobot { std::string name, base; mh_io_artic art; std::vector<UrdfGeom> geoms; std::vector<std::string> link_names; };
+
+int parse_urdf(const char* path, UrdfRobot& rob)
+{
+  xmlDoc* doc = xmlReadFile(path, nullptr, XML_PARSE_NONET | XML_PARSE_NOERROR | XML_PARSE_NOWARNING);
+  if (!doc) return fail("cannot parse %s", path);
+  struct Guard { xmlDoc* d; ~Guard() { xmlFreeDoc(d); } } guard{doc};
+  xmlNode* root = xmlDocGetRootElement(doc);
+  if (!root || strcasecmp((const char*)root->name, "robot") != 0) return fail("%s: the root element of a URDF file is <robot>", path);   // URDFReader.cpp:124-135
+  { const Attrs a = attrs_of(root); if (!a.has("name")) return fail("%s: <robot> without a name", path); rob.name = a.str("name"); }   // :147-160
+  std::vector<UrdfLink> links; std::vector<UrdfJoint> joints;
+  for (xmlNode* c = root->children; c; c = c->next) {
+    if (c->type != XML_ELEMENT_NODE) continue;
+    const Attrs a = attrs_of(c);
+    if (strcasecmp((const char*)c->name, "link") == 0) {                        // read_link / read_inertial / read_collision (:180-203, 599-636, 781-811)
+      UrdfLink L; if (!a.has("name")) return fail("%s: a <link> without a name", path);
+      L.name = a.str("name"); L.inertial = identity_pose(); L.cg_pose = identity_pose();
+      if (xmlNode* in = child_named(c, "inertial")) {
+        L.has_inertial = true;
+        if (!urdf_origin(in, L.inertial)) return fail("link %s: bad inertial <origin>", L.name.c_str());
+        if (xmlNode* mn = child_named(in, "mass")) { const Attrs ma = attrs_of(mn); if (ma.has("value")) L.mass = std::atof(ma.str("value").c_str()); }
+        double I[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (xmlNode* im = child_named(in, "inertia")) { const Attrs ia = attrs_of(im);
+          auto g = [&](const char* k) { return ia.has(k) ? std::atof(ia.str(k).c_str()) : 0.0; };
+          I[0] = g("ixx"); I[4] = g("iyy"); I[8] = g("izz"); I[1] = I[3] = g("ixy"); I[2] = I[6] = g("ixz"); I[5] = I[7] = g("iyz"); }
+        double Tm[9]; mat3mul(L.inertial.R, I, Tm);                               // the tensor is given in the inertial frame: into the link's axes
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) L.I[3*i+j] = Tm[3*i] * L.inertial.R[3*j] + Tm[3*i+1] * L.inertial.R[3*j+1] + Tm[3*i+2] * L.inertial.R[3*j+2];
+      }
+      if (xmlNode* col = child_named(c, "collision")) {                            // the first <collision> only, as the reference
+        if (xmlNode* ge = child_named(col, "geometry")) {
+          xmlNode* sp = child_named(ge, "sphere");
+          // read_primitive tries box, cylinder, sphere in that order (:813-836)
+          if (child_named(ge, "box")) { L.cg = 2; L.cg_kind = "box"; }
+          else if (child_named(ge, "cylinder")) { L.cg = 2; L.cg_kind = "cylinder"; }
+          else if (sp && attrs_of(sp).has("radius")) { L.cg = 1; L.cg_kind = "sphere"; L.cg_radius = std::atof(attrs_of(sp).str("radius").c_str()); }
+          if (L.cg && !urdf_origin(col, L.cg_pose)) return fail("link %s: bad collision <origin>", L.name.c_str());
+        }
+      }
+      links.push_back(L);
+    } else if (strcasecmp((const char*)c->name, "joint") == 0) {                 // read_joint (:299-403)
+      UrdfJoint J; if (!a.has("name") || !a.has("type")) return fail("%s: a <joint> needs a name and a type", path);
+      J.name = a.str("name");
+      const std::string type = a.str("type");
+      if (strcasecmp(type.c_str(), "revolute") == 0) { J.type = MH_JOINT_REVOLUTE; J.lo = -M_PI_2; J.hi = M_PI_2; }
+      else if (strcasecmp(type.c_str(), "continuous") == 0) { J.type = MH_JOINT_REVOLUTE; J.lo = -10000.0; J.hi = 10000.0; }
+      else if (strcasecmp(type.c_str(), "prismatic") == 0) { J.type = MH_JOINT_PRISMATIC; J.lo = -10000.0; J.hi = 10000.0; }
+      else if (strcasecmp(type.c_str(), "fixed") == 0) J.type = URDF_FIXED;
+      else return fail("joint %s: type '%s' is not supported (revolute, continuous, prismatic, fixed; the reference drops floating and planar joints too)", J.name.c_str(), type.c_str());
+      xmlNode* pn = child_named(c, "parent"); xmlNode* cn = child_named(c, "child");
+      if (!pn || !attrs_of(pn).has("link")) return fail("joint %s: no <parent link=...>", J.name.c_str());
+      if (!cn || !attrs_of(cn).has("link")) return fail("joint %s: no <child link=...>", J.name.c_str());
+      J.parent = attrs_of(pn).str("link"); J.child = attrs_of(cn).str("link");
+      if (!urdf_origin(c, J.origin)) return fail("joint %s: bad <origin>", J.name.c_str());
+      if (xmlNode* ax = child_named(c, "axis")) { const Attrs xa = attrs_of(ax);  // read_axis (:456-496): default (1, 0, 0), in the joint's frame
+        if (xa.has("xyz")) { const std::vector<double> v = numbers(xa.str("xyz")); if (v.size() != 3) return fail("joint %s: bad <axis>", J.name.c_str()); for (int i = 0; i < 3; i++) J.axis[i] = v[i]; } }
+      if (J.type != URDF_FIXED) if (xmlNode* lim = child_named(c, "limit")) { const Attrs la = attrs_of(lim);   // read_limits (:532-566)
+        if (la.has("effort") || la.has("lower") || la.has("upper")) {
+          if (la.has("lower")) J.lo = std::atof(la.str("lower").c_str());
+          if (la.has("upper")) J.hi = std::atof(la.str("upper").c_str()); } }
+      // <dynamics damping friction> become Joint::mu_fv / mu_fc (:499-529), which only MCArticulatedBody reads (MCArticulatedBody.cpp:419-420,
+      // 564-565): a reduced-coordinate body steps without them in the reference, and so here
+      joints.push_back(J);
+    }
+  }
+  if (links.empty()) return fail("%s: no links", path);
+  std::map<std::string, int> link_of; for (size_t i = 0; i < links.size(); i++) { if (link_of.count(links[i].name)) return fail("%s: two links named %s", path, links[i].name.c_str()); link_of[links[i].name] = (int)i; }
+  std::map<std::string, int> inner;                                               // child link -> its joint
+  for (size_t j = 0; j < joints.size(); j++) {
+    if (!link_of.count(joints[j].parent) || !link_of.count(joints[j].child)) return fail("joint %s: unknown link", joints[j].name.c_str());
+    if (inner.count(joints[j].child)) return fail("link %s is the child of two joints (closed chains are not supported)", joints[j].child.c_str());
+    inner[joints[j].child] = (int)j;
+  }
+  int nbase = 0; for (const UrdfLink& L : links) if (!inner.count(L.name)) { rob.base = L.name; nbase++; }
+  if (nbase != 1) return fail("%s: %d links are carried by no joint (exactly one base link expected)", path, nbase);
+  // parents first, file order within a level.  carrier[l]: the model link whose frame link l is rigidly attached to (-1 = base) + its pose there
+  struct Placed { int carrier; Pose pose; };
+  std::map<std::string, Placed> placed; placed[rob.base] = Placed{ -1, identity_pose() };
+  struct Part { double mass; double com[3]; double I[9]; };
+  std::vector<std::vector<Part> > parts;                                          // per model link: its own inertia, then what fixed joints hang on it
+  std::memset(&rob.art, 0, sizeof(rob.art));
+  mh_artic_model& m = rob.art.model;
+  std::vector<char> used(joints.size(), 0);
+  size_t done = 0;
+  auto add_part = [&](int carrier, const Pose& P, const UrdfLink& L) {
+    if (carrier < 0 || !L.has_inertial) return;
+    Part p; p.mass = L.mass;
+    double c[3]; mat3vec(P.R, L.inertial.x, c); for (int k = 0; k < 3; k++) p.com[k] = c[k] + P.x[k];
+    double Tm[9]; mat3mul(P.R, L.I, Tm);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) p.I[3*i+j] = Tm[3*i] * P.R[3*j] + Tm[3*i+1] * P.R[3*j+1] + Tm[3*i+2] * P.R[3*j+2];
+    parts[carrier].push_back(p);
+  };
+  auto add_geom = [&](int carrier, const Pose& P, const UrdfLink& L) {
+    if (!L.cg) return;
+    UrdfGeom g; g.link = carrier; g.id = L.name; g.sphere = (L.cg == 1); g.radius = L.cg_radius; g.kind = L.cg_kind;
+    double c[3]; mat3vec(P.R, L.cg_pose.x, c); for (int k = 0; k < 3; k++) g.center[k] = c[k] + P.x[k];
+    rob.geoms.push_back(g);
+  };
+  add_geom(-1, identity_pose(), links[link_of[rob.base]]);
+  while (done < joints.size()) {
+    bool progress = false;
+    for (size_t j = 0; j < joints.size(); j++) {
+      if (used[j] || !placed.count(joints[j].parent)) continue;
+      const UrdfJoint& J = joints[j]; const Placed& PP = placed[J.parent]; const UrdfLink& L = links[link_of[J.child]];
+      Pose F;                                                                      // the joint's (= the child link's) frame in the carrier's frame
+      mat3mul(PP.pose.R, J.origin.R, F.R);
+      { double tt[3]; mat3vec(PP.pose.R, J.origin.x, tt); for (int k = 0; k < 3; k++) F.x[k] = tt[k] + PP.pose.x[k]; }
+      if (J.type == URDF_FIXED) {
+        placed[J.child] = Placed{ PP.carrier, F };
+        add_part(PP.carrier, F, L); add_geom(PP.carrier, F, L);
+      } else {
+        if (m.nj >= MH_ARTIC_MAX_JOINTS) return fail("%s: more than %d moving joints", path, MH_ARTIC_MAX_JOINTS);
+        const int i = m.nj++;
+        m.parent[i] = PP.carrier; m.jtype[i] = J.type;
+        for (int k = 0; k < 9; k++) m.Rrel[i][k] = F.R[k];
+        for (int k = 0; k < 3; k++) m.trel[i][k] = F.x[k];
+        const double nrm = std::sqrt(J.axis[0]*J.axis[0] + J.axis[1]*J.axis[1] + J.axis[2]*J.axis[2]);
+        if (!(nrm > 0.0)) return fail("joint %s: zero axis", J.name.c_str());
+        for (int k = 0; k < 3; k++) m.axis[i][k] = J.axis[k] / nrm;
+        m.lolimit[i] = J.lo; m.hilimit[i] = J.hi; m.limit_restitution[i] = 0.0;
+        snprintf(rob.art.link_id[i], MH_IO_ID_LEN, "%s", L.name.c_str());
+        snprintf(rob.art.joint_id[i], MH_IO_ID_LEN, "%s", J.name.c_str());
+        parts.push_back(std::vector<Part>());
+        placed[J.child] = Placed{ i, identity_pose() };
+        add_part(i, identity_pose(), L); add_geom(i, identity_pose(), L);
+      }
+      used[j] = 1; done++; progress = true;
+    }
+    if (!progress) return fail("%s: joints that do not hang from the base link %s", path, rob.base.c_str());
+  }
+  if (m.nj == 0) return fail("%s: no moving joint: a single rigid body, not an articulated one", path);
+  for (int i = 0; i < m.nj; i++) {
+    const std::vector<Part>& ps = parts[i];
+    if (ps.size() == 1) {                                                          // the link alone: its numbers as the file states them
+      m.mass[i] = ps[0].mass; for (int k = 0; k < 3; k++) m.com[i][k] = ps[0].com[k]; for (int k = 0; k < 9; k++) m.inertia[i][k] = ps[0].I[k];
+    } else {                                                                       // + the links fixed to it: one rigid body (parallel-axis theorem about the common COM)
+      double M = 0.0, c[3] = { 0.0, 0.0, 0.0 };
+      for (const Part& p : ps) { M += p.mass; for (int k = 0; k < 3; k++) c[k] += p.mass * p.com[k]; }
+      if (M > 0.0) for (int k = 0; k < 3; k++) c[k] /= M;
+      double I[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (const Part& p : ps) { const double d[3] = { p.com[0] - c[0], p.com[1] - c[1], p.com[2] - c[2] }; const double dd = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
+        for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) I[3*r+q] += p.I[3*r+q] + p.mass * (((r == q) ? dd : 0.0) - d[r] * d[q]); }
+      m.mass[i] = M; for (int k = 0; k < 3; k++) m.com[i][k] = c[k]; for (int k = 0; k < 9; k++) m.inertia[i][k] = I[k];
+    }
+    // URDFReader::read_inertial disables a link without mass or with a tensor that is not positive definite (:613-616); a disabled link
+    // inside the tree has no dynamics in the reference either, so the model is refused
+    if (!(m.mass[i] > 0.0)) return fail("link %s: no mass (the reference disables such a link)", rob.art.link_id[i]);
+  }
+  for (const UrdfLink& L : links) rob.link_names.push_back(L.name);
+  m.cstab_eps = std::sqrt(2.220446049250313e-16);
+  return 0;
+}
+}  // namespace
+
+extern "C" int mh_io_load_urdf(const char* path, const double gravity[3], mh_io_artic* out)
+{
+  if (!path || !out) return fail("null argument");
+  UrdfRobot rob;
+  if (parse_urdf(path, rob)) return 1;
+  *out = rob.art;
+  for (int k = 0; k < 3; k++) out->model.gravity[k] = gravity ? gravity[k] : 0.0;
+  return 0;
+}
+
+
 extern "C" {
 
 const char* mh_io_last_error(void) { return g_err; }
@@ -451,6 +633,15 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
   const Attrs aa = attrs_of(ab);
   if (aa.has("floating-base") && boolean(aa.str("floating-base"))) return fail("RCArticulatedBody %s: floating bases are not supported", aa.str("id").c_str());
   if (aa.has("translate") || aa.has("rpy")) return fail("RCArticulatedBody %s: translate / rpy are not supported", aa.str("id").c_str());
+  // ArticulatedBody::load_from_xml (ArticulatedBody.cpp:250-273): with urdf-filename the links and joints come from the URDF file (found relative
+  // to the XML file, XMLReader changes into its directory) and nothing else under the element is read
+  const bool from_urdf = aa.has("urdf-filename");
+  UrdfRobot rob;
+  if (from_urdf) {
+    std::string up = aa.str("urdf-filename");
+    if (!up.empty() && up[0] != '/') { const std::string xp = path; const size_t sl = xp.find_last_of('/'); if (sl != std::string::npos) up = xp.substr(0, sl + 1) + up; }
+    if (parse_urdf(up.c_str(), rob)) return 1;
+  }
   // ---- primitives: mass properties (SpherePrimitive.cpp:138-155, BoxPrimitive.cpp:692-712, CylinderPrimitive.cpp:524-547) ----
   std::map<std::string, Prim> prims;
   { std::vector<xmlNode*> v; collect(root, "Sphere", v);
@@ -475,7 +666,7 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
   struct XLink { std::string id; double x[3]; double R[9]; double mass; double J[3]; std::string geom; bool has_cg; };
   struct XJoint { std::string id, in, out; int type; double loc[3], axis[3], lo, hi, q, qd, resti; };
   std::vector<XLink> links; std::vector<XJoint> joints;
-  for (xmlNode* c = ab->children; c; c = c->next) {
+  for (xmlNode* c = from_urdf ? nullptr : ab->children; c; c = c->next) {
     if (c->type != XML_ELEMENT_NODE) continue;
     const Attrs a = attrs_of(c);
     const std::string nm = (const char*)c->name;
@@ -520,9 +711,10 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
       joints.push_back(J);
     } else if (nm.size() > 5 && nm.compare(nm.size() - 5, 5, "Joint") == 0) return fail("%s %s: only revolute and prismatic joints are supported", nm.c_str(), a.str("id").c_str());
   }
-  if (joints.empty()) return fail("%s: an articulated body without joints", path);
+  if (!from_urdf && joints.empty()) return fail("%s: an articulated body without joints", path);
   if ((int)joints.size() > MH_ARTIC_MAX_JOINTS) return fail("%zu joints > %d", joints.size(), MH_ARTIC_MAX_JOINTS);
   std::map<std::string, int> link_of; for (size_t i = 0; i < links.size(); i++) link_of[links[i].id] = (int)i;
+  if (from_urdf) for (size_t i = 0; i < rob.link_names.size(); i++) link_of[rob.link_names[i]] = (int)i;   // (ids only: ContactParameters / DisabledPair may name a link)
   std::map<std::string, int> carried;                                      // outboard link -> joint
   for (size_t j = 0; j < joints.size(); j++) {
     if (!link_of.count(joints[j].in) || !link_of.count(joints[j].out)) return fail("joint %s: unknown link", joints[j].id.c_str());
@@ -531,6 +723,7 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
   }
   std::string base; int nbase = 0;
   for (const XLink& L : links) if (!carried.count(L.id)) { base = L.id; nbase++; }
+  if (from_urdf) { base = rob.base; nbase = 1; }
   if (nbase != 1) return fail("%s: %d links are carried by no joint (exactly one base link expected)", path, nbase);
   std::vector<int> order; std::map<std::string, int> pos_of;               // parents first, file order within a level
   std::vector<char> used(joints.size(), 0);
@@ -594,8 +787,17 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
   { std::string alg = aa.has("fdyn-algorithm") ? aa.str("fdyn-algorithm") : "crb"; for (char& ch : alg) ch = (char)tolower(ch);
     alg.erase(0, alg.find_first_not_of(" \t\n\r")); alg.erase(alg.find_last_not_of(" \t\n\r") + 1);
     if (alg == "fsab") m.algorithm = MH_ARTIC_FSAB; else if (alg == "crb") m.algorithm = MH_ARTIC_CRB; else return fail("fdyn-algorithm '%s': crb or fsab", alg.c_str()); }
-  const XLink& B0 = links[link_of[base]];
-  for (int i = 0; i < m.nj; i++) {
+  XLink urdf_base; urdf_base.id = base; urdf_base.mass = 0.0; urdf_base.has_cg = false;      // a URDF robot's base link frame is the model frame
+  for (int k = 0; k < 3; k++) { urdf_base.x[k] = 0.0; urdf_base.J[k] = 0.0; }
+  for (int k = 0; k < 9; k++) urdf_base.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+  const XLink& B0 = from_urdf ? urdf_base : links[link_of[base]];
+  if (from_urdf) {
+    const int alg = m.algorithm; double g3[3]; for (int k = 0; k < 3; k++) g3[k] = m.gravity[k];
+    *out = rob.art;                                                          // kinematics, inertias, limits, ids; q = qd = 0 (a URDF file holds no state)
+    m.algorithm = alg; for (int k = 0; k < 3; k++) m.gravity[k] = g3[k];
+    for (int i = 0; i < m.nj; i++) { if (q0) q0[i] = 0.0; if (qd0) qd0[i] = 0.0; }
+  }
+  for (int i = 0; i < (from_urdf ? 0 : m.nj); i++) {
     const XJoint& J = joints[order[i]];
     const XLink& L = links[link_of[J.out]];
     const bool from_base = (J.in == base);
@@ -638,32 +840,34 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
     for (const auto& d : disabled) if ((d.first == x && d.second == y) || (d.first == y && d.second == x)) return true;
     return false;
   };
-  std::vector<int> cg_links;                                                 // model links that carry collision geometry
-  for (int i = 0; i < m.nj; i++) if (links[link_of[joints[order[i]].out]].has_cg) cg_links.push_back(i);
-  const bool base_cg = B0.has_cg;
-  if (plane_body.empty()) {
-    // nothing but the body itself: every pair of its geometries must be disabled (the whole body, or link by link)
-    if (!pair_disabled(abid, abid)) {
-      std::vector<std::string> ids; if (base_cg) ids.push_back(base); for (int i : cg_links) ids.push_back(out->link_id[i]);
-      for (size_t x = 0; x < ids.size(); x++) for (size_t y = x + 1; y < ids.size(); y++)
-        if (!pair_disabled(ids[x], ids[y])) return fail("links %s and %s can collide: link-link contact is not supported (add a <DisabledPair>)", ids[x].c_str(), ids[y].c_str());
-    }
-  } else {
-    if (!pair_disabled(abid, abid)) {
-      std::vector<std::string> ids; if (base_cg) ids.push_back(base); for (int i : cg_links) ids.push_back(out->link_id[i]);
-      for (size_t x = 0; x < ids.size(); x++) for (size_t y = x + 1; y < ids.size(); y++)
-        if (!pair_disabled(ids[x], ids[y])) return fail("links %s and %s can collide: link-link contact is not supported (add a <DisabledPair>)", ids[x].c_str(), ids[y].c_str());
-    }
-    for (int i : cg_links) {
+  // collision geometries of the body: model link (-1 = base), id for <DisabledPair>, a sphere's centre in the model link's frame
+  std::vector<UrdfGeom> geoms;
+  if (from_urdf) geoms = rob.geoms;
+  else {
+    if (B0.has_cg) { UrdfGeom g; g.link = -1; g.id = base; g.sphere = false; g.radius = 0.0; g.center[0] = g.center[1] = g.center[2] = 0.0; geoms.push_back(g); }
+    for (int i = 0; i < m.nj; i++) {
       const XLink& L = links[link_of[joints[order[i]].out]];
-      if (pair_disabled(L.id, plane_body) || pair_disabled(abid, plane_body)) continue;
-      if (!prims.count(L.geom) || prims[L.geom].type != MH_GEOM_SPHERE) return fail("link %s: only Sphere collision geometry can meet the plane (others: disable the pair)", L.id.c_str());
-      if (m.nspheres >= MH_ARTIC_MAX_SPHERES) return fail("more than %d link spheres", MH_ARTIC_MAX_SPHERES);
-      const Prim& P = prims[L.geom];
-      const int s = m.nspheres++;
-      m.sphere_link[s] = i; m.sphere_radius[s] = P.dim[0];
+      if (!L.has_cg) continue;
+      UrdfGeom g; g.link = i; g.id = L.id; g.sphere = prims.count(L.geom) && prims[L.geom].type == MH_GEOM_SPHERE; g.radius = g.sphere ? prims[L.geom].dim[0] : 0.0;
       // centre in the model link frame (origin at the joint): COM offset + the primitive's own offset in the link's axes
-      for (int k = 0; k < 3; k++) m.sphere_center[s][k] = m.com[i][k] + P.o[k];
+      for (int k = 0; k < 3; k++) g.center[k] = m.com[i][k] + (g.sphere ? prims[L.geom].o[k] : 0.0);
+      geoms.push_back(g);
+    }
+  }
+  // every pair of the body's own geometries must be disabled (the whole body, or link by link) -- geometries riding on one link cannot meet
+  if (!pair_disabled(abid, abid))
+    for (size_t x = 0; x < geoms.size(); x++) for (size_t y = x + 1; y < geoms.size(); y++)
+      if (geoms[x].link != geoms[y].link && !pair_disabled(geoms[x].id, geoms[y].id))
+        return fail("links %s and %s can collide: link-link contact is not supported (add a <DisabledPair>)", geoms[x].id.c_str(), geoms[y].id.c_str());
+  if (!plane_body.empty()) {
+    for (const UrdfGeom& g : geoms) {
+      if (g.link < 0) continue;                                              // rides on the fixed base: static against the static plane
+      if (pair_disabled(g.id, plane_body) || pair_disabled(abid, plane_body)) continue;
+      if (!g.sphere) return fail("link %s: only Sphere collision geometry can meet the plane (others: disable the pair)", g.id.c_str());
+      if (m.nspheres >= MH_ARTIC_MAX_SPHERES) return fail("more than %d link spheres", MH_ARTIC_MAX_SPHERES);
+      const int s = m.nspheres++;
+      m.sphere_link[s] = g.link; m.sphere_radius[s] = g.radius;
+      for (int k = 0; k < 3; k++) m.sphere_center[s][k] = g.center[k];
     }
     // the plane: PlanePrimitive's +Y is the normal; body pose times primitive pose, expressed in the model (base) frame
     double Rw[9]; mat3mul(plane_Rb, plane_prim.R, Rw);

@@ -155,6 +155,19 @@ def test_xml_arm_on_table_steps_like_the_oracle(oracle, tmp_path):
     assert np.allclose([float(x) for x in rows[399][1:]], qg[0], rtol=0, atol=1e-5 * np.abs(qg[0]).max() + 1e-6)      # 6 printed digits
 
 
+def test_urdf_arm_on_table_steps_like_the_oracle(oracle):
+    """tests/scenes/arm_on_table_urdf.xml: the arm read from a URDF file (mh_io_load_xml_artic, urdf-filename; a tool welded to the slider's
+    link by a fixed joint carries the tip sphere), perturbed states bit for bit against the oracle through landings and resting contacts"""
+    m = A.load_xml(os.path.join(HERE, "scenes", "arm_on_table_urdf.xml"))[0]
+    assert m.nspheres == 2 and m.nj == 3
+    B = 8
+    rng = np.random.default_rng(22)
+    q = np.tile([0.9, 0.3, 0.0], (B, 1)); qd = np.tile([0.0, 0.5, 0.0], (B, 1)); q[1:] += rng.uniform(-0.05, 0.05, (B - 1, 3)); qd[1:] += rng.uniform(-0.3, 0.3, (B - 1, 3))
+    q[:, 2] = np.clip(q[:, 2], -0.04, 0.09)
+    aux = run(oracle, m, q, qd, nsteps=300, chunks=4, dt=1e-3)
+    assert (aux["lcp_solves"] > 0).all() and (aux["mini_steps"] > aux["steps"]).all() and (aux["status"] & ~S.MH_WORLD_IMPACT_TOL == 0).all()
+
+
 @pytest.mark.parametrize("mu,nk,want_flag", [(100.0, 4, False), (0.5, 4, False), (0.5, 16, False), (0.5, 20, True), (0.0, 64, True)])
 def test_capacity_edges_four_contacts_and_limits(oracle, mu, nk, want_flag):
     """all MH_ARTIC_MAX_SPHERES spheres of one link land together while a second joint sits on its limit: the no-slip LCP has

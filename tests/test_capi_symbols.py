@@ -31,7 +31,7 @@ def test_io_library_exports_every_declared_symbol():
     from moby_amd import io as mio
     lib = mio.load()
     declared = [n for n in _declared_symbols("moby_hip_io.h") if n.startswith("mh_io_")]
-    assert sorted(declared) == ["mh_io_compare_trajs", "mh_io_format_row", "mh_io_last_error", "mh_io_load_sdf", "mh_io_load_xml", "mh_io_load_xml_artic"]
+    assert sorted(declared) == ["mh_io_compare_trajs", "mh_io_format_row", "mh_io_last_error", "mh_io_load_sdf", "mh_io_load_urdf", "mh_io_load_xml", "mh_io_load_xml_artic"]
     for name in declared:
         assert hasattr(lib, name), "libmoby_hip_io.so does not export %s" % name
 
