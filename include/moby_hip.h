@@ -226,7 +226,9 @@ int  mh_debug_set(int key, int value);   /* key 2: block LCP solver (n > 64) thr
                                             (the lcp_lemke kinds with n <= 512 only; the lcp_fast kinds keep the choice of 0);
                                             key 3: lcp_lemke's bases (n > 64) through the structure-exploiting LU (1, default) or the dense one (0);
                                             key 4: the Lemke ladder of the island pipeline in sequence (0), as (world, attempt) tasks (1),
-                                                   tasks started beside lcp_fast when n >= 256 (2, default);
+                                                   tasks started beside lcp_fast when n >= 256 (2); 3 (default) = 2, and when the batch fills the chip
+                                                   with LCPs of 384..512 rows the tasks follow lcp_fast's launch on a second stream, behind a gate that
+                                                   opens once its last workgroup has started; 4 = 3 for LCPs of any size;
                                             key 5: lcp_fast (n > 64) skips the repetitions of a repeating pivot sequence (1, default) or
                                                    runs every iteration (0);
                                             key 6: the structure-exploiting LU reuses the factors of the unchanged leading columns from one Lemke
@@ -235,6 +237,8 @@ int  mh_debug_set(int key, int value);   /* key 2: block LCP solver (n > 64) thr
                                             key 8: thread geometry of the lcp_fast kinds alone for n <= 512 (0 choose, 1-4 as key 2);
                                             key 9: fixed-base CRB articulated bodies without spheres / stabiliser stepped two worlds per wavefront (1; default 0:
                                                    measured no faster, profiles/r04_a_artic_issue.json).
+                                            key 10: lcp_fast in the 1024-thread geometry solves a nonbasic system of up to 191 rows in the registers of
+                                                   its sixteen waves (1, default) or through the HBM workspace (0).
                                             None of the switches changes a result */
 void mh_scene_defaults(mh_scene* s);   /* zero + the reference's default tolerances */
 void mh_world_aux_init(mh_world_aux* a, uint32_t seed);

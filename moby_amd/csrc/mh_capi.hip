@@ -174,12 +174,13 @@ int mh_rand_next(uint32_t* st)
   return (int)(v >> 1);
 }
 
-int mh_g_debug_tasks = 2;      // mh_debug_set(4, v): 0 = the Lemke ladder in sequence, 1 = as (world, attempt) tasks, 2 = tasks + speculation beside lcp_fast, 3 = 2 + at full chip the tasks launched behind lcp_fast on a second stream
+int mh_g_debug_tasks = 3;      // mh_debug_set(4, v): 0 = the Lemke ladder in sequence, 1 = as (world, attempt) tasks, 2 = tasks + speculation beside lcp_fast, 3 = 2 + at full chip (n <= 512) the tasks launched behind lcp_fast and a gate on a second stream, 4 = 3 at any n
 int mh_g_debug_repeats = 1;  // mh_debug_set(5, v): 1 = lcp_fast (n > 64) skips the repetitions of a repeating pivot sequence (mh_lcp_block.h), 0 = runs them
 int mh_g_debug_sched = 1;    // mh_debug_set(7, v): 1 = the ladder's tasks are handed out by need (pick_task), 0 = by block index, attempt-major
 int mh_g_debug_reuse = 1;    // mh_debug_set(6, v): 1 = the structure-exploiting LU keeps the factors of the columns before the one a Lemke pivot changed, 0 = factorises from scratch
 int mh_g_debug_compact = 1;  // mh_debug_set(3, v): 1 = Lemke's bases through the structure-exploiting LU (mh_lu_compact.inc), 0 = dense LU only
 int mh_g_debug_artic_pack = 0;
+int mh_g_debug_reglu = 1;    // mh_debug_set(10, v): 1 = lcp_fast (n > 64, 1024-thread geometry) solves _Msub of up to 191 rows in registers (mh_lu_reg.inc), 0 = through the HBM workspace
 int mh_g_debug_fastgeom = 0; // mh_debug_set(8, v): the lcp_fast kinds' thread geometry for n <= 512 -- 0 choose, 1 = 256, 2 = 1024, 3 = 64, 4 = 128 threads per problem
 int mh_g_debug_blk = 0;      // mh_debug_set(2, v): 0 = choose, 1 = 256-thread block solver, 2 = 1024-thread block solver, 3 = one wavefront per problem (lcp_lemke kinds, n <= 512)
 int mh_g_debug_ka = 64;          // LDS LU block edge of the world kernel (clamped to the variant MHW_KA_V); mh_debug_set(1, 0) forces the HBM workspace path
@@ -223,7 +224,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
                            const int* z_size_in, int* z_size_out,
                            uint32_t* rng, int* status, unsigned* pivots,
                            int32_t* trace, int trace_cap, int* trace_len,
-                           const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i, const int* n_arr, double* work, int wave_only)
+                           const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i, const int* n_arr, double* work, int wave_only, int* started)
 {
   mh::LcpParams P;
   int rc = lcp_params(kind, opts, P);
@@ -260,7 +261,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
                                                                  : (mh_g_debug_fastgeom == 3) ? mh_launch_lcp_blk1 : mh_launch_lcp_blk2;
     if (wsd && wsi) {
       const hipError_t le = (wave_only == 1) ? hipSuccess : launcher(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2), work, 0, nullptr);
+                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2) | (mh_g_debug_reglu << 4), work, 0, lemke_kind ? nullptr : started);
       MH_HIP(le);
       if (n_arr) {          // the problems of this call that fit one wavefront (n_arr[b] <= 64) take the wave solver
         const size_t ldsw = (size_t)(2 * MH_LCP_MAX_N_WAVE * MH_LCP_MAX_N_WAVE + MH_LCP_MAX_N_WAVE) * sizeof(double);
@@ -277,7 +278,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     hipError_t e = hipMallocAsync((void**)&wsi, ni * sizeof(int), (hipStream_t)stream);
     if (e != hipSuccess) { (void)hipFreeAsync(wsd, (hipStream_t)stream); return fail(MH_ERR_HIP, "workspace allocation failed: %s", hipGetErrorString(e)); }
     const hipError_t le = launcher(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2), work, 0, nullptr);
+                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2) | (mh_g_debug_reglu << 4), work, 0, lemke_kind ? nullptr : started);
     e = le;
     (void)hipFreeAsync(wsd, (hipStream_t)stream); (void)hipFreeAsync(wsi, (hipStream_t)stream);
     if (e != hipSuccess) return fail(MH_ERR_HIP, "block LCP launch failed: %s", hipGetErrorString(e));
@@ -345,10 +346,11 @@ int mh_lcp_solve_batch(int kind, int B, int n,
 extern "C" int mh_debug_set(int key, int value)
 {
   if (key == 1) { if (value < 0 || value > 64) return fail(MH_ERR_INVALID_ARG, "LU block edge outside [0, 64]"); mh_g_debug_ka = value; return MH_OK; }
+  if (key == 10) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "register-LU switch outside {0, 1}"); mh_g_debug_reglu = value; return MH_OK; }
   if (key == 9) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "articulated packing outside {0, 1}"); mh_g_debug_artic_pack = value; return MH_OK; }
   if (key == 8) { if (value < 0 || value > 4) return fail(MH_ERR_INVALID_ARG, "lcp_fast geometry outside {0 .. 4}"); mh_g_debug_fastgeom = value; return MH_OK; }
   if (key == 2) { if (value < 0 || value > 4) return fail(MH_ERR_INVALID_ARG, "block solver geometry outside {0, 1, 2, 3, 4}"); mh_g_debug_blk = value; return MH_OK; }
-  if (key == 4) { if (value < 0 || value > 3) return fail(MH_ERR_INVALID_ARG, "ladder-task switch outside {0, 1, 2, 3}"); mh_g_debug_tasks = value; return MH_OK; }
+  if (key == 4) { if (value < 0 || value > 4) return fail(MH_ERR_INVALID_ARG, "ladder-task switch outside {0 .. 4}"); mh_g_debug_tasks = value; return MH_OK; }
   if (key == 7) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "task-scheduling switch outside {0, 1}"); mh_g_debug_sched = value; return MH_OK; }
   if (key == 6) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "factor-reuse switch outside {0, 1}"); mh_g_debug_reuse = value; return MH_OK; }
   if (key == 5) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "repeat-skipping switch outside {0, 1}"); mh_g_debug_repeats = value; return MH_OK; }

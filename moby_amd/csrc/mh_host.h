@@ -48,8 +48,9 @@ MH_HIDDEN int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
                                       const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i,
                                       const int* n_arr,    // n_arr: per-problem sizes (<= n, M compact with ld = its n) or NULL
                                       double* work = nullptr,    // B x MH_WORK doubles or NULL: += the 2/3 k^3 flops / 8 k^2 bytes of every factorisation (n > 64), issued flops, ticks
-                                      int wave_only = 0);        // 1: only the problems of at most 64 rows (n_arr) -- the caller runs the others itself; 2: the block solver in its
+                                      int wave_only = 0,         // 1: only the problems of at most 64 rows (n_arr) -- the caller runs the others itself; 2: the block solver in its
                                                                  // narrow geometry (the caller has other workgroups on the chip for it to share the CUs with)
+                                      int* started = nullptr);   // the lcp_fast kinds, n > 64: every workgroup adds 1 to *started when it begins (core_solve_round's gate)
 extern MH_HIDDEN int mh_g_debug_repeats;             // mh_debug_set(5, v)
 extern MH_HIDDEN int mh_g_debug_sched;               // mh_debug_set(7, v)
 extern MH_HIDDEN int mh_g_debug_reuse;               // mh_debug_set(6, v)
@@ -92,5 +93,6 @@ extern MH_HIDDEN int mh_g_debug_ka;
 extern MH_HIDDEN int mh_g_debug_blk;
 extern MH_HIDDEN int mh_g_debug_fastgeom;
 extern MH_HIDDEN int mh_g_debug_artic_pack;          // mh_debug_set(9, v): the articulated stepper with two worlds per wavefront (k_artic_step_p2)
+extern MH_HIDDEN int mh_g_debug_reglu;               // mh_debug_set(10, v): lcp_fast's register-resident dense LU (mh_lu_reg.inc)
 
 }  // extern "C"

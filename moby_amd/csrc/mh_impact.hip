@@ -1327,7 +1327,7 @@ static int core_ladder_alloc(mh_imp_core* c, long ntasks)
          && hipMalloc((void**)&c->t_z, nt * n * 8) == hipSuccess && hipMalloc((void**)&c->t_st, nt * 4) == hipSuccess
          && hipMalloc((void**)&c->t_piv, nt * 4) == hipSuccess && hipMalloc((void**)&c->t_zsz, nt * 4) == hipSuccess
          && hipMalloc((void**)&c->t_rng, nt * MH_RAND_WORDS * 4) == hipSuccess && hipMalloc((void**)&c->t_work, nt * MH_WORK * 8) == hipSuccess;
-  if (ok && !c->solved_at) ok = hipMalloc((void**)&c->solved_at, 3 * (size_t)c->B * 4) == hipSuccess;   // + next attempt, attempts over (mh_lcp_block.h pick_task)
+  if (ok && !c->solved_at) ok = hipMalloc((void**)&c->solved_at, (3 * (size_t)c->B + 1) * 4) == hipSuccess;   // (+ the gate's counter, core_solve_round)   // + next attempt, attempts over (mh_lcp_block.h pick_task)
   if (ok) ok = hipMemset(c->t_rng, 0, nt * MH_RAND_WORDS * 4) == hipSuccess;
   if (!ok) {                                                      // no room: the caller runs the ladder in sequence
     void* qs[] = { c->t_wsd, c->t_wsi, c->t_z, c->t_st, c->t_piv, c->t_zsz, c->t_rng, c->t_work };
@@ -1420,6 +1420,20 @@ static int core_lemke_stage(mh_imp_core* c, hipStream_t s, const mh_lcp_opts* o,
   return rc != MH_OK ? rc : core_ladder_finish(c, s, L, need, lst, piv);
 }
 
+// The gate between lcp_fast's kernel and the ladder's tasks on the second stream: one thread that waits until every workgroup of lcp_fast has
+// STARTED (they count themselves in, mh_lcp_block.h).  Launched earlier, the tasks' workgroups -- which stay until no task is left -- hold CUs that
+// 1024-thread workgroups still waiting for their turn need whole; launched behind the gate they only take what finished worlds leave.
+// (Bounded: it gives up after 20 s of the constant-rate clock -- the tasks then merely start early.)
+__global__ void k_gate(const int* started, int target)
+{
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64();
+  while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(127);
+    if (wall_clock64() - t0 > 2000000000ull) break;
+  }
+}
+
 // the solver chain of one round over the worlds with run_if set
 static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, int mode)
 {
@@ -1439,10 +1453,13 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   // buys nothing there, and the tasks are better handed out by need afterwards (31.7 s instead of 35.7 s per full step)
   const bool full_chip = mh_g_debug_sched != 0 && n >= 384 && B >= 3 * mh_cu_count();
   // Full chip, mh_debug_set(4, 3) (default): lcp_fast's kernel is launched FIRST, in its own (1024-thread) geometry, and the ladder's tasks -- handed
-  // out by need -- right behind it on the second stream.  That kernel's time is its slowest world's (a few worlds per thousand run all 2n
-  // iterations of every rung, seconds, while the mean world is done in tens of milliseconds): the CUs the finished worlds leave take the ladder's
-  // workgroups instead of idling until the last world is through.
-  const bool overlap = mh_g_debug_tasks >= 3 && full_chip && n >= 256;
+  // out by need -- behind it on the second stream, behind a GATE (k_gate) that opens when the last of lcp_fast's workgroups has started.  That
+  // kernel's time is its slowest world's (16-box stacks x 1024: the workgroups sum to 0.9 s of the chip, the slowest runs 3-4 s): the CUs the
+  // finished worlds leave take the ladder's workgroups instead of idling until the last world is through.  Measured (profiles/r04_d_config4_*):
+  // cold step 25.05 -> 22.04 s; warm steps 9.8 -> 9.6 s only, the two kernels slow each other down (lcp_fast's tail 4.2 -> 5.5 s, the ladder
+  // 3.4 -> 6.7 s) by about what the overlap saves.  Without the gate (round 4's first attempt) the tasks' workgroups, which stay until no task is
+  // left, held CUs that waiting 1024-thread workgroups need whole: 25.8 / 12.0 s.  Above n = 512 it has not been measured: 4 forces it there.
+  const bool overlap = full_chip && n >= 256 && (mh_g_debug_tasks >= 4 || (mh_g_debug_tasks == 3 && n <= 512));
   const bool spec_wanted = (mh_g_debug_tasks >= 2 && n >= 256 && !full_chip) || overlap;
   if (spec_wanted) L = core_ladder_plan(c, nullptr);
   bool spec = spec_wanted && L.ok;
@@ -1454,7 +1471,9 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   }
   // (lcp_fast then runs in the narrow geometry: a 1024-thread workgroup needs a whole CU and would wait for the tasks' workgroups to leave
   //  it -- 16 boxes x 256 worlds: 4.05 -> 3.55 s per cold call)
+  int* const gate = (spec && overlap) ? c->solved_at + 3 * (size_t)B : nullptr;
   if (spec) {
+    if (gate) MH_HIP(hipMemsetAsync(gate, 0, 4, s));
     MH_HIP(hipEventRecord((hipEvent_t)c->ev0, s));
     MH_HIP(hipStreamWaitEvent((hipStream_t)c->s2, (hipEvent_t)c->ev0, 0));
     if (!overlap) {
@@ -1467,12 +1486,13 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   if (mode == MH_CORE_IMPACT) {
     mh_lcp_opts o1; o1.min_exp = -20; o1.step_exp = 4u; o1.max_exp = -8; o1.piv_tol = -1.0; o1.zero_tol = -1.0;   // ICH-QP:219
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, nullptr, c->rng, c->lst1, c->piv1,
-                                 nullptr, 0, nullptr, &o1, run_if, c->ws_d, c->ws_i, c->ncur, c->work, fast_geom);
+                                 nullptr, 0, nullptr, &o1, run_if, c->ws_d, c->ws_i, c->ncur, c->work, fast_geom, gate);
   } else {
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, c->lst1, c->piv1,
-                                 nullptr, 0, nullptr, nullptr, run_if, c->ws_d, c->ws_i, c->ncur, c->work, fast_geom);   // CStab:954
+                                 nullptr, 0, nullptr, nullptr, run_if, c->ws_d, c->ws_i, c->ncur, c->work, fast_geom, gate);   // CStab:954
   }
-  if (rc == MH_OK && spec && overlap) {                          // the ladder's tasks, by need, behind lcp_fast's launch
+  if (rc == MH_OK && spec && overlap) {                          // the ladder's tasks, by need, behind lcp_fast's launch and the gate
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, (hipStream_t)c->s2, gate, B);
     rc = core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, true);
     if (rc == MH_OK) { const hipError_t e = hipEventRecord((hipEvent_t)c->ev1, (hipStream_t)c->s2); if (e != hipSuccess) rc = fail(MH_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e)); }
     if (rc != MH_OK) { (void)hipStreamSynchronize((hipStream_t)c->s2); return rc; }

@@ -464,6 +464,7 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
 
 #include "mh_lu_compact.inc"
 #include "mh_lu_left.inc"
+#include "mh_lu_reg.inc"
 
 // LCP.cpp:199-209 over the variables i with member(i) (list order = index order); val(i) reads
 // the candidate.  Consumes exactly one rand().  Returns the chosen variable (uniform).
@@ -521,7 +522,7 @@ MH_DEV void rand_skip(unsigned m) {      // m rand() calls whose values nobody l
 }
 
 MH_DEV bool lcp_fast(const Mat& M, double lam, const Ws& W, const double* q, double* z, int& zsize, double zero_tol,
-                     double nrm_lam, unsigned& pivots, Trace2& tr, bool skip_repeats)
+                     double nrm_lam, unsigned& pivots, Trace2& tr, bool skip_repeats, bool reg_lu)
 {
   const int n = M.n, t = tid();
   if (zero_tol < 0.0) zero_tol = (double)n * nrm_lam * MH_DBL_EPS;
@@ -578,6 +579,21 @@ MH_DEV bool lcp_fast(const Mat& M, double lam, const Ws& W, const double* q, dou
     unsigned long long tq = bp_tick();
     const int k = build_list(n, W);
     bp_tock(BP_LIST, tq); tq = bp_tick();
+#ifdef MH_BLK_HAS_REGLU
+    if (k > 0 && k <= RL_KMAX && reg_lu) {                  // the whole system in the registers of the sixteen waves (mh_lu_reg.inc)
+      for (int i = t; i < k; i += T) s_list[i] = W.list[i];
+      sync();
+      bp_tock(BP_GATHER, tq);
+      account_lu(k);
+      tq = bp_tick();
+      const int info = lu_gather_solve_reg(M, lam, q, k, W.A, W.b);
+      bp_tock(BP_C_PANEL, tq);                              // (diagnostic builds: its cycles, calls and rows under the compact LU's names, unused by this kernel)
+#ifdef MH_BLK_PROF
+      if (t == 0) { s_prof[BP_C_STEPS] += 1ull; s_prof[BP_C_PANELS] += (unsigned long long)k; }
+#endif
+      if (info != 0) return false;
+    } else
+#endif
     if (k > 0) {
       { int r = t % k, c = t / k;                          // element e = t + m T, walked without a division per element
         const int dr = T % k, dc = T / k;
@@ -811,7 +827,7 @@ MH_DEV bool lcp_lemke(const Mat& M, double lam, const Ws& W, const double* q, do
 // the four public solvers (lcp_solve_wave's attempt loop)
 template <int FAM>      // 0: the lcp_fast kinds, 1: the lcp_lemke kinds -- one kernel each, so that neither carries the other's registers
 MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, const Ws& W, const double* q, double* z, int& zsize,
-                      unsigned& pivots, Trace2& tr, bool compact, bool skip_repeats, bool reuse, int att_first, int att_count, const LadderTask& task)
+                      unsigned& pivots, Trace2& tr, bool compact, bool skip_repeats, bool reuse, bool reg_lu, int att_first, int att_count, const LadderTask& task)
 {
   const int n = M.n, t = tid();
   const bool reg = (P.kind == MH_LCP_FAST_REG) || (P.kind == MH_LCP_LEMKE_REG);
@@ -844,7 +860,7 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
     }
     if (reg) tr.push(0x40000000 | attempt);
     bool ok;
-    if constexpr (FAM == 0) ok = lcp_fast(M, lam, W, q, z, zsize, P.zero_tol, nrm, pivots, tr, skip_repeats);
+    if constexpr (FAM == 0) ok = lcp_fast(M, lam, W, q, z, zsize, P.zero_tol, nrm, pivots, tr, skip_repeats, reg_lu);
     else ok = lcp_lemke(M, lam, W, q, z, zsize, P.piv_tol, P.zero_tol, nrm, pivots, tr, compact, reuse, task);
     if (!reg) return ok;
     const bool good = ok && verify(M, lam, W, q, z, ZERO_TOL, attempt > 0);
@@ -909,6 +925,9 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   // b % task_worlds).  Two ways of handing tasks out: by block index, attempt-major, so that the lower attempts of every problem are
   // dispatched first (one task per workgroup); or, flags & 8, by pick_task below (a workgroup takes tasks until none is left).
   const int t = tid();
+  // the lcp_fast kinds have no tasks: solved_at, when given, counts the workgroups that have STARTED (the gate in front of the ladder's
+  // tasks on the second stream waits for the last one: core_solve_round, mh_impact.hip)
+  if (FAM == 0 && task_worlds == 0 && solved_at != nullptr && t == 0) atomicAdd(solved_at, 1);
   const int n_launch = n, ld_launch = ld;
   const bool queue = (FAM == 1) && task_worlds > 0 && (flags & 8) != 0;     // (the lcp_fast kinds have no tasks: their kernel keeps the single pass)
   for (int round = 0; FAM == 1 || round < 1; round++) {
@@ -946,10 +965,11 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   sync();
   const unsigned long long t_kernel = bp_tick();
 #endif
-  const bool ok = lcp_solve<FAM>(P, p10, M, W, q, z, zsize, piv, tr, (flags & 1) != 0, (flags & 2) != 0, (flags & 4) != 0, (task.rung >= 0) ? task.rung : 0, (task.rung >= 0) ? 1 : 0x3fffffff, task);
+  const bool ok = lcp_solve<FAM>(P, p10, M, W, q, z, zsize, piv, tr, (flags & 1) != 0, (flags & 2) != 0, (flags & 4) != 0, (flags & 16) != 0, (task.rung >= 0) ? task.rung : 0, (task.rung >= 0) ? 1 : 0x3fffffff, task);
   if (task.rung >= 0 && ok && t == 0) atomicMin(task.solved_at, task.rung);
   sync();
 #ifdef MH_BLK_PROF
+  if (t == 0 && FAM == 0) printf("fastblk %d %u %.3f %llu %llu\n", b, piv, (double)(wall_clock64() - t_task) * 1e-5, s_prof[BP_C_STEPS], s_prof[BP_C_PANELS]);
   if (t == 0 && (b == 0 || b == 5)) printf("blk prof (cycles, block %d, %u pivots, %.3f ms wall, %llu ticks in all): list %llu gather %llu panel %llu swap %llu trail %llu solve %llu gemv %llu randmin %llu compact %llu [setup %llu panel %llu u12 %llu trail %llu back %llu; dense steps %llu panels %llu]\n", b, piv, (double)(wall_clock64() - t_task) * 1e-5, bp_tick() - t_kernel,
                                s_prof[0], s_prof[1], s_prof[2], s_prof[3], s_prof[4], s_prof[5], s_prof[6], s_prof[7], s_prof[8], s_prof[9], s_prof[10], s_prof[11], s_prof[12], s_prof[13], s_prof[14], s_prof[15]);
 #endif

@@ -283,6 +283,32 @@ def test_structure_exploiting_lu_route_equals_the_dense_route_in_full_steps():
     assert (res[1][1]["lcp_pivots"] > 1000).all()
 
 
+def test_ladder_tasks_behind_the_gate_change_nothing():
+    """A batch that fills the chip with LCPs of 384 rows (12-box stacks x 768 worlds: mh_impact.hip core_solve_round's `full_chip`): by default
+    (mh_debug_set key 4 = 3) the Lemke ladder's tasks are launched on a second stream behind lcp_fast's kernel and a gate that opens when its
+    last workgroup has started; with key 4 = 2 they start after lcp_fast has finished.  One full step both ways: states, rand() streams,
+    pivot counts, flags and the warm-start vectors equal bit for bit."""
+    from moby_amd import _lib
+    N, B = 12, 768
+    sc = K.box_stack_scene(N)
+    st0 = K.box_stack_state(N, B)
+    lib = _lib.load()
+    res = {}
+    try:
+        for tasks in (3, 2):
+            _lib.check(lib.mh_debug_set(4, tasks))
+            bb = K.BigBatch(sc, st0)
+            bb.step(1e-3, 1)
+            res[tasks] = bb.download()
+            bb.close()
+    finally:
+        _lib.check(lib.mh_debug_set(4, 3))
+    assert np.array_equal(res[3][0], res[2][0])
+    for f in FIELDS:
+        assert np.array_equal(res[3][1][f], res[2][1][f]), f
+    assert (res[3][1]["lcp_pivots"] > 500).mean() > 0.9 and (res[3][1]["status"] & S.MH_WORLD_LCP_FAILED == 0).mean() > 0.9
+
+
 def test_factor_reuse_across_lemke_pivots_changes_nothing():
     """mh_lu_compact.inc keeps, from one Lemke pivot to the next, the factors of the columns before the one the pivot changed
     (mh_debug_set key 6; 0 = every basis factorised from scratch).  Same 16-box worlds, one full step, both ways: states, rand()
@@ -302,7 +328,7 @@ def test_factor_reuse_across_lemke_pivots_changes_nothing():
             res[(tasks, reuse, sched)] = bb.download()
             bb.close()
     finally:
-        _lib.check(lib.mh_debug_set(4, 2)); _lib.check(lib.mh_debug_set(6, 1)); _lib.check(lib.mh_debug_set(7, 1))
+        _lib.check(lib.mh_debug_set(4, 3)); _lib.check(lib.mh_debug_set(6, 1)); _lib.check(lib.mh_debug_set(7, 1))
     ref = res[(2, 0, 1)]
     for k in ((2, 1, 1), (0, 1, 1), (1, 1, 1), (1, 1, 0)):
         assert np.array_equal(res[k][0], ref[0]), k

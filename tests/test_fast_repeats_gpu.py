@@ -72,6 +72,26 @@ def test_block_solver_with_and_without_the_skip(oracle):
             np.testing.assert_array_equal(a, b)
 
 
+def test_box_stack_lcps_through_the_register_lu(oracle):
+    """the 1024-thread geometry's lcp_fast with its nonbasic systems in registers (mh_lu_reg.inc) on box-stack LCPs -- exact zeros, ties in
+    the pivot search, singular systems that end an attempt: the oracle's bits, and the same bits with the routine off (key 10)"""
+    lib = _lib.load()
+    for nboxes, world, steps in ((4, 3, 2), (6, 1, 1)):
+        probs = [p for p in dumped_lcps(oracle, nboxes, world, steps) if len(p[1]) == 32 * nboxes]
+        outs = []
+        _lib.check(lib.mh_debug_set(2, 2))
+        try:
+            check_against_oracle(oracle, probs)
+            for on in (1, 0):
+                _lib.check(lib.mh_debug_set(10, on))
+                ok, z, lcp = solve_gpu(probs)
+                outs.append((np.array(ok).copy(), z.copy(), lcp.pivots.copy(), lcp.rng.copy(), lcp.trace.copy(), lcp.trace_len.copy(), lcp.z_size.copy()))
+        finally:
+            _lib.check(lib.mh_debug_set(2, 0)); _lib.check(lib.mh_debug_set(10, 1))
+        for a, b in zip(outs[0], outs[1]):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_slow_worlds_of_a_long_sphere_stack_run(oracle):
     """Step 4200 of the headline batch: the worlds with the most pivots over the next 100 steps (lcp_fast runs into MAX_PIV about once a
     step there, four fifths of its iterations on one index set) against the oracle from the same states, 40 steps, bit for bit."""

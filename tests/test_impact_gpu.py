@@ -413,7 +413,7 @@ def test_ap_ladder_trivial_exit_draws_nothing(ap_oracle, tasks):
             assert not np.array_equal(aux["rng"][2], rng0[2])
         ib.close()
     finally:
-        _lib.check(lib.mh_debug_set(4, 2))
+        _lib.check(lib.mh_debug_set(4, 3))
 
 
 def test_ap_model_argument_check():

@@ -189,6 +189,42 @@ def test_block_solver_lists_beyond_the_lds_caps(oracle):
     assert ok[0]
 
 
+@pytest.mark.parametrize("active", [1, 15, 16, 17, 33, 100, 176, 190, 191, 192, 200])
+def test_register_lu_block_edges(oracle, active):
+    """mh_lu_reg.inc: in the 1024-thread geometry lcp_fast solves a nonbasic system of up to 191 rows in the registers of its sixteen waves
+    (columns by wave, sixteen per register slot).  Warm starts whose nonbasic block has exactly `active` rows -- one wave's worth, one slot's
+    worth and one more, the last size the registers take, the first that goes through the workspace -- against the oracle, bit for bit."""
+    n = 400                                   # (wide geometry from n = 384 up)
+    M, q = _pd_problem(2, n, seed=100 + active, active=active)
+    z0 = np.zeros((2, n)); z0[:, :active] = 1.0 + 1e-3 * np.random.default_rng(active).standard_normal((2, active))
+    ok = assert_parity(oracle, FAST, M, q, z0=z0)
+    assert ok.all()
+
+
+@pytest.mark.parametrize("n,seed", [(150, 1), (190, 2), (260, 3)])
+def test_register_lu_with_row_exchanges(oracle, n, seed):
+    """general (unsymmetric, indefinite) matrices in the 1024-thread geometry: every factorisation exchanges rows, lcp_fast wanders through
+    nonbasic sets of all sizes (n = 260: on both sides of the 191-row limit) and mostly gives up -- pivots, traces, rand() streams and
+    whatever it solves equal the oracle's; the same bits with the register routine off (key 10)"""
+    from moby_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(seed)
+    B = 3
+    M = rng.standard_normal((B, n, n)) + 0.5 * np.eye(n); q = rng.standard_normal((B, n))
+    M[1] = M[1] @ M[1].T / n + 0.05 * rng.standard_normal((n, n))          # nearly symmetric: many pivots before it ends
+    _lib.check(lib.mh_debug_set(2, 2))
+    try:
+        assert_parity(oracle, FAST, M, q, z_size=np.zeros(B, dtype=np.int32))
+        a = run_gpu(FAST_REG, M, q, z_size=np.zeros(B, dtype=np.int32), exps=(-20, 4, -8))
+        _lib.check(lib.mh_debug_set(10, 0))
+        b = run_gpu(FAST_REG, M, q, z_size=np.zeros(B, dtype=np.int32), exps=(-20, 4, -8))
+    finally:
+        _lib.check(lib.mh_debug_set(2, 0)); _lib.check(lib.mh_debug_set(10, 1))
+    np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+    for f in ("pivots", "rng", "trace", "trace_len", "z_size"):
+        np.testing.assert_array_equal(getattr(a[2], f), getattr(b[2], f), err_msg=f)
+
+
 @pytest.mark.parametrize("n", [1024, 2048, 4096])
 def test_block_solver_config4_sizes_properties(n):
     """The sizes BASELINE config 4 rests on (n = 1024: 32-box stacks, n = 2048: 64-box stacks) and the entry's advertised maximum

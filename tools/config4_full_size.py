@@ -18,6 +18,10 @@ if os.environ.get("MH_COMPACT_LU"):        # mh_debug_set key 3 (0: the dense LU
     _lib.check(_lib.load().mh_debug_set(3, int(os.environ["MH_COMPACT_LU"])))
 if os.environ.get("MH_FAST_GEOM"):         # mh_debug_set key 8 (the lcp_fast kinds' thread geometry for n <= 512)
     _lib.check(_lib.load().mh_debug_set(8, int(os.environ["MH_FAST_GEOM"])))
+if os.environ.get("MH_TASKS"):             # mh_debug_set key 4 (3: the ladder's tasks behind lcp_fast on a second stream)
+    _lib.check(_lib.load().mh_debug_set(4, int(os.environ["MH_TASKS"])))
+if os.environ.get("MH_REG_LU"):            # mh_debug_set key 10 (0: lcp_fast's nonbasic systems through the HBM workspace)
+    _lib.check(_lib.load().mh_debug_set(10, int(os.environ["MH_REG_LU"])))
 _opt = {"--dump-world": 2, "--states-of": 1, "--dump-failed": 1}
 args, _k = [], 1
 while _k < len(sys.argv):

@@ -16,6 +16,8 @@ nbx, W, copies = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 geom = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 if geom:
     _lib.check(_lib.load().mh_debug_set(2, geom))
+if os.environ.get("MH_REG_LU"):            # mh_debug_set key 10 (0: the nonbasic systems through the HBM workspace)
+    _lib.check(_lib.load().mh_debug_set(10, int(os.environ["MH_REG_LU"])))
 mass, J, st, cs = I.box_stack(nbx, B=max(W, 2))
 ib = I.ImpactBatch(max(W, 2), nbx, 4 * nbx, 4, mass, J)
 ib.upload(st, cs); ib.process_async(); ib.download()
