@@ -261,7 +261,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
                                                                  : (mh_g_debug_fastgeom == 3) ? mh_launch_lcp_blk1 : mh_launch_lcp_blk2;
     if (wsd && wsi) {
       const hipError_t le = (wave_only == 1) ? hipSuccess : launcher(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2) | (mh_g_debug_reglu << 4), work, 0, lemke_kind ? nullptr : started);
+                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2) | (mh_g_debug_reglu << 4) | ((started && !lemke_kind) ? 32 : 0), work, 0, lemke_kind ? nullptr : started);
       MH_HIP(le);
       if (n_arr) {          // the problems of this call that fit one wavefront (n_arr[b] <= 64) take the wave solver
         const size_t ldsw = (size_t)(2 * MH_LCP_MAX_N_WAVE * MH_LCP_MAX_N_WAVE + MH_LCP_MAX_N_WAVE) * sizeof(double);
@@ -278,7 +278,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     hipError_t e = hipMallocAsync((void**)&wsi, ni * sizeof(int), (hipStream_t)stream);
     if (e != hipSuccess) { (void)hipFreeAsync(wsd, (hipStream_t)stream); return fail(MH_ERR_HIP, "workspace allocation failed: %s", hipGetErrorString(e)); }
     const hipError_t le = launcher(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2) | (mh_g_debug_reglu << 4), work, 0, lemke_kind ? nullptr : started);
+                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2) | (mh_g_debug_reglu << 4) | ((started && !lemke_kind) ? 32 : 0), work, 0, lemke_kind ? nullptr : started);
     e = le;
     (void)hipFreeAsync(wsd, (hipStream_t)stream); (void)hipFreeAsync(wsi, (hipStream_t)stream);
     if (e != hipSuccess) return fail(MH_ERR_HIP, "block LCP launch failed: %s", hipGetErrorString(e));

@@ -1327,7 +1327,7 @@ static int core_ladder_alloc(mh_imp_core* c, long ntasks)
          && hipMalloc((void**)&c->t_z, nt * n * 8) == hipSuccess && hipMalloc((void**)&c->t_st, nt * 4) == hipSuccess
          && hipMalloc((void**)&c->t_piv, nt * 4) == hipSuccess && hipMalloc((void**)&c->t_zsz, nt * 4) == hipSuccess
          && hipMalloc((void**)&c->t_rng, nt * MH_RAND_WORDS * 4) == hipSuccess && hipMalloc((void**)&c->t_work, nt * MH_WORK * 8) == hipSuccess;
-  if (ok && !c->solved_at) ok = hipMalloc((void**)&c->solved_at, (3 * (size_t)c->B + 1) * 4) == hipSuccess;   // (+ the gate's counter, core_solve_round)   // + next attempt, attempts over (mh_lcp_block.h pick_task)
+  if (ok && !c->solved_at) ok = hipMalloc((void**)&c->solved_at, (4 * (size_t)c->B + 1) * 4) == hipSuccess;   // (+ the gate's counter and lcp_fast's verdicts, core_solve_round)   // + next attempt, attempts over (mh_lcp_block.h pick_task)
   if (ok) ok = hipMemset(c->t_rng, 0, nt * MH_RAND_WORDS * 4) == hipSuccess;
   if (!ok) {                                                      // no room: the caller runs the ladder in sequence
     void* qs[] = { c->t_wsd, c->t_wsi, c->t_z, c->t_st, c->t_piv, c->t_zsz, c->t_rng, c->t_work };
@@ -1362,7 +1362,7 @@ static LadderPlan core_ladder_plan(mh_imp_core* c, const mh_lcp_opts* o)
 }
 // sched: the tasks are handed out by need (mh_lcp_block.h pick_task: as many workgroups as the chip holds, each taking tasks until none is
 // left) instead of by block index.  Not beside lcp_fast: workgroups that stay would keep its kernel off the CUs they occupy.
-static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& L, const int* mask, bool sched)
+static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& L, const int* mask, bool sched, bool by_verdict = false)
 {
   const int B = c->B, n = c->nmax;
   const mh_lcp_opts* o = L.has_o ? &L.o : nullptr;
@@ -1378,7 +1378,7 @@ static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& 
   const bool one_wave = n <= 512 && (mh_g_debug_blk == 3 || (mh_g_debug_blk == 0 && L.ntasks >= (long)MH_BLK1_MIN_PER_CU * mh_cu_count()));
   const bool two_waves = n <= 512 && (mh_g_debug_blk == 4 || (mh_g_debug_blk == 0 && B >= MH_BLK2_MIN_PER_CU * mh_cu_count()));   // (B worlds: the ladder then runs in sequence per world, paced by throughput)
   const hipError_t le = (two_waves ? mh_launch_lcp_blk2 : one_wave ? mh_launch_lcp_blk1 : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk))(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
-      c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2) | (sched ? 8 : 0), c->t_work, B, c->solved_at);
+      c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2) | (sched ? 8 : 0) | ((sched && by_verdict) ? 32 : 0), c->t_work, B, c->solved_at);
   MH_HIP(le);
   return MH_OK;
 }
@@ -1473,7 +1473,7 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   //  it -- 16 boxes x 256 worlds: 4.05 -> 3.55 s per cold call)
   int* const gate = (spec && overlap) ? c->solved_at + 3 * (size_t)B : nullptr;
   if (spec) {
-    if (gate) MH_HIP(hipMemsetAsync(gate, 0, 4, s));
+    if (gate) MH_HIP(hipMemsetAsync(gate, 0, ((size_t)B + 1) * 4, s));         // the counter, then one verdict per world (0: lcp_fast has not spoken)
     MH_HIP(hipEventRecord((hipEvent_t)c->ev0, s));
     MH_HIP(hipStreamWaitEvent((hipStream_t)c->s2, (hipEvent_t)c->ev0, 0));
     if (!overlap) {
@@ -1493,7 +1493,7 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   }
   if (rc == MH_OK && spec && overlap) {                          // the ladder's tasks, by need, behind lcp_fast's launch and the gate
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, (hipStream_t)c->s2, gate, B);
-    rc = core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, true);
+    rc = core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, true, true);
     if (rc == MH_OK) { const hipError_t e = hipEventRecord((hipEvent_t)c->ev1, (hipStream_t)c->s2); if (e != hipSuccess) rc = fail(MH_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e)); }
     if (rc != MH_OK) { (void)hipStreamSynchronize((hipStream_t)c->s2); return rc; }
   } else

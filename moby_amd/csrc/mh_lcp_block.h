@@ -879,15 +879,26 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
 // lowest index) -- the attempt-major order of the block-index launch, which spends the spare workgroups on the attempts most likely
 // to be the one selected (fewest-running first ran 19 % more pivots there).
 // Returns the task index attempt * Bw + w, or -1 when nothing is left to hand out (block-uniform).
-MH_DEV int pick_task(int Bw, int R, int* st, const int* __restrict__ run_if, const int* __restrict__ n_arr)
+// verdict (or NULL): per problem 0 = lcp_fast is still at work on it, 1 = it failed (the ladder is needed), 2 = it solved the problem -- written by
+// lcp_fast's kernel, which runs beside this one (core_solve_round, mh_impact.hip).  Only problems with verdict 1 are handed out; while some are
+// still at 0 a workgroup without a task waits instead of leaving.  Bounded: after 30 s of the constant-rate clock the undecided problems are
+// taken as failed (their tasks then merely run ahead of the verdict, as the speculation of mh_debug_set(4, 2) does).
+MH_DEV int pick_task(int Bw, int R, int* st, const int* __restrict__ run_if, const int* __restrict__ n_arr, const int* verdict)
 {
   const int t = tid();
   volatile int* solved = st; volatile int* next = st + Bw; volatile int* done = st + 2 * Bw;
+  const unsigned long long t_wait0 = wall_clock64();
+  bool undecided_too = false;
   for (;;) {                                       // (a lost compare-and-swap means another workgroup took a task: the whole makes progress)
-    double best = inf(), lowest = inf(); int bw = 0x7fffffff, lw = 0x7fffffff, open_ = 0;
+    double best = inf(), lowest = inf(); int bw = 0x7fffffff, lw = 0x7fffffff, open_ = 0, pend = 0;
     for (int w = t; w < Bw; w += T) {
       if (run_if && run_if[w] == 0) continue;
       if (n_arr && n_arr[w] <= MH_LCP_MAX_N_WAVE) continue;
+      if (verdict) {
+        const int v = __hip_atomic_load(verdict + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == 0 && !undecided_too) { pend++; continue; }
+        if (v == 2) continue;
+      }
       const int nr = next[w];
       if (nr >= R || solved[w] < nr) continue;
       open_++;
@@ -896,7 +907,13 @@ MH_DEV int pick_task(int Bw, int R, int* st, const int* __restrict__ run_if, con
       if ((double)nr < lowest) { lowest = (double)nr; lw = w; }
     }
     double dmin; int w, w2; red_min_first(best, bw, dmin, w); red_min_first(lowest, lw, dmin, w2);
-    if (w == 0x7fffffff) return -1;
+    if (w == 0x7fffffff) {
+      if (verdict == nullptr || red_sum_int(pend) == 0) return -1;
+      // nothing to do yet, but lcp_fast has not spoken on every problem: wait a little and look again
+      for (int i = 0; i < 8; i++) __builtin_amdgcn_s_sleep(127);
+      if (bcast_i((wall_clock64() - t_wait0 > 3000000000ull) ? 1 : 0)) undecided_too = true;
+      continue;
+    }
     if (red_sum_int(open_) < (int)gridDim.x) w = w2;
     int got = -2;
     if (t == 0) {
@@ -932,7 +949,7 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   const bool queue = (FAM == 1) && task_worlds > 0 && (flags & 8) != 0;     // (the lcp_fast kinds have no tasks: their kernel keeps the single pass)
   for (int round = 0; FAM == 1 || round < 1; round++) {
   int b;
-  if (queue) { b = pick_task(task_worlds, B / task_worlds, solved_at, run_if, n_arr); if (b < 0) return; }
+  if (queue) { b = pick_task(task_worlds, B / task_worlds, solved_at, run_if, n_arr, (flags & 32) ? solved_at + 3 * (size_t)task_worlds + 1 : nullptr); if (b < 0) return; }
   else { if (round > 0) return; b = blockIdx.x; if (b >= B) return; }
   n = n_launch; ld = ld_launch;
   const int bw = (task_worlds > 0) ? b % task_worlds : b;
@@ -982,6 +999,10 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
     if (zsz_out) zsz_out[b] = zsize | ((task.rung >= 0 && s_nodraw) ? MH_TASK_NODRAW : 0);   // (task mode only: bit 30 = this attempt would not have drawn)
     if (trace_len) trace_len[b] = tr.len;
     if (queue) atomicAdd(solved_at + 2 * task_worlds + bw, 1);          // one more attempt of this problem is over
+    if (FAM == 0 && task_worlds == 0 && solved_at != nullptr && (flags & 32)) {    // the verdict the ladder's tasks on the second stream wait for (pick_task)
+      __threadfence();
+      __hip_atomic_store(solved_at + 1 + b, ok ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   sync();
   }   // (the next task of this workgroup)
