@@ -1327,7 +1327,7 @@ static int core_ladder_alloc(mh_imp_core* c, long ntasks)
          && hipMalloc((void**)&c->t_z, nt * n * 8) == hipSuccess && hipMalloc((void**)&c->t_st, nt * 4) == hipSuccess
          && hipMalloc((void**)&c->t_piv, nt * 4) == hipSuccess && hipMalloc((void**)&c->t_zsz, nt * 4) == hipSuccess
          && hipMalloc((void**)&c->t_rng, nt * MH_RAND_WORDS * 4) == hipSuccess && hipMalloc((void**)&c->t_work, nt * MH_WORK * 8) == hipSuccess;
-  if (ok && !c->solved_at) ok = hipMalloc((void**)&c->solved_at, (4 * (size_t)c->B + 1) * 4) == hipSuccess;   // (+ the gate's counter and lcp_fast's verdicts, core_solve_round)   // + next attempt, attempts over (mh_lcp_block.h pick_task)
+  if (ok && !c->solved_at) ok = hipMalloc((void**)&c->solved_at, (4 * (size_t)c->B + 2) * 4) == hipSuccess;   // (+ the gate's counter and lcp_fast's verdicts, core_solve_round)   // + next attempt, attempts over (mh_lcp_block.h pick_task)
   if (ok) ok = hipMemset(c->t_rng, 0, nt * MH_RAND_WORDS * 4) == hipSuccess;
   if (!ok) {                                                      // no room: the caller runs the ladder in sequence
     void* qs[] = { c->t_wsd, c->t_wsi, c->t_z, c->t_st, c->t_piv, c->t_zsz, c->t_rng, c->t_work };
@@ -1473,7 +1473,7 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   //  it -- 16 boxes x 256 worlds: 4.05 -> 3.55 s per cold call)
   int* const gate = (spec && overlap) ? c->solved_at + 3 * (size_t)B : nullptr;
   if (spec) {
-    if (gate) MH_HIP(hipMemsetAsync(gate, 0, ((size_t)B + 1) * 4, s));         // the counter, then one verdict per world (0: lcp_fast has not spoken)
+    if (gate) MH_HIP(hipMemsetAsync(gate, 0, ((size_t)B + 2) * 4, s));         // workgroups started, verdicts published, then one verdict per world (0: lcp_fast has not spoken)
     MH_HIP(hipEventRecord((hipEvent_t)c->ev0, s));
     MH_HIP(hipStreamWaitEvent((hipStream_t)c->s2, (hipEvent_t)c->ev0, 0));
     if (!overlap) {

@@ -890,6 +890,8 @@ MH_DEV int pick_task(int Bw, int R, int* st, const int* __restrict__ run_if, con
   const unsigned long long t_wait0 = wall_clock64();
   bool undecided_too = false;
   for (;;) {                                       // (a lost compare-and-swap means another workgroup took a task: the whole makes progress)
+    // verdict[-1]: how many verdicts lcp_fast has published -- read BEFORE the scan, so that one published during it is not slept through
+    const int published = (verdict && t == 0) ? __hip_atomic_load(verdict - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0;
     double best = inf(), lowest = inf(); int bw = 0x7fffffff, lw = 0x7fffffff, open_ = 0, pend = 0;
     for (int w = t; w < Bw; w += T) {
       if (run_if && run_if[w] == 0) continue;
@@ -909,9 +911,16 @@ MH_DEV int pick_task(int Bw, int R, int* st, const int* __restrict__ run_if, con
     double dmin; int w, w2; red_min_first(best, bw, dmin, w); red_min_first(lowest, lw, dmin, w2);
     if (w == 0x7fffffff) {
       if (verdict == nullptr || red_sum_int(pend) == 0) return -1;
-      // nothing to do yet, but lcp_fast has not spoken on every problem: wait a little and look again
-      for (int i = 0; i < 8; i++) __builtin_amdgcn_s_sleep(127);
-      if (bcast_i((wall_clock64() - t_wait0 > 3000000000ull) ? 1 : 0)) undecided_too = true;
+      // nothing to do yet, but lcp_fast has not spoken on every problem: ONE thread polls ONE word until another verdict is out (a thousand
+      // workgroups re-reading the verdicts themselves kept the L2 channel that holds them busy enough to slow lcp_fast's last worlds twentyfold)
+      int late = 0;
+      if (t == 0) {
+        while (__hip_atomic_load(verdict - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == published) {
+          for (int i = 0; i < 8; i++) __builtin_amdgcn_s_sleep(127);
+          if (wall_clock64() - t_wait0 > 3000000000ull) { late = 1; break; }
+        }
+      }
+      if (bcast_i(late)) undecided_too = true;
       continue;
     }
     if (red_sum_int(open_) < (int)gridDim.x) w = w2;
@@ -949,7 +958,7 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   const bool queue = (FAM == 1) && task_worlds > 0 && (flags & 8) != 0;     // (the lcp_fast kinds have no tasks: their kernel keeps the single pass)
   for (int round = 0; FAM == 1 || round < 1; round++) {
   int b;
-  if (queue) { b = pick_task(task_worlds, B / task_worlds, solved_at, run_if, n_arr, (flags & 32) ? solved_at + 3 * (size_t)task_worlds + 1 : nullptr); if (b < 0) return; }
+  if (queue) { b = pick_task(task_worlds, B / task_worlds, solved_at, run_if, n_arr, (flags & 32) ? solved_at + 3 * (size_t)task_worlds + 2 : nullptr); if (b < 0) return; }
   else { if (round > 0) return; b = blockIdx.x; if (b >= B) return; }
   n = n_launch; ld = ld_launch;
   const int bw = (task_worlds > 0) ? b % task_worlds : b;
@@ -1001,7 +1010,8 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
     if (queue) atomicAdd(solved_at + 2 * task_worlds + bw, 1);          // one more attempt of this problem is over
     if (FAM == 0 && task_worlds == 0 && solved_at != nullptr && (flags & 32)) {    // the verdict the ladder's tasks on the second stream wait for (pick_task)
       __threadfence();
-      __hip_atomic_store(solved_at + 1 + b, ok ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(solved_at + 2 + b, ok ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(solved_at + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);     // (solved_at[0]: workgroups started, [1]: verdicts published, [2 + b]: the verdicts)
     }
   }
   sync();
