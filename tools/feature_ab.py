@@ -1,5 +1,5 @@
 """A/B of everything this build schedules differently from the reference's loops on full steps of box stacks: the
-same worlds with all switches at their defaults and with all of them off (dense LU for Lemke's bases, the ladder in sequence, every
+same worlds with all switches at their defaults and with all of them off (dense LU for Lemke's bases, the ladder in sequence, lcp_fast through the HBM workspace, every
 lcp_fast iteration run, every basis factorised from scratch, tasks by block index).  States, rand() streams, counters and flags must
 agree bit for bit.     python tools/feature_ab.py "nboxes:B" ..."""
 import json, os, sys, time
@@ -10,7 +10,7 @@ from moby_amd import _lib, stack as K
 
 FIELDS = ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "stab_iters", "lcp_alg_bytes", "stab_rows",
           "zlast_size", "zbuf_size", "zbuf_cap")
-DEFAULTS = {3: 1, 4: 2, 5: 1, 6: 1, 7: 1}
+DEFAULTS = {3: 1, 4: 3, 5: 1, 6: 1, 7: 1, 10: 1}
 lib = _lib.load()
 for a in sys.argv[1:]:
     nbx, B = [int(x) for x in a.split(":")]
