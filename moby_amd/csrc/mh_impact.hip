@@ -1362,14 +1362,18 @@ static LadderPlan core_ladder_plan(mh_imp_core* c, const mh_lcp_opts* o)
 }
 // sched: the tasks are handed out by need (mh_lcp_block.h pick_task: as many workgroups as the chip holds, each taking tasks until none is
 // left) instead of by block index.  Not beside lcp_fast: workgroups that stay would keep its kernel off the CUs they occupy.
-static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& L, const int* mask, bool sched, bool by_verdict = false)
+// by_verdict: beside lcp_fast's kernel, only the worlds it has failed on (mh_lcp_block.h pick_task); resume: the second launch of that scheme -- the
+// hand-out continues where the first left it (nothing is reset)
+static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& L, const int* mask, bool sched, bool by_verdict = false, bool resume = false)
 {
   const int B = c->B, n = c->nmax;
   const mh_lcp_opts* o = L.has_o ? &L.o : nullptr;
-  MH_HIP(hipMemsetAsync(c->solved_at, 0x7f, (size_t)B * 4, st));
-  MH_HIP(hipMemsetAsync(c->solved_at + B, 0, 2 * (size_t)B * 4, st));
-  if (sched) MH_HIP(hipMemsetAsync(c->t_st, 0xff, (size_t)L.ntasks * 4, st));                     // -1: never handed out
-  MH_HIP(hipMemsetAsync(c->t_work, 0, (size_t)L.ntasks * MH_WORK * 8, st));
+  if (!resume) {
+    MH_HIP(hipMemsetAsync(c->solved_at, 0x7f, (size_t)B * 4, st));
+    MH_HIP(hipMemsetAsync(c->solved_at + B, 0, 2 * (size_t)B * 4, st));
+    if (sched) MH_HIP(hipMemsetAsync(c->t_st, 0xff, (size_t)L.ntasks * 4, st));                     // -1: never handed out
+    MH_HIP(hipMemsetAsync(c->t_work, 0, (size_t)L.ntasks * MH_WORK * 8, st));
+  }
   mh::LcpParams P; P.kind = MH_LCP_LEMKE_REG; P.min_exp = o ? o->min_exp : -20; P.step_exp = o ? o->step_exp : 1u; P.max_exp = o ? o->max_exp : 1;
   P.piv_tol = o ? o->piv_tol : -1.0; P.zero_tol = o ? o->zero_tol : -1.0;
   static const mh::Pow10Table p10 = [] { mh::Pow10Table t; for (int i = 0; i < 64; i++) t.v[i] = std::pow(10.0, (double)(i - 32)); return t; }();
@@ -1503,6 +1507,10 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
     if (e != hipSuccess) { if (spec) (void)hipStreamWaitEvent(s, (hipEvent_t)c->ev1, 0); return fail(MH_ERR_HIP, "k_lemke_prep failed: %s", hipGetErrorString(e)); } }
   if (spec) {                                                     // the tasks have been running beside lcp_fast: wait for them, then select
     MH_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->ev1, 0));
+    if (overlap) {                                                // what lcp_fast decided after the first launch's workgroups had left
+      rc = core_ladder_launch(c, s, L, c->need2, true, false, true);
+      if (rc != MH_OK) return rc;
+    }
     return core_ladder_finish(c, s, L, c->need2, c->lst2, c->piv2);
   }
   return core_lemke_stage(c, s, nullptr, c->need2, c->lst2, c->piv2);                                                // ICH-QP:224, CStab:955

@@ -880,25 +880,29 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
 // to be the one selected (fewest-running first ran 19 % more pivots there).
 // Returns the task index attempt * Bw + w, or -1 when nothing is left to hand out (block-uniform).
 // verdict (or NULL): per problem 0 = lcp_fast is still at work on it, 1 = it failed (the ladder is needed), 2 = it solved the problem -- written by
-// lcp_fast's kernel, which runs beside this one (core_solve_round, mh_impact.hip).  Only problems with verdict 1 are handed out; while some are
-// still at 0 a workgroup without a task waits instead of leaving.  Bounded: after 30 s of the constant-rate clock the undecided problems are
-// taken as failed (their tasks then merely run ahead of the verdict, as the speculation of mh_debug_set(4, 2) does).
+// lcp_fast's kernel, which runs beside this one (core_solve_round, mh_impact.hip).  Only problems with verdict 1 are handed out.  A workgroup that
+// finds nothing while verdicts are outstanding looks again a few times, a millisecond apart, and then LEAVES: the problems lcp_fast decides later are
+// taken by the second launch of this kernel, after lcp_fast's (the state of the hand-out -- next attempt, attempts over, solved_at -- carries over).
+// Waiting for the last verdict instead was tried and is not safe: with several hundred workgroups resident and waiting, lcp_fast's remaining workgroups
+// -- on other CUs, at the full shader clock -- took 40-70 s for what takes them 3 (profiles/r04_d_waiting_workgroups_stall.txt; not the polling: one
+// thread per workgroup looked at one word once a millisecond).
 MH_DEV int pick_task(int Bw, int R, int* st, const int* __restrict__ run_if, const int* __restrict__ n_arr, const int* verdict)
 {
   const int t = tid();
   volatile int* solved = st; volatile int* next = st + Bw; volatile int* done = st + 2 * Bw;
-  const unsigned long long t_wait0 = wall_clock64();
-  bool undecided_too = false;
+  int looks = 0;
   for (;;) {                                       // (a lost compare-and-swap means another workgroup took a task: the whole makes progress)
-    // verdict[-1]: how many verdicts lcp_fast has published -- read BEFORE the scan, so that one published during it is not slept through
-    const int published = (verdict && t == 0) ? __hip_atomic_load(verdict - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    // verdict[-1]: how many verdicts lcp_fast has published -- read BEFORE the scan, so that one published during it is not slept through.
+    // (RELAXED loads: an agent-scope ACQUIRE invalidates the XCD's L2; nothing read after the wait needs ordering -- the verdicts are read with
+    //  atomic loads too, and the tasks only read M and q, written before either kernel started)
+    const int published = (verdict && t == 0) ? __hip_atomic_load(verdict - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     double best = inf(), lowest = inf(); int bw = 0x7fffffff, lw = 0x7fffffff, open_ = 0, pend = 0;
     for (int w = t; w < Bw; w += T) {
       if (run_if && run_if[w] == 0) continue;
       if (n_arr && n_arr[w] <= MH_LCP_MAX_N_WAVE) continue;
       if (verdict) {
         const int v = __hip_atomic_load(verdict + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v == 0 && !undecided_too) { pend++; continue; }
+        if (v == 0) { pend++; continue; }
         if (v == 2) continue;
       }
       const int nr = next[w];
@@ -910,17 +914,11 @@ MH_DEV int pick_task(int Bw, int R, int* st, const int* __restrict__ run_if, con
     }
     double dmin; int w, w2; red_min_first(best, bw, dmin, w); red_min_first(lowest, lw, dmin, w2);
     if (w == 0x7fffffff) {
-      if (verdict == nullptr || red_sum_int(pend) == 0) return -1;
-      // nothing to do yet, but lcp_fast has not spoken on every problem: ONE thread polls ONE word until another verdict is out (a thousand
-      // workgroups re-reading the verdicts themselves kept the L2 channel that holds them busy enough to slow lcp_fast's last worlds twentyfold)
-      int late = 0;
-      if (t == 0) {
-        while (__hip_atomic_load(verdict - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == published) {
-          for (int i = 0; i < 8; i++) __builtin_amdgcn_s_sleep(127);
-          if (wall_clock64() - t_wait0 > 3000000000ull) { late = 1; break; }
-        }
-      }
-      if (bcast_i(late)) undecided_too = true;
+      if (verdict == nullptr || red_sum_int(pend) == 0 || looks >= 8) return -1;
+      looks++;
+      if (t == 0 && __hip_atomic_load(verdict - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == published)
+        for (int i = 0; i < 300; i++) __builtin_amdgcn_s_sleep(127);          // about a millisecond
+      sync();
       continue;
     }
     if (red_sum_int(open_) < (int)gridDim.x) w = w2;
@@ -978,6 +976,9 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   if (t < 32) s_rng[t] = rngg[(size_t)b * MH_RAND_WORDS + t];
   if (t == 0) { s_luc_bug = 0; s_work[0] = 0.0; s_work[1] = 0.0; s_work[2] = 0.0; s_work[3] = 0.0; s_nodraw = 0; }
   const unsigned long long t_task = wall_clock64();
+#ifdef MH_GATE_DIAG
+  const unsigned long long c_task = __builtin_amdgcn_s_memtime();
+#endif
   Mat M; M.M = Mg + (size_t)bw * strideM; M.ld = ld; M.n = n;
   const double* q = qg + (size_t)bw * nstride;
   double* z = zg + (size_t)b * nstride;
@@ -1012,6 +1013,9 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
       __threadfence();
       __hip_atomic_store(solved_at + 2 + b, ok ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(solved_at + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);     // (solved_at[0]: workgroups started, [1]: verdicts published, [2 + b]: the verdicts)
+#ifdef MH_GATE_DIAG
+      if (wall_clock64() - t_task > 600000000ull) printf("lcp_fast: world %d started at clock %llu, took %.1f s, %u pivots, shader clock %.0f MHz on average\n", b, t_task, (double)(wall_clock64() - t_task) * 1e-8, piv, (double)(__builtin_amdgcn_s_memtime() - c_task) / ((double)(wall_clock64() - t_task) * 1e-2));
+#endif
     }
   }
   sync();
