@@ -1379,8 +1379,11 @@ static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& 
   static const mh::Pow10Table p10 = [] { mh::Pow10Table t; for (int i = 0; i < 64; i++) t.v[i] = std::pow(10.0, (double)(i - 32)); return t; }();
   // the ladder offers B x (8-12) useful workgroups at once: the narrow geometry (three problems per CU) unless its compact path does not take n
   const bool wide = mh_g_debug_blk ? mh_g_debug_blk == 2 && n >= 192 : n > 512;
-  const bool one_wave = n <= 512 && (mh_g_debug_blk == 3 || (mh_g_debug_blk == 0 && L.ntasks >= (long)MH_BLK1_MIN_PER_CU * mh_cu_count()));
-  const bool two_waves = n <= 512 && (mh_g_debug_blk == 4 || (mh_g_debug_blk == 0 && B >= MH_BLK2_MIN_PER_CU * mh_cu_count()));   // (B worlds: the ladder then runs in sequence per world, paced by throughput)
+  const bool one_wave = n <= 512 && (mh_g_debug_blk == 3 || (mh_g_debug_blk == 0 && !(by_verdict || resume) && L.ntasks >= (long)MH_BLK1_MIN_PER_CU * mh_cu_count()));
+  // (B worlds: the ladder then runs in sequence per world, paced by throughput.  Beside lcp_fast's kernel -- by_verdict / resume -- the step is paced by the
+  //  longest attempt, and that runs faster with two 256-thread problems on a CU than with four of 128: warm steps 7.4 -> 6.7 s, cold the same,
+  //  profiles/r04_d_config4_steps.txt)
+  const bool two_waves = n <= 512 && (mh_g_debug_blk == 4 || (mh_g_debug_blk == 0 && !(by_verdict || resume) && B >= MH_BLK2_MIN_PER_CU * mh_cu_count()));
   const hipError_t le = (two_waves ? mh_launch_lcp_blk2 : one_wave ? mh_launch_lcp_blk1 : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk))(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
       c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2) | (sched ? 8 : 0) | ((sched && by_verdict) ? 32 : 0), c->t_work, B, c->solved_at);
   MH_HIP(le);
