@@ -1458,6 +1458,9 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   LadderPlan L; L.ok = false;
   // ... unless the batch fills the chip with LCPs on which lcp_fast practically never succeeds (16-box stacks, n = 512, x 1024): running ahead
   // buys nothing there, and the tasks are better handed out by need afterwards (31.7 s instead of 35.7 s per full step)
+  // (Smaller batches keep the speculation: with the full-chip launch order 16-box stacks x 64 / 256 / 512 worlds took 2.78 / 2.90 / 4.03 s per cold
+  //  impact-handler call against 2.48 / 3.37 / 4.70 s, but 2.5 / 13 / 9.1 s per warm call against 3.3 / 4.7 / 5.3 s: when every world's lcp_fast starts at
+  //  once there are no verdicts yet for the first launch's workgroups, they leave, and the ladder runs after lcp_fast's slowest world.)
   const bool full_chip = mh_g_debug_sched != 0 && n >= 384 && B >= 3 * mh_cu_count();
   // Full chip, mh_debug_set(4, 3) (default): lcp_fast's kernel is launched FIRST, in its own (1024-thread) geometry, and the ladder's tasks -- handed
   // out by need -- behind it on the second stream, behind a GATE (k_gate) that opens when the last of lcp_fast's workgroups has started.  That
