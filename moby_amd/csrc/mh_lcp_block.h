@@ -411,52 +411,65 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
   }
   const unsigned long long ts = bp_tick();
   // triangular solves (the rhs is in LDS when k <= RHS_CAP)
-  // NB columns per barrier round: the NB x NB diagonal block is staged in LDS and finished by one thread, the
-  // rows outside it then take their NB updates in the same (ascending / descending) column order as dgetrs
-  for (int kb = 0; kb < k; kb += NB) {                   // unit lower
-    const int nbk = (k - kb < NB) ? k - kb : NB;
-    if (t < NB * NB) { const int r = t % NB, c = t / NB; if (r < nbk && c < nbk) s_u[0][t] = A[(kb + r) + (size_t)k * (kb + c)]; }
+  // SNB columns per round of two barriers: the SNB x SNB diagonal block is staged in LDS and finished by one wave (lane r = row r, values broadcast
+  // with v_readlane), the rows outside it then take their SNB updates in the same (ascending / descending) column order as dgetrs -- and while they
+  // do, the NEXT diagonal block is already on its way from the workspace (it holds factors, which the solves do not change).  Sixteen columns and
+  // the early request since round 4's second half (eight, three barriers and two round trips per block before): the solves were 16 % of the time
+  // of lcp_fast's slowest worlds, which pace a warm config-4 step.
+  constexpr int SNB = (T >= 256) ? 16 : 8;
+  static_assert(2 * SNB * SNB <= NB * (UCH + 8), "two staging areas in s_u");
+  double* const su = &s_u[0][0];
+  auto stage = [&](int kb, int nbk, int buf) {
+    if (t < SNB * SNB) { const int r = t % SNB, c = t / SNB; if (r < nbk && c < nbk) su[buf * SNB * SNB + t] = A[(kb + r) + (size_t)k * (kb + c)]; }
+  };
+  { int buf = 0;
+    stage(0, (k < SNB) ? k : SNB, 0);
     sync();
-    if (t < 64) {                                          // the diagonal block: lane r = row r, values broadcast with v_readlane
-      const int lane = t;
-      double v = (lane < nbk) ? bb[kb + lane] : 0.0, Lr[NB];
+    for (int kb = 0; kb < k; kb += SNB, buf ^= 1) {            // unit lower
+      const int nbk = (k - kb < SNB) ? k - kb : SNB;
+      if (t < 64) {
+        const int lane = t;
+        double v = (lane < nbk) ? bb[kb + lane] : 0.0, Lr[SNB];
 #pragma unroll
-      for (int c = 0; c < NB; c++) Lr[c] = (lane < nbk && c < nbk) ? s_u[0][lane + NB * c] : 0.0;
+        for (int c = 0; c < SNB; c++) Lr[c] = (lane < nbk && c < nbk) ? su[buf * SNB * SNB + lane + SNB * c] : 0.0;
 #pragma unroll
-      for (int c = 0; c < NB; c++) if (c < nbk) { const double bk = read_lane(v, c); if (lane > c) v = v - bk * Lr[c]; }
-      if (lane < nbk) bb[kb + lane] = v;
-    }
+        for (int c = 0; c < SNB; c++) if (c < nbk) { const double bk = read_lane(v, c); if (lane > c) v = v - bk * Lr[c]; }
+        if (lane < nbk) bb[kb + lane] = v;
+      }
+      sync();
+      if (kb + SNB < k) stage(kb + SNB, (k - kb - SNB < SNB) ? k - kb - SNB : SNB, buf ^ 1);
+      for (int i = kb + nbk + t; i < k; i += T) {
+        double v = bb[i];
+#pragma unroll
+        for (int c = 0; c < SNB; c++) if (c < nbk) v = v - bb[kb + c] * A[i + (size_t)k * (kb + c)];
+        bb[i] = v;
+      }
+      sync();
+    } }
+  { int buf = 0;
+    { const int kb0 = (k - SNB > 0) ? k - SNB : 0; stage(kb0, k - kb0, 0); }
     sync();
-    for (int i = kb + nbk + t; i < k; i += T) {
-      double v = bb[i];
+    for (int ke = k; ke > 0; ke -= SNB, buf ^= 1) {            // upper, blocks [kb, ke) from the bottom
+      const int kb = (ke - SNB > 0) ? ke - SNB : 0, nbk = ke - kb;
+      if (t < 64) {
+        const int lane = t;
+        double v = (lane < nbk) ? bb[kb + lane] : 0.0, Ur[SNB];
 #pragma unroll
-      for (int c = 0; c < NB; c++) if (c < nbk) v = v - bb[kb + c] * A[i + (size_t)k * (kb + c)];
-      bb[i] = v;
-    }
-    sync();
-  }
-  for (int ke = k; ke > 0; ke -= NB) {                   // upper, blocks [kb, ke) from the bottom
-    const int kb = (ke - NB > 0) ? ke - NB : 0, nbk = ke - kb;
-    if (t < NB * NB) { const int r = t % NB, c = t / NB; if (r < nbk && c < nbk) s_u[0][t] = A[(kb + r) + (size_t)k * (kb + c)]; }
-    sync();
-    if (t < 64) {
-      const int lane = t;
-      double v = (lane < nbk) ? bb[kb + lane] : 0.0, Ur[NB];
+        for (int c = 0; c < SNB; c++) Ur[c] = (lane < nbk && c < nbk) ? su[buf * SNB * SNB + lane + SNB * c] : 1.0;
 #pragma unroll
-      for (int c = 0; c < NB; c++) Ur[c] = (lane < nbk && c < nbk) ? s_u[0][lane + NB * c] : 1.0;
+        for (int c = SNB - 1; c >= 0; c--) if (c < nbk) { if (lane == c) v = v / Ur[c]; const double bk = read_lane(v, c); if (lane < c) v = v - bk * Ur[c]; }
+        if (lane < nbk) bb[kb + lane] = v;
+      }
+      sync();
+      if (kb > 0) { const int kbn = (kb - SNB > 0) ? kb - SNB : 0; stage(kbn, kb - kbn, buf ^ 1); }
+      for (int i = t; i < kb; i += T) {
+        double v = bb[i];
 #pragma unroll
-      for (int c = NB - 1; c >= 0; c--) if (c < nbk) { if (lane == c) v = v / Ur[c]; const double bk = read_lane(v, c); if (lane < c) v = v - bk * Ur[c]; }
-      if (lane < nbk) bb[kb + lane] = v;
-    }
-    sync();
-    for (int i = t; i < kb; i += T) {
-      double v = bb[i];
-#pragma unroll
-      for (int c = NB - 1; c >= 0; c--) if (c < nbk) v = v - bb[kb + c] * A[i + (size_t)k * (kb + c)];
-      bb[i] = v;
-    }
-    sync();
-  }
+        for (int c = SNB - 1; c >= 0; c--) if (c < nbk) v = v - bb[kb + c] * A[i + (size_t)k * (kb + c)];
+        bb[i] = v;
+      }
+      sync();
+    } }
   if (b_lds) { for (int i = t; i < k; i += T) b[i] = s_b[i]; sync(); }
   bp_tock(BP_SOLVE, ts);
   return 0;
