@@ -62,6 +62,9 @@ typedef struct mh_lcp_opts {
 } mh_lcp_opts;
 
 /* library / device ------------------------------------------------------- */
+/* 100 * major + minor.  101: mh_impact_batch_lu_work / mh_big_batch_lu_work fill B x 4 doubles per call (100: B x 2) -- a caller built against the
+ * two-column layout must check for >= 101 and size its buffer accordingly (#define MH_VERSION is what this header describes). */
+#define MH_VERSION 101
 int         mh_version(void);
 const char* mh_last_error(void);
 int         mh_device_count(void);

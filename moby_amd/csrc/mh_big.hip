@@ -57,6 +57,7 @@ struct Dev {
   double* kk_JiM;                            // B x kk_nisl x (kk_mmax x 6 MH_IJOINT_MAX_BODIES) scratch
   double* time; unsigned long long* steps; unsigned long long* mini_steps; unsigned long long* stab_iters;
   int* status; int* anyflag;
+  const int* thrown;          // the island pipeline's (mh_imp_core.h): an exception of the impact handler in the mini-step's process_constraints
 };
 
 MH_DEV double norm3(P3 a) { return sqrt(dot3(a, a)); }
@@ -667,6 +668,8 @@ __global__ void k_mini_post(Dev d, double dt_step)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= d.B || !d.mini_active[b]) return;
+  // an exception of the impact handler (mh_imp_core.h: thrown) leaves do_mini_step before TSS:215 and step_si_Euler's loop with it: the world's run is over
+  if (d.thrown[b]) { d.mini_active[b] = 0; return; }
   const double h = d.hmini[b];
   d.time[b] += h; d.mini_steps[b] += 1ull;
   const double hd = d.hdone[b] + h;
@@ -681,7 +684,8 @@ __global__ void k_step_begin(Dev d)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= d.B) return;
-  d.hdone[b] = 0.0; d.guard[b] = 0u; d.mini_active[b] = 1;
+  // a world that carries MH_WORLD_LCP_FAILED is not stepped: the exception ended the run of the simulator that owned it (oracle World::step)
+  d.hdone[b] = 0.0; d.guard[b] = 0u; d.mini_active[b] = (d.status[b] & MH_WORLD_LCP_FAILED) ? 0 : 1;
 }
 
 // pairwise distances on the simulator's pair list -> s_uc[0 .. np), returns the minimum (CStab:88-131)
@@ -703,13 +707,14 @@ MH_DEV void set_q_scaled(W& w, const double* q, const double* dq, double tt, int
 
 // ConstraintStabilization::stabilize, before the loop (CStab:181-191)
 __global__ __launch_bounds__(T)
-void k_stab_begin(Dev d)
+void k_stab_begin(Dev d, int in_step)
 {
   const int b = blockIdx.x, t = threadIdx.x;
   W w(d, d.state + (size_t)b * d.nb * 13);
   const int nb = d.nb;
   __shared__ double s_uc[NPMAX];
   if (d.cstab_maxit == 0u) { if (t == 0) d.stab_active[b] = 0; return; }
+  if (in_step && (d.status[b] & MH_WORLD_LCP_FAILED)) { if (t == 0) d.stab_active[b] = 0; return; }     // (step() was left by the exception: TSS:97 is not reached)
   for (int i = t; i < nb * 6; i += T) d.vsave[(size_t)b * nb * 6 + i] = w.st[13 * (i / 6) + 7 + (i % 6)];
   for (int i = t; i < nb * 7; i += T) d.qstab[(size_t)b * nb * 7 + i] = w.st[13 * (i / 7) + (i % 7)];
   const double mu = eval_unilateral(w, d.ptc + (size_t)b * d.npairs, d.nptc[b], s_uc);
@@ -1077,6 +1082,7 @@ __global__ void k_stab_end(Dev d, int count_step)
 {
   const int b = blockIdx.x, t = threadIdx.x;
   const int nb = d.nb;
+  if (count_step && (d.status[b] & MH_WORLD_LCP_FAILED)) return;      // (nothing was saved, the step is not counted: see k_stab_begin)
   if (d.cstab_maxit != 0u) {
     double* st = d.state + (size_t)b * nb * 13;
     for (int i = t; i < nb * 6; i += blockDim.x) st[13 * (i / 6) + 7 + (i % 6)] = d.vsave[(size_t)b * nb * 6 + i];
@@ -1122,7 +1128,7 @@ int run_stabilize(mh_big_batch* bb, hipStream_t s, int count_step)
   namespace bg = mh::big;
   const int B = bb->B;
   MH_HIP(hipMemsetAsync(bb->d.anyflag, 0, sizeof(int), s));
-  hipLaunchKernelGGL(bg::k_stab_begin, dim3(B), dim3(bg::T), 0, s, bb->d);
+  hipLaunchKernelGGL(bg::k_stab_begin, dim3(B), dim3(bg::T), 0, s, bb->d, count_step);
   MH_HIP(hipGetLastError());
   int any = 0;
   int rc = read_flag(bb, s, &any);
@@ -1330,7 +1336,7 @@ int mh_big_batch_create(const mh_big_scene* sc, int B, mh_big_batch** out)
   if (!okall) { mh_big_batch_destroy(bb); return fail(MH_ERR_HIP, "device allocation / upload failed"); }
   mh_imp_core& c = bb->core;
   c.mass = d.mass; c.inertia = d.inertia; c.state = d.state; c.contacts = d.contacts; c.ncount = d.ncount; c.cdist = d.cdist;
-  c.stab_eps = d.cstab_eps; c.rng = bb->d_rng; c.status = d.status;
+  c.stab_eps = d.cstab_eps; c.rng = bb->d_rng; c.status = d.status; d.thrown = c.thrown;
   *out = bb;
   return MH_OK;
 }

@@ -117,7 +117,7 @@ void mh_k_lcp_wave(int B, int n, const double* __restrict__ Mg, int ld, long str
 // ---------------------------------------------------------------------------
 extern "C" {
 
-int mh_version(void) { return 100; }
+int mh_version(void) { return MH_VERSION; }
 const char* mh_last_error(void) { return g_err; }
 
 int mh_device_count(void)
@@ -257,19 +257,23 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     const bool one_wave = lemke_kind && n <= 512 && (mh_g_debug_blk == 3 || (mh_g_debug_blk == 0 && B >= MH_BLK1_MIN_PER_CU * mh_cu_count()));
     const bool two_waves = lemke_kind && n <= 512 && (mh_g_debug_blk == 4 || (mh_g_debug_blk == 0 && B >= MH_BLK2_MIN_PER_CU * mh_cu_count()));
     auto launcher = two_waves ? mh_launch_lcp_blk2 : one_wave ? mh_launch_lcp_blk1 : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk);
+    if (lemke_kind && n >= MH_BLKX_MIN_N && n <= MH_BLKX_MAX_N && (mh_g_debug_blk == 0 || mh_g_debug_blk == 2)) launcher = mh_launch_lcp_blkx;   // two rows per lane (mh_lcp_blkx.hip)
     if (!lemke_kind && n <= 512 && mh_g_debug_fastgeom) launcher = (mh_g_debug_fastgeom == 1) ? mh_launch_lcp_blk : (mh_g_debug_fastgeom == 2) ? mh_launch_lcp_blkw
                                                                  : (mh_g_debug_fastgeom == 3) ? mh_launch_lcp_blk1 : mh_launch_lcp_blk2;
     if (wsd && wsi) {
-      const hipError_t le = (wave_only == 1) ? hipSuccess : launcher(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2) | (mh_g_debug_reglu << 4) | ((started && !lemke_kind) ? 32 : 0), work, 0, lemke_kind ? nullptr : started);
-      MH_HIP(le);
       if (n_arr) {          // the problems of this call that fit one wavefront (n_arr[b] <= 64) take the wave solver
+        // FIRST: the two kernels share no problem, and the wave solver's workgroups ask for 66 KB of LDS each -- behind the block solver's launch they could not be
+        // placed beside the ladder's resident workgroups of the other stream and sat in the queue for seconds (profiles/r04_e_config4_3steps_kernel_trace.txt:
+        // 5.3 s of "duration" for a launch whose every workgroup returns at once when all problems have more than 64 rows)
         const size_t ldsw = (size_t)(2 * MH_LCP_MAX_N_WAVE * MH_LCP_MAX_N_WAVE + MH_LCP_MAX_N_WAVE) * sizeof(double);
         hipLaunchKernelGGL(mh_k_lcp_wave, dim3(B), dim3(64), ldsw, (hipStream_t)stream,
                            B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
                            trace, trace_cap, trace_len, P, p10, run_if, n_arr);
         MH_HIP(hipGetLastError());
       }
+      const hipError_t le = (wave_only == 1) ? hipSuccess : launcher(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
+                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2) | (mh_g_debug_reglu << 4) | ((started && !lemke_kind) ? 32 : 0), work, 0, lemke_kind ? nullptr : started);
+      MH_HIP(le);
       return MH_OK;
     }
     if (n_arr) return fail(MH_ERR_INVALID_ARG, "per-problem sizes need a caller-owned workspace");

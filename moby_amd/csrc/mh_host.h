@@ -72,6 +72,9 @@ namespace mh { struct LcpParams; struct Pow10Table; }
   const mh::LcpParams* P, const mh::Pow10Table* p10, double* wsd, int* wsi, const int* run_if, const int* n_arr, int flags, double* work, int task_worlds, int* solved_at
 MH_HIDDEN hipError_t mh_launch_lcp_blk(MH_LCP_BLOCK_LAUNCH_ARGS);
 MH_HIDDEN hipError_t mh_launch_lcp_blkw(MH_LCP_BLOCK_LAUNCH_ARGS);
+MH_HIDDEN hipError_t mh_launch_lcp_blkx(MH_LCP_BLOCK_LAUNCH_ARGS);   // the lcp_lemke kinds with 1024 < n <= 2048: 1024 threads, two rows per lane (mh_lcp_blkx.hip)
+#define MH_BLKX_MIN_N 1025
+#define MH_BLKX_MAX_N 2048
 #define MH_BLK2_MIN_PER_CU 4      /* problems (worlds of a ladder launch) per CU from which the lcp_lemke kinds take the 128-thread geometry: four problems share
                                      a CU there (measured, 16-box stacks: 363 k pivots/s on a full chip against 262 k with 256 threads at two per CU and 323 k
                                      with the round-3 right-looking LU at three; below that the 256-thread geometry finishes a problem sooner) */

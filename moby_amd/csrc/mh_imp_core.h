@@ -20,6 +20,10 @@ struct mh_imp_core {
   double stab_eps;                                  // ConstraintStabilization::eps
   uint32_t* rng;                                    // B x MH_RAND_WORDS
   int* status;                                      // B, MH_WORLD_* bits (sticky)
+  // An exception of the reference's handler (LCPSolverException ICH-QP:225, runtime_error ICH:1282, std::exception ICH-AP:334, the assert of ICH:1184-1186) is
+  // caught nowhere up to main(): it unwinds process_constraints.  thrown[b] = 1 from the kernel that sets MH_WORLD_LCP_FAILED in mode IMPACT; k_unwind, after
+  // the round, then takes the world's remaining islands away (nisl = 0: no later round, no tolerance check).  Zeroed by k_prep: one call = one process_constraints.
+  int* thrown;
   // island tables and per-contact problem data, in island order
   int* order; int* cbody; double* cpar; double* W; double* XJ; double* Cv; double* xinv;
   int* nisl; int* isl_start; int* isl_len; int* isl_model; int* maxisl;   // isl_model: 0 Drumwright-Shell, 1 no-slip (ICH:123-135); maxisl: max over worlds of nisl

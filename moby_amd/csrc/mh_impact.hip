@@ -145,7 +145,7 @@ void k_prep(Dev d, int mode)
       }
     }
     s_flag[2] = cnt; s_flag[3] = nisl;
-    d.nisl[b] = nisl; d.run[b] = 0; d.need2[b] = 0; d.again[b] = 0; d.ncur[b] = 0;
+    d.nisl[b] = nisl; d.run[b] = 0; d.need2[b] = 0; d.again[b] = 0; d.ncur[b] = 0; d.thrown[b] = 0;
     d.lst1[b] = 1; d.lst2[b] = 1; d.piv1[b] = 0u; d.piv2[b] = 0u;
     atomicMax(d.maxisl, nisl);
   }
@@ -410,7 +410,7 @@ void k_post(Dev d, int r, int phase)
   const bool ok = d.lst1[b] != 0 || d.lst2[b] != 0;
   if (t == 0) {
     account(d, b, n);
-    if (!ok) d.status[b] |= MH_WORLD_LCP_FAILED;        // LCPSolverException (ICH-QP:225)
+    if (!ok) { d.status[b] |= MH_WORLD_LCP_FAILED; d.thrown[b] = 1; }        // LCPSolverException (ICH-QP:225)
     if (phase == 0) d.again[b] = 0;
     s_any = 0;
   }
@@ -522,7 +522,7 @@ void k_post_ap(Dev d, int r, int phase)
     const int n = d.ncur[b];
     unsigned long long* c = d.cnt + (size_t)b * 5;
     c[0] += 1ull; c[1] += (unsigned long long)n; c[2] += (unsigned long long)d.piv1[b]; c[3] += 8ull * ((unsigned long long)n * n + 2ull * n);
-    if (!ok) d.status[b] |= MH_WORLD_LCP_FAILED;        // throw std::exception() (ICH-AP:334): nothing is applied
+    if (!ok) { d.status[b] |= MH_WORLD_LCP_FAILED; d.thrown[b] = 1; }        // throw std::exception() (ICH-AP:334): nothing is applied
     if (phase == 0) d.again[b] = 0;
     d.need2[b] = 0;
     s_any = 0;
@@ -1049,7 +1049,7 @@ void k_noslip(Dev d, int r, mh::Pow10Table p10)
   }
   __syncthreads();
   const int m = s_m[0], ns = s_m[1], nt = m - ns;
-  if (m < 0) { if (lane == 0) d.status[b] |= MH_WORLD_LCP_FAILED; return; }       // assert(success), ICH:1184-1186
+  if (m < 0) { if (lane == 0) { d.status[b] |= MH_WORLD_LCP_FAILED; d.thrown[b] = 1; } return; }       // assert(success), ICH:1184-1186
   // lcp_fast(_MM, _qq, _v), then the Lemke ladder
   const bool valid = lane < nc;
   double nrm0 = 0.0;
@@ -1074,7 +1074,7 @@ void k_noslip(Dev d, int r, mh::Pow10Table p10)
   if (lane == 0) {
     unsigned long long* c = d.cnt + (size_t)b * 5;
     c[0] += 1ull; c[1] += (unsigned long long)nc; c[2] += (unsigned long long)total; c[3] += 8ull * ((unsigned long long)nc * nc + 2ull * nc);
-    if (!ok) d.status[b] |= MH_WORLD_LCP_FAILED;          // std::runtime_error("Unable to solve constraint LCP!")
+    if (!ok) { d.status[b] |= MH_WORLD_LCP_FAILED; d.thrown[b] = 1; }          // std::runtime_error("Unable to solve constraint LCP!")
   }
   if (!ok) return;
   if (valid) { d.vns[(size_t)b * NSC + lane] = zi; s_c[0][lane] = zi; s_c[1][lane] = 0.0; s_c[2][lane] = 0.0; }
@@ -1139,6 +1139,13 @@ void k_noslip(Dev d, int r, mh::Pow10Table p10)
 
 // ImpactToleranceException test (ICH:157-167) over the contacts of the processed islands: any still approaching
 // faster than NEAR_ZERO
+// the exception unwinds process_constraints (mh_imp_core.h: thrown): the islands after the failing one are not processed, the tolerance check is not reached
+__global__ void k_unwind(Dev d)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < d.B && d.thrown[b]) d.nisl[b] = 0;
+}
+
 __global__ __launch_bounds__(T)
 void k_finish(Dev d)
 {
@@ -1201,6 +1208,7 @@ int mh_imp_core_create(mh_imp_core* c, int B, int nb, int ncmax, int nk, int nma
   c->order = (int*)A(sB * snc * 4, true); c->cbody = (int*)A(sB * snc * 8, true); c->cpar = (double*)A(sB * snc * 32, true);
   c->W = (double*)A(sB * snc * 36 * 8, true); c->XJ = (double*)A(sB * snc * 36 * 8, true);
   c->Cv = (double*)A(sB * 3 * snc * 8, true); c->xinv = (double*)A(sB * nb * 80, true);
+  c->thrown = (int*)A(sB * 4, true);
   c->nisl = (int*)A(sB * 4, true); c->isl_start = (int*)A(sB * c->islmax * 4, true); c->isl_len = (int*)A(sB * c->islmax * 4, true);
   c->isl_model = (int*)A(sB * c->islmax * 4, true);
   c->vns = (double*)A(sB * MH_NOSLIP_MAX * 8, true); c->vns_size = (int*)A(sB * 4, true);
@@ -1384,7 +1392,8 @@ static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& 
   //  longest attempt, and that runs faster with two 256-thread problems on a CU than with four of 128: warm steps 7.4 -> 6.7 s, cold the same,
   //  profiles/r04_d_config4_steps.txt)
   const bool two_waves = n <= 512 && (mh_g_debug_blk == 4 || (mh_g_debug_blk == 0 && !(by_verdict || resume) && B >= MH_BLK2_MIN_PER_CU * mh_cu_count()));
-  const hipError_t le = (two_waves ? mh_launch_lcp_blk2 : one_wave ? mh_launch_lcp_blk1 : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk))(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
+  const bool wide2 = n >= MH_BLKX_MIN_N && n <= MH_BLKX_MAX_N && (mh_g_debug_blk == 0 || mh_g_debug_blk == 2);     // (two rows per lane: the structure-exploiting LU up to 2048 rows)
+  const hipError_t le = (wide2 ? mh_launch_lcp_blkx : two_waves ? mh_launch_lcp_blk2 : one_wave ? mh_launch_lcp_blk1 : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk))(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
       c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2) | (sched ? 8 : 0) | ((sched && by_verdict) ? 32 : 0), c->t_work, B, c->solved_at);
   MH_HIP(le);
   return MH_OK;
@@ -1503,6 +1512,7 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   }
   if (rc == MH_OK && spec && overlap) {                          // the ladder's tasks, by need, behind lcp_fast's launch and the gate
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, (hipStream_t)c->s2, gate, B);
+    { const hipError_t ge = hipGetLastError(); if (ge != hipSuccess) { (void)hipStreamSynchronize((hipStream_t)c->s2); return fail(MH_ERR_HIP, "k_gate failed: %s", hipGetErrorString(ge)); } }
     rc = core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, true, true);
     if (rc == MH_OK) { const hipError_t e = hipEventRecord((hipEvent_t)c->ev1, (hipStream_t)c->s2); if (e != hipSuccess) rc = fail(MH_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e)); }
     if (rc != MH_OK) { (void)hipStreamSynchronize((hipStream_t)c->s2); return rc; }
@@ -1567,6 +1577,7 @@ int mh_imp_core_process(mh_imp_core* c, void* stream, int mode)
     stage("post 1", r);
     static const mh::Pow10Table p10 = [] { mh::Pow10Table t; for (int i = 0; i < 64; i++) t.v[i] = std::pow(10.0, (double)(i - 32)); return t; }();   // LCP.cpp:285
     hipLaunchKernelGGL(im::k_noslip, dim3(B), dim3(64), 0, s, *c, r, p10);      // the islands of this round that take the no-slip model
+    hipLaunchKernelGGL(im::k_unwind, dim3((B + 63) / 64), dim3(64), 0, s, *c);
     MH_HIP(hipGetLastError());
   }
   if (mode == MH_CORE_IMPACT) { hipLaunchKernelGGL(im::k_finish, dim3(B), dim3(im::T), 0, s, *c); MH_HIP(hipGetLastError()); }
@@ -1617,8 +1628,8 @@ int mh_impact_batch_create(int B, int nb, int nc, int nk, const double* mass, co
   }
   if (mh_device_count() <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
   mh_impact_batch* ib = new mh_impact_batch();
-  if (hipGetDevice(&ib->device) != hipSuccess) { delete ib; return fail(MH_ERR_HIP, "hipGetDevice failed"); }
   std::memset(ib, 0, sizeof(*ib));
+  if (hipGetDevice(&ib->device) != hipSuccess) { delete ib; return fail(MH_ERR_HIP, "hipGetDevice failed"); }     // (after the memset: the batch belongs to the device current at create)
   ib->B = B; ib->nb = nb; ib->nc = nc; ib->nk = nk; ib->n = (int)n;
   int rc = mh_imp_core_create(&ib->c, B, nb, nc, nk, (int)n);
   if (rc != MH_OK) { delete ib; return rc; }

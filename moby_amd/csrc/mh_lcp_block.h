@@ -1044,10 +1044,15 @@ extern "C" MH_HIDDEN hipError_t MH_BLK_LAUNCHER(void* stream, int kind, int B, i
                                      double* wsd, int* wsi, const int* run_if, const int* n_arr, int flags, double* work, int task_worlds, int* solved_at)
 {
   namespace ns = mh::MH_BLK_NS;
+#ifdef MH_BLK_LEMKE_ONLY      /* a geometry that exists for the lcp_lemke kinds only (mh_lcp_blkx.hip) */
+  if (kind == MH_LCP_FAST || kind == MH_LCP_FAST_REG) return hipErrorInvalidValue;
+#else
   if (kind == MH_LCP_FAST || kind == MH_LCP_FAST_REG)
     hipLaunchKernelGGL(ns::k_lcp_block<0>, dim3(B), dim3(ns::T), 0, (hipStream_t)stream, B, n, M, ld, strideM, q, z, zsz_in, zsz_out, rng, status, pivots,
                        trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags, work, task_worlds, solved_at);
-  else {
+  else
+#endif
+  {
     int grid = B;
     if (task_worlds > 0 && (flags & 8)) {                               // as many workgroups as the chip holds at once; each takes tasks until none is left
       static int per_cu = 0;

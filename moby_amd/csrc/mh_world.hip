@@ -16,10 +16,13 @@ struct Pow10TableH { double v[64]; };
 }
 #include <mutex>
 namespace {
-std::once_flag g_tables_once;
-hipError_t g_tables_err = hipSuccess;
-void init_tables()
+// The __constant__ tables are one copy per DEVICE (hipMemcpyToSymbol writes the current device's): uploaded once per device, keyed on the
+// device current at create, under a lock -- as mh_artic_batch_create does for its own table.
+std::mutex g_tables_mu;
+std::vector<char> g_tables_done;
+hipError_t init_tables()
 {
+  hipError_t g_tables_err = hipSuccess;
   static mh::FricTableH ft;
   for (int kh = 0; kh < 33; kh++)
     for (int j = 0; j < 32; j++) {
@@ -31,6 +34,17 @@ void init_tables()
   for (int i = 0; i < 64; i++) p10.v[i] = std::pow(10.0, (double)(i - 32)); // LCP.cpp:285
   const mh_world_variant* vs[3] = { mh_world_variant_small(), mh_world_variant_wheel(), mh_world_variant_large() };
   for (int i = 0; i < 3 && g_tables_err == hipSuccess; i++) g_tables_err = vs[i]->upload_tables(&ft, sizeof(ft), &p10, sizeof(p10));
+  return g_tables_err;
+}
+hipError_t tables_for_current_device()
+{
+  std::lock_guard<std::mutex> lk(g_tables_mu);
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if ((int)g_tables_done.size() <= dev) g_tables_done.resize(dev + 1, 0);
+  if (!g_tables_done[dev]) { e = init_tables(); if (e == hipSuccess) g_tables_done[dev] = 1; }
+  return e;
 }
 int check_scene(const mh_scene* sc)
 {
@@ -121,8 +135,8 @@ int mh_world_batch_create(const mh_scene* scene, int B, mh_world_batch** out)
   if (rc != MH_OK) return rc;
   if (B <= 0) return fail(MH_ERR_INVALID_ARG, "batch must be > 0");
   if (mh_device_count() <= 0) return fail(MH_ERR_NO_DEVICE, "no HIP device visible");
-  std::call_once(g_tables_once, init_tables);
-  if (g_tables_err != hipSuccess) return fail(MH_ERR_HIP, "constant table upload failed: %s", hipGetErrorString(g_tables_err));
+  { const hipError_t te = tables_for_current_device();
+    if (te != hipSuccess) return fail(MH_ERR_HIP, "constant table upload failed: %s", hipGetErrorString(te)); }
   mh_world_batch* wb = new mh_world_batch();
   if (hipGetDevice(&wb->device) != hipSuccess) { delete wb; return fail(MH_ERR_HIP, "hipGetDevice failed"); }
   wb->scene = *scene; wb->B = B;

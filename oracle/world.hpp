@@ -1003,7 +1003,7 @@ class World {
       std::fwrite(MM.data(), 8, (size_t)n * n, g_lcp_dump); std::fwrite(qq.data(), 8, n, g_lcp_dump); std::fwrite(z_in.data(), 8, n, g_lcp_dump);
       std::fflush(g_lcp_dump);
     }
-    if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; return false; }   // LCPSolverException
+    if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; thrown_ = true; return false; }   // LCPSolverException
     // _zlast = z (ICH-QP:233)
     aux->zlast_size = n;
     for (int i = 0; i < n; i++) zlast_[i] = z[i];
@@ -1092,7 +1092,7 @@ class World {
     }
     const int ns = (int)S.size(), nt = (int)T.size();
     const int m = build_Y(false);                            // ICH:1166-1183
-    if (!chol_factor(m, Y.data(), m)) { aux->status |= MH_WORLD_LCP_FAILED; return false; }   // assert(success)
+    if (!chol_factor(m, Y.data(), m)) { aux->status |= MH_WORLD_LCP_FAILED; thrown_ = true; return false; }   // assert(success)
     // Q X X^T (nc x m): [Cn X Cs^T(:,S)  Cn X Ct^T(:,T)] (ICH:1198-1203)
     std::vector<double> QX((size_t)nc * m);
     for (int i = 0; i < nc; i++) {
@@ -1136,7 +1136,7 @@ class World {
     trace_len += tr.len;
     std::memcpy(aux->rng, &rs, sizeof(rs));
     lcp_account(nc, piv);
-    if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; return false; }   // std::runtime_error("Unable to solve constraint LCP!")
+    if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; thrown_ = true; return false; }   // std::runtime_error("Unable to solve constraint LCP!")
     for (int i = 0; i < nc; i++) aux->vns[i] = z[i];
     aux->vns_size = nc;
     // [cs; ct] = -(Y^-1 X v + Y^-1 (QX)^T v) (ICH:1293-1298)
@@ -1235,7 +1235,7 @@ class World {
     trace_len += tr.len;
     std::memcpy(aux->rng, &rs, sizeof(rs));
     lcp_account(n, lcp.pivots);
-    if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; return false; }   // throw std::exception()
+    if (!ok) { aux->status |= MH_WORLD_LCP_FAILED; thrown_ = true; return false; }   // throw std::exception()
     const int nc = pd.nc;
     for (int i = 0; i < nc; i++) {                                   // ICH-AP:336-342
       pd.cn[i] = z[i];
@@ -1336,7 +1336,15 @@ class World {
   }
 
   // calc_impacting_unilateral_constraint_forces (CSim:298-355) + apply_model (ICH:96-168)
+  // An exception of the impact handler -- LCPSolverException (ICH-QP:225), std::runtime_error("Unable to solve constraint LCP!") (ICH:1282),
+  // std::exception (ICH-AP:334), the assert of ICH:1184-1186 -- is caught nowhere between apply_model and main() (CSim:342-350 catches
+  // ImpactToleranceException only; programs/driver.cpp, programs/regress.cpp catch nothing): it unwinds process_constraints, do_mini_step and step,
+  // and the run of this simulator is over.  thrown_: it has happened in this call; the islands after the failing one are not processed, the
+  // tolerance check (ICH:157-167) is not reached, do_mini_step does not advance current_time (TSS:215), step does not stabilise; a world whose
+  // status carries MH_WORLD_LCP_FAILED is not stepped again (step() returns at once: the process that owned it has terminated).
+  bool thrown_ = false;
   void handle_impacts(const std::vector<Contact>& cs) {
+    thrown_ = false;
     if (cs.empty()) return;
     bool none = true;
     for (const Contact& c : cs) if (contact_vel(c, c.n) < -NEAR_ZERO) { none = false; break; }
@@ -1355,6 +1363,7 @@ class World {
       if (all_inf) apply_no_slip_model_to_island(cs, isl);              // ICH:134-135
       else if (impact_model == MH_IMPACT_MODEL_AP) apply_ap_model_to_island(cs, isl);   // ICH:139-142
       else apply_model(cs, isl);
+      if (thrown_) return;
     }
     for (const Island& isl : active)
       for (int ci : isl.contacts) if (contact_vel(cs[ci], cs[ci].n) < -NEAR_ZERO) { aux->status |= MH_WORLD_IMPACT_TOL; }
@@ -1404,6 +1413,7 @@ class World {
     std::vector<Contact> cs;                                       // find_unilateral_constraints (CSim:488-537)
     for (const PairDist& d : pairwise) if (d.dist < sc->contact_dist_thresh) find_contacts(d.pair, sc->contact_dist_thresh, cs);
     handle_impacts(cs);                                            // TSS:212
+    if (thrown_) return h;                                         // (the exception leaves before TSS:215)
     aux->time += h;
     aux->mini_steps++;
     return h;
@@ -1824,12 +1834,14 @@ class World {
 
   // TimeSteppingSimulator::step (TSS:52-111)
   void step(double dt) {
+    if (aux->status & MH_WORLD_LCP_FAILED) return;                 // the run ended with an exception of the impact handler (see handle_impacts)
     broad_phase(dt, pairs_to_check);
     calc_pairwise_distances(pairs_to_check, pairwise);
     double h = 0.0;
     unsigned guard = 0;
     while (h < dt) {
       h += do_mini_step(dt - h);
+      if (thrown_) return;
       if (++guard > 100000u) { aux->status |= MH_WORLD_STALLED; break; }   // the reference would spin forever
     }
     stabilize();

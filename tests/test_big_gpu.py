@@ -235,6 +235,43 @@ def test_config4_largest_solvable_size_properties():
     assert np.abs(b[:, :, 7:13]).max() < 5e-2
 
 
+def test_config4_at_the_size_baseline_states_against_the_oracles_fixture():
+    """BASELINE config 4 at the size BASELINE states: stacks of 64 boxes (impact LCP n = 2048; the pattern of example/stacks/stack.xml:36-96,
+    regress/stacks.setup's dt), 8 worlds, one full TimeSteppingSimulator::step.  The CPU oracle needs minutes per world here, so what it leaves behind
+    was generated in the build container (tests/golden/make_config4_64_boxes.py -> tests/golden/config4_64_boxes.npz) and is held against the device bit
+    for bit: state, status flags, rand() ring, every counter, time, and the handler's _zlast, for the unperturbed world (solved: lcp_fast fails on all four
+    rungs, the Lemke ladder gets through) and a perturbed one (the reference's whole chain fails: LCPSolverException, ICH-QP:225 -- the step is left
+    there and not counted, tests/test_oracle_exception.py).  lcp_lemke's 2048-row bases go through the structure-exploiting LU with two rows per lane
+    (mh_lcp_blkx.hip); until round 5 every pivot there was a dense dgesv and this step did not finish inside a 1200-second GPU call."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config4_64_boxes.npz"))
+    N, B = int(d["boxes"]), int(d["batch"])
+    assert N == 64 and int(d["steps"]) == 1
+    sc = K.box_stack_scene(N)
+    st0 = K.box_stack_state(N, B)
+    bb = K.BigBatch(sc, st0)
+    assert bb.cap == 32 * N
+    bb.step(float(d["dt"]), 1)
+    st, aux = bb.download()
+    ss = bb.solver_state()
+    bb.close()
+    assert len(d["worlds"]) >= 2
+    for k, w in enumerate(d["worlds"]):
+        w = int(w); ao = d["aux"][k:k + 1]
+        assert np.array_equal(d["st0"][k], st0[w])                       # the fixture's start state is this batch's
+        for f in FIELDS:
+            assert np.array_equal(aux[f][w], ao[f][0]), "world %d %s: gpu %r oracle %r" % (w, f, aux[f][w], ao[f][0])
+        assert np.array_equal(st[w], d["st"][k]), "world %d: max |diff| = %.3e" % (w, np.abs(st[w] - d["st"][k]).max())
+        n = int(ao["zlast_size"][0])
+        assert np.array_equal(ss["zlast"][w, :n], d["zlast"][k][:n])
+    failed = (aux["status"] & S.MH_WORLD_LCP_FAILED) != 0
+    assert not failed[0] and aux["steps"][0] == 1 and aux["zlast_size"][0] == 32 * N
+    assert failed[1:].all() and (aux["steps"][1:] == 0).all() and (aux["time"][1:] == 0.0).all()       # the perturbed stacks defeat the reference's chain
+    assert (aux["lcp_pivots"] > 8000).all()
+    b = st.reshape(B, N, 13)
+    assert np.abs(b[0, :, 1] - 0.5 - np.arange(N)).max() < 1e-4 and np.abs(b[0, :, 7:13]).max() < 5e-2
+
+
 def test_every_lemke_geometry_gives_the_same_full_steps():
     """The lcp_lemke kinds' thread geometries (mh_debug_set key 2: 256 / 1024 / 64 / 128 threads per problem; panels of 16 / 16 / 8 / 12
     columns, rounds of 16 / 16 / 4 / 8 steps in the left-looking LU) through the same 16-box worlds, one full step: states, rand()
@@ -404,8 +441,9 @@ def test_box_stacks_step_with_the_anitescu_potra_model(oracle):
 def test_anitescu_potra_box_stacks_properties_at_scale(oracle):
     """256 worlds of 4-box stacks with the A-P impact model, three full steps: nothing sinks or flies, identical worlds give
     identical results wherever they sit in the batch.  On the redundant corner contacts the A-P Lemke ladder (capped at
-    lambda = 1e-3, ICH-AP:333) now and then fails on every rung -- the reference throws there; those worlds are flagged
-    MH_WORLD_LCP_FAILED exactly where the oracle flags them."""
+    lambda = 1e-3, ICH-AP:333) now and then fails on every rung -- the reference throws there (an exception nothing catches: the run is over,
+    tests/test_oracle_exception.py); those worlds are flagged MH_WORLD_LCP_FAILED exactly where the oracle flags them, their failing step is not
+    counted, and they are not stepped again."""
     N, B = 4, 256
     sc = K.box_stack_scene(N, mu=0.3, impact_model=1)
     st0 = K.box_stack_state(N, B)
@@ -416,7 +454,7 @@ def test_anitescu_potra_box_stacks_properties_at_scale(oracle):
     bb.close()
     assert np.array_equal(st[B // 2:], st[:B // 2]) and np.array_equal(aux["lcp_pivots"][B // 2:], aux["lcp_pivots"][:B // 2])
     failed = (aux["status"] & S.MH_WORLD_LCP_FAILED) != 0
-    assert ((aux["status"] & ~(S.MH_WORLD_IMPACT_TOL | S.MH_WORLD_LCP_FAILED)) == 0).all() and (aux["steps"] == 3).all() and failed.sum() <= B // 16
+    assert ((aux["status"] & ~(S.MH_WORLD_IMPACT_TOL | S.MH_WORLD_LCP_FAILED)) == 0).all() and (aux["steps"][~failed] == 3).all() and (aux["steps"][failed] < 3).all() and 1 <= failed.sum() <= B // 16
     assert (aux["zlast_size"] == 0).all() and (aux["lcp_rows"] > 0).all()
     b = st.reshape(B, N, 13)
     assert np.abs(b[:, :, 1] - 0.5 - np.arange(N)).max() < 1e-4 and np.abs(b[:, :, 7:13]).max() < 5e-2
@@ -425,3 +463,5 @@ def test_anitescu_potra_box_stacks_properties_at_scale(oracle):
         so = st0[w].copy(); ao = S.new_aux(1)
         oracle.big_step(sc, so, ao, 1e-3, 3)
         assert ao["status"][0] == aux["status"][w] and ao["lcp_pivots"][0] == aux["lcp_pivots"][w] and np.array_equal(so, st[w])
+        for f in ("steps", "mini_steps", "time", "stab_iters", "lcp_solves", "rng"):
+            assert np.array_equal(ao[f][0], aux[f][w]), (w, f)

@@ -252,6 +252,33 @@ def test_block_solver_config4_sizes_properties(n):
     np.testing.assert_allclose(z[0, :4], 1.0, atol=1e-9)
 
 
+@pytest.mark.parametrize("n,active,kind", [(1025, 30, LEMKE), (1536, 60, LEMKE_REG), (2048, 90, LEMKE)])
+def test_structure_exploiting_lu_above_1024_rows(oracle, n, active, kind):
+    """1024 < n <= 2048: lcp_lemke's bases go through the structure-exploiting LU with TWO rows per lane (mh_lcp_blkx.hip; until round 5 every pivot
+    there was a dense dgesv of the assembled basis).  Dense PD problems whose solution has `active` positive variables: Lemke walks at least that many
+    pivots, the basis fills with dense columns one at a time, fill-ins and panel boundaries included.  Against the oracle bit for bit (status, pivots,
+    trace, rand(), z); the oracle solves its bases with its bit-equal model of the same routine (tests/test_oracle_compact_lu.py holds that to the dense
+    dgesv) -- and the device's DENSE route (mh_debug_set(3, 0)) must give the same answer as its structure-exploiting one."""
+    from moby_amd import _lib
+    M, q = _pd_problem(2, n, seed=7 * n, active=active)
+    oracle.lib.oracle_dbg_lemke_compact(8)
+    try:
+        ok = assert_parity(oracle, kind, M, q, z_size=np.array([n, 0], dtype=np.int32))
+    finally:
+        oracle.lib.oracle_dbg_lemke_compact(0)
+    assert ok.all()
+    a = run_gpu(kind, M[:1], q[:1], z_size=np.array([n], dtype=np.int32))
+    assert int(a[2].pivots[0]) >= active
+    _lib.check(_lib.load().mh_debug_set(3, 0))
+    try:
+        b = run_gpu(kind, M[:1], q[:1], z_size=np.array([n], dtype=np.int32))
+    finally:
+        _lib.check(_lib.load().mh_debug_set(3, 1))
+    np.testing.assert_array_equal(a[1], b[1])
+    for f in ("pivots", "trace_len", "rng"):
+        np.testing.assert_array_equal(getattr(a[2], f), getattr(b[2], f), err_msg=f)
+
+
 def test_cpp_adapter_example():
     """The Moby::LCP-shaped C++ adapter (moby_amd/cpp/MobyHipLCP.h) links against
     the C ABI and reproduces the KAT."""
