@@ -208,7 +208,8 @@ def config4_cpu_sample(nboxes, batch):
     own core); `all_cores`: all of them over the wall clock."""
     import multiprocessing as mp
     try:
-        ncores = int(os.environ.get("MH_BENCH_CPU_PROCS", usable_cpus()))
+        # (at most 8 processes: sixteen copies of this memory-bound sample slow each other down 3.5x -- 74 s per world against 21 s alone, 120 s of wall clock)
+        ncores = min(8, int(os.environ.get("MH_BENCH_CPU_PROCS", usable_cpus())))
         ws = [1 + (k % max(1, batch - 1)) for k in range(ncores)]
         t0 = time.perf_counter()
         with mp.get_context("fork").Pool(ncores) as pool:
@@ -259,7 +260,7 @@ def config4_cpu_sample_collect(proc, nboxes, timeout=400):
         return {"error": repr(e)}
 
 
-def config4_full_step_leg(torch, nboxes, B, steps, cpu_proc=None, cpu_part=None):
+def config4_full_step_leg(torch, nboxes, B, steps, cpu_proc=None, cpu_part=None, note=None):
     """BASELINE config 4 as FULL simulator steps (include/moby_hip_stack.h) at the bench size (16 boxes, n = 512;
     tests/test_big_gpu.py::test_config4_bench_size_full_batch): B stacks of `nboxes` boxes, each step = conservative advancement
     + contact generation + process_constraints over every island + stabilisation, all on the device.  The first step is cold.
@@ -270,7 +271,7 @@ def config4_full_step_leg(torch, nboxes, B, steps, cpu_proc=None, cpu_part=None)
         from moby_amd import stack as K
         sc = K.box_stack_scene(nboxes)
         bb = K.BigBatch(sc, K.box_stack_state(nboxes, B))
-        res = {"workload": "box stack of %d (impact LCP n = %d) x%d worlds, full TimeSteppingSimulator::step, dt = 1e-3" % (nboxes, 32 * nboxes, B),
+        res = {"workload": "box stack of %d (impact LCP n = %d) x%d worlds, full TimeSteppingSimulator::step, dt = 1e-3" % (nboxes, 32 * nboxes, B) + (("; " + note) if note else ""),
                "steps": []}
         prev = None; total_s = 0.0
         for k in range(steps):
@@ -283,6 +284,7 @@ def config4_full_step_leg(torch, nboxes, B, steps, cpu_proc=None, cpu_part=None)
         wk = bb.lu_work()
         work = wk.sum(axis=0)
         res["worlds_with_errors"] = int(((aux["status"] & ~2) != 0).sum())
+        res["worlds_lcp_solver_exception"] = int(((aux["status"] & 1) != 0).sum())     # MH_WORLD_LCP_FAILED: the reference's whole solver chain fails (LCPSolverException, ICH-QP:225)
         # how busy the solver kept the chip: seconds workgroups spent on problems (every ladder attempt) over slots x wall time.  Slots: what the
         # Lemke kinds' kernel holds at once (the lcp_fast kinds' kernel holds one 1024-thread problem per CU: priced against the larger number)
         cus = torch.cuda.get_device_properties(0).multi_processor_count
@@ -674,6 +676,9 @@ def main():
     ap.add_argument("--config4-boxes", type=int, default=16, help="box stack height of the config-4 full-step leg (n = 32 x boxes; 16 = the bench size, n = 512: BASELINE names 64 boxes, which the reference's own solver chain cannot solve -- DESIGN 4.2)")
     ap.add_argument("--config4-worlds", type=int, default=1024)
     ap.add_argument("--config4-steps", type=int, default=3, help="full steps of the config-4 leg: the first cold, the others warm-started from _zlast")
+    ap.add_argument("--config4-tall-boxes", type=int, default=28, help="the `config4_tall_stack` leg: the largest stack of which 64 worlds take one full cold step in under 60 s on one MI355X "
+                    "(measured, profiles/r05_*: 24 boxes 21.7 s, 28 boxes 37.3 s, 32 boxes 60.1 s; 64 boxes -- BASELINE's size, n = 2048 -- 135 s with 62 of 64 worlds ending in LCPSolverException); 0 = skip")
+    ap.add_argument("--config4-tall-worlds", type=int, default=64)
     ap.add_argument("--no-long-horizon", action="store_true")
     ap.add_argument("--long-horizon-start", type=int, default=4000)
     args = ap.parse_args()
@@ -804,6 +809,10 @@ def main():
     if rank == 0 and world_size == 1 and not args.no_config4:
         out["config4_impact_handler"] = config4_leg(torch)             # after the timed region; informational
         out["config4_full_step"] = config4_full_step_leg(torch, args.config4_boxes, args.config4_worlds, args.config4_steps, None, c4cpu_part)
+    if rank == 0 and world_size == 1 and not args.no_config4 and args.config4_tall_boxes > 0:
+        out["config4_tall_stack"] = config4_full_step_leg(torch, args.config4_tall_boxes, args.config4_tall_worlds, 1, None, None,
+            note="the largest stack of BASELINE config 4's family of which 64 worlds take one full COLD step in under 60 s on one MI355X (32 boxes, n = 1024: 60.1 s; "
+                 "BASELINE's own 64 boxes, n = 2048: 135 s for 64 worlds, 62 of them ending in LCPSolverException -- tests/test_big_gpu.py holds 64 boxes x 8 worlds to the oracle's fixture)")
     if rank == 0 and world_size == 1 and not args.no_config3:
         out["config3_rimless_wheel"] = config3_leg(torch, S, WorldBatchDevice, c3cpu)
     if rank == 0 and world_size == 1 and not args.no_config5:

@@ -257,6 +257,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     const bool one_wave = lemke_kind && n <= 512 && (mh_g_debug_blk == 3 || (mh_g_debug_blk == 0 && B >= MH_BLK1_MIN_PER_CU * mh_cu_count()));
     const bool two_waves = lemke_kind && n <= 512 && (mh_g_debug_blk == 4 || (mh_g_debug_blk == 0 && B >= MH_BLK2_MIN_PER_CU * mh_cu_count()));
     auto launcher = two_waves ? mh_launch_lcp_blk2 : one_wave ? mh_launch_lcp_blk1 : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk);
+    if (lemke_kind && n > 512 && n <= 1024 && (mh_g_debug_blk == 5 || (mh_g_debug_blk == 0 && B >= MH_BLKY_MIN_TASKS_PER_CU * mh_cu_count()))) launcher = mh_launch_lcp_blky;   // four rows per lane, two problems per CU (mh_lcp_blky.hip)
     if (lemke_kind && n >= MH_BLKX_MIN_N && n <= MH_BLKX_MAX_N && (mh_g_debug_blk == 0 || mh_g_debug_blk == 2)) launcher = mh_launch_lcp_blkx;   // two rows per lane (mh_lcp_blkx.hip)
     if (!lemke_kind && n <= 512 && mh_g_debug_fastgeom) launcher = (mh_g_debug_fastgeom == 1) ? mh_launch_lcp_blk : (mh_g_debug_fastgeom == 2) ? mh_launch_lcp_blkw
                                                                  : (mh_g_debug_fastgeom == 3) ? mh_launch_lcp_blk1 : mh_launch_lcp_blk2;
@@ -353,7 +354,7 @@ extern "C" int mh_debug_set(int key, int value)
   if (key == 10) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "register-LU switch outside {0, 1}"); mh_g_debug_reglu = value; return MH_OK; }
   if (key == 9) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "articulated packing outside {0, 1}"); mh_g_debug_artic_pack = value; return MH_OK; }
   if (key == 8) { if (value < 0 || value > 4) return fail(MH_ERR_INVALID_ARG, "lcp_fast geometry outside {0 .. 4}"); mh_g_debug_fastgeom = value; return MH_OK; }
-  if (key == 2) { if (value < 0 || value > 4) return fail(MH_ERR_INVALID_ARG, "block solver geometry outside {0, 1, 2, 3, 4}"); mh_g_debug_blk = value; return MH_OK; }
+  if (key == 2) { if (value < 0 || value > 5) return fail(MH_ERR_INVALID_ARG, "block solver geometry outside {0 .. 5}"); mh_g_debug_blk = value; return MH_OK; }
   if (key == 4) { if (value < 0 || value > 4) return fail(MH_ERR_INVALID_ARG, "ladder-task switch outside {0 .. 4}"); mh_g_debug_tasks = value; return MH_OK; }
   if (key == 7) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "task-scheduling switch outside {0, 1}"); mh_g_debug_sched = value; return MH_OK; }
   if (key == 6) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "factor-reuse switch outside {0, 1}"); mh_g_debug_reuse = value; return MH_OK; }

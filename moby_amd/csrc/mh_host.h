@@ -73,6 +73,8 @@ namespace mh { struct LcpParams; struct Pow10Table; }
 MH_HIDDEN hipError_t mh_launch_lcp_blk(MH_LCP_BLOCK_LAUNCH_ARGS);
 MH_HIDDEN hipError_t mh_launch_lcp_blkw(MH_LCP_BLOCK_LAUNCH_ARGS);
 MH_HIDDEN hipError_t mh_launch_lcp_blkx(MH_LCP_BLOCK_LAUNCH_ARGS);   // the lcp_lemke kinds with 1024 < n <= 2048: 1024 threads, two rows per lane (mh_lcp_blkx.hip)
+MH_HIDDEN hipError_t mh_launch_lcp_blky(MH_LCP_BLOCK_LAUNCH_ARGS);   // the lcp_lemke kinds with 512 < n <= 1024 and more tasks than CUs: 256 threads, four rows per lane (mh_lcp_blky.hip)
+#define MH_BLKY_MIN_TASKS_PER_CU 2
 #define MH_BLKX_MIN_N 1025
 #define MH_BLKX_MAX_N 2048
 #define MH_BLK2_MIN_PER_CU 4      /* problems (worlds of a ladder launch) per CU from which the lcp_lemke kinds take the 128-thread geometry: four problems share

@@ -1393,7 +1393,9 @@ static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& 
   //  profiles/r04_d_config4_steps.txt)
   const bool two_waves = n <= 512 && (mh_g_debug_blk == 4 || (mh_g_debug_blk == 0 && !(by_verdict || resume) && B >= MH_BLK2_MIN_PER_CU * mh_cu_count()));
   const bool wide2 = n >= MH_BLKX_MIN_N && n <= MH_BLKX_MAX_N && (mh_g_debug_blk == 0 || mh_g_debug_blk == 2);     // (two rows per lane: the structure-exploiting LU up to 2048 rows)
-  const hipError_t le = (wide2 ? mh_launch_lcp_blkx : two_waves ? mh_launch_lcp_blk2 : one_wave ? mh_launch_lcp_blk1 : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk))(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
+  // 512 < n <= 1024 with more tasks than the chip has CUs: two 256-thread problems per CU, four rows per lane (mh_lcp_blky.hip); mh_debug_set(2, 2) keeps the wide one
+  const bool narrow4 = n > 512 && n <= 1024 && (mh_g_debug_blk == 5 || (mh_g_debug_blk == 0 && L.ntasks >= (long)MH_BLKY_MIN_TASKS_PER_CU * mh_cu_count()));
+  const hipError_t le = (narrow4 ? mh_launch_lcp_blky : wide2 ? mh_launch_lcp_blkx : two_waves ? mh_launch_lcp_blk2 : one_wave ? mh_launch_lcp_blk1 : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk))(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
       c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2) | (sched ? 8 : 0) | ((sched && by_verdict) ? 32 : 0), c->t_work, B, c->solved_at);
   MH_HIP(le);
   return MH_OK;

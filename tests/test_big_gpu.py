@@ -137,16 +137,8 @@ def test_box_tower_scene_file_steps_like_the_oracle(oracle):
     assert (r[1]["lcp_rows"] >= 12 * 96).all() and (r[1]["status"] & ~S.MH_WORLD_IMPACT_TOL == 0).all()
 
 
-def test_sixteen_box_stack_one_step_matches_oracle(oracle):
-    """n = 512 impact LCP (the wide block solver, Lemke fallback) inside a full step."""
-    N, B = 16, 2
-    sc = K.box_stack_scene(N)
-    st0 = K.box_stack_state(N, B)
-    r = run_both(oracle, sc, st0, 1e-3, 1)
-    assert_parity(*r)
-    assert (r[1]["lcp_rows"] >= 512).all()
-
-
+# (n = 512 against the oracle: test_config4_bench_size_full_batch below -- two worlds of the 1024-world batch over two steps, the default full-chip schedule;
+#  round 4's 16 boxes x 2 worlds x 1 step test is subsumed by it and by the multi-step tests here, which run the small-batch branch)
 @pytest.mark.parametrize("nboxes,B,nsteps", [(8, 3, 3), (12, 2, 2)])
 def test_tall_stacks_several_steps_match_the_oracle(oracle, nboxes, B, nsteps):
     """The block solver (n = 256 / 384) against the ORACLE over several steps with every scheduling switch at its default: the
@@ -185,34 +177,49 @@ def test_config4_bench_size_properties():
     assert np.abs(b[:, :, 7:13]).max() < 5e-2
 
 
-def test_config4_bench_size_full_batch():
-    """BASELINE config 4 at the bench size (16 boxes, impact LCP n = 512: BASELINE names 64 boxes per scene, which the reference's own
-    solver chain cannot solve -- DESIGN 4.2; 32 is the largest it does) AND the batch size the configuration names: 1024 worlds, one
-    full TimeSteppingSimulator::step (what bench.py's `config4_full_step` leg runs first).
-    No world fails, identical worlds give identical results wherever they sit in the batch, the stacks stay put, momentum
-    is what gravity put in, and the solver chain did the work the CPU oracle does on such worlds (thousands of pivots each)."""
-    N, B = CONFIG4_BOXES, 1024
+def test_config4_bench_size_full_batch(oracle):
+    """BASELINE config 4 at the bench size (16 boxes, impact LCP n = 512) AND the batch size the configuration names: 1024 worlds, TWO full
+    TimeSteppingSimulator::step calls, the first cold, the second warm-started from _zlast (what bench.py's `config4_full_step` leg runs first).
+    This is the batch on which the DEFAULT full-chip schedule is active (mh_impact.hip core_solve_round: lcp_fast's kernel first, the ladder's tasks by
+    verdict behind the gate on a second stream, a second launch for the late verdicts), so the oracle is held against it directly: world 0 and the
+    world that needed the most pivots go through oracle.big_step for the same two steps -- state, rand() stream, every counter, flags, the warm-start
+    vector _zlast, bit for bit.  Beside that: no world fails, identical worlds give identical results wherever they sit in the batch, the stacks stay
+    put, momentum is what gravity put in, and the solver chain did the work the CPU oracle does on such worlds (thousands of pivots each)."""
+    N, B, STEPS = CONFIG4_BOXES, 1024, 2
     sc = K.box_stack_scene(N)
     st0 = K.box_stack_state(N, B)
     st0[B // 2:] = st0[:B // 2]
     bb = K.BigBatch(sc, st0)
+    cap = bb.cap
+    bb.step(1e-3, 1)
+    _, aux1 = bb.download()
     bb.step(1e-3, 1)
     st, aux = bb.download()
+    ss = bb.solver_state()
     bb.close()
     assert ((aux["status"] & ~S.MH_WORLD_IMPACT_TOL) == 0).all()                   # no failed world
     assert ((aux["status"] & S.MH_WORLD_IMPACT_TOL) != 0).sum() <= B // 50         # the handler's tolerance warning stays rare
     assert np.array_equal(st[B // 2:], st[:B // 2])
     for f in ("lcp_pivots", "lcp_rows", "lcp_solves", "rng", "stab_iters", "status"):
         assert np.array_equal(aux[f][B // 2:], aux[f][:B // 2]), f
-    assert (aux["steps"] == 1).all() and (aux["lcp_rows"] >= 32 * N).all()
+    assert (aux["steps"] == STEPS).all() and (aux["lcp_rows"] >= 32 * N * STEPS).all()
     b = st.reshape(B, N, 13)
     assert np.abs(b[:, :, 1] - 0.5 - np.arange(N)).max() < 1e-5                    # heights (measured 4.8e-7)
     assert np.abs(b[:, :, 7:13]).max() < 5e-3                                       # at rest up to one step of gravity
     mom = (sc.mass[None, :] * b[:, :, 8]).sum(axis=1)                               # what is left is carried by the ground
     assert np.abs(mom).max() < 1e-3 * sc.mass.sum() * 9.81e-3 * 10
-    piv = aux["lcp_pivots"].astype(np.int64)
-    assert 2000 < piv.mean() < 40000 and piv.max() < 200000                        # measured: mean 11 534, max 27 286
-    assert aux["lcp_solves"].min() >= 2 and aux["stab_rows"].mean() > 100          # impact + stabilisation LCPs were solved
+    piv = aux1["lcp_pivots"].astype(np.int64)
+    assert 2000 < piv.mean() < 40000 and piv.max() < 200000                        # cold step, measured: mean 11 534, max 27 286
+    assert aux["lcp_solves"].min() >= STEPS + 1 and aux["stab_rows"].mean() > 100  # impact (+ stabilisation) LCPs were solved in every step
+    # the oracle on two worlds of THIS batch: the unperturbed one and the one with the most pivots over both steps
+    for w in sorted({0, int(np.argmax(aux["lcp_pivots"][:B // 2]))}):
+        so = st0[w].copy(); ao = S.new_aux(1); zl = np.zeros(cap); zb = np.zeros(cap)
+        oracle.big_step(sc, so, ao, 1e-3, STEPS, zlast=zl, zbuf=zb, cap=cap)
+        for f in FIELDS:
+            assert np.array_equal(aux[f][w], ao[f][0]), "world %d %s: gpu %r oracle %r" % (w, f, aux[f][w], ao[f][0])
+        assert np.array_equal(st[w], so), "world %d: max |diff| = %.3e" % (w, np.abs(st[w] - so).max())
+        n = int(ao["zlast_size"][0])
+        assert np.array_equal(ss["zlast"][w, :n], zl[:n]), "world %d: _zlast" % w
 
 
 def test_config4_largest_solvable_size_properties():
@@ -272,52 +279,39 @@ def test_config4_at_the_size_baseline_states_against_the_oracles_fixture():
     assert np.abs(b[0, :, 1] - 0.5 - np.arange(N)).max() < 1e-4 and np.abs(b[0, :, 7:13]).max() < 5e-2
 
 
-def test_every_lemke_geometry_gives_the_same_full_steps():
-    """The lcp_lemke kinds' thread geometries (mh_debug_set key 2: 256 / 1024 / 64 / 128 threads per problem; panels of 16 / 16 / 8 / 12
-    columns, rounds of 16 / 16 / 4 / 8 steps in the left-looking LU) through the same 16-box worlds, one full step: states, rand()
-    streams, pivot counts and flags equal bit for bit.  (The oracle checks the default choice: the tests above.)"""
+def test_every_route_through_the_block_solver_gives_the_same_full_steps():
+    """The same six 16-box worlds, one full step, through every switch of the workgroup-per-problem solver -- states, rand() streams, pivot counts,
+    flags and warm-start sizes equal bit for bit (the oracle checks the default choice: the tests above and test_config4_bench_size_full_batch):
+      * the lcp_lemke kinds' thread geometries (mh_debug_set key 2: 256 / 1024 / 64 / 128 threads per problem; panels of 16 / 16 / 8 / 12 columns,
+        rounds of 16 / 16 / 4 / 8 steps in the left-looking LU);
+      * the two LU routes for Lemke's bases (key 3: the structure-exploiting one / the dense dgesv on the assembled basis);
+      * the factors of the columns before the changed one kept from pivot to pivot or not (key 6), with the ladder as tasks beside lcp_fast, as tasks
+        after it (handed out by need, key 7, or by block index) and in sequence (key 4).
+    (Round 4 had three tests of 6 / 12 / 12 worlds for this: 77 s of the GPU suite.)"""
     from moby_amd import _lib
     N, B = CONFIG4_BOXES, 6
     sc = K.box_stack_scene(N)
     st0 = K.box_stack_state(N, B)
-    res = {}
+    lib = _lib.load()
+    defaults = {2: 0, 3: 1, 4: 3, 6: 1, 7: 1}
+    runs = [{}, {2: 1}, {2: 2}, {2: 3}, {2: 4}, {3: 0}, {4: 2}, {4: 2, 6: 0}, {4: 0}, {4: 1}, {4: 1, 7: 0}]
+    res = []
     try:
-        for geom in (1, 2, 3, 4):
-            _lib.check(_lib.load().mh_debug_set(2, geom))
+        for sw in runs:
+            for k, v in defaults.items():
+                _lib.check(lib.mh_debug_set(k, sw.get(k, v)))
             bb = K.BigBatch(sc, st0)
             bb.step(1e-3, 1)
-            res[geom] = bb.download()
+            res.append(bb.download())
             bb.close()
     finally:
-        _lib.check(_lib.load().mh_debug_set(2, 0))
-    for geom in (2, 3, 4):
-        assert np.array_equal(res[1][0], res[geom][0]), geom
+        for k, v in defaults.items():
+            _lib.check(lib.mh_debug_set(k, v))
+    for sw, r in zip(runs[1:], res[1:]):
+        assert np.array_equal(res[0][0], r[0]), sw
         for f in FIELDS:
-            assert np.array_equal(res[1][1][f], res[geom][1][f]), (geom, f)
-    assert (res[1][1]["lcp_pivots"] > 1000).all()
-
-
-def test_structure_exploiting_lu_route_equals_the_dense_route_in_full_steps():
-    """The block solver's two LU routes for Lemke's bases (mh_lu_compact.inc / the dense dgesv on the assembled basis, mh_debug_set
-    key 3) through the same 16-box worlds, full steps: states, rand() streams, pivot counts and flags equal bit for bit."""
-    from moby_amd import _lib
-    N, B = CONFIG4_BOXES, 12
-    sc = K.box_stack_scene(N)
-    st0 = K.box_stack_state(N, B)
-    res = {}
-    try:
-        for route in (1, 0):
-            _lib.check(_lib.load().mh_debug_set(3, route))
-            bb = K.BigBatch(sc, st0)
-            bb.step(1e-3, 1)
-            res[route] = bb.download()
-            bb.close()
-    finally:
-        _lib.check(_lib.load().mh_debug_set(3, 1))
-    assert np.array_equal(res[1][0], res[0][0])
-    for f in FIELDS:
-        assert np.array_equal(res[1][1][f], res[0][1][f]), f
-    assert (res[1][1]["lcp_pivots"] > 1000).all()
+            assert np.array_equal(res[0][1][f], r[1][f]), (sw, f)
+    assert (res[0][1]["lcp_pivots"] > 1000).all()
 
 
 def test_ladder_tasks_behind_the_gate_change_nothing():
@@ -344,34 +338,6 @@ def test_ladder_tasks_behind_the_gate_change_nothing():
     for f in FIELDS:
         assert np.array_equal(res[3][1][f], res[2][1][f]), f
     assert (res[3][1]["lcp_pivots"] > 500).mean() > 0.9 and (res[3][1]["status"] & S.MH_WORLD_LCP_FAILED == 0).mean() > 0.9
-
-
-def test_factor_reuse_across_lemke_pivots_changes_nothing():
-    """mh_lu_compact.inc keeps, from one Lemke pivot to the next, the factors of the columns before the one the pivot changed
-    (mh_debug_set key 6; 0 = every basis factorised from scratch).  Same 16-box worlds, one full step, both ways: states, rand()
-    streams, pivot counts and flags equal bit for bit -- with the ladder as tasks beside lcp_fast, as tasks after it (handed out by need,
-    key 7, or by block index) and in sequence (key 4)."""
-    from moby_amd import _lib
-    N, B = CONFIG4_BOXES, 12
-    sc = K.box_stack_scene(N)
-    st0 = K.box_stack_state(N, B)
-    res = {}
-    lib = _lib.load()
-    try:
-        for tasks, reuse, sched in ((2, 1, 1), (2, 0, 1), (0, 1, 1), (1, 1, 1), (1, 1, 0)):
-            _lib.check(lib.mh_debug_set(4, tasks)); _lib.check(lib.mh_debug_set(6, reuse)); _lib.check(lib.mh_debug_set(7, sched))
-            bb = K.BigBatch(sc, st0)
-            bb.step(1e-3, 1)
-            res[(tasks, reuse, sched)] = bb.download()
-            bb.close()
-    finally:
-        _lib.check(lib.mh_debug_set(4, 3)); _lib.check(lib.mh_debug_set(6, 1)); _lib.check(lib.mh_debug_set(7, 1))
-    ref = res[(2, 0, 1)]
-    for k in ((2, 1, 1), (0, 1, 1), (1, 1, 1), (1, 1, 0)):
-        assert np.array_equal(res[k][0], ref[0]), k
-        for f in FIELDS:
-            assert np.array_equal(res[k][1][f], ref[1][f]), (k, f)
-    assert (ref[1]["lcp_pivots"] > 1000).all()
 
 
 def test_upload_restores_or_resets_the_handlers_warm_start():

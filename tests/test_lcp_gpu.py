@@ -279,6 +279,32 @@ def test_structure_exploiting_lu_above_1024_rows(oracle, n, active, kind):
         np.testing.assert_array_equal(getattr(a[2], f), getattr(b[2], f), err_msg=f)
 
 
+@pytest.mark.parametrize("n,active,kind", [(513, 25, LEMKE), (800, 50, LEMKE_REG), (1024, 70, LEMKE)])
+def test_four_rows_per_lane_geometry_between_512_and_1024_rows(oracle, n, active, kind):
+    """512 < n <= 1024 in the 256-thread geometry (mh_lcp_blky.hip: four rows per lane, two problems per CU -- what the ladder's tasks take when there
+    are more of them than CUs; mh_debug_set(2, 5) forces it): against the oracle bit for bit, and equal to the 1024-thread geometry's answer."""
+    from moby_amd import _lib
+    M, q = _pd_problem(2, n, seed=11 * n, active=active)
+    lib = _lib.load()
+    _lib.check(lib.mh_debug_set(2, 5))
+    try:
+        oracle.lib.oracle_dbg_lemke_compact(8)
+        try:
+            ok = assert_parity(oracle, kind, M, q, z_size=np.array([n, 0], dtype=np.int32))
+        finally:
+            oracle.lib.oracle_dbg_lemke_compact(0)
+        assert ok.all()
+        a = run_gpu(kind, M, q, z_size=np.array([n, 0], dtype=np.int32))
+        _lib.check(lib.mh_debug_set(2, 2))
+        b = run_gpu(kind, M, q, z_size=np.array([n, 0], dtype=np.int32))
+    finally:
+        _lib.check(lib.mh_debug_set(2, 0))
+    assert (a[2].pivots >= active).all()
+    np.testing.assert_array_equal(a[1], b[1])
+    for f in ("pivots", "trace_len", "rng"):
+        np.testing.assert_array_equal(getattr(a[2], f), getattr(b[2], f), err_msg=f)
+
+
 def test_cpp_adapter_example():
     """The Moby::LCP-shaped C++ adapter (moby_amd/cpp/MobyHipLCP.h) links against
     the C ABI and reproduces the KAT."""
