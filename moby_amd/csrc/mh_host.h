@@ -94,6 +94,9 @@ struct mh_world_variant {
 MH_HIDDEN const mh_world_variant* mh_world_variant_small();
 MH_HIDDEN const mh_world_variant* mh_world_variant_wheel();
 MH_HIDDEN const mh_world_variant* mh_world_variant_large();
+MH_HIDDEN const mh_world_variant* mh_world_variant_small_prof();     // the same kernels with the phase profiler's stamps compiled in (mh_world_*_prof.hip)
+MH_HIDDEN const mh_world_variant* mh_world_variant_wheel_prof();
+MH_HIDDEN const mh_world_variant* mh_world_variant_large_prof();
 
 // mh_debug_set keys 1 / 2 (test hooks; defined in mh_capi.hip)
 extern MH_HIDDEN int mh_g_debug_ka;

@@ -218,6 +218,13 @@ __shared__ int s_ipiv[NB];
 __shared__ int s_sk[4];
 __shared__ unsigned char s_nz[UCH];
 MH_DEV bool finite_d(double x) { return fabs(x) <= 1.7976931348623157e308; }
+// a - l*u of dgesv.  -DMH_BLK_FMA_EXPERIMENT (timing / outcome experiment only, DESIGN 8 "the oracle's dgesv above n = 64"): fused, one rounding -- what
+// oracle_dbg_lu_fma makes of the oracle; the shipped build and the oracle's definition are the unfused form at every size
+#ifdef MH_BLK_FMA_EXPERIMENT
+MH_DEV double blk_upd(double a, double l, double u) { return __builtin_fma(-l, u, a); }
+#else
+MH_DEV double blk_upd(double a, double l, double u) { return a - l * u; }
+#endif
 
 // A22[r][c] -= L[r][j0+s] * U12[s][c], s ascending; one row per thread, its multipliers in registers.
 // Thread (tr, tc): rows c0 + tr + 64 i, columns tc, tc + 4, ... of the chunk -- a wave still reads 64 consecutive
@@ -251,11 +258,7 @@ MH_DEV void trail_update(double* __restrict__ A, int k, int j0, int c0, int cb, 
           double v = a[u4];
 #pragma unroll
           for (int s2 = 0; s2 < NB; s2++) if (FULL || s2 < nbk) {
-#ifdef MH_BLK_FMA_EXPERIMENT     /* what an FP64 MFMA trailing update would compute: fused a - l*u, one rounding */
-            v = __builtin_fma(-l[s2], s_u[s2][c], v);
-#else
-            v = v - l[s2] * s_u[s2][c];
-#endif
+            v = blk_upd(v, l[s2], s_u[s2][c]);      /* (fused under -DMH_BLK_FMA_EXPERIMENT: what an FP64 MFMA trailing update would compute) */
           }
           A[r + (size_t)k * (cb + c)] = v;
         }
@@ -311,7 +314,7 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
             const bool all_fin = mh::ballot(!lfin) == 0ull;
             for (int c = jj + 1; c < nbk; c++) { const double u = s_panel[jj + R * c];
               if (u == 0.0 && all_fin) continue;              // a - l*0 = a: exact no-op (see s_sk above)
-              for (int r = jj + 1 + lane; r < R; r += 64) s_panel[r + R * c] = s_panel[r + R * c] - s_panel[r + R * jj] * u; }
+              for (int r = jj + 1 + lane; r < R; r += 64) s_panel[r + R * c] = blk_upd(s_panel[r + R * c], s_panel[r + R * jj], u); }
             wsync();
           }
         }
@@ -340,7 +343,7 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
         sync();
         if (nbk - jj - 1 > 0) {
           for (int c = j + 1; c < j0 + nbk; c++) { const double u = A[j + (size_t)k * c];
-            for (int r = j + 1 + t; r < k; r += T) A[r + (size_t)k * c] = A[r + (size_t)k * c] - A[r + (size_t)k * j] * u; }
+            for (int r = j + 1 + t; r < k; r += T) A[r + (size_t)k * c] = blk_upd(A[r + (size_t)k * c], A[r + (size_t)k * j], u); }
           sync();
         }
       }
@@ -387,7 +390,7 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
           {                                                // nbk == NB here (see trail_update)
             double a = A[(j0 + s2) + (size_t)k * (cb + c)];
 #pragma unroll
-            for (int s1 = 0; s1 < NB; s1++) if (s1 < s2) a = a - (in_lds ? s_panel[s2 + R * s1] : A[(j0 + s2) + (size_t)k * (j0 + s1)]) * u[s1];
+            for (int s1 = 0; s1 < NB; s1++) if (s1 < s2) a = blk_upd(a, (in_lds ? s_panel[s2 + R * s1] : A[(j0 + s2) + (size_t)k * (j0 + s1)]), u[s1]);
             u[s2] = a;
             A[(j0 + s2) + (size_t)k * (cb + c)] = a;
             s_u[s2][c] = a;
@@ -433,7 +436,7 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
 #pragma unroll
         for (int c = 0; c < SNB; c++) Lr[c] = (lane < nbk && c < nbk) ? su[buf * SNB * SNB + lane + SNB * c] : 0.0;
 #pragma unroll
-        for (int c = 0; c < SNB; c++) if (c < nbk) { const double bk = read_lane(v, c); if (lane > c) v = v - bk * Lr[c]; }
+        for (int c = 0; c < SNB; c++) if (c < nbk) { const double bk = read_lane(v, c); if (lane > c) v = blk_upd(v, bk, Lr[c]); }
         if (lane < nbk) bb[kb + lane] = v;
       }
       sync();
@@ -441,7 +444,7 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
       for (int i = kb + nbk + t; i < k; i += T) {
         double v = bb[i];
 #pragma unroll
-        for (int c = 0; c < SNB; c++) if (c < nbk) v = v - bb[kb + c] * A[i + (size_t)k * (kb + c)];
+        for (int c = 0; c < SNB; c++) if (c < nbk) v = blk_upd(v, bb[kb + c], A[i + (size_t)k * (kb + c)]);
         bb[i] = v;
       }
       sync();
@@ -457,7 +460,7 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
 #pragma unroll
         for (int c = 0; c < SNB; c++) Ur[c] = (lane < nbk && c < nbk) ? su[buf * SNB * SNB + lane + SNB * c] : 1.0;
 #pragma unroll
-        for (int c = SNB - 1; c >= 0; c--) if (c < nbk) { if (lane == c) v = v / Ur[c]; const double bk = read_lane(v, c); if (lane < c) v = v - bk * Ur[c]; }
+        for (int c = SNB - 1; c >= 0; c--) if (c < nbk) { if (lane == c) v = v / Ur[c]; const double bk = read_lane(v, c); if (lane < c) v = blk_upd(v, bk, Ur[c]); }
         if (lane < nbk) bb[kb + lane] = v;
       }
       sync();
@@ -465,7 +468,7 @@ MH_DEV int lu_solve(int k, double* A, double* b) {
       for (int i = t; i < kb; i += T) {
         double v = bb[i];
 #pragma unroll
-        for (int c = SNB - 1; c >= 0; c--) if (c < nbk) v = v - bb[kb + c] * A[i + (size_t)k * (kb + c)];
+        for (int c = SNB - 1; c >= 0; c--) if (c < nbk) v = blk_upd(v, bb[kb + c], A[i + (size_t)k * (kb + c)]);
         bb[i] = v;
       }
       sync();

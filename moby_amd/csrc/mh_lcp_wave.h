@@ -32,8 +32,16 @@ namespace mh {
 enum { LP_SETUP = 0, LP_GATHER, LP_LU, LP_GEMV, LP_RANDMIN, LP_VERIFY, LP_LEMKE, LP_COUNT };
 __shared__ unsigned long long g_lcp_prof[LP_COUNT];
 __shared__ int g_lcp_prof_on;
+// Compiled in only in the PROFILE translation units (-DMH_PROFILE_BUILD: mh_world_*_prof.hip, what mh_world_batch_profile launches).  Until round 5 the
+// switch was the run-time flag alone and every stamp point of the production kernels paid a ds_read + s_waitcnt lgkmcnt(0) + branch for it -- a full LDS
+// round trip on the dependent chain of a latency-bound kernel, about a hundred times per world-step.
+#ifdef MH_PROFILE_BUILD
 MH_DEV unsigned long long lp_tick() { return g_lcp_prof_on ? __builtin_amdgcn_s_memtime() : 0ull; }
 MH_DEV void lp_tock(int ph, unsigned long long t0) { if (g_lcp_prof_on) { const unsigned long long d = __builtin_amdgcn_s_memtime() - t0; if (lane_id() == 0) g_lcp_prof[ph] += d; } }
+#else
+MH_DEV unsigned long long lp_tick() { return 0ull; }
+MH_DEV void lp_tock(int, unsigned long long) {}
+#endif
 
 struct Trace {
   int32_t* buf; int cap; int len;

@@ -32,8 +32,9 @@ hipError_t init_tables()
     }
   mh::Pow10TableH p10;
   for (int i = 0; i < 64; i++) p10.v[i] = std::pow(10.0, (double)(i - 32)); // LCP.cpp:285
-  const mh_world_variant* vs[3] = { mh_world_variant_small(), mh_world_variant_wheel(), mh_world_variant_large() };
-  for (int i = 0; i < 3 && g_tables_err == hipSuccess; i++) g_tables_err = vs[i]->upload_tables(&ft, sizeof(ft), &p10, sizeof(p10));
+  const mh_world_variant* vs[6] = { mh_world_variant_small(), mh_world_variant_wheel(), mh_world_variant_large(),
+                                    mh_world_variant_small_prof(), mh_world_variant_wheel_prof(), mh_world_variant_large_prof() };     // (one copy of the tables per code object)
+  for (int i = 0; i < 6 && g_tables_err == hipSuccess; i++) g_tables_err = vs[i]->upload_tables(&ft, sizeof(ft), &p10, sizeof(p10));
   return g_tables_err;
 }
 hipError_t tables_for_current_device()
@@ -248,7 +249,9 @@ int mh_world_batch_profile(mh_world_batch* wb, double dt, int nsteps, double* ph
   const size_t sz = (size_t)wb->B * PHC * sizeof(unsigned long long);
   MH_HIP(hipMalloc(&dprof, sz));
   MH_HIP(hipMemset(dprof, 0, sz));
-  hipLaunchKernelGGL(wb->kernel, dim3(wb->B), dim3(64), 0, (hipStream_t)nullptr,
+  // the PROFILE build of the batch's variant: the production kernel has no stamp code (mh_lcp_wave.h lp_tick)
+  const mh_world_kernel kprof = (wb->variant == 0 ? mh_world_variant_small_prof() : wb->variant == 2 ? mh_world_variant_wheel_prof() : mh_world_variant_large_prof())->kernel;
+  hipLaunchKernelGGL(kprof, dim3(wb->B), dim3(64), 0, (hipStream_t)nullptr,
                      (const mh_scene*)wb->d_scene, wb->B, dt, nsteps, wb->d_state, wb->d_aux, (double*)nullptr, wb->nmax, wb->d_lu_ws, mh_g_debug_ka, dprof, (const int*)nullptr);
   hipError_t e = hipDeviceSynchronize();
   std::vector<unsigned long long> h((size_t)wb->B * PHC);

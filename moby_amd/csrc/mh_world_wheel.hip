@@ -3,7 +3,13 @@
 #include <hip/hip_runtime.h>
 #include "../../include/moby_hip.h"
 #include "mh_host.h"
+#ifdef MH_PROFILE_BUILD      /* mh_world_wheel_prof.hip: the same kernel with the s_memtime stamps compiled in (mh_world_batch_profile) */
+#define MHW_NS wheel_prof
+#define MHW_VARIANT_GETTER mh_world_variant_wheel_prof
+#else
 #define MHW_NS wheel
+#define MHW_VARIANT_GETTER mh_world_variant_wheel
+#endif
 #define MHW_NOSLIP 1
 #define MHW_BOX 0
 #define MHW_NB 2
@@ -22,8 +28,8 @@ static hipError_t upload_tables(const void* fric, size_t fric_bytes, const void*
   return e;
 }
 
-const mh_world_variant* mh_world_variant_wheel()
+const mh_world_variant* MHW_VARIANT_GETTER()
 {
-  static const mh_world_variant v = { mh::wheel::mh_k_world_step, mh::wheel::PH_COUNT, upload_tables };
+  static const mh_world_variant v = { mh::MHW_NS::mh_k_world_step, mh::MHW_NS::PH_COUNT, upload_tables };
   return &v;
 }

@@ -117,7 +117,7 @@ inline int lu_solve_compact(int n, const int* kind, const int* idx, const double
         for (int i : freerows) { double l = pj[i]; l = big ? l * rcp : l / piv; if (!fin(l)) return CL_FALLBACK; pj[i] = l; }
         for (int c2 = jj + 1; c2 < npc; c2++) {
           double* pc = &P[(size_t)n * c2]; const double uu = pc[r];
-          if (uu != 0.0) for (int i : freerows) pc[i] = pc[i] - pj[i] * uu;
+          if (uu != 0.0) for (int i : freerows) pc[i] = lu_upd(pc[i], pj[i], uu);
         } }
       nbk++;
     }
@@ -139,7 +139,7 @@ inline int lu_solve_compact(int n, const int* kind, const int* idx, const double
       bool any = false;
       for (int s = 0; s < nbk; s++) {
         double a = x[drow[first_step + s]];
-        for (int t = 0; t < s; t++) a = a - Lpp[s + (size_t)NB * t] * u[t];
+        for (int t = 0; t < s; t++) a = lu_upd(a, Lpp[s + (size_t)NB * t], u[t]);
         if (!fin(a)) return false;
         u[s] = a; x[drow[first_step + s]] = a;
         any = any || (a != 0.0);
@@ -148,7 +148,7 @@ inline int lu_solve_compact(int n, const int* kind, const int* idx, const double
       for (int s = 0; s < nbk; s++) {                              // (per element still ascending in s)
         const double us = u[s]; if (us == 0.0) continue;
         const double* ls = &P[(size_t)n * s];
-        for (int i : rowsv) if (s < reachv[i]) x[i] = x[i] - ls[i] * us;
+        for (int i : rowsv) if (s < reachv[i]) x[i] = lu_upd(x[i], ls[i], us);
       }
       return true;
     };
@@ -164,7 +164,7 @@ inline int lu_solve_compact(int n, const int* kind, const int* idx, const double
     const double* col = &D[(size_t)n * dslot[s]];
     const double xs = b[drow[s]] / col[drow[s]];
     b[drow[s]] = xs;
-    for (int i = 0; i < n; i++) if (pivstep[i] < dpos[s]) b[i] = b[i] - xs * col[i];
+    for (int i = 0; i < n; i++) if (pivstep[i] < dpos[s]) b[i] = lu_upd(b[i], xs, col[i]);
   }
   std::vector<double> x(n);
   for (int j = 0; j < n; j++) {
@@ -264,7 +264,7 @@ inline int lu_solve_compact_keep(CompactLuKeep& K, int n, const int* kind, const
     bool any = false;
     for (int s = 0; s < nbk; s++) {
       double a = x[drow[first_step + s]];
-      for (int t = 0; t < s; t++) a = a - Lpp[s + (size_t)NB * t] * u[t];
+      for (int t = 0; t < s; t++) a = lu_upd(a, Lpp[s + (size_t)NB * t], u[t]);
       if (!fin(a)) return false;
       u[s] = a; x[drow[first_step + s]] = a;
       any = any || (a != 0.0);
@@ -273,7 +273,7 @@ inline int lu_solve_compact_keep(CompactLuKeep& K, int n, const int* kind, const
     for (int s = 0; s < nbk; s++) {
       const double us = u[s]; if (us == 0.0) continue;
       const double* ls = &P[(size_t)n * s];
-      for (int i : rowsv) if (s < reachv[i]) x[i] = x[i] - ls[i] * us;
+      for (int i : rowsv) if (s < reachv[i]) x[i] = lu_upd(x[i], ls[i], us);
     }
     return true;
   };
@@ -330,7 +330,7 @@ inline int lu_solve_compact_keep(CompactLuKeep& K, int n, const int* kind, const
         for (int i : freerows) { double l = pj[i]; l = big ? l * rcp : l / piv; if (!fin(l)) return CL_FALLBACK; pj[i] = l; }
         for (int c2 = jj + 1; c2 < npc; c2++) {
           double* pc = &P[(size_t)n * c2]; const double uu = pc[r];
-          if (uu != 0.0) for (int i : freerows) pc[i] = pc[i] - pj[i] * uu;
+          if (uu != 0.0) for (int i : freerows) pc[i] = lu_upd(pc[i], pj[i], uu);
         } }
       nbk++;
     }
@@ -350,7 +350,7 @@ inline int lu_solve_compact_keep(CompactLuKeep& K, int n, const int* kind, const
     const double* col = &D[(size_t)n * dpos[s]];
     const double xs = b[drow[s]] / col[drow[s]];
     b[drow[s]] = xs;
-    for (int i = 0; i < n; i++) if (pivstep[i] < dpos[s]) b[i] = b[i] - xs * col[i];
+    for (int i = 0; i < n; i++) if (pivstep[i] < dpos[s]) b[i] = lu_upd(b[i], xs, col[i]);
   }
   std::vector<double> x(n);
   for (int j = 0; j < n; j++) {

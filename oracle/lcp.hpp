@@ -130,6 +130,7 @@ class LCP {
     const unsigned N = n;
     const unsigned UINF = std::numeric_limits<unsigned>::max();
     auto Mat = [&](unsigned r, unsigned c) { return (r == c) ? M[r + ld*c] + diag_add : M[r + ld*c]; };
+    g_lu_fma_now = (g_lu_fma && n > 64) ? 1 : 0;                   // (EXPERIMENT switch of linalg.hpp; 0 unless oracle_dbg_lu_fma was called)
     if (N == 0) { z.set_zero(0); return true; }
     if (zero_tol < 0.0) {
       double nrm = 0.0; // norm_inf of the (regularised) matrix
@@ -283,6 +284,7 @@ class LCP {
     const unsigned n = nn;
     const unsigned MAXITER = std::min((unsigned)1000, 50*n);
     auto Mat = [&](unsigned r, unsigned c) { return (r == c) ? M[r + ld*c] + diag_add : M[r + ld*c]; };
+    g_lu_fma_now = (g_lu_fma && nn > 64) ? 1 : 0;                  // (EXPERIMENT switch of linalg.hpp)
     pivots = 0;
     if (n == 0) { z.resize(0); return true; }
     z.set_zero();                 // :564 keeps z.size()

@@ -29,7 +29,12 @@ namespace oracle {
 // its LU factors, b by the solution.  Returns LAPACK `info`: 0 = ok,
 // j>0 = U(j,j) is exactly zero (Ravelin throws SingularException; the
 // solution is then NOT computed, b is left untouched).
-static unsigned long long g_lu_nan_pivots = 0;   // diagnostic: columns whose diagonal entry was NaN at its pivot search
+static unsigned long long g_lu_nan_pivots = 0;
+// EXPERIMENT (oracle_dbg_lu_fma; DESIGN 8, "the oracle's dgesv above n = 64"): every multiply-subtract of dgesv -- dgetf2's rank-1 updates, both triangular
+// solves -- as ONE fused operation while an LCP of more than 64 rows is being solved (g_lu_fma_now, set by lcp.hpp).  Off by default: the oracle's definition,
+// and the device's, is the unfused one at every size.  No .dat pin can see the switch (every recorded scene has n <= 48).
+static int g_lu_fma = 0, g_lu_fma_now = 0;
+inline double lu_upd(double a, double l, double u) { return g_lu_fma_now ? std::fma(-l, u, a) : a - l * u; }   // diagnostic: columns whose diagonal entry was NaN at its pivot search
 inline int lu_solve(int n, double* A, int ld, double* b, int* ipiv_out = nullptr)
 {
   std::vector<int> ipiv_local;
@@ -64,7 +69,7 @@ inline int lu_solve(int n, double* A, int ld, double* b, int* ipiv_out = nullptr
     for (int c = j+1; c < n; c++) {
       const double u = A[j + ld*c];
       for (int i = j+1; i < n; i++)
-        A[i + ld*c] = A[i + ld*c] - A[i + ld*j] * u;
+        A[i + ld*c] = lu_upd(A[i + ld*c], A[i + ld*j], u);
     }
   }
   if (info != 0) return info;
@@ -74,13 +79,13 @@ inline int lu_solve(int n, double* A, int ld, double* b, int* ipiv_out = nullptr
   // L y = b (unit lower), column oriented
   for (int k = 0; k < n; k++) {
     const double bk = b[k];
-    for (int i = k+1; i < n; i++) b[i] = b[i] - bk * A[i + ld*k];
+    for (int i = k+1; i < n; i++) b[i] = lu_upd(b[i], bk, A[i + ld*k]);
   }
   // U x = y
   for (int k = n-1; k >= 0; k--) {
     b[k] = b[k] / A[k + ld*k];
     const double bk = b[k];
-    for (int i = 0; i < k; i++) b[i] = b[i] - bk * A[i + ld*k];
+    for (int i = 0; i < k; i++) b[i] = lu_upd(b[i], bk, A[i + ld*k]);
   }
   return 0;
 }

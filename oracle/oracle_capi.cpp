@@ -125,6 +125,7 @@ void oracle_dbg_fast_repeats(int on, unsigned long long* out) { if (out) for (in
 void oracle_dbg_lcp_dump(const char* path) { if (g_lcp_dump) { std::fclose(g_lcp_dump); g_lcp_dump = nullptr; } if (path) g_lcp_dump = std::fopen(path, "wb"); }
 // the model of the device's structure-exploiting LU (compact_lu.hpp): nb = panel width of the check (0 = off)
 void oracle_dbg_lemke_compact(int nb) { g_lemke_compact = nb; }
+void oracle_dbg_lu_fma(int on) { g_lu_fma = on; }     // EXPERIMENT: fused multiply-subtracts in dgesv for LCPs of more than 64 rows (linalg.hpp)
 void oracle_dbg_compact_check(int nb) { g_compact_check = nb; for (auto& v : g_compact_stats) v = 0; }
 void oracle_dbg_compact_stats(unsigned long long* out) { for (int i = 0; i < 8; i++) out[i] = g_compact_stats[i]; }
 // kind / idx: n entries (CL_UNIT: -e_idx, CL_DENSE: column idx of dense (n x *, ld)); b in/out; returns info or CL_FALLBACK
