@@ -249,7 +249,7 @@ extern "C" int mh_io_load_sdf(const char* path, const double gravity[3], mh_io_a
 
 // ---- URDF (src/URDFReader.cpp) ----------------------------------------------------------------------------
 namespace {
-struct UrdfLink { std::string name; bool has_inertial = false; Pose inertial; double mass = 0.0; double I[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+struct UrdfLink { std::string name; bool has_inertial = false; bool bad_inertia = false; Pose inertial; double mass = 0.0; double I[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
                   int cg = 0; Pose cg_pose; double cg_radius = 0.0; std::string cg_kind; };      // cg: 0 none, 1 sphere, 2 box / cylinder
 struct UrdfJoint { std::string name, parent, child; int type = 0; Pose origin; double axis[3] = {1.0, 0.0, 0.0}; double lo = 0.0, hi = 0.0; };
 constexpr int URDF_FIXED = 2;
@@ -290,6 +290,11 @@ int parse_urdf(const char* path, UrdfRobot& rob)
         if (xmlNode* im = child_named(in, "inertia")) { const Attrs ia = attrs_of(im);
           auto g = [&](const char* k) { return ia.has(k) ? std::atof(ia.str(k).c_str()) : 0.0; };
           I[0] = g("ixx"); I[4] = g("iyy"); I[8] = g("izz"); I[1] = I[3] = g("ixy"); I[2] = I[6] = g("ixz"); I[5] = I[7] = g("iyz"); }
+        // read_inertial (:613-616) disables a link whose tensor is not SPD just as it disables one without mass; this build has no disabled links
+        // (a massless link is refused below), so the same refusal: Sylvester's criterion on the tensor as given
+        { const double d1 = I[0], d2 = I[0] * I[4] - I[1] * I[3],
+                       d3 = I[0] * (I[4] * I[8] - I[5] * I[7]) - I[1] * (I[3] * I[8] - I[5] * I[6]) + I[2] * (I[3] * I[7] - I[4] * I[6]);
+          if (child_named(in, "inertia") && !(d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) L.bad_inertia = true; }
         double Tm[9]; mat3mul(L.inertial.R, I, Tm);                               // the tensor is given in the inertial frame: into the link's axes
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) L.I[3*i+j] = Tm[3*i] * L.inertial.R[3*j] + Tm[3*i+1] * L.inertial.R[3*j+1] + Tm[3*i+2] * L.inertial.R[3*j+2];
       }
@@ -320,10 +325,15 @@ int parse_urdf(const char* path, UrdfRobot& rob)
       if (!urdf_origin(c, J.origin)) return fail("joint %s: bad <origin>", J.name.c_str());
       if (xmlNode* ax = child_named(c, "axis")) { const Attrs xa = attrs_of(ax);  // read_axis (:456-496): default (1, 0, 0), in the joint's frame
         if (xa.has("xyz")) { const std::vector<double> v = numbers(xa.str("xyz")); if (v.size() != 3) return fail("joint %s: bad <axis>", J.name.c_str()); for (int i = 0; i < 3; i++) J.axis[i] = v[i]; } }
-      if (J.type != URDF_FIXED) if (xmlNode* lim = child_named(c, "limit")) { const Attrs la = attrs_of(lim);   // read_limits (:532-566)
-        if (la.has("effort") || la.has("lower") || la.has("upper")) {
+      if (J.type != URDF_FIXED)                                                 // read_limits (:532-566): the FIRST <limit> child that carries effort, lower or upper
+        for (xmlNode* lim = c->children; lim; lim = lim->next) {                // (one with a velocity only is passed over and the search goes on)
+          if (lim->type != XML_ELEMENT_NODE || strcasecmp((const char*)lim->name, "limit") != 0) continue;
+          const Attrs la = attrs_of(lim);
+          if (!(la.has("effort") || la.has("lower") || la.has("upper"))) continue;
           if (la.has("lower")) J.lo = std::atof(la.str("lower").c_str());
-          if (la.has("upper")) J.hi = std::atof(la.str("upper").c_str()); } }
+          if (la.has("upper")) J.hi = std::atof(la.str("upper").c_str());
+          break;                                                                  // "multiple tags unsupported" (:561-562)
+        }
       // <dynamics damping friction> become Joint::mu_fv / mu_fc (:499-529), which only MCArticulatedBody reads (MCArticulatedBody.cpp:419-420,
       // 564-565): a reduced-coordinate body steps without them in the reference, and so here
       joints.push_back(J);
@@ -339,6 +349,7 @@ int parse_urdf(const char* path, UrdfRobot& rob)
   }
   int nbase = 0; for (const UrdfLink& L : links) if (!inner.count(L.name)) { rob.base = L.name; nbase++; }
   if (nbase != 1) return fail("%s: %d links are carried by no joint (exactly one base link expected)", path, nbase);
+  for (const UrdfLink& L : links) if (L.bad_inertia && L.name != rob.base) return fail("link %s: the inertia tensor is not positive definite (the reference disables such a link, URDFReader.cpp:613-616)", L.name.c_str());
   // parents first, file order within a level.  carrier[l]: the model link whose frame link l is rigidly attached to (-1 = base) + its pose there
   struct Placed { int carrier; Pose pose; };
   std::map<std::string, Placed> placed; placed[rob.base] = Placed{ -1, identity_pose() };

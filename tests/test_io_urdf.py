@@ -100,6 +100,26 @@ def test_unsupported_urdf_files_are_rejected(tmp_path):
         A.load_xml(str(x))
 
 
+def test_limit_search_and_tensor_check_follow_the_reference(tmp_path):
+    """URDFReader::read_limits (URDFReader.cpp:532-566) takes the FIRST <limit> child that carries effort, lower or upper -- one with a velocity only is passed
+    over -- and read_inertial (:613-616) disables a link whose tensor is not positive definite just as it disables one without mass (refused here: a disabled
+    link inside the tree has no dynamics)."""
+    txt = open(URDF).read()
+    assert '<limit lower="-2.5" upper="2.5"' in txt or "<limit" in txt
+    import re
+    m0, _, _ = A.load_urdf(URDF, gravity=(0.0, -9.81, 0.0))
+    first = re.search(r"<limit[^>]*/>", txt).group(0)
+    two = txt.replace(first, '<limit velocity="3.0"/>\n    ' + first, 1)           # a velocity-only tag in front of the real one
+    p = tmp_path / "two_limits.urdf"; p.write_text(two)
+    m1, _, _ = A.load_urdf(str(p), gravity=(0.0, -9.81, 0.0))
+    assert list(m1.lolimit[:3]) == list(m0.lolimit[:3]) and list(m1.hilimit[:3]) == list(m0.hilimit[:3])
+    bad = re.sub(r'ixx="[^"]*"', 'ixx="-1.0"', txt, count=1)
+    q = tmp_path / "bad_tensor.urdf"; q.write_text(bad)
+    with pytest.raises(Exception) as e:
+        A.load_urdf(str(q), gravity=(0.0, -9.81, 0.0))
+    assert "positive definite" in str(e.value)
+
+
 def test_revolute_joints_without_limits_get_a_quarter_turn(tmp_path):
     p = tmp_path / "x.urdf"; p.write_text(open(URDF).read().replace('<limit lower="-2" upper="2" effort="0" />', '<limit velocity="1" />'))
     m = A.load_urdf(str(p))[0]
