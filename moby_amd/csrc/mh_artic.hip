@@ -80,8 +80,11 @@ struct Lay {
     q = o; o += n; qd = o; o += n; qdd = o; o += n; C = o; o += n;
     H = o; o += n * n; L = o; o += n * n; X = o; o += n * n;
     const int u = o;
-    R = o; o += 9 * n; x = o; o += 3 * n; Rl = o; o += 9 * n; tl = o; o += 3 * n;
+    R = o; o += 9 * n; x = o; o += 3 * n;
     S = o; o += 6 * n; I6 = o; o += 36 * n; v = o; o += 6 * n; a = o; o += 6 * n; f = o; o += 6 * n; F = o; o += 6 * n; Iv = o; o += 12;
+    // the local transforms live only from kin_inertia's first loop to the end of its chain walk, before anything writes v or a (RNEA / the articulated-body
+    // recursion come after): they share those 12 n doubles (round 5: 1252 -> 1132 doubles at 10 joints = 18 images per CU instead of 16)
+    Rl = v; tl = v + 9 * n;
     const int end_dyn = o;
     o = u;
     MM = o; o += nlcap * nlcap; A = o; o += nlcap * nlcap; art = o; o += nlcap; Lv = o; o += nlcap; l = o; o += nlcap;
@@ -92,7 +95,7 @@ struct Lay {
 constexpr int NLSTAB = 2 * NJ;      // the stabiliser's LCP has a row for every finite limit (CStab:257-304): up to two per joint
 static size_t lds_bytes(int nj, int nlcap = NLMAX) {
   const int n = nj;
-  const int dyn = 90 * n + 12, lim = 2 * nlcap * nlcap + 4 * nlcap;
+  const int dyn = 78 * n + 12, lim = 2 * nlcap * nlcap + 4 * nlcap;
   return sizeof(double) * (size_t)(4 * n + 3 * n * n + (dyn > lim ? dyn : lim));
 }
 
@@ -661,12 +664,17 @@ MH_DEV void artic_step_body(const Model* __restrict__ Mg, int B, double dt, int 
 // The same step at three register budgets: 128 VGPRs (4 waves per SIMD = the 16 worlds per CU the 10 KB LDS image allows; 95 spilled
 // VGPRs), 168 (3 per SIMD, 14 spilled) and 193 (2 per SIMD, none).  The kernel waits on ~250 LDS round trips per step, so
 // resident waves win over spills: ur10 x 8192, 200 steps: 25.6 / 31.2 / 39.0 ms (profiles/r02_c_artic_occupancy.jsonl).
-// Default 4; MH_ARTIC_WAVES=2|3 selects the others (experiments).
+// Default 4; MH_ARTIC_WAVES=2|3|5 selects the others (experiments).  Round 5: with the local transforms sharing v / a the image is 9 KB = 18 worlds per CU, and the
+// five-waves build (96 VGPRs, 132 spilled) was measured on them: 29.2 ms against 25.5 -- at this point the SPILLS cost more than the fifth wave hides, so a smaller
+// image alone buys nothing: the routine needs fewer live registers first (profiles/r05_d_artic_occupancy.txt).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_artic_step_w3(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
                      mh_world_aux* __restrict__ auxg) { artic_step_body<false>(Mg, B, dt, nsteps, qg, qdg, auxg); }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_artic_step_w4(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
+                     mh_world_aux* __restrict__ auxg) { artic_step_body<false>(Mg, B, dt, nsteps, qg, qdg, auxg); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5)))
+void k_artic_step_w5(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
                      mh_world_aux* __restrict__ auxg) { artic_step_body<false>(Mg, B, dt, nsteps, qg, qdg, auxg); }
 __global__ __launch_bounds__(64)
 void k_artic_step_w2(const Model* __restrict__ Mg, int B, double dt, int nsteps, double* __restrict__ qg, double* __restrict__ qdg,
@@ -931,8 +939,8 @@ int mh_artic_batch_step(mh_artic_batch* ab, void* stream, double dt, int nsteps)
     MH_HIP(hipGetLastError());
     return MH_OK;
   }
-  static const int waves = [] { const char* e = std::getenv("MH_ARTIC_WAVES"); const int w = e ? std::atoi(e) : 4; return (w == 2 || w == 3) ? w : 4; }();
-  hipLaunchKernelGGL(waves == 4 ? ar::k_artic_step_w4 : (waves == 2 ? ar::k_artic_step_w2 : ar::k_artic_step_w3), dim3(ab->B), dim3(64), ar::lds_bytes(ab->nj), (hipStream_t)stream,
+  static const int waves = [] { const char* e = std::getenv("MH_ARTIC_WAVES"); const int w = e ? std::atoi(e) : 4; return (w == 2 || w == 3 || w == 5) ? w : 4; }();
+  hipLaunchKernelGGL(waves == 5 ? ar::k_artic_step_w5 : waves == 4 ? ar::k_artic_step_w4 : (waves == 2 ? ar::k_artic_step_w2 : ar::k_artic_step_w3), dim3(ab->B), dim3(64), ar::lds_bytes(ab->nj), (hipStream_t)stream,
                      (const ar::Model*)ab->d_model, ab->B, dt, nsteps, ab->d_q, ab->d_qd, ab->d_aux);
   MH_HIP(hipGetLastError());
   return MH_OK;
