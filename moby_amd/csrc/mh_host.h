@@ -70,6 +70,9 @@ namespace mh { struct LcpParams; struct Pow10Table; }
 #define MH_LCP_BLOCK_LAUNCH_ARGS void* stream, int kind, int B, int n, const double* M, int ld, long strideM, const double* q, double* z, \
   const int* zsz_in, int* zsz_out, uint32_t* rng, int* status, unsigned* pivots, int32_t* trace, int trace_cap, int* trace_len, \
   const mh::LcpParams* P, const mh::Pow10Table* p10, double* wsd, int* wsi, const int* run_if, const int* n_arr, int flags, double* work, int task_worlds, int* solved_at
+// LU workspaces of a TASK launch (flags & 8 or & 64: persistent workgroups, one workspace each): an upper bound on the workgroups any geometry keeps resident --
+// up to eight one-wave problems per CU for n <= 512 (mh_lcp_blk1.hip), two above (mh_lcp_blk.hip / blky; blkw / blkx hold one)
+static inline long mh_task_slots(int n) { return (long)((n <= 512) ? 8 : 2) * mh_cu_count(); }
 MH_HIDDEN hipError_t mh_launch_lcp_blk(MH_LCP_BLOCK_LAUNCH_ARGS);
 MH_HIDDEN hipError_t mh_launch_lcp_blkw(MH_LCP_BLOCK_LAUNCH_ARGS);
 MH_HIDDEN hipError_t mh_launch_lcp_blkx(MH_LCP_BLOCK_LAUNCH_ARGS);   // the lcp_lemke kinds with 1024 < n <= 2048: 1024 threads, two rows per lane (mh_lcp_blkx.hip)

@@ -56,7 +56,7 @@ struct mh_imp_core {
   // task mode of the Lemke ladder (one workgroup per (world, attempt), mh_lcp_block.h): per-task workspace, z, status, pivots, sizes,
   // rand() scratch, model work; solved_at per world.  Allocated on first use for t_cap tasks.
   void* s2; void* ev0; void* ev1;                   // second stream + events: the ladder's tasks beside lcp_fast (speculation, core_solve_round)
-  double* t_wsd; int* t_wsi; double* t_z; int* t_st; unsigned* t_piv; int* t_zsz; uint32_t* t_rng; double* t_work; int* solved_at; long t_cap;
+  double* t_wsd; int* t_wsi; double* t_z; int* t_st; unsigned* t_piv; int* t_zsz; uint32_t* t_rng; double* t_work; int* solved_at; long t_cap; long t_slots;     // t_cap tasks (z, status, pivots, sizes, rand() scratch, work), t_slots LU workspaces (mh_task_slots: the persistent workgroups)
   double* work;                                     // B x MH_WORK (mh_host.h): SURVEY 8(d)'s model work of the block solver's factorisations (2/3 k^3 flops, 8 k^2 bytes), accumulated
   int* hmax;                                        // pinned host copy of maxisl
   void* allocs[64]; int nallocs;

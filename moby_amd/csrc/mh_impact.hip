@@ -1331,7 +1331,9 @@ static int core_ladder_alloc(mh_imp_core* c, long ntasks)
   for (void* q : ps) if (q) (void)hipFree(q);
   c->t_cap = 0;
   const size_t n = (size_t)c->nmax, nt = (size_t)ntasks;
-  bool ok = hipMalloc((void**)&c->t_wsd, nt * (n * n + 5 * n) * 8) == hipSuccess && hipMalloc((void**)&c->t_wsi, nt * 4 * n * 4) == hipSuccess
+  const size_t nsl = (size_t)((ntasks < mh_task_slots(c->nmax)) ? ntasks : mh_task_slots(c->nmax));     // one LU workspace per PERSISTENT workgroup, not per task
+  c->t_slots = (long)nsl;
+  bool ok = hipMalloc((void**)&c->t_wsd, nsl * (n * n + 5 * n) * 8) == hipSuccess && hipMalloc((void**)&c->t_wsi, nsl * 4 * n * 4) == hipSuccess
          && hipMalloc((void**)&c->t_z, nt * n * 8) == hipSuccess && hipMalloc((void**)&c->t_st, nt * 4) == hipSuccess
          && hipMalloc((void**)&c->t_piv, nt * 4) == hipSuccess && hipMalloc((void**)&c->t_zsz, nt * 4) == hipSuccess
          && hipMalloc((void**)&c->t_rng, nt * MH_RAND_WORDS * 4) == hipSuccess && hipMalloc((void**)&c->t_work, nt * MH_WORK * 8) == hipSuccess;
@@ -1360,9 +1362,11 @@ static LadderPlan core_ladder_plan(mh_imp_core* c, const mh_lcp_opts* o)
   const int min_exp = o ? o->min_exp : -20, max_exp = o ? o->max_exp : 1; const unsigned step = o ? o->step_exp : 1u;
   L.R = 1; if (step > 0) for (int rf = min_exp; rf < max_exp; rf += (int)step) L.R++;
   L.ntasks = (long)c->B * L.R;
-  const double bytes = (double)L.ntasks * (((double)n * n + 5.0 * n) * 8.0 + 16.0 * n + 8.0 * n + 200.0);
-  // the tasks' workspaces (one per (world, attempt): n^2 + 5 n doubles each -- 48 GB for 16-box stacks x 1024 worlds) are kept until
-  // the batch is destroyed; they may take at most 70 % of what the device has free when they are first allocated, otherwise the ladder runs in sequence
+  const double nsl = (double)((L.ntasks < mh_task_slots(n)) ? L.ntasks : mh_task_slots(n));
+  const double bytes = nsl * (((double)n * n + 5.0 * n) * 8.0 + 16.0 * n) + (double)L.ntasks * (8.0 * n + 200.0);
+  // the tasks' LU workspaces (n^2 + 5 n doubles each) number the persistent workgroups of a task launch since round 5 (mh_task_slots: 2 GB at most for 16-box stacks,
+  // where round 4's one per (world, attempt) took 48 GB at 1024 worlds and made larger batches run their ladders in sequence); per task only z, sizes, rand() scratch and
+  // counters are kept.  Everything is kept until the batch is destroyed and may take at most 70 % of what the device has free when first allocated
   bool fits = c->t_cap >= L.ntasks;
   if (!fits) { size_t fr = 0, tot = 0; fits = hipMemGetInfo(&fr, &tot) == hipSuccess && bytes < 0.7 * (double)fr; (void)hipGetLastError(); }
   L.ok = mh_g_debug_tasks != 0 && n > MH_LCP_MAX_N_WAVE && step > 0 && fits && core_ladder_alloc(c, L.ntasks) == MH_OK;
@@ -1396,7 +1400,7 @@ static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& 
   // 512 < n <= 1024 with more tasks than the chip has CUs: two 256-thread problems per CU, four rows per lane (mh_lcp_blky.hip); mh_debug_set(2, 2) keeps the wide one
   const bool narrow4 = n > 512 && n <= 1024 && (mh_g_debug_blk == 5 || (mh_g_debug_blk == 0 && L.ntasks >= (long)MH_BLKY_MIN_TASKS_PER_CU * mh_cu_count()));
   const hipError_t le = (narrow4 ? mh_launch_lcp_blky : wide2 ? mh_launch_lcp_blkx : two_waves ? mh_launch_lcp_blk2 : one_wave ? mh_launch_lcp_blk1 : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk))(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
-      c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2) | (sched ? 8 : 0) | ((sched && by_verdict) ? 32 : 0), c->t_work, B, c->solved_at);
+      c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2) | (sched ? 8 : 64) | ((sched && by_verdict) ? 32 : 0), c->t_work, B, c->solved_at);
   MH_HIP(le);
   return MH_OK;
 }
@@ -1492,16 +1496,14 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   }
   // (lcp_fast then runs in the narrow geometry: a 1024-thread workgroup needs a whole CU and would wait for the tasks' workgroups to leave
   //  it -- 16 boxes x 256 worlds: 4.05 -> 3.55 s per cold call)
-  int* const gate = (spec && overlap) ? c->solved_at + 3 * (size_t)B : nullptr;
+  // The gate in BOTH speculative forms since round 5: a task launch's workgroups are persistent now (one LU workspace each, mh_lcp_block.h), so launched ahead of
+  // lcp_fast's kernel they would hold every CU until the last task is done and lcp_fast would run AFTER the ladder instead of beside it.  lcp_fast's kernel goes first,
+  // the gate opens when its last workgroup has started, and the ladder's workgroups take what is left of the chip -- and the rest as lcp_fast's worlds finish.
+  int* const gate = spec ? c->solved_at + 3 * (size_t)B : nullptr;
   if (spec) {
-    if (gate) MH_HIP(hipMemsetAsync(gate, 0, ((size_t)B + 2) * 4, s));         // workgroups started, verdicts published, then one verdict per world (0: lcp_fast has not spoken)
+    MH_HIP(hipMemsetAsync(gate, 0, ((size_t)B + 2) * 4, s));         // workgroups started, verdicts published, then one verdict per world (0: lcp_fast has not spoken)
     MH_HIP(hipEventRecord((hipEvent_t)c->ev0, s));
     MH_HIP(hipStreamWaitEvent((hipStream_t)c->s2, (hipEvent_t)c->ev0, 0));
-    if (!overlap) {
-      rc = core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, false);
-      if (rc != MH_OK) return rc;
-      MH_HIP(hipEventRecord((hipEvent_t)c->ev1, (hipStream_t)c->s2));
-    }
   }
   const int fast_geom = (spec && !overlap) ? 2 : 0;
   if (mode == MH_CORE_IMPACT) {
@@ -1512,14 +1514,14 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, c->lst1, c->piv1,
                                  nullptr, 0, nullptr, nullptr, run_if, c->ws_d, c->ws_i, c->ncur, c->work, fast_geom, gate);   // CStab:954
   }
-  if (rc == MH_OK && spec && overlap) {                          // the ladder's tasks, by need, behind lcp_fast's launch and the gate
+  if (rc == MH_OK && spec) {                                     // the ladder's tasks behind lcp_fast's launch and the gate: by need and verdict on a full chip, every masked world's otherwise
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, (hipStream_t)c->s2, gate, B);
     { const hipError_t ge = hipGetLastError(); if (ge != hipSuccess) { (void)hipStreamSynchronize((hipStream_t)c->s2); return fail(MH_ERR_HIP, "k_gate failed: %s", hipGetErrorString(ge)); } }
-    rc = core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, true, true);
+    rc = overlap ? core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, true, true) : core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, false);
     if (rc == MH_OK) { const hipError_t e = hipEventRecord((hipEvent_t)c->ev1, (hipStream_t)c->s2); if (e != hipSuccess) rc = fail(MH_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e)); }
     if (rc != MH_OK) { (void)hipStreamSynchronize((hipStream_t)c->s2); return rc; }
   } else
-  if (rc != MH_OK) { if (spec && !overlap) (void)hipStreamWaitEvent(s, (hipEvent_t)c->ev1, 0); return rc; }     // (the tasks' stream joins this one on every way out)
+  if (rc != MH_OK) { if (spec) (void)hipStreamSynchronize((hipStream_t)c->s2); return rc; }     // (the tasks' stream joins this one on every way out)
   hipLaunchKernelGGL(im::k_lemke_prep, dim3(B), dim3(im::T), 0, s, *c, run_if, mode);
   { const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { if (spec) (void)hipStreamWaitEvent(s, (hipEvent_t)c->ev1, 0); return fail(MH_ERR_HIP, "k_lemke_prep failed: %s", hipGetErrorString(e)); } }

@@ -970,9 +970,15 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   if (FAM == 0 && task_worlds == 0 && solved_at != nullptr && t == 0) atomicAdd(solved_at, 1);
   const int n_launch = n, ld_launch = ld;
   const bool queue = (FAM == 1) && task_worlds > 0 && (flags & 8) != 0;     // (the lcp_fast kinds have no tasks: their kernel keeps the single pass)
+  // flags & 64: tasks in BLOCK-INDEX order (attempt-major) from a counter -- the order the hardware would dispatch one-task workgroups in -- by as many workgroups as
+  // the chip holds at once.  Either way a workgroup of a task launch is PERSISTENT and owns ONE LU workspace (by blockIdx.x) for all the tasks it runs: the workspaces
+  // number the resident workgroups, not the tasks (round 4 allocated one per (world, attempt): 48 GB for 16-box stacks x 1024 worlds, and batches whose tasks did not
+  // fit the device ran their ladders in sequence).  The counter is the first word of the hand-out's `next` array, which this order does not use.
+  const bool cqueue = (FAM == 1) && task_worlds > 0 && !queue && (flags & 64) != 0;
   for (int round = 0; FAM == 1 || round < 1; round++) {
   int b;
   if (queue) { b = pick_task(task_worlds, B / task_worlds, solved_at, run_if, n_arr, (flags & 32) ? solved_at + 3 * (size_t)task_worlds + 2 : nullptr); if (b < 0) return; }
+  else if (cqueue) { b = bcast_i((t == 0) ? atomicAdd(solved_at + task_worlds, 1) : 0); if (b >= B) return; }
   else { if (round > 0) return; b = blockIdx.x; if (b >= B) return; }
   n = n_launch; ld = ld_launch;
   const int bw = (task_worlds > 0) ? b % task_worlds : b;
@@ -981,8 +987,9 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   // (block-uniform: thread 0 reads solved_at once and broadcasts -- another workgroup's atomicMin may land between the loads of two waves)
   if (task_worlds > 0 && bcast_i(task.pointless() ? 1 : 0)) { if (t == 0) status[b] = -1; if (queue && t == 0) atomicAdd(solved_at + 2 * task_worlds + bw, 1); continue; }     // -1: not run
   Ws W;
-  double* wd = wsd + (size_t)b * ws_doubles(n);
-  int* wi = wsi + (size_t)b * ws_ints(n);
+  const size_t wslot = (queue || cqueue) ? (size_t)blockIdx.x : (size_t)b;      // (persistent workgroups: one workspace each)
+  double* wd = wsd + wslot * ws_doubles(n);
+  int* wi = wsi + wslot * ws_ints(n);
   // per-problem sizes: strides of q / z / M / the workspace stay those of the largest problem (the launch's n), M is
   // compact (ld = its own n); problems of at most 64 rows belong to the wave solver of the same call
   const int nstride = n;
@@ -1057,10 +1064,11 @@ extern "C" MH_HIDDEN hipError_t MH_BLK_LAUNCHER(void* stream, int kind, int B, i
 #endif
   {
     int grid = B;
-    if (task_worlds > 0 && (flags & 8)) {                               // as many workgroups as the chip holds at once; each takes tasks until none is left
+    if (task_worlds > 0 && (flags & (8 | 64))) {                        // as many workgroups as the chip holds at once; each takes tasks until none is left
       static int per_cu = 0;
       if (per_cu == 0) { int v = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, ns::k_lcp_block<1>, ns::T, 0) != hipSuccess || v < 1) v = 1; per_cu = v; }
-      const int cap = per_cu * mh_cu_count(); grid = (B < cap) ? B : cap;
+      long cap = (long)per_cu * mh_cu_count(); if (cap > mh_task_slots(n)) cap = mh_task_slots(n);        // (the caller sized the workspaces by mh_task_slots)
+      grid = (B < cap) ? B : (int)cap;
     }
     hipLaunchKernelGGL(ns::k_lcp_block<1>, dim3(grid), dim3(ns::T), 0, (hipStream_t)stream, B, n, M, ld, strideM, q, z, zsz_in, zsz_out, rng, status, pivots,
                        trace, trace_cap, trace_len, *P, *p10, wsd, wsi, run_if, n_arr, flags, work, task_worlds, solved_at);
