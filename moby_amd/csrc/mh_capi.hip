@@ -176,6 +176,7 @@ int mh_rand_next(uint32_t* st)
 
 int mh_g_debug_tasks = 3;      // mh_debug_set(4, v): 0 = the Lemke ladder in sequence, 1 = as (world, attempt) tasks, 2 = tasks + speculation beside lcp_fast, 3 = 2 + at full chip (n <= 512) the tasks launched behind lcp_fast and a gate on a second stream, 4 = 3 at any n
 int mh_g_debug_repeats = 1;  // mh_debug_set(5, v): 1 = lcp_fast (n > 64) skips the repetitions of a repeating pivot sequence (mh_lcp_block.h), 0 = runs them
+int mh_g_debug_lpt = 0;      // mh_debug_set(11, v): (measured, no gain: profiles/r05_g_config4_launch_order_lpt.txt; off) 1 = on a full chip lcp_fast's workgroups and the ladder's hand-out take the worlds in the order of the solver time they have used so far (longest first), 0 = by index
 int mh_g_debug_sched = 1;    // mh_debug_set(7, v): 1 = the ladder's tasks are handed out by need (pick_task), 0 = by block index, attempt-major
 int mh_g_debug_reuse = 1;    // mh_debug_set(6, v): 1 = the structure-exploiting LU keeps the factors of the columns before the one a Lemke pivot changed, 0 = factorises from scratch
 int mh_g_debug_compact = 1;  // mh_debug_set(3, v): 1 = Lemke's bases through the structure-exploiting LU (mh_lu_compact.inc), 0 = dense LU only
@@ -224,7 +225,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
                            const int* z_size_in, int* z_size_out,
                            uint32_t* rng, int* status, unsigned* pivots,
                            int32_t* trace, int trace_cap, int* trace_len,
-                           const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i, const int* n_arr, double* work, int wave_only, int* started)
+                           const mh_lcp_opts* opts, const int* run_if, double* ws_d, int* ws_i, const int* n_arr, double* work, int wave_only, int* started, int ordered)
 {
   mh::LcpParams P;
   int rc = lcp_params(kind, opts, P);
@@ -273,7 +274,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
         MH_HIP(hipGetLastError());
       }
       const hipError_t le = (wave_only == 1) ? hipSuccess : launcher(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2) | (mh_g_debug_reglu << 4) | ((started && !lemke_kind) ? 32 : 0), work, 0, lemke_kind ? nullptr : started);
+                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2) | (mh_g_debug_reglu << 4) | ((started && !lemke_kind) ? 32 : 0) | ((started && !lemke_kind && ordered) ? 128 : 0), work, 0, lemke_kind ? nullptr : started);
       MH_HIP(le);
       return MH_OK;
     }
@@ -283,7 +284,7 @@ int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
     hipError_t e = hipMallocAsync((void**)&wsi, ni * sizeof(int), (hipStream_t)stream);
     if (e != hipSuccess) { (void)hipFreeAsync(wsd, (hipStream_t)stream); return fail(MH_ERR_HIP, "workspace allocation failed: %s", hipGetErrorString(e)); }
     const hipError_t le = launcher(stream, kind, B, n, M, ld, strideM, q, z, z_size_in, z_size_out, rng, status, pivots,
-                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2) | (mh_g_debug_reglu << 4) | ((started && !lemke_kind) ? 32 : 0), work, 0, lemke_kind ? nullptr : started);
+                                   trace, trace_cap, trace_len, &P, &p10, wsd, wsi, run_if, n_arr, mh_g_debug_compact | (mh_g_debug_repeats << 1) | (mh_g_debug_reuse << 2) | (mh_g_debug_reglu << 4) | ((started && !lemke_kind) ? 32 : 0) | ((started && !lemke_kind && ordered) ? 128 : 0), work, 0, lemke_kind ? nullptr : started);
     e = le;
     (void)hipFreeAsync(wsd, (hipStream_t)stream); (void)hipFreeAsync(wsi, (hipStream_t)stream);
     if (e != hipSuccess) return fail(MH_ERR_HIP, "block LCP launch failed: %s", hipGetErrorString(e));
@@ -356,6 +357,7 @@ extern "C" int mh_debug_set(int key, int value)
   if (key == 8) { if (value < 0 || value > 4) return fail(MH_ERR_INVALID_ARG, "lcp_fast geometry outside {0 .. 4}"); mh_g_debug_fastgeom = value; return MH_OK; }
   if (key == 2) { if (value < 0 || value > 5) return fail(MH_ERR_INVALID_ARG, "block solver geometry outside {0 .. 5}"); mh_g_debug_blk = value; return MH_OK; }
   if (key == 4) { if (value < 0 || value > 4) return fail(MH_ERR_INVALID_ARG, "ladder-task switch outside {0 .. 4}"); mh_g_debug_tasks = value; return MH_OK; }
+  if (key == 11) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "launch-order switch outside {0, 1}"); mh_g_debug_lpt = value; return MH_OK; }
   if (key == 7) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "task-scheduling switch outside {0, 1}"); mh_g_debug_sched = value; return MH_OK; }
   if (key == 6) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "factor-reuse switch outside {0, 1}"); mh_g_debug_reuse = value; return MH_OK; }
   if (key == 5) { if (value < 0 || value > 1) return fail(MH_ERR_INVALID_ARG, "repeat-skipping switch outside {0, 1}"); mh_g_debug_repeats = value; return MH_OK; }

@@ -50,11 +50,13 @@ MH_HIDDEN int mh_lcp_solve_dev_masked(void* stream, int kind, int B, int n,
                                       double* work = nullptr,    // B x MH_WORK doubles or NULL: += the 2/3 k^3 flops / 8 k^2 bytes of every factorisation (n > 64), issued flops, ticks
                                       int wave_only = 0,         // 1: only the problems of at most 64 rows (n_arr) -- the caller runs the others itself; 2: the block solver in its
                                                                  // narrow geometry (the caller has other workgroups on the chip for it to share the CUs with)
-                                      int* started = nullptr);   // the lcp_fast kinds, n > 64 (core_solve_round, mh_impact.hip): B + 2 ints, zeroed by the caller --
+                                      int* started = nullptr,    // the lcp_fast kinds, n > 64 (core_solve_round, mh_impact.hip): B + 2 ints, zeroed by the caller --
                                                                  // started[0] += 1 when a workgroup begins (the gate waits for B), started[2 + b] = 1 (failed) / 2 (solved)
                                                                  // when problem b is through, then started[1] += 1 (the ladder's tasks are handed out by these verdicts)
+                                      int ordered = 0);          // 1: started[B + 2 ..] holds a permutation of the problems: workgroup i takes problem started[B + 2 + i]
 extern MH_HIDDEN int mh_g_debug_repeats;             // mh_debug_set(5, v)
 extern MH_HIDDEN int mh_g_debug_sched;               // mh_debug_set(7, v)
+extern MH_HIDDEN int mh_g_debug_lpt;                 // mh_debug_set(11, v): longest-processing-time-first launch order on a full chip (core_solve_round)
 extern MH_HIDDEN int mh_g_debug_reuse;               // mh_debug_set(6, v)
 extern MH_HIDDEN int mh_g_debug_compact;             // mh_debug_set(3, v)
 extern MH_HIDDEN int mh_g_debug_tasks;               // mh_debug_set(4, v): the Lemke ladder of the island pipeline as (world, attempt) tasks (1, default) or in sequence (0)

@@ -1337,7 +1337,7 @@ static int core_ladder_alloc(mh_imp_core* c, long ntasks)
          && hipMalloc((void**)&c->t_z, nt * n * 8) == hipSuccess && hipMalloc((void**)&c->t_st, nt * 4) == hipSuccess
          && hipMalloc((void**)&c->t_piv, nt * 4) == hipSuccess && hipMalloc((void**)&c->t_zsz, nt * 4) == hipSuccess
          && hipMalloc((void**)&c->t_rng, nt * MH_RAND_WORDS * 4) == hipSuccess && hipMalloc((void**)&c->t_work, nt * MH_WORK * 8) == hipSuccess;
-  if (ok && !c->solved_at) ok = hipMalloc((void**)&c->solved_at, (4 * (size_t)c->B + 2) * 4) == hipSuccess;   // (+ the gate's counter and lcp_fast's verdicts, core_solve_round)   // + next attempt, attempts over (mh_lcp_block.h pick_task)
+  if (ok && !c->solved_at) ok = hipMalloc((void**)&c->solved_at, (5 * (size_t)c->B + 2) * 4) == hipSuccess;   // (+ the launch order of a full-chip round)   // (+ the gate's counter and lcp_fast's verdicts, core_solve_round)   // + next attempt, attempts over (mh_lcp_block.h pick_task)
   if (ok) ok = hipMemset(c->t_rng, 0, nt * MH_RAND_WORDS * 4) == hipSuccess;
   if (!ok) {                                                      // no room: the caller runs the ladder in sequence
     void* qs[] = { c->t_wsd, c->t_wsi, c->t_z, c->t_st, c->t_piv, c->t_zsz, c->t_rng, c->t_work };
@@ -1376,7 +1376,7 @@ static LadderPlan core_ladder_plan(mh_imp_core* c, const mh_lcp_opts* o)
 // left) instead of by block index.  Not beside lcp_fast: workgroups that stay would keep its kernel off the CUs they occupy.
 // by_verdict: beside lcp_fast's kernel, only the worlds it has failed on (mh_lcp_block.h pick_task); resume: the second launch of that scheme -- the
 // hand-out continues where the first left it (nothing is reset)
-static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& L, const int* mask, bool sched, bool by_verdict = false, bool resume = false)
+static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& L, const int* mask, bool sched, bool by_verdict = false, bool resume = false, bool ordered = false)
 {
   const int B = c->B, n = c->nmax;
   const mh_lcp_opts* o = L.has_o ? &L.o : nullptr;
@@ -1400,7 +1400,7 @@ static int core_ladder_launch(mh_imp_core* c, hipStream_t st, const LadderPlan& 
   // 512 < n <= 1024 with more tasks than the chip has CUs: two 256-thread problems per CU, four rows per lane (mh_lcp_blky.hip); mh_debug_set(2, 2) keeps the wide one
   const bool narrow4 = n > 512 && n <= 1024 && (mh_g_debug_blk == 5 || (mh_g_debug_blk == 0 && L.ntasks >= (long)MH_BLKY_MIN_TASKS_PER_CU * mh_cu_count()));
   const hipError_t le = (narrow4 ? mh_launch_lcp_blky : wide2 ? mh_launch_lcp_blkx : two_waves ? mh_launch_lcp_blk2 : one_wave ? mh_launch_lcp_blk1 : (wide ? mh_launch_lcp_blkw : mh_launch_lcp_blk))(st, MH_LCP_LEMKE_REG, (int)L.ntasks, n, c->MM, n, (long)n * n, c->qq, c->t_z, nullptr, c->t_zsz,
-      c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2) | (sched ? 8 : 64) | ((sched && by_verdict) ? 32 : 0), c->t_work, B, c->solved_at);
+      c->t_rng, c->t_st, c->t_piv, nullptr, 0, nullptr, &P, &p10, c->t_wsd, c->t_wsi, mask, c->ncur, mh_g_debug_compact | (mh_g_debug_reuse << 2) | (sched ? 8 : 64) | ((sched && by_verdict) ? 32 : 0) | ((sched && ordered) ? 128 : 0), c->t_work, B, c->solved_at);
   MH_HIP(le);
   return MH_OK;
 }
@@ -1446,6 +1446,19 @@ static int core_lemke_stage(mh_imp_core* c, hipStream_t s, const mh_lcp_opts* o,
 // STARTED (they count themselves in, mh_lcp_block.h).  Launched earlier, the tasks' workgroups -- which stay until no task is left -- hold CUs that
 // 1024-thread workgroups still waiting for their turn need whole; launched behind the gate they only take what finished worlds leave.
 // (Bounded: it gives up after 20 s of the constant-rate clock -- the tasks then merely start early.)
+// Longest processing time first: the worlds ranked by the solver time they have used since the batch was created (work[.][3], ticks: lcp_fast's kernel and the
+// ladder's tasks both add to it), the most expensive first; ties by index.  order[] is a permutation of 0 .. B-1.  On a full chip lcp_fast's kernel lasts as long as
+// its slowest world PLUS the time that world waited for a CU (a second, with four dispatch rounds of 256), and the ladder's hand-out breaks its ties this way.
+__global__ void k_rank(const double* __restrict__ work, int* __restrict__ order, int B)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double key = work[MH_WORK * (size_t)b + 3];
+  int rank = 0;
+  for (int j = 0; j < B; j++) { const double kj = work[MH_WORK * (size_t)j + 3]; rank += (kj > key || (kj == key && j < b)) ? 1 : 0; }
+  order[rank] = b;
+}
+
 __global__ void k_gate(const int* started, int target)
 {
   if (threadIdx.x != 0) return;
@@ -1500,8 +1513,10 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   // lcp_fast's kernel they would hold every CU until the last task is done and lcp_fast would run AFTER the ladder instead of beside it.  lcp_fast's kernel goes first,
   // the gate opens when its last workgroup has started, and the ladder's workgroups take what is left of the chip -- and the rest as lcp_fast's worlds finish.
   int* const gate = spec ? c->solved_at + 3 * (size_t)B : nullptr;
+  const bool ordered = spec && overlap && mh_g_debug_lpt != 0;
   if (spec) {
     MH_HIP(hipMemsetAsync(gate, 0, ((size_t)B + 2) * 4, s));         // workgroups started, verdicts published, then one verdict per world (0: lcp_fast has not spoken)
+    if (ordered) { hipLaunchKernelGGL(k_rank, dim3((B + 255) / 256), dim3(256), 0, s, c->work, gate + B + 2, B); MH_HIP(hipGetLastError()); }
     MH_HIP(hipEventRecord((hipEvent_t)c->ev0, s));
     MH_HIP(hipStreamWaitEvent((hipStream_t)c->s2, (hipEvent_t)c->ev0, 0));
   }
@@ -1509,15 +1524,15 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   if (mode == MH_CORE_IMPACT) {
     mh_lcp_opts o1; o1.min_exp = -20; o1.step_exp = 4u; o1.max_exp = -8; o1.piv_tol = -1.0; o1.zero_tol = -1.0;   // ICH-QP:219
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST_REG, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, nullptr, c->rng, c->lst1, c->piv1,
-                                 nullptr, 0, nullptr, &o1, run_if, c->ws_d, c->ws_i, c->ncur, c->work, fast_geom, gate);
+                                 nullptr, 0, nullptr, &o1, run_if, c->ws_d, c->ws_i, c->ncur, c->work, fast_geom, gate, ordered ? 1 : 0);
   } else {
     rc = mh_lcp_solve_dev_masked(s, MH_LCP_FAST, B, n, c->MM, n, (long)n * n, c->qq, c->z, c->zsz, c->zsz, c->rng, c->lst1, c->piv1,
-                                 nullptr, 0, nullptr, nullptr, run_if, c->ws_d, c->ws_i, c->ncur, c->work, fast_geom, gate);   // CStab:954
+                                 nullptr, 0, nullptr, nullptr, run_if, c->ws_d, c->ws_i, c->ncur, c->work, fast_geom, gate, ordered ? 1 : 0);   // CStab:954
   }
   if (rc == MH_OK && spec) {                                     // the ladder's tasks behind lcp_fast's launch and the gate: by need and verdict on a full chip, every masked world's otherwise
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, (hipStream_t)c->s2, gate, B);
     { const hipError_t ge = hipGetLastError(); if (ge != hipSuccess) { (void)hipStreamSynchronize((hipStream_t)c->s2); return fail(MH_ERR_HIP, "k_gate failed: %s", hipGetErrorString(ge)); } }
-    rc = overlap ? core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, true, true) : core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, false);
+    rc = overlap ? core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, true, true, false, ordered) : core_ladder_launch(c, (hipStream_t)c->s2, L, run_if, false);
     if (rc == MH_OK) { const hipError_t e = hipEventRecord((hipEvent_t)c->ev1, (hipStream_t)c->s2); if (e != hipSuccess) rc = fail(MH_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e)); }
     if (rc != MH_OK) { (void)hipStreamSynchronize((hipStream_t)c->s2); return rc; }
   } else
@@ -1528,7 +1543,7 @@ static int core_solve_round(mh_imp_core* c, hipStream_t s, const int* run_if, in
   if (spec) {                                                     // the tasks have been running beside lcp_fast: wait for them, then select
     MH_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->ev1, 0));
     if (overlap) {                                                // what lcp_fast decided after the first launch's workgroups had left
-      rc = core_ladder_launch(c, s, L, c->need2, true, false, true);
+      rc = core_ladder_launch(c, s, L, c->need2, true, false, true, ordered);
       if (rc != MH_OK) return rc;
     }
     return core_ladder_finish(c, s, L, c->need2, c->lst2, c->piv2);

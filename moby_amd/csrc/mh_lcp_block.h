@@ -902,7 +902,9 @@ MH_DEV bool lcp_solve(const LcpParams& P, const Pow10Table& p10, const Mat& M, c
 // Waiting for the last verdict instead was tried and is not safe: with several hundred workgroups resident and waiting, lcp_fast's remaining workgroups
 // -- on other CUs, at the full shader clock -- took 40-70 s for what takes them 3 (profiles/r04_d_waiting_workgroups_stall.txt; not the polling: one
 // thread per workgroup looked at one word once a millisecond).
-MH_DEV int pick_task(int Bw, int R, int* st, const int* __restrict__ run_if, const int* __restrict__ n_arr, const int* verdict)
+// order (or NULL): a permutation of the problems, the ones expected to take longest first (core_solve_round ranks the worlds by the solver time they have
+// used so far): ties between candidates go to the earlier place in it instead of the lower index -- longest processing time first, the classic cure for a tail.
+MH_DEV int pick_task(int Bw, int R, int* st, const int* __restrict__ run_if, const int* __restrict__ n_arr, const int* verdict, const int* __restrict__ order)
 {
   const int t = tid();
   volatile int* solved = st; volatile int* next = st + Bw; volatile int* done = st + 2 * Bw;
@@ -913,7 +915,8 @@ MH_DEV int pick_task(int Bw, int R, int* st, const int* __restrict__ run_if, con
     //  atomic loads too, and the tasks only read M and q, written before either kernel started)
     const int published = (verdict && t == 0) ? __hip_atomic_load(verdict - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     double best = inf(), lowest = inf(); int bw = 0x7fffffff, lw = 0x7fffffff, open_ = 0, pend = 0;
-    for (int w = t; w < Bw; w += T) {
+    for (int i = t; i < Bw; i += T) {
+      const int w = order ? order[i] : i;
       if (run_if && run_if[w] == 0) continue;
       if (n_arr && n_arr[w] <= MH_LCP_MAX_N_WAVE) continue;
       if (verdict) {
@@ -925,10 +928,11 @@ MH_DEV int pick_task(int Bw, int R, int* st, const int* __restrict__ run_if, con
       if (nr >= R || solved[w] < nr) continue;
       open_++;
       const double d = (double)(nr - done[w]);
-      if (d < best) { best = d; bw = w; }
-      if ((double)nr < lowest) { lowest = (double)nr; lw = w; }
+      if (d < best) { best = d; bw = i; }
+      if ((double)nr < lowest) { lowest = (double)nr; lw = i; }
     }
     double dmin; int w, w2; red_min_first(best, bw, dmin, w); red_min_first(lowest, lw, dmin, w2);
+    if (order) { if (w != 0x7fffffff) w = order[w]; if (w2 != 0x7fffffff) w2 = order[w2]; }       // (places in the order back to problems)
     if (w == 0x7fffffff) {
       if (verdict == nullptr || red_sum_int(pend) == 0 || looks >= 8) return -1;
       looks++;
@@ -977,9 +981,13 @@ void k_lcp_block(int B, int n, const double* __restrict__ Mg, int ld, long strid
   const bool cqueue = (FAM == 1) && task_worlds > 0 && !queue && (flags & 64) != 0;
   for (int round = 0; FAM == 1 || round < 1; round++) {
   int b;
-  if (queue) { b = pick_task(task_worlds, B / task_worlds, solved_at, run_if, n_arr, (flags & 32) ? solved_at + 3 * (size_t)task_worlds + 2 : nullptr); if (b < 0) return; }
+  if (queue) { b = pick_task(task_worlds, B / task_worlds, solved_at, run_if, n_arr, (flags & 32) ? solved_at + 3 * (size_t)task_worlds + 2 : nullptr,
+                             (flags & 128) ? solved_at + 4 * (size_t)task_worlds + 2 : nullptr); if (b < 0) return; }
   else if (cqueue) { b = bcast_i((t == 0) ? atomicAdd(solved_at + task_worlds, 1) : 0); if (b >= B) return; }
-  else { if (round > 0) return; b = blockIdx.x; if (b >= B) return; }
+  else { if (round > 0) return; b = blockIdx.x; if (b >= B) return;
+         // the lcp_fast kinds on a full chip (flags & 128): workgroup i takes the problem at place i of the order (behind the gate's counter and the B verdicts), so
+         // the worlds expected to run longest START first -- the kernel lasts as long as its slowest world plus the time that world waited for a CU
+         if (FAM == 0 && task_worlds == 0 && solved_at != nullptr && (flags & 128)) b = solved_at[B + 2 + b]; }
   n = n_launch; ld = ld_launch;
   const int bw = (task_worlds > 0) ? b % task_worlds : b;
   LadderTask task; task.solved_at = (task_worlds > 0) ? solved_at + bw : nullptr; task.rung = (task_worlds > 0) ? b / task_worlds : -1;

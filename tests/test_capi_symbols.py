@@ -139,8 +139,8 @@ def test_scheduling_switches_validate_their_values_without_gpu():
     """mh_debug_set: every documented key takes its documented values and refuses others; defaults restored."""
     from moby_amd import _lib
     lib = _lib.load()
-    ranges = {2: (0, 5), 3: (0, 1), 4: (0, 4), 5: (0, 1), 6: (0, 1), 7: (0, 1), 8: (0, 4), 9: (0, 1), 10: (0, 1)}
-    defaults = {2: 0, 3: 1, 4: 3, 5: 1, 6: 1, 7: 1, 8: 0, 9: 0, 10: 1}
+    ranges = {2: (0, 5), 3: (0, 1), 4: (0, 4), 5: (0, 1), 6: (0, 1), 7: (0, 1), 8: (0, 4), 9: (0, 1), 10: (0, 1), 11: (0, 1)}
+    defaults = {2: 0, 3: 1, 4: 3, 5: 1, 6: 1, 7: 1, 8: 0, 9: 0, 10: 1, 11: 0}
     try:
         for key, (lo, hi) in ranges.items():
             for v in range(lo, hi + 1):

@@ -22,6 +22,8 @@ if os.environ.get("MH_TASKS"):             # mh_debug_set key 4 (3: the ladder's
     _lib.check(_lib.load().mh_debug_set(4, int(os.environ["MH_TASKS"])))
 if os.environ.get("MH_REG_LU"):            # mh_debug_set key 10 (0: lcp_fast's nonbasic systems through the HBM workspace)
     _lib.check(_lib.load().mh_debug_set(10, int(os.environ["MH_REG_LU"])))
+if os.environ.get("MH_LPT"):               # mh_debug_set key 11 (0: full-chip launches take the worlds by index, not by the solver time they have used)
+    _lib.check(_lib.load().mh_debug_set(11, int(os.environ["MH_LPT"])))
 _opt = {"--dump-world": 2, "--states-of": 1, "--dump-failed": 1}
 args, _k = [], 1
 while _k < len(sys.argv):
