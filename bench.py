@@ -208,8 +208,10 @@ def config4_cpu_sample(nboxes, batch):
     own core); `all_cores`: all of them over the wall clock."""
     import multiprocessing as mp
     try:
-        # (at most 8 processes: sixteen copies of this memory-bound sample slow each other down 3.5x -- 74 s per world against 21 s alone, 120 s of wall clock)
-        ncores = min(8, int(os.environ.get("MH_BENCH_CPU_PROCS", usable_cpus())))
+        # (FOUR processes, to keep the default run within a few minutes: a perturbed 16-box world costs the oracle 40-75 s per step on this host -- measured with
+        #  16 processes 74 s per world / 120 s of wall clock, with 8 processes 76 s / 119 s (profiles/r05_f_bench.json) -- so the sample is stated per core and the
+        #  `all_cores` figure is what these four processes did together, its core count beside it)
+        ncores = min(4, int(os.environ.get("MH_BENCH_CPU_PROCS", usable_cpus())))
         ws = [1 + (k % max(1, batch - 1)) for k in range(ncores)]
         t0 = time.perf_counter()
         with mp.get_context("fork").Pool(ncores) as pool:
@@ -677,7 +679,7 @@ def main():
     ap.add_argument("--config4-worlds", type=int, default=1024)
     ap.add_argument("--config4-steps", type=int, default=3, help="full steps of the config-4 leg: the first cold, the others warm-started from _zlast")
     ap.add_argument("--config4-tall-boxes", type=int, default=28, help="the `config4_tall_stack` leg: the largest stack of which 64 worlds take one full cold step in under 60 s on one MI355X "
-                    "(measured, profiles/r05_*: 24 boxes 21.7 s, 28 boxes 37.3 s, 32 boxes 60.1 s; 64 boxes -- BASELINE's size, n = 2048 -- 135 s with 62 of 64 worlds ending in LCPSolverException); 0 = skip")
+                    "(measured, profiles/r05_*: 24 boxes 21.7 s, 28 boxes 36-38 s, 32 boxes 55-60 s; 64 boxes -- BASELINE's size, n = 2048 -- 135 s with 62 of 64 worlds ending in LCPSolverException); 0 = skip")
     ap.add_argument("--config4-tall-worlds", type=int, default=64)
     ap.add_argument("--no-long-horizon", action="store_true")
     ap.add_argument("--long-horizon-start", type=int, default=4000)
@@ -811,8 +813,8 @@ def main():
         out["config4_full_step"] = config4_full_step_leg(torch, args.config4_boxes, args.config4_worlds, args.config4_steps, None, c4cpu_part)
     if rank == 0 and world_size == 1 and not args.no_config4 and args.config4_tall_boxes > 0:
         out["config4_tall_stack"] = config4_full_step_leg(torch, args.config4_tall_boxes, args.config4_tall_worlds, 1, None, None,
-            note="the largest stack of BASELINE config 4's family of which 64 worlds take one full COLD step in under 60 s on one MI355X (32 boxes, n = 1024: 60.1 s; "
-                 "BASELINE's own 64 boxes, n = 2048: 135 s for 64 worlds, 62 of them ending in LCPSolverException -- tests/test_big_gpu.py holds 64 boxes x 8 worlds to the oracle's fixture)")
+            note="the largest stack of BASELINE config 4's family of which 64 worlds take one full COLD step well inside 60 s on one MI355X (28 boxes: 36-38 s; 32 boxes, "
+                 "n = 1024: 55-60 s; BASELINE's own 64 boxes, n = 2048: 135 s for 64 worlds, 62 of them ending in LCPSolverException -- tests/test_big_gpu.py holds 64 boxes x 8 worlds to the oracle's fixture)")
     if rank == 0 and world_size == 1 and not args.no_config3:
         out["config3_rimless_wheel"] = config3_leg(torch, S, WorldBatchDevice, c3cpu)
     if rank == 0 and world_size == 1 and not args.no_config5:
