@@ -20,8 +20,10 @@ sys.path.insert(0, ROOT)
 from tests.oracle_api import Oracle
 from moby_amd import scene as S, stack as K
 
-BOXES, BATCH, STEPS, DT = 64, 8, 1, 1e-3
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config4_64_boxes.npz")
+# MH_FIXTURE_BOXES / MH_FIXTURE_STEPS: the same generator for other stack heights (32 boxes x 2 steps -> config4_32_boxes_2steps.npz: the largest stack the
+# reference's chain solves, a cold and a warm step; 10-25 minutes of CPU per world)
+BOXES, BATCH, STEPS, DT = int(os.environ.get("MH_FIXTURE_BOXES", "64")), 8, int(os.environ.get("MH_FIXTURE_STEPS", "1")), 1e-3
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config4_%d_boxes%s.npz" % (BOXES, "" if STEPS == 1 else "_%dsteps" % STEPS))
 
 
 def run_world(w):

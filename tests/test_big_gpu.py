@@ -279,6 +279,36 @@ def test_config4_at_the_size_baseline_states_against_the_oracles_fixture():
     assert np.abs(b[0, :, 1] - 0.5 - np.arange(N)).max() < 1e-4 and np.abs(b[0, :, 7:13]).max() < 5e-2
 
 
+def test_config4_largest_solvable_size_against_the_oracles_fixture():
+    """32 boxes per stack (impact LCP n = 1024: the largest stack of config 4's family that the reference's own chain solves), 8 worlds, TWO full steps -- a cold one
+    and one warm-started from _zlast -- against tests/golden/config4_32_boxes_2steps.npz, which the CPU oracle wrote in the build container (tests/golden/
+    make_config4_64_boxes.py with MH_FIXTURE_BOXES=32 MH_FIXTURE_STEPS=2: 10-25 minutes of CPU per world): state, flags, rand() ring, every counter, time and _zlast of
+    the worlds the fixture holds, bit for bit.  n = 1024 goes through the 1024-thread geometry for lcp_fast and (176 ladder tasks: fewer than two per CU) for the
+    lcp_lemke kinds as well."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config4_32_boxes_2steps.npz")
+    d = np.load(path)
+    N, B, steps = int(d["boxes"]), int(d["batch"]), int(d["steps"])
+    assert N == 32 and steps == 2
+    sc = K.box_stack_scene(N)
+    st0 = K.box_stack_state(N, B)
+    bb = K.BigBatch(sc, st0)
+    bb.step(float(d["dt"]), steps)
+    st, aux = bb.download()
+    ss = bb.solver_state()
+    bb.close()
+    assert len(d["worlds"]) >= 2
+    for k, w in enumerate(d["worlds"]):
+        w = int(w); ao = d["aux"][k:k + 1]
+        assert np.array_equal(d["st0"][k], st0[w])
+        for f in FIELDS:
+            assert np.array_equal(aux[f][w], ao[f][0]), "world %d %s: gpu %r oracle %r" % (w, f, aux[f][w], ao[f][0])
+        assert np.array_equal(st[w], d["st"][k]), "world %d: max |diff| = %.3e" % (w, np.abs(st[w] - d["st"][k]).max())
+        n = int(ao["zlast_size"][0])
+        assert np.array_equal(ss["zlast"][w, :n], d["zlast"][k][:n])
+    assert ((aux["status"] & ~S.MH_WORLD_IMPACT_TOL) == 0).all() and (aux["steps"] == steps).all()
+
+
 def test_every_route_through_the_block_solver_gives_the_same_full_steps():
     """The same six 16-box worlds, one full step, through every switch of the workgroup-per-problem solver -- states, rand() streams, pivot counts,
     flags and warm-start sizes equal bit for bit (the oracle checks the default choice: the tests above and test_config4_bench_size_full_batch):
