@@ -205,6 +205,32 @@ def test_random_multi_island_graphs_match_oracle(oracle, seed, nb, nc, nk):
     ib.close()
 
 
+def test_every_batch_type_lives_on_the_device_current_at_create():
+    """Device affinity (include/moby_hip.h, Devices): a batch belongs to the device that was current when it was created.  mh_impact_batch_create used to zero the
+    field after reading it, so the query is held here for every batch type -- on the one device of the test box (a second GPU is what it takes
+    to see the difference; the multi-GPU example checks placement there)."""
+    from moby_amd import _lib, scene as S, stack as K, artic as A
+    from moby_amd.world import WorldBatchDevice
+    import os
+    lib = _lib.load()
+    dev = lib.mh_device_get()
+    assert dev >= 0
+    mass, J, st, cs = I.box_stack(2, B=2)
+    ib = I.ImpactBatch(2, 2, 8, 4, mass, J)
+    assert lib.mh_impact_batch_device(ib.handle) == dev
+    ib.close()
+    wb = WorldBatchDevice(S.sphere_stack_scene(), S.sphere_stack_state(2))
+    assert lib.mh_world_batch_device(wb.handle) == dev
+    wb.close()
+    bb = K.BigBatch(K.box_stack_scene(2), K.box_stack_state(2, 2))
+    assert lib.mh_big_batch_device(bb.handle) == dev
+    bb.close()
+    m, _, _ = A.load_sdf(os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes", "ten_joint_arm.sdf"))
+    ab = A.ArticBatch(m, np.zeros((2, m.nj)), np.zeros((2, m.nj)))
+    assert lib.mh_artic_batch_device(ab.handle) == dev
+    ab.close()
+
+
 def test_upload_rejects_malformed_contacts():
     lib = _lib.load()
     mass, J, st, cs = I.box_stack(2, B=1)
