@@ -201,26 +201,24 @@ def _cpu_stack_worker(arg):
     return secs, int(aux["lcp_rows"][0]), int(aux["lcp_pivots"][0])
 
 
-def config4_cpu_sample(nboxes, batch):
-    """The CPU side of the config-4 leg, BEFORE the GPU is touched (round 4 ran it beside the GPU leg and cost that ~10 %):
-    one process per usable core, each stepping ONE world of the same batch (worlds 1 .. cores: perturbed stacks, the ones that walk the whole
-    solver chain) through one full cold step with the CPU oracle.  `value`: the mean single-thread rate of those processes (each is one thread on its
-    own core); `all_cores`: all of them over the wall clock."""
+def config4_cpu_sample(nboxes, batch, world=2):
+    """The CPU side of the config-4 leg, BEFORE the GPU is touched (round 4 ran it beside the GPU leg and cost that ~10 %): one process per usable
+    core, each stepping the SAME world of the batch -- world 2, a perturbed stack that walks the whole solver chain with 8 552 pivots in its cold step (the batch's mean is
+    11.5 k) -- through one full cold step with the CPU oracle.  One world, because a cold step of a 16-box world costs the oracle 25 s to 4 min depending on the world
+    (measured on worlds 1-9: profiles/r05_f_bench.json and DESIGN 5), and a pool over different worlds lasts as long as its slowest (120 s with worlds 1-4).
+    `value`: the mean single-thread rate of those processes (each is one thread on its own core); `all_cores`: all of them over the wall clock."""
     import multiprocessing as mp
     try:
-        # (FOUR processes, to keep the default run within a few minutes: a perturbed 16-box world costs the oracle 40-75 s per step on this host -- measured with
-        #  16 processes 74 s per world / 120 s of wall clock, with 8 processes 76 s / 119 s (profiles/r05_f_bench.json) -- so the sample is stated per core and the
-        #  `all_cores` figure is what these four processes did together, its core count beside it)
-        ncores = min(4, int(os.environ.get("MH_BENCH_CPU_PROCS", usable_cpus())))
-        ws = [1 + (k % max(1, batch - 1)) for k in range(ncores)]
+        ncores = int(os.environ.get("MH_BENCH_CPU_PROCS", usable_cpus()))
+        w = min(world, max(0, batch - 1))
         t0 = time.perf_counter()
         with mp.get_context("fork").Pool(ncores) as pool:
-            res = pool.map(_cpu_stack_worker, [(nboxes, w, batch) for w in ws])
+            res = pool.map(_cpu_stack_worker, [(nboxes, w, batch)] * ncores)
         wall = time.perf_counter() - t0
         secs = sum(r[0] for r in res); rows = sum(r[1] for r in res); piv = sum(r[2] for r in res)
         return {"value": rows / secs, "unit": "LCP rows/s", "world_steps_per_sec": len(res) / secs, "cores": 1, "kind": "port",
-                "sample": "worlds 1..%d of the same batch (box stack of %d), one full cold step each, CPU oracle (oracle/world.hpp), one thread per world on its own core, "
-                          "before the GPU legs: %.1f s per world on average, %d pivots per world" % (len(res), nboxes, secs / len(res), piv // len(res)),
+                "sample": "world %d of the same batch (box stack of %d), one full cold step, CPU oracle (oracle/world.hpp), one thread: %.1f s, %d pivots (mean of %d processes, "
+                          "each on its own core, before the GPU legs)" % (w, nboxes, secs / len(res), piv // len(res), len(res)),
                 "all_cores": {"value": rows / wall, "unit": "LCP rows/s", "world_steps_per_sec": len(res) / wall, "cores": ncores,
                               "sample": "the same %d processes over the wall clock (%.1f s incl. process start)" % (ncores, wall)}}
     except Exception as e:          # noqa: BLE001

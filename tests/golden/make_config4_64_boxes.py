@@ -22,8 +22,11 @@ from moby_amd import scene as S, stack as K
 
 # MH_FIXTURE_BOXES / MH_FIXTURE_STEPS: the same generator for other stack heights (32 boxes x 2 steps -> config4_32_boxes_2steps.npz: the largest stack the
 # reference's chain solves, a cold and a warm step; 10-25 minutes of CPU per world)
-BOXES, BATCH, STEPS, DT = int(os.environ.get("MH_FIXTURE_BOXES", "64")), 8, int(os.environ.get("MH_FIXTURE_STEPS", "1")), 1e-3
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config4_%d_boxes%s.npz" % (BOXES, "" if STEPS == 1 else "_%dsteps" % STEPS))
+# MH_FIXTURE_BATCH: the batch the worlds are taken from (the perturbations are drawn per batch): 1024 with 16 boxes and 2 steps -> config4_16_boxes_x1024_2steps.npz, the
+# worlds of the bench-size batch that tests/test_big_gpu.py::test_config4_bench_size_full_batch holds the default full-chip schedule to (world 0 and the worlds with the
+# most pivots over the two steps: 497, 328)
+BOXES, BATCH, STEPS, DT = int(os.environ.get("MH_FIXTURE_BOXES", "64")), int(os.environ.get("MH_FIXTURE_BATCH", "8")), int(os.environ.get("MH_FIXTURE_STEPS", "1")), 1e-3
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config4_%d_boxes%s%s.npz" % (BOXES, "" if BATCH == 8 else "_x%d" % BATCH, "" if STEPS == 1 else "_%dsteps" % STEPS))
 
 
 def run_world(w):
