@@ -203,7 +203,7 @@ def _cpu_stack_worker(arg):
 
 def config4_cpu_sample(nboxes, batch, world=2):
     """The CPU side of the config-4 leg, BEFORE the GPU is touched (round 4 ran it beside the GPU leg and cost that ~10 %): one process per usable
-    core, each stepping the SAME world of the batch -- world 2, a perturbed stack that walks the whole solver chain with 8 552 pivots in its cold step (the batch's mean is
+    core, each stepping the SAME world of the batch -- world 2, a perturbed stack that walks the whole solver chain with 12.5 k pivots in its cold step (the batch's mean is
     11.5 k) -- through one full cold step with the CPU oracle.  One world, because a cold step of a 16-box world costs the oracle 25 s to 4 min depending on the world
     (measured on worlds 1-9: profiles/r05_f_bench.json and DESIGN 5), and a pool over different worlds lasts as long as its slowest (120 s with worlds 1-4).
     `value`: the mean single-thread rate of those processes (each is one thread on its own core); `all_cores`: all of them over the wall clock."""
