@@ -1,0 +1,71 @@
+"""Fuzz of the impact handler's exception path in the one-wavefront kernels: harsh sphere piles (tests/test_world_gpu.py::_harsh_scene: masses and inertias over six
+decades, friction just under the no-slip threshold, viscous friction, huge compliance, fast spins) on which the reference's whole solver chain fails now and then
+(LCPSolverException, ImpactConstraintHandlerQP.cpp:225: the world's run is over).  The oracle runs first, one child process per seed; a seed the oracle cannot
+finish in SKIP_AFTER seconds (worlds that also STALL cost millions of mini-steps) is dropped.  GPU (two launches: 30 + 10 steps) against the oracle bit for bit.
+    python tests/tools/fuzz_throw.py [seed0] [cases]"""
+import multiprocessing as mp, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from moby_amd import scene as S
+import importlib.util
+_spec = importlib.util.spec_from_file_location("_twg", os.path.join(ROOT, "tests", "test_world_gpu.py")); _twg = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_twg)
+FIELDS = ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "stab_iters", "zlast_size")
+SKIP_AFTER = 6.0
+
+
+def oracle_case(seed, q):
+    from tests.oracle_api import Oracle
+    o = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+    sc, st0 = _twg._harsh_scene(seed)
+    so = st0.copy(); ao = S.new_aux(st0.shape[0]); out = []
+    for nsteps in (30, 10):
+        for w in range(st0.shape[0]):
+            o.world_step(sc, so[w], ao[w:w + 1], 1e-3, nsteps, want_traj=False)
+        out.append((so.copy(), ao.copy()))
+    q.put((seed, out))
+
+
+if __name__ == "__main__":
+    seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    ctx = mp.get_context("fork"); q = ctx.Queue(); ora = {}
+    procs = [(s, ctx.Process(target=oracle_case, args=(s, q))) for s in range(seed0, seed0 + cases)]
+    live = []
+    for s, p in procs:                      # at most 8 children at a time, each with its own deadline
+        while len(live) >= 8:
+            while not q.empty():
+                k, v = q.get(); ora[k] = v
+            live = [(s2, p2, t2) for s2, p2, t2 in live if p2.is_alive() and (time.time() - t2 < SKIP_AFTER or (p2.kill() or False))]
+            time.sleep(0.05)
+        p.start(); live.append((s, p, time.time()))
+    t_end = time.time() + SKIP_AFTER
+    while time.time() < t_end and any(p.is_alive() for _, p, _ in live):
+        while not q.empty():
+            k, v = q.get(); ora[k] = v
+        time.sleep(0.05)
+    for _, p, _ in live:
+        if p.is_alive(): p.kill()
+    while not q.empty():
+        k, v = q.get(); ora[k] = v
+    from moby_amd.world import WorldBatch
+    bad = 0; thrown_worlds = 0; compared = 0; heavy = 0; wild = 0
+    for seed in range(seed0, seed0 + cases):
+        if seed not in ora: continue
+        # a world that STALLS, or crawls through thousands of conservative-advancement mini-steps, costs one wavefront minutes where it costs a CPU core seconds: dropped
+        if (ora[seed][1][1]["status"] & S.MH_WORLD_STALLED).any() or (ora[seed][1][1]["mini_steps"] > 3000).any(): heavy += 1; continue
+        # a world whose velocities have OVERFLOWED (compliance 1e3 with a mass ratio of 1e6 does that within a few steps) hands the solvers a _qq with infinities
+        # and NaNs: both sides then fail the LCP, but their scans order NaNs differently (documented deviation 11) and the pivot counts part -- outside
+        # the parity claim, dropped (tests/tools/throw_lcp_replay.py shows such an LCP side by side)
+        if not all(np.isfinite(so).all() and np.abs(so).max() < 1e100 for so, _ in ora[seed]): wild += 1; continue
+        print("seed %d ..." % seed, flush=True)
+        sc, st0 = _twg._harsh_scene(seed)
+        wb = WorldBatch(sc, st0.copy()); ok = True
+        for (so, ao), nsteps in zip(ora[seed], (30, 10)):
+            wb.step(1e-3, nsteps)
+            ok = ok and np.array_equal(wb.state, so, equal_nan=True) and all(np.array_equal(wb.aux[f], ao[f]) for f in FIELDS)
+        compared += 1; thrown_worlds += int(((ora[seed][1][1]["status"] & S.MH_WORLD_LCP_FAILED) != 0).sum())
+        if not ok:
+            bad += 1; print("MISMATCH seed %d: status gpu %r oracle %r" % (seed, wb.aux["status"].tolist(), ora[seed][1][1]["status"].tolist()), flush=True)
+    print("fuzz_throw: %d seeds from %d, %d compared (%d dropped as stalling / crawling, %d because a state overflowed, the others too slow for the oracle), %d mismatches; "
+          "%d worlds ended by an exception of the impact handler" % (cases, seed0, compared, heavy, wild, bad, thrown_worlds))
