@@ -500,7 +500,10 @@ MH_DEV bool verify_wave(int n, const MatT& M, double lam, double qi, double zi, 
   const int lane = lane_id();
   const bool valid = lane < n;
   const double nT = -ZERO_TOL;
-  if (ballot(valid && !(strict ? (zi > nT) : (zi >= nT))) != 0ull) return false;
+  // (a NaN among the values -- a world whose velocities have overflowed -- takes the tests through std::min_element's own semantics, as the reference's
+  //  *std::min_element(...) >= -ZERO_TOL does: skipped unless it is the first element)
+  if (ballot(valid && zi != zi) != 0ull) { const double mz = min_element_value(zi, valid); if (!(strict ? (mz > nT) : (mz >= nT))) return false; }
+  else if (ballot(valid && !(strict ? (zi > nT) : (zi >= nT))) != 0ull) return false;
   double w = 0.0;
   uint64_t nz = ballot(valid && zi != 0.0);
   while (nz) {
@@ -510,8 +513,14 @@ MH_DEV bool verify_wave(int n, const MatT& M, double lam, double qi, double zi, 
     if (valid) w = w + t * m;
   }
   w = w + qi;
-  if (ballot(valid && !(strict ? (w > nT) : (w >= nT))) != 0ull) return false;
   const double zw = zi * w;
+  if (ballot(valid && (w != w || zw != zw)) != 0ull) {
+    const double mw = min_element_value(w, valid);
+    if (!(strict ? (mw > nT) : (mw >= nT))) return false;
+    const double mn = min_element_value(zw, valid), mx = max_element_value(zw, valid);
+    return (strict ? (mn > nT) : (mn >= nT)) && mx < ZERO_TOL;
+  }
+  if (ballot(valid && !(strict ? (w > nT) : (w >= nT))) != 0ull) return false;
   if (ballot(valid && !(strict ? (zw > nT) : (zw >= nT))) != 0ull) return false;
   return ballot(valid && !(zw < ZERO_TOL)) == 0ull;
 }

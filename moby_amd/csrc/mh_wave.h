@@ -83,10 +83,25 @@ MH_DEV double wave_min(double v) { MH_DPP_REDUCE(v, MH_PICK_MIN); return read_la
 // Ties resolve to the lowest lane, as std::min_element does: reduce the value,
 // then ballot the lanes that hold it.
 MH_DEV void argmin_first(double v, bool valid, double& vmin, int& imin) {
+  // std::min_element keeps its FIRST element when that is a NaN (nothing compares less than a NaN), and skips a NaN anywhere else -- the reduction below skips them all
+  // (v_min_f64 returns the other operand), so the first-lane case is put right by hand; it only arises in worlds whose velocities have overflowed (tests/tools/fuzz_throw.py)
+  const uint64_t nanm = ballot(valid && v != v);
+  const uint64_t vm = nanm ? ballot(valid) : 0ull;
   if (!valid) v = __longlong_as_double(0x7ff0000000000000ll); // +inf
   vmin = wave_min(v);
   const uint64_t m = ballot(valid && v == vmin);
   imin = m ? ctz(m) : 0x7fffffff;
+  if (nanm & (vm & (0ull - vm))) { imin = ctz(vm); vmin = __longlong_as_double(0x7ff8000000000000ll); }
+}
+// *std::min_element / *std::max_element over the lanes with valid == true, NaN semantics included (a NaN is skipped unless it is the FIRST element, which then stays)
+MH_DEV double min_element_value(double v, bool valid) { double m; int i; argmin_first(v, valid, m, i); return m; }
+MH_DEV double max_element_value(double v, bool valid) {
+  const uint64_t nanm = ballot(valid && v != v);
+  const uint64_t vm = nanm ? ballot(valid) : 0ull;
+  if (nanm & (vm & (0ull - vm))) return __longlong_as_double(0x7ff8000000000000ll);
+  if (!valid) v = __longlong_as_double(0xfff0000000000000ll); // -inf
+  MH_DPP_REDUCE(v, MH_PICK_MAX);
+  return read_lane(v, 63);
 }
 // first-index argmax (idamax over |a| supplied by the caller, a >= 0)
 MH_DEV void argmax_first(double v, bool valid, double& vmax, int& imax) {
