@@ -36,7 +36,7 @@ extern "C" {
 #define MH_ARTIC_FSAB 1
 #define MH_ARTIC_MAX_SPHERES 4    /* sphere primitives carried by links (contacts against the one static plane) */
 
-/* Joint i carries link i; joints are listed parents first.  All quantities are LOCAL (constant), as a reader of
+/* Joint i carries link i; joints are listed parents first.  A link may be massless as long as its joint moves mass (something outboard of it has mass).  All quantities are LOCAL (constant), as a reader of
  * model.sdf derives them once at q = 0 (mh_io_load_sdf, moby_amd/host/mh_io.cpp):
  *   Rrel, trel   pose of link i's frame in its parent link's frame at q = 0 (row-major rotation; parent -1 = model frame)
  *   axis         joint axis in link i's frame, unit (revolute: rotation about it through the link origin; prismatic:
@@ -60,7 +60,13 @@ typedef struct mh_artic_model {
                             reader sets eCRB, src/SDFReader.cpp:934): MH_ARTIC_CRB (0) or MH_ARTIC_FSAB -- forward dynamics by
                             Featherstone's articulated-body recursion; the impact handler's X = H^-1 is the generalized inertia's
                             inverse either way (ICH:1600-1607) */
-  int    pad;
+  int    floating_base;  /* RCArticulatedBody floating-base="true" (src/RCArticulatedBody.cpp:172-175), carried by VIRTUAL joints: 1 = joints 0..2 are prismatic
+                            along the global x, y, z (Rrel = identity; trel of joint 0 = the base link's COM at q = 0) and joints 3..5 revolute about the base
+                            link's own x, y, z through that COM, links 0..4 massless, link 5 the base link; the body's own joints follow (what
+                            mh_io_load_xml_artic builds).  The dynamics, calc_jacobian and the contact rows need no special case -- six more 1-DOF columns;
+                            the one place that reads the flag is conservative advancement, which adds the base's linear velocity along the direction of
+                            approach as CCD::calc_max_dist does for a moving base (CCD.cpp:547-555).  NOT Ravelin's base coordinates (spatial velocity +
+                            unit quaternion): the orientation is integrated in three angles, singular when joint 4 reaches +-pi/2.  0 = fixed base */
   /* Collision geometry (optional; nspheres = 0 is the robot alone: no pairs, one mini-step per step).  Sphere primitives fixed to
    * links against ONE static plane -- the closed-form pair of CCD.inl:804-847; the body's own pairs are disabled as ur10.xml:12
    * does.  With spheres the step is TimeSteppingSimulator::step in full: conservative advancement over the pairs

@@ -26,7 +26,7 @@ class mh_artic_model(ctypes.Structure):
                 ("Rrel", (ctypes.c_double * 9) * _NJ), ("trel", (ctypes.c_double * 3) * _NJ), ("axis", (ctypes.c_double * 3) * _NJ),
                 ("com", (ctypes.c_double * 3) * _NJ), ("inertia", (ctypes.c_double * 9) * _NJ), ("mass", ctypes.c_double * _NJ),
                 ("lolimit", ctypes.c_double * _NJ), ("hilimit", ctypes.c_double * _NJ), ("limit_restitution", ctypes.c_double * _NJ),
-                ("gravity", ctypes.c_double * 3), ("algorithm", ctypes.c_int), ("pad", ctypes.c_int),
+                ("gravity", ctypes.c_double * 3), ("algorithm", ctypes.c_int), ("floating_base", ctypes.c_int),
                 ("nspheres", ctypes.c_int), ("sphere_link", ctypes.c_int * _NS), ("sphere_center", (ctypes.c_double * 3) * _NS),
                 ("sphere_radius", ctypes.c_double * _NS), ("plane_R", ctypes.c_double * 9), ("plane_o", ctypes.c_double * 3),
                 ("cp_epsilon", ctypes.c_double), ("cp_mu_coulomb", ctypes.c_double), ("min_step_size", ctypes.c_double),

@@ -838,12 +838,26 @@ int mh_artic_batch_create(const mh_artic_model* model, int B, mh_artic_batch** o
     const int p = model->parent[i];
     if (p >= i || p < -1) return fail(MH_ERR_INVALID_ARG, "joint %d: parent %d must come before it (-1 = base)", i, p);
     if (model->jtype[i] != MH_JOINT_REVOLUTE && model->jtype[i] != MH_JOINT_PRISMATIC) return fail(MH_ERR_INVALID_ARG, "joint %d: type %d is not built (revolute, prismatic)", i, model->jtype[i]);
-    if (!(model->mass[i] > 0.0)) return fail(MH_ERR_INVALID_ARG, "link %d: mass must be > 0", i);
+    if (!(model->mass[i] >= 0.0)) return fail(MH_ERR_INVALID_ARG, "link %d: mass must be >= 0", i);
     const double* a = model->axis[i]; const double nn = a[0]*a[0] + a[1]*a[1] + a[2]*a[2];
     if (!(nn > 0.999999 && nn < 1.000001)) return fail(MH_ERR_INVALID_ARG, "joint %d: axis is not a unit vector", i);
     if (!(model->lolimit[i] <= model->hilimit[i])) return fail(MH_ERR_INVALID_ARG, "joint %d: lower limit above the upper one", i);
     hm.anc[i] = (1u << i) | (p >= 0 ? hm.anc[p] : 0u);
   }
+  if (model->floating_base != 0 && model->floating_base != 1) return fail(MH_ERR_INVALID_ARG, "floating_base = %d: 0 or 1", model->floating_base);
+  if (model->floating_base) {                                        // the layout include/moby_hip_artic.h states (conservative advancement reads joints 0..2 as the base's velocity)
+    if (nj < 6) return fail(MH_ERR_INVALID_ARG, "floating_base needs the six virtual joints in front (nj = %d)", nj);
+    for (int v = 0; v < 6; v++) {
+      bool ok = model->parent[v] == v - 1 && model->jtype[v] == ((v < 3) ? MH_JOINT_PRISMATIC : MH_JOINT_REVOLUTE);
+      for (int k = 0; k < 3; k++) ok = ok && model->axis[v][k] == ((k == v % 3) ? 1.0 : 0.0) && model->com[v][k] == 0.0 && (v == 0 || model->trel[v][k] == 0.0);
+      for (int k = 0; k < 9; k++) ok = ok && (v == 3 || model->Rrel[v][k] == ((k % 4 == 0) ? 1.0 : 0.0));
+      if (!ok) return fail(MH_ERR_INVALID_ARG, "floating_base: joint %d is not the virtual joint the layout states (sliders along global x, y, z, then hinges about the base link's x, y, z through its COM)", v);
+    }
+  }
+  // a link may be massless (the virtual links under a floating base, mh_io_load_xml_artic) as long as every joint moves mass: the composite inertia outboard of it
+  { double sub[MH_ARTIC_MAX_JOINTS];
+    for (int i = 0; i < nj; i++) sub[i] = model->mass[i];
+    for (int i = nj - 1; i >= 0; i--) { if (!(sub[i] > 0.0)) return fail(MH_ERR_INVALID_ARG, "joint %d carries no mass (its link and everything outboard of it are massless)", i); if (model->parent[i] >= 0) sub[model->parent[i]] += sub[i]; } }
   if (model->nspheres < 0 || model->nspheres > MH_ARTIC_MAX_SPHERES) return fail(MH_ERR_INVALID_ARG, "nspheres = %d outside [0, %d]", model->nspheres, MH_ARTIC_MAX_SPHERES);
   for (int s = 0; s < model->nspheres; s++) {
     if (model->sphere_link[s] < 0 || model->sphere_link[s] >= nj) return fail(MH_ERR_INVALID_ARG, "sphere %d: link %d outside [0, %d)", s, model->sphere_link[s], nj);

@@ -642,11 +642,24 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
   if (abs.size() != 1) return fail("%s: expected exactly one <RCArticulatedBody>, found %zu", path, abs.size());
   xmlNode* ab = abs[0];
   const Attrs aa = attrs_of(ab);
-  if (aa.has("floating-base") && boolean(aa.str("floating-base"))) return fail("RCArticulatedBody %s: floating bases are not supported", aa.str("id").c_str());
-  if (aa.has("translate") || aa.has("rpy")) return fail("RCArticulatedBody %s: translate / rpy are not supported", aa.str("id").c_str());
+  // floating-base="true" (RCArticulatedBody.cpp:172-175): the base link rides on SIX VIRTUAL 1-DOF JOINTS -- three prismatic ones along the global axes, then three
+  // revolute ones about the base link's own x, y, z -- carried by massless links (mh_artic_model joints 0..5; the base link is link 5, the file's joints follow).  At
+  // q = 0 they are at the pose the file states, and their rates are the base's linear velocity (global axes, at its COM) and its angular velocity in its own axes.  The
+  // batch then needs nothing new: CRBA / the articulated-body recursion, calc_jacobian and the contact rows see six more columns.  What this is NOT: Ravelin's base
+  // coordinates (a spatial velocity and a unit quaternion, Ravelin absent from the tree) -- the rotation is integrated in three angles, so a trajectory agrees with a
+  // quaternion integrator's to O(dt) in the orientation and the middle angle must stay away from +-90 degrees of the START orientation.
+  const bool floating = aa.has("floating-base") && boolean(aa.str("floating-base"));
+  if (aa.has("rpy")) return fail("RCArticulatedBody %s: rpy is not supported", aa.str("id").c_str());
+  double shift[3] = { 0.0, 0.0, 0.0 };                                       // translate="x,y,z" moves the whole body (RCArticulatedBody.cpp:176-199); taken for floating bases only
+  if (aa.has("translate")) {
+    if (!floating) return fail("RCArticulatedBody %s: translate is not supported on a fixed base", aa.str("id").c_str());
+    const std::vector<double> t = numbers(aa.str("translate")); if (t.size() != 3) return fail("RCArticulatedBody %s: bad translate", aa.str("id").c_str());
+    for (int i = 0; i < 3; i++) shift[i] = t[i];
+  }
   // ArticulatedBody::load_from_xml (ArticulatedBody.cpp:250-273): with urdf-filename the links and joints come from the URDF file (found relative
   // to the XML file, XMLReader changes into its directory) and nothing else under the element is read
   const bool from_urdf = aa.has("urdf-filename");
+  if (from_urdf && floating) return fail("RCArticulatedBody %s: a floating base with urdf-filename is not supported", aa.str("id").c_str());
   UrdfRobot rob;
   if (from_urdf) {
     std::string up = aa.str("urdf-filename");
@@ -674,7 +687,7 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
       if (prim_common(a, p, 0.0, "Plane")) return 1;
       prims[a.str("id")] = p; } }
   // ---- links and joints of the body ----
-  struct XLink { std::string id; double x[3]; double R[9]; double mass; double J[3]; std::string geom; bool has_cg; };
+  struct XLink { std::string id; double x[3]; double R[9]; double mass; double J[3]; std::string geom; bool has_cg; double v[3], w[3]; };
   struct XJoint { std::string id, in, out; int type; double loc[3], axis[3], lo, hi, q, qd, resti; };
   std::vector<XLink> links; std::vector<XJoint> joints;
   for (xmlNode* c = from_urdf ? nullptr : ab->children; c; c = c->next) {
@@ -683,9 +696,12 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
     const std::string nm = (const char*)c->name;
     if (nm == "RigidBody") {
       XLink L; L.id = a.str("id"); L.mass = 0.0; L.J[0] = L.J[1] = L.J[2] = 0.0; L.has_cg = false;
-      for (int i = 0; i < 3; i++) L.x[i] = 0.0;
+      for (int i = 0; i < 3; i++) L.x[i] = L.v[i] = L.w[i] = 0.0;
       for (int i = 0; i < 9; i++) L.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
       if (a.has("position")) { const std::vector<double> p = numbers(a.str("position")); if (p.size() != 3) return fail("link %s: bad position", L.id.c_str()); for (int i = 0; i < 3; i++) L.x[i] = p[i]; }
+      for (int i = 0; i < 3; i++) L.x[i] += shift[i];
+      if (a.has("linear-velocity")) { const std::vector<double> p = numbers(a.str("linear-velocity")); if (p.size() != 3) return fail("link %s: bad linear-velocity", L.id.c_str()); for (int i = 0; i < 3; i++) L.v[i] = p[i]; }
+      if (a.has("angular-velocity")) { const std::vector<double> p = numbers(a.str("angular-velocity")); if (p.size() != 3) return fail("link %s: bad angular-velocity", L.id.c_str()); for (int i = 0; i < 3; i++) L.w[i] = p[i]; }
       if (a.has("rpy")) { const std::vector<double> r = numbers(a.str("rpy")); if (r.size() != 3) return fail("link %s: bad rpy", L.id.c_str()); rpy_to_R(r[0], r[1], r[2], L.R); }
       if (a.has("quat")) { const std::vector<double> q = numbers(a.str("quat")); if (q.size() != 4) return fail("link %s: bad quat", L.id.c_str());
         const double nr = std::sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]); if (!(nr > 0.0)) return fail("link %s: zero quat", L.id.c_str());
@@ -711,7 +727,7 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
       const std::vector<double> loc = numbers(a.str("location")), ax = numbers(a.str("axis"));
       if (loc.size() != 3) return fail("joint %s: needs a global location", J.id.c_str());
       if (ax.size() != 3) return fail("joint %s: needs a global axis", J.id.c_str());
-      for (int i = 0; i < 3; i++) { J.loc[i] = loc[i]; J.axis[i] = ax[i]; }
+      for (int i = 0; i < 3; i++) { J.loc[i] = loc[i] + shift[i]; J.axis[i] = ax[i]; }
       J.lo = -1.7976931348623157e308; J.hi = 1.7976931348623157e308; J.q = 0.0; J.qd = 0.0; J.resti = 0.0;       // Joint.cpp:33-54
       auto one = [&](const char* key, double& dst) -> int { if (!a.has(key)) return 0; const std::vector<double> v = numbers(a.str(key)); if (v.size() != 1) return 1; dst = v[0]; return 0; };
       if (one("lower-limits", J.lo) || one("upper-limits", J.hi) || one("q", J.q) || one("qd", J.qd)) return fail("joint %s: a 1-DOF joint takes one number per attribute", J.id.c_str());
@@ -722,8 +738,9 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
       joints.push_back(J);
     } else if (nm.size() > 5 && nm.compare(nm.size() - 5, 5, "Joint") == 0) return fail("%s %s: only revolute and prismatic joints are supported", nm.c_str(), a.str("id").c_str());
   }
-  if (!from_urdf && joints.empty()) return fail("%s: an articulated body without joints", path);
-  if ((int)joints.size() > MH_ARTIC_MAX_JOINTS) return fail("%zu joints > %d", joints.size(), MH_ARTIC_MAX_JOINTS);
+  if (!from_urdf && joints.empty() && !floating) return fail("%s: an articulated body without joints", path);
+  const int nv = floating ? 6 : 0;                                           // virtual joints in front of the file's
+  if ((int)joints.size() + nv > MH_ARTIC_MAX_JOINTS) return fail("%zu joints%s > %d", joints.size(), floating ? " + 6 of the floating base" : "", MH_ARTIC_MAX_JOINTS);
   std::map<std::string, int> link_of; for (size_t i = 0; i < links.size(); i++) link_of[links[i].id] = (int)i;
   if (from_urdf) for (size_t i = 0; i < rob.link_names.size(); i++) link_of[rob.link_names[i]] = (int)i;   // (ids only: ContactParameters / DisabledPair may name a link)
   std::map<std::string, int> carried;                                      // outboard link -> joint
@@ -793,7 +810,7 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
   // ---- the model ----
   std::memset(out, 0, sizeof(*out));
   mh_artic_model& m = out->model;
-  m.nj = (int)order.size();
+  m.nj = (int)order.size() + nv;
   for (int k = 0; k < 3; k++) m.gravity[k] = grav[k];
   { std::string alg = aa.has("fdyn-algorithm") ? aa.str("fdyn-algorithm") : "crb"; for (char& ch : alg) ch = (char)tolower(ch);
     alg.erase(0, alg.find_first_not_of(" \t\n\r")); alg.erase(alg.find_last_not_of(" \t\n\r") + 1);
@@ -808,15 +825,35 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
     m.algorithm = alg; for (int k = 0; k < 3; k++) m.gravity[k] = g3[k];
     for (int i = 0; i < m.nj; i++) { if (q0) q0[i] = 0.0; if (qd0) qd0[i] = 0.0; }
   }
-  for (int i = 0; i < (from_urdf ? 0 : m.nj); i++) {
-    const XJoint& J = joints[order[i]];
+  if (floating) {
+    m.floating_base = 1;
+    if (!(B0.mass > 0.0) || !(B0.J[0] > 0.0) || !(B0.J[1] > 0.0) || !(B0.J[2] > 0.0)) return fail("link %s: a floating base link needs mass and inertia", B0.id.c_str());
+    static const char* const vname[6] = { "tx", "ty", "tz", "rx", "ry", "rz" };
+    for (int v = 0; v < 6; v++) {
+      m.parent[v] = v - 1;
+      m.jtype[v] = (v < 3) ? MH_JOINT_PRISMATIC : MH_JOINT_REVOLUTE;
+      for (int k = 0; k < 9; k++) m.Rrel[v][k] = (v == 3) ? B0.R[k] : ((k % 4 == 0) ? 1.0 : 0.0);
+      for (int k = 0; k < 3; k++) { m.trel[v][k] = (v == 0) ? B0.x[k] : 0.0; m.axis[v][k] = (k == v % 3) ? 1.0 : 0.0; m.com[v][k] = 0.0; }
+      for (int k = 0; k < 9; k++) m.inertia[v][k] = 0.0;
+      m.mass[v] = 0.0;
+      m.lolimit[v] = -1.7976931348623157e308; m.hilimit[v] = 1.7976931348623157e308; m.limit_restitution[v] = 0.0;
+      if (q0) q0[v] = 0.0;
+      if (v == 5) snprintf(out->link_id[v], MH_IO_ID_LEN, "%s", B0.id.c_str()); else snprintf(out->link_id[v], MH_IO_ID_LEN, "%.40s.virtual-%s", B0.id.c_str(), vname[v]);
+      snprintf(out->joint_id[v], MH_IO_ID_LEN, "%.40s.base-%s", abid.c_str(), vname[v]);
+    }
+    m.mass[5] = B0.mass; m.inertia[5][0] = B0.J[0]; m.inertia[5][4] = B0.J[1]; m.inertia[5][8] = B0.J[2];
+    if (qd0) { double wl[3]; mat3Tvec(B0.R, B0.w, wl); for (int k = 0; k < 3; k++) { qd0[k] = B0.v[k]; qd0[3 + k] = wl[k]; } }
+  }
+  for (int i0 = 0; i0 < (from_urdf ? 0 : m.nj - nv); i0++) {
+    const int i = i0 + nv;
+    const XJoint& J = joints[order[i0]];
     const XLink& L = links[link_of[J.out]];
     const bool from_base = (J.in == base);
     // the model's link frame i: origin at the joint location, axes of the link; the base link's frame is the model frame
     const double* Rp = from_base ? B0.R : links[link_of[J.in]].R;
     double xp[3];                                                            // origin of the parent frame: its own joint's location (base: the base link's position)
     if (from_base) for (int k = 0; k < 3; k++) xp[k] = B0.x[k]; else for (int k = 0; k < 3; k++) xp[k] = joints[order[pos_of[J.in]]].loc[k];
-    m.parent[i] = from_base ? -1 : pos_of[J.in];
+    m.parent[i] = from_base ? nv - 1 : pos_of[J.in] + nv;                     // (a floating base link is link 5)
     m.jtype[i] = J.type;
     mat3Tmul(Rp, L.R, m.Rrel[i]);
     const double d[3] = { J.loc[0] - xp[0], J.loc[1] - xp[1], J.loc[2] - xp[2] };
@@ -840,7 +877,7 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
   // the base link's frame must be the model frame for the kinematics above: move everything into it
   {
     bool ident = true; for (int k = 0; k < 9; k++) if (B0.R[k] != ((k % 4 == 0) ? 1.0 : 0.0)) ident = false;
-    if (!ident || B0.x[0] != 0.0 || B0.x[1] != 0.0 || B0.x[2] != 0.0) {
+    if (!floating && (!ident || B0.x[0] != 0.0 || B0.x[1] != 0.0 || B0.x[2] != 0.0)) {        // (a floating body's model frame is the global frame)
       // joints hanging from the base: Rrel / trel were taken relative to the base pose; the model frame is then the base frame,
       // so gravity and the plane have to be expressed in it as well
       double g2[3]; mat3Tvec(B0.R, grav, g2); for (int k = 0; k < 3; k++) m.gravity[k] = g2[k];
@@ -855,9 +892,14 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
   std::vector<UrdfGeom> geoms;
   if (from_urdf) geoms = rob.geoms;
   else {
-    if (B0.has_cg) { UrdfGeom g; g.link = -1; g.id = base; g.sphere = false; g.radius = 0.0; g.center[0] = g.center[1] = g.center[2] = 0.0; geoms.push_back(g); }
-    for (int i = 0; i < m.nj; i++) {
-      const XLink& L = links[link_of[joints[order[i]].out]];
+    if (B0.has_cg && !floating) { UrdfGeom g; g.link = -1; g.id = base; g.sphere = false; g.radius = 0.0; g.center[0] = g.center[1] = g.center[2] = 0.0; geoms.push_back(g); }
+    if (B0.has_cg && floating) {                                             // the floating base link moves: link 5, its frame's origin is its COM
+      UrdfGeom g; g.link = 5; g.id = base; g.sphere = prims.count(B0.geom) && prims[B0.geom].type == MH_GEOM_SPHERE; g.radius = g.sphere ? prims[B0.geom].dim[0] : 0.0;
+      for (int k = 0; k < 3; k++) g.center[k] = g.sphere ? prims[B0.geom].o[k] : 0.0;
+      geoms.push_back(g);
+    }
+    for (int i = nv; i < m.nj; i++) {
+      const XLink& L = links[link_of[joints[order[i - nv]].out]];
       if (!L.has_cg) continue;
       UrdfGeom g; g.link = i; g.id = L.id; g.sphere = prims.count(L.geom) && prims[L.geom].type == MH_GEOM_SPHERE; g.radius = g.sphere ? prims[L.geom].dim[0] : 0.0;
       // centre in the model link frame (origin at the joint): COM offset + the primitive's own offset in the link's axes
@@ -883,9 +925,12 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
     // the plane: PlanePrimitive's +Y is the normal; body pose times primitive pose, expressed in the model (base) frame
     double Rw[9]; mat3mul(plane_Rb, plane_prim.R, Rw);
     double ow[3]; mat3vec(plane_Rb, plane_prim.o, ow); for (int k = 0; k < 3; k++) ow[k] += plane_x[k];
-    mat3Tmul(B0.R, Rw, m.plane_R);
-    const double dd[3] = { ow[0] - B0.x[0], ow[1] - B0.x[1], ow[2] - B0.x[2] };
-    mat3Tvec(B0.R, dd, m.plane_o);
+    if (floating) { for (int k = 0; k < 9; k++) m.plane_R[k] = Rw[k]; for (int k = 0; k < 3; k++) m.plane_o[k] = ow[k]; }
+    else {
+      mat3Tmul(B0.R, Rw, m.plane_R);
+      const double dd[3] = { ow[0] - B0.x[0], ow[1] - B0.x[1], ow[2] - B0.x[2] };
+      mat3Tvec(B0.R, dd, m.plane_o);
+    }
     m.cp_nk = 4;
     for (const CP& p : cps) {
       const std::string other = (p.a == plane_body) ? p.b : ((p.b == plane_body) ? p.a : std::string());

@@ -338,10 +338,11 @@ class Artic {
     plane_n(c.n); orthonormal_basis(c.n, c.sv, c.tv);
     return true;
   }
-  // the articulated CCD::calc_max_dist (CCD.cpp:545-583): fixed base (velocity 0), the chain of inner joints up to the base;
-  // a joint's pose is its link's frame origin
-  double calc_max_dist(int link, double rmax) const {
+  // the articulated CCD::calc_max_dist (CCD.cpp:545-583): the base's linear velocity along n (0 for a fixed base; for mh_artic_model.floating_base the rates of the
+  // three virtual sliders, which ARE the base link's COM velocity in global axes), then the chain of inner joints up to the base; a joint's pose is its link's frame origin
+  double calc_max_dist(int link, const double n[3], double rmax) const {
     double mv = 0.0;
+    if (m->floating_base) mv = (n[0] * qd[0] + n[1] * qd[1]) + n[2] * qd[2];
     int inner = link;
     mv = mv + (2.0 * rmax) * std::fabs(qd[inner]);
     while (m->parent[inner] >= 0) {
@@ -373,7 +374,9 @@ class Artic {
       if (point_vel_dir(V[c.link], c.p, c.n) < -A_NEAR_ZERO) return 0.0;
       return A_INF;
     }
-    const double tA = calc_max_dist(m->sphere_link[s], rmax_of(s));   // the plane's body is disabled: 0
+    double pn[3]; plane_n(pn);                                       // n0 = from the plane to the sphere; body A moves toward B along -n0 (CCD.cpp:214)
+    const double mn[3] = { -pn[0], -pn[1], -pn[2] };
+    const double tA = calc_max_dist(m->sphere_link[s], mn, rmax_of(s));   // the plane's body is disabled: 0
     double total = tA + 0.0;
     if (total < 0.0) total = 0.0;
     const double cand = dist / total;

@@ -1,0 +1,94 @@
+"""CPU: floating-base articulated bodies (RCArticulatedBody floating-base="true", src/RCArticulatedBody.cpp:172-175) as mh_io_load_xml_artic builds them -- six virtual
+1-DOF joints under the base link (include/moby_hip_artic.h, mh_artic_model.floating_base) -- and the one pin a reduced-coordinate body can have here: a floating base of
+ONE link is a free rigid body, which the maximal-coordinate oracle (oracle/world.hpp, pinned by the reference's own recordings) steps too."""
+import os
+
+import numpy as np
+import pytest
+
+from moby_amd import artic as A
+from moby_amd import io as mio
+from moby_amd import scene as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BALL = os.path.join(HERE, "scenes", "floating_spinning_ball.xml")
+PAIR = os.path.join(HERE, "scenes", "floating_hinged_pair.xml")
+
+
+def test_reader_puts_six_virtual_joints_under_a_floating_base():
+    m, links, joints, q0, qd0, dt = A.load_xml(PAIR)
+    assert m.nj == 7 and m.floating_base == 1 and dt == 0.001
+    assert links[5:] == ["torso", "foot"] and joints[6] == "hip" and joints[:6] == ["hopper.base-" + s for s in ("tx", "ty", "tz", "rx", "ry", "rz")]
+    assert list(m.parent[:7]) == [-1, 0, 1, 2, 3, 4, 5]
+    assert list(m.jtype[:7]) == [A.MH_JOINT_PRISMATIC] * 3 + [A.MH_JOINT_REVOLUTE] * 4
+    assert list(m.mass[:7]) == [0, 0, 0, 0, 0, 2.0, 0.5]
+    for v in range(6):
+        assert list(m.axis[v]) == [float(k == v % 3) for k in range(3)] and list(m.com[v]) == [0.0, 0.0, 0.0]
+        assert m.lolimit[v] == -np.finfo(float).max and m.hilimit[v] == np.finfo(float).max
+    # translate="0 0.25 0" moved the whole body: the base link's COM, the hinge, the foot
+    assert np.allclose(m.trel[0], [0.0, 0.30, 0.0], atol=1e-15) and list(m.trel[6]) == [0.2, 0.0, 0.0] and np.allclose(m.com[6], [0.25, -0.05, 0.0], atol=1e-15)
+    assert np.array_equal(q0, np.zeros(7)) and np.array_equal(qd0, [0.3, -0.5, 0.1, 0.2, 0.4, -1.5, 1.0])      # the base's velocities are the virtual joints' rates
+    assert (m.lolimit[6], m.hilimit[6], m.limit_restitution[6]) == (-0.6, 0.4, 0.0)
+    assert m.nspheres == 2 and list(m.sphere_link[:2]) == [5, 6] and list(m.gravity) == [0.0, -9.81, 0.0]      # the model frame is the global frame
+    assert m.cstab_max_iterations == 10 and m.cp_mu_coulomb == 100.0
+    # the turned ball: the link's frame is a quarter turn about z, the spin about the global vertical is the FIRST virtual hinge's
+    m, links, joints, q0, qd0, dt = A.load_xml(BALL)
+    assert m.nj == 6 and m.floating_base == 1 and links[5] == "ball" and m.nspheres == 1 and m.sphere_link[0] == 5
+    assert np.allclose(np.array(m.Rrel[3]).reshape(3, 3), [[0, -1, 0], [1, 0, 0], [0, 0, 1]], atol=1e-15) and list(m.trel[0]) == [0.0, 1.5, 0.0]
+    assert qd0[3] == 10.0 and abs(qd0[4]) < 1e-14 and qd0[5] == 0.0 and not qd0[:3].any()
+
+
+def test_reader_refusals(tmp_path):
+    src = open(PAIR).read()
+    p = tmp_path / "a.xml"
+    p.write_text(src.replace('floating-base="true"', 'floating-base="false"'))
+    with pytest.raises(mio.SceneError, match="translate is not supported on a fixed base"):
+        A.load_xml(str(p))
+    p.write_text(src.replace('translate="0 0.25 0"', 'translate="0 0.25 0" rpy="0 0 1"'))
+    with pytest.raises(mio.SceneError, match="rpy is not supported"):
+        A.load_xml(str(p))
+    p.write_text(src.replace('<Sphere id="torso-ball" radius="0.2" mass="2.0"/>', '<Sphere id="torso-ball" radius="0.2" mass="0.0"/>'))
+    with pytest.raises(mio.SceneError):
+        A.load_xml(str(p))
+    # eleven joints of the body's own + the six virtual ones do not fit MH_ARTIC_MAX_JOINTS
+    extra = "".join('<RigidBody id="x%d" position="%g 0 0"><InertiaFromPrimitive primitive-id="foot-ball"/></RigidBody>'
+                    '<RevoluteJoint id="jx%d" location="%g 0 0" inboard-link-id="%s" outboard-link-id="x%d" axis="0 0 1"/>' % (k, 0.5 + 0.1 * k, k, 0.45 + 0.1 * k, "foot" if k == 0 else "x%d" % (k - 1), k)
+                    for k in range(10))
+    p.write_text(src.replace("</RCArticulatedBody>", extra + "</RCArticulatedBody>"))
+    with pytest.raises(mio.SceneError, match="6 of the floating base"):
+        A.load_xml(str(p))
+
+
+@pytest.mark.parametrize("dt,steps,tol", [(1e-3, 3000, 1e-12), (0.025, 120, 1e-6)])
+def test_a_floating_base_of_one_link_is_the_free_rigid_body(oracle, dt, steps, tol):
+    """tests/scenes/floating_spinning_ball.xml against tests/scenes/dropped_spinning_ball.xml (BASELINE config 1 through oracle/world.hpp, the rigid-body stepper that the reference's four recordings pin --
+    sphere stack, sitting box, rimless wheel, pendulum; this scene itself has no recording in the tree): same ball, same drop, same spin; height, vertical velocity and spin over three seconds of bounces.  At dt = 1e-3 the two
+    agree to round-off; at the recording's dt = 0.025 to 1e-6 (conservative advancement bounds an articulated link's rotation differently: CCD.cpp:545-583 against :585-610)."""
+    m, _, _, q0, qd0, _ = A.load_xml(BALL)
+    sc, st0, ids, _ = mio.load_xml(os.path.join(HERE, "scenes", "dropped_spinning_ball.xml"))
+    q = q0.reshape(1, -1).copy(); qd = qd0.reshape(1, -1).copy(); aux = S.new_aux(1)
+    st = st0.copy().reshape(-1); auxw = S.new_aux(1)
+    traj = oracle.world_step(sc, st, auxw, dt, steps)["traj"]
+    b = ids.index("ball")
+    ya = np.zeros(steps)
+    for k in range(steps):
+        oracle.artic_step_general(m, q, qd, aux, dt, 1)
+        ya[k] = 1.5 + q[0, 1]
+    assert np.abs(ya - traj[:, b, 1]).max() < tol
+    assert abs(qd[0, 1] - st[13 * b + 8]) < 10 * tol and abs(qd[0, 3] - st[13 * b + 11]) < 1e-12          # vertical velocity; the spin about the vertical
+    assert aux["status"][0] == 0 and auxw["status"][0] == 0 and aux["lcp_solves"][0] == auxw["lcp_solves"][0] >= 3 and aux["mini_steps"][0] == auxw["mini_steps"][0] > steps
+    assert ya.min() > 1.0 - 1e-9                                                                          # conservative advancement sees the base coming down
+
+
+def test_generalized_inertia_of_a_floating_body_against_numpy(oracle):
+    """H(q) with the six virtual columns against sum_i J_i' M_i J_i (plain numpy kinematics), at random poses; its base block is what a free body's is:
+    total mass on the three sliders' diagonal."""
+    from tests.test_oracle_artic import numpy_H_and_energy
+    m, _, _, _, _, _ = A.load_xml(PAIR)
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        q = rng.uniform(-0.5, 0.5, 7); qd = rng.uniform(-1, 1, 7)
+        r = oracle.artic_fwd_dyn(m, q, qd)
+        H, _ = numpy_H_and_energy(m, q, qd)
+        assert r["ok"] and np.allclose(r["H"], H, rtol=1e-12, atol=1e-13)
+        assert np.allclose(np.diag(r["H"])[:3], 2.5, rtol=1e-13) and np.allclose(r["H"][:3, :3], 2.5 * np.eye(3), atol=1e-13)

@@ -1,0 +1,98 @@
+"""GPU parity of floating-base articulated bodies (mh_artic_model.floating_base: six virtual joints under the base link, include/moby_hip_artic.h) against
+oracle/artic.hpp, bit for bit through the C ABI: the contact kernels (Drumwright-Shell and no-slip models), the stabiliser's contact + limit rows, conservative
+advancement with the base's velocity, forward dynamics and calc_jacobian with the six base columns."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from moby_amd import artic as A
+from moby_amd import scene as S
+from tests.test_artic_contacts_gpu import run
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BALL = os.path.join(HERE, "scenes", "floating_spinning_ball.xml")
+PAIR = os.path.join(HERE, "scenes", "floating_hinged_pair.xml")
+
+
+def test_floating_ball_bounces_like_the_oracle(oracle):
+    """the free ball as a floating base of one link (tests/test_artic_floating.py ties the oracle's run to the rigid-body stepper): perturbed drops, restitution 1,
+    no friction -> the Drumwright-Shell model on the base link's contact; three seconds of bounces at two step sizes"""
+    m, _, _, q0, qd0, dt = A.load_xml(BALL)
+    B = 6
+    rng = np.random.default_rng(31)
+    q = np.tile(q0, (B, 1)); qd = np.tile(qd0, (B, 1))
+    q[1:, :3] += rng.uniform(-0.2, 0.2, (B - 1, 3)); qd[1:, :3] += rng.uniform(-0.5, 0.5, (B - 1, 3)); qd[1:, 3] += rng.uniform(-3, 3, B - 1)
+    aux = run(oracle, m, q, qd, nsteps=30, chunks=4, dt=dt)
+    assert (aux["lcp_solves"] > 0).all() and (aux["mini_steps"] > aux["steps"]).all() and (aux["status"] == 0).all()
+    aux = run(oracle, m, q, qd, nsteps=500, chunks=4, dt=1e-3)
+    assert (aux["lcp_solves"] > 0).all() and (aux["status"] == 0).all()
+
+
+@pytest.mark.parametrize("mu,iters", [(100.0, 10), (0.5, 10), (100.0, 0)])
+def test_floating_hinged_pair_lands_like_the_oracle(oracle, mu, iters):
+    """tests/scenes/floating_hinged_pair.xml: torso + foot on a hinge with limits, thrown onto the floor with spin; contact rows on the base link AND on the hinged link,
+    the hinge's limit, the stabiliser's mixed LCP (iters > 0) -- no-slip model (mu = 100) and Drumwright-Shell (mu = 0.5); perturbed copies of the file's state"""
+    m, _, _, q0, qd0, dt = A.load_xml(PAIR)
+    m.cp_mu_coulomb = mu; m.cstab_max_iterations = iters
+    B = 4 if iters else 8                     # (the oracle's stabiliser is what this test's seconds go to)
+    rng = np.random.default_rng(77)
+    q = np.tile(q0, (B, 1)); qd = np.tile(qd0, (B, 1))
+    q[1:, :3] += rng.uniform(-0.05, 0.05, (B - 1, 3)); q[1:, 3:6] += rng.uniform(-0.3, 0.3, (B - 1, 3)); q[1:, 6] = rng.uniform(-0.5, 0.3, B - 1)
+    qd[1:] += rng.uniform(-0.5, 0.5, (B - 1, 7))
+    aux = run(oracle, m, q, qd, nsteps=60 if iters else 150, chunks=4, dt=dt)
+    assert (aux["lcp_solves"] > 0).all() and (aux["mini_steps"] > aux["steps"]).all()
+    assert ((aux["status"] & ~S.MH_WORLD_IMPACT_TOL) == 0).all()
+    if iters:
+        assert (aux["stab_iters"] > 0).any()
+
+
+def test_floating_forward_dynamics_and_jacobian_seams(oracle):
+    """seam B4 and calc_jacobian with the six base columns: qdd, H(q), link poses and J at random states, both algorithms"""
+    m, _, _, _, _, _ = A.load_xml(PAIR)
+    B = 6
+    rng = np.random.default_rng(3)
+    q0 = rng.uniform(-0.6, 0.6, (B, 7)); qd0 = rng.uniform(-1, 1, (B, 7)); tau = rng.uniform(-1, 1, (B, 7))
+    pts = rng.uniform(-0.5, 0.5, (B, 3))
+    for alg in (A.MH_ARTIC_CRB, A.MH_ARTIC_FSAB):
+        m.algorithm = alg
+        ab = A.ArticBatch(m, q0, qd0)
+        qdd, H = ab.fwd_dyn(tau); poses = ab.link_poses()
+        for w in range(B):
+            r = oracle.artic_fwd_dyn(m, q0[w], qd0[w], tau[w])
+            assert np.array_equal(qdd[w], r["qdd"]) and np.array_equal(H[w], r["H"]) and np.array_equal(poses[w], r["poses"])
+        for link in (5, 6):
+            J = ab.jacobian(link, pts)
+            for w in range(B):
+                assert np.array_equal(J[w], oracle.artic_jacobian(m, q0[w], link, pts[w]))
+        ab.close()
+    # a free body falls: the sliders' accelerations are gravity whatever the pose, the hinges' bias is the gyroscopic one
+    m.algorithm = A.MH_ARTIC_CRB
+    ab = A.ArticBatch(m, q0, np.zeros_like(qd0)); qdd, _ = ab.fwd_dyn(None, want_H=False); ab.close()
+    assert np.allclose(qdd[:, :3], [0.0, -9.81, 0.0], atol=1e-12)
+
+
+def test_create_refuses_a_floating_layout_it_does_not_know():
+    """mh_artic_batch_create checks the virtual joints conservative advancement relies on, and that every joint moves mass"""
+    from moby_amd import _lib
+    lib = _lib.load()
+    def create(m):
+        h = ctypes.c_void_p()
+        rc = lib.mh_artic_batch_create(ctypes.byref(m), 1, ctypes.byref(h))
+        if rc == 0: lib.mh_artic_batch_destroy(h)
+        return rc
+    m = A.load_xml(PAIR)[0]
+    assert create(m) == 0
+    m.jtype[1] = A.MH_JOINT_REVOLUTE
+    assert create(m) != 0 and b"virtual joint" in lib.mh_last_error()
+    m = A.load_xml(PAIR)[0]; m.trel[2][0] = 0.1
+    assert create(m) != 0
+    m = A.load_xml(PAIR)[0]; m.floating_base = 2
+    assert create(m) != 0
+    m = A.load_xml(PAIR)[0]; m.mass[5] = 0.0; m.mass[6] = 0.0
+    assert create(m) != 0 and b"carries no mass" in lib.mh_last_error()
+    m = A.load_xml(PAIR)[0]; m.mass[5] = -1.0
+    assert create(m) != 0

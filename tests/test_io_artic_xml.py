@@ -51,7 +51,7 @@ def test_reference_example_files_load():
     assert m5.nj == 5 and list(m5.parent[:5]) == [-1, 0, 1, 2, 3]
     m1 = A.load_xml(os.path.join(REF, "reduced-coords", "pendulum.xml"))[0]
     assert m1.nj == 1 and m1.algorithm == A.MH_ARTIC_FSAB
-    for bad, why in (("reduced-coords/pendulum-gears-impact.xml", "floating"), ("tare/pendulum.xml", "q-tare"), ("reduced-coords/chain.xml", "Plane")):
+    for bad, why in (("reduced-coords/pendulum-gears-impact.xml", "q-tare"), ("fixed-joint/fixed-articulated-table.xml", "FixedJoint"), ("tare/pendulum.xml", "q-tare"), ("reduced-coords/chain.xml", "Plane")):
         with pytest.raises(mio.SceneError, match=why):
             A.load_xml(os.path.join(REF, bad))
 
