@@ -2,7 +2,8 @@
  * example/ur10/model.sdf x8192 initial states): reduced-coordinate forward dynamics by the composite-rigid-body
  * algorithm + Cholesky, and joint limits as unilateral constraints.
  *
- * Replaces, per world (one Moby::RCArticulatedBody with a fixed base and 1-DOF revolute / prismatic joints, which is
+ * Replaces, per world (one Moby::RCArticulatedBody with 1-DOF revolute / prismatic joints and a fixed base -- or a floating one carried by six virtual joints,
+ * mh_artic_model.floating_base -- which is
  * what SDFReader::read_model builds: eCRB + eLinkCOM, src/SDFReader.cpp:934-935),
  *   TimeSteppingSimulator::step / do_mini_step                        src/TimeSteppingSimulator.cpp:52-222
  *   Ravelin::RCArticulatedBodyd::calc_fwd_dyn (CRB or FSAB, mh_artic_model.algorithm)  [seam B4]

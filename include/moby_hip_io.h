@@ -72,7 +72,12 @@ int mh_io_load_sdf(const char* path, const double gravity[3], mh_io_artic* out);
  * Collision geometry is skipped here as in mh_io_load_sdf; mh_io_load_xml_artic (urdf-filename) keeps the <collision> spheres.  0 on success. */
 int mh_io_load_urdf(const char* path, const double gravity[3], mh_io_artic* out);
 
-/* A Moby XML file with ONE fixed-base <RCArticulatedBody> (the files of example/joint-limits, example/reduced-coords: RigidBody links
+/* A Moby XML file with ONE <RCArticulatedBody> -- fixed base, or floating-base="true" (RCArticulatedBody.cpp:172-175): then six VIRTUAL joints come first in the model
+ * (mh_artic_model.floating_base, include/moby_hip_artic.h: sliders along the global x, y, z and hinges about the base link's own x, y, z through its COM; link 5 is the base
+ * link, "<body id>.base-tx" ... "-rz" the joint ids), q0[0..5] = 0 is the pose the file states, qd0[0..2] the base link's linear-velocity and qd0[3..5] its angular-velocity in
+ * its own axes, translate="x y z" moves the whole body (:176-199; taken with a floating base only), the model frame is the global frame and the base link's collision geometry
+ * moves like any link's --
+ * (the files of example/joint-limits, example/reduced-coords: RigidBody links
  * with InertiaFromPrimitive | mass / inertia, <RevoluteJoint> / <PrismaticJoint> with location / axis in the global frame, lower-limits,
  * upper-limits, restitution-coeff, q, qd -- RCArticulatedBody.cpp:162-260, Joint.cpp:184-345, RevoluteJoint.cpp:39-55,
  * PrismaticJoint.cpp; or urdf-filename="..." (ArticulatedBody.cpp:250-273: links and joints from the URDF file next to the XML file, as

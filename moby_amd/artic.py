@@ -71,7 +71,7 @@ def load_urdf(path, gravity=(0.0, 0.0, -9.81)):
 
 
 def load_xml(path):
-    """-> (mh_artic_model, link names, joint names, q0, qd0, step size): a Moby XML file with one fixed-base RCArticulatedBody
+    """-> (mh_artic_model, link names, joint names, q0, qd0, step size): a Moby XML file with one RCArticulatedBody (fixed base, or floating-base="true": six virtual joints first, include/moby_hip_io.h)
     (include/moby_hip_io.h: mh_io_load_xml_artic) -- the model at q = 0, the joints' q / qd attributes as the initial state."""
     lib = mio.load()
     lib.mh_io_load_xml_artic.restype = ctypes.c_int

@@ -1,6 +1,7 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
 //
-// CPU restatement of one Moby world that holds ONE fixed-base RCArticulatedBody with 1-DOF joints (BASELINE config 5,
+// CPU restatement of one Moby world that holds ONE RCArticulatedBody with 1-DOF joints and a fixed base (a floating one: six virtual joints of the model,
+// mh_artic_model.floating_base; only conservative advancement reads the flag) (BASELINE config 5,
 // example/ur10): TimeSteppingSimulator::step -> forward dynamics (CRB or articulated-body algorithm) -> joint-limit constraints ->
 // the impact handler's no-slip path with NC = 0; and, when links carry sphere primitives (mh_artic_model.nspheres), the full step:
 // conservative advancement, mini-steps, contact rows through calc_jacobian, the no-slip model or the Drumwright-Shell QP over
