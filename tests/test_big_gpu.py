@@ -316,7 +316,7 @@ def test_config4_largest_solvable_size_against_the_oracles_fixture():
 
 
 def test_every_route_through_the_block_solver_gives_the_same_full_steps():
-    """The same six 16-box worlds, one full step, through every switch of the workgroup-per-problem solver -- states, rand() streams, pivot counts,
+    """The same six 12-box worlds (LCPs of 384 rows: every geometry's own size range, round 5: was 16 boxes and 64 s of the suite), one full step, through every switch of the workgroup-per-problem solver -- states, rand() streams, pivot counts,
     flags and warm-start sizes equal bit for bit (the oracle checks the default choice: the tests above and test_config4_bench_size_full_batch):
       * the lcp_lemke kinds' thread geometries (mh_debug_set key 2: 256 / 1024 / 64 / 128 threads per problem; panels of 16 / 16 / 8 / 12 columns,
         rounds of 16 / 16 / 4 / 8 steps in the left-looking LU);
@@ -325,7 +325,7 @@ def test_every_route_through_the_block_solver_gives_the_same_full_steps():
         after it (handed out by need, key 7, or by block index) and in sequence (key 4).
     (Round 4 had three tests of 6 / 12 / 12 worlds for this: 77 s of the GPU suite.)"""
     from moby_amd import _lib
-    N, B = CONFIG4_BOXES, 6
+    N, B = 12, 6
     sc = K.box_stack_scene(N)
     st0 = K.box_stack_state(N, B)
     lib = _lib.load()
@@ -347,7 +347,7 @@ def test_every_route_through_the_block_solver_gives_the_same_full_steps():
         assert np.array_equal(res[0][0], r[0]), sw
         for f in FIELDS:
             assert np.array_equal(res[0][1][f], r[1][f]), (sw, f)
-    assert (res[0][1]["lcp_pivots"] > 1000).all()
+    assert (res[0][1]["lcp_pivots"] > 300).all()
 
 
 def test_ladder_tasks_behind_the_gate_change_nothing(oracle):
