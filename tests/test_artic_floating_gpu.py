@@ -38,12 +38,17 @@ def test_floating_hinged_pair_lands_like_the_oracle(oracle, mu, iters):
     the hinge's limit, the stabiliser's mixed LCP (iters > 0) -- no-slip model (mu = 100) and Drumwright-Shell (mu = 0.5); perturbed copies of the file's state"""
     m, _, _, q0, qd0, dt = A.load_xml(PAIR)
     m.cp_mu_coulomb = mu; m.cstab_max_iterations = iters
-    B = 4 if iters else 8                     # (the oracle's stabiliser is what this test's seconds go to)
-    rng = np.random.default_rng(77)
+    # with the stabiliser on the run is short and starts just above the floor: the stabiliser parks a sphere ~2.5e-8 ABOVE the floor, and do_mini_step's conservative
+    # advancement (TSS:114-222) then creeps towards it in steps of min_step_size = 1.5e-8 s -- some twenty thousand kinematics passes per step of 1e-3 s while the body
+    # settles, in the oracle (13 ms per step) as on the device (0.1-0.4 s per step on one wavefront; tests/tools/floating_stab_timing.py).  The reference's algorithm, not
+    # a defect of either side -- so the long run with the hinge driven into its limit is the iters = 0 one
+    B = 3 if iters else 8
+    rng = np.random.default_rng(79 if iters else 77)
     q = np.tile(q0, (B, 1)); qd = np.tile(qd0, (B, 1))
     q[1:, :3] += rng.uniform(-0.05, 0.05, (B - 1, 3)); q[1:, 3:6] += rng.uniform(-0.3, 0.3, (B - 1, 3)); q[1:, 6] = rng.uniform(-0.5, 0.3, B - 1)
     qd[1:] += rng.uniform(-0.5, 0.5, (B - 1, 7))
-    aux = run(oracle, m, q, qd, nsteps=60 if iters else 150, chunks=4, dt=dt)
+    if iters: q[:, 1] -= 0.07
+    aux = run(oracle, m, q, qd, nsteps=20 if iters else 150, chunks=4, dt=dt)
     assert (aux["lcp_solves"] > 0).all() and (aux["mini_steps"] > aux["steps"]).all()
     assert ((aux["status"] & ~S.MH_WORLD_IMPACT_TOL) == 0).all()
     if iters:
