@@ -87,9 +87,18 @@ def load_xml(path):
             np.array(q0[:n]), np.array(qd0[:n]), dt.value)
 
 
-def model_from_links(links, gravity=(0.0, 0.0, -9.81)):
+def model_from_links(links, gravity=(0.0, 0.0, -9.81), floating_base=None):
     """links: dicts (parents first) with parent (-1 = base), type, R0 (3x3, model frame at q = 0), x0, axis (model frame),
-    com (link frame), inertia (3x3 about the COM, link axes), mass, lo, hi, restitution."""
+    com (link frame), inertia (3x3 about the COM, link axes), mass, lo, hi, restitution.
+    floating_base = dict(R0, x0, mass, inertia): the base link (pose of its COM frame in the global frame, inertia in its own axes) is carried by the six
+    virtual joints of mh_artic_model.floating_base (include/moby_hip_artic.h) -- joints 0..5 of the returned model, the base link is link 5, `links` follow
+    as joints 6.. with parent -1 meaning the base link; exactly what mh_io_load_xml_artic builds for floating-base="true"."""
+    if floating_base is not None:
+        Rb = np.asarray(floating_base["R0"], dtype=float); xb = np.asarray(floating_base["x0"], dtype=float)
+        virt = [dict(parent=v - 1, type=MH_JOINT_PRISMATIC if v < 3 else MH_JOINT_REVOLUTE, R0=np.eye(3) if v < 3 else Rb, x0=xb,
+                     axis=(np.eye(3) if v < 3 else Rb)[:, v % 3], com=(0.0, 0.0, 0.0), inertia=floating_base["inertia"] if v == 5 else np.zeros((3, 3)),
+                     mass=float(floating_base["mass"]) if v == 5 else 0.0) for v in range(6)]
+        links = virt + [dict(L, parent=5 if L["parent"] < 0 else L["parent"] + 6) for L in links]
     m = mh_artic_model()
     m.nj = len(links)
     for i, L in enumerate(links):
@@ -109,6 +118,14 @@ def model_from_links(links, gravity=(0.0, 0.0, -9.81)):
         m.limit_restitution[i] = L.get("restitution", 0.0)
     for k in range(3):
         m.gravity[k] = gravity[k]
+    if floating_base is not None:          # the layout mh_artic_batch_create checks, free of the round-off of Rb' Rb
+        m.floating_base = 1
+        for v in range(6):
+            for k in range(3):
+                m.axis[v][k] = float(k == v % 3)
+                if v > 0: m.trel[v][k] = 0.0
+            if v != 3:
+                for k in range(9): m.Rrel[v][k] = float(k % 4 == 0)
     m.cstab_eps = S.NEAR_ZERO              # ConstraintStabilization::eps (CStab:59); stabilisation itself off until cstab_max_iterations is set
     return m
 

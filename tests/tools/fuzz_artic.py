@@ -1,7 +1,8 @@
 """Fuzz of the articulated stepper with link contacts (mh_artic_model.nspheres > 0) against the oracle: random trees of 1-8
 revolute / prismatic joints, random link frames, masses and inertias, 1-4 spheres on random links, a random plane below the body,
 random limits (some active), restitution at limits and contacts, both forward-dynamics algorithms, random states; q, qd, the rand()
-stream, the warm start and the counters bit for bit.     python tests/tools/fuzz_artic.py [seed0] [cases]"""
+stream, the warm start and the counters bit for bit.  With `floating` every body rides on a FLOATING base (mh_artic_model.floating_base: six virtual joints under a
+base link of random pose and inertia, 0-6 joints of its own, spheres on any link including the base link).     python tests/tools/fuzz_artic.py [seed0] [cases] [floating]"""
 import os
 import sys
 import time
@@ -22,9 +23,12 @@ def rot(rng):
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
+FLOATING = False
+
+
 def make_case(seed):
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(1, 9))
+    n = int(rng.integers(0, 7)) if FLOATING else int(rng.integers(1, 9))
     links = []
     for i in range(n):
         p = -1 if i == 0 else int(rng.integers(max(0, i - 2), i))           # chains with a few branches
@@ -36,12 +40,20 @@ def make_case(seed):
         links.append(dict(parent=p, type=A.MH_JOINT_PRISMATIC if pris else A.MH_JOINT_REVOLUTE, R0=rot(rng), x0=xp + rng.uniform(-0.4, 0.4, 3) + np.array([0, 0, -0.3]),
                           axis=ax, com=rng.uniform(-0.15, 0.15, 3), inertia=J, mass=float(rng.uniform(0.5, 3.0)),
                           lo=lo * rng.uniform(0.3, 1.0), hi=hi * rng.uniform(0.3, 1.0), restitution=float(rng.choice([0.0, 0.0, 0.5]))))
-    m = A.model_from_links(links, gravity=(float(rng.uniform(-1, 1)), 0.0, -9.81))
+    fb = None
+    if FLOATING:
+        I = rot(rng); J = I @ np.diag(rng.uniform(0.02, 0.2, 3)) @ I.T
+        fb = dict(R0=rot(rng), x0=rng.uniform(-0.3, 0.3, 3), mass=float(rng.uniform(1.0, 5.0)), inertia=0.5 * (J + J.T))
+    m = A.model_from_links(links, gravity=(float(rng.uniform(-1, 1)), 0.0, -9.81), floating_base=fb)
     m.algorithm = int(rng.random() < 0.4)
     B = 4
-    q0 = np.column_stack([rng.uniform(0.8 * L["lo"], 0.8 * L["hi"], B) for L in links]); qd0 = rng.uniform(-2.0, 2.0, (B, n))
+    q0 = np.column_stack([rng.uniform(0.8 * L["lo"], 0.8 * L["hi"], B) for L in links]) if n else np.zeros((B, 0))
+    qd0 = rng.uniform(-2.0, 2.0, (B, n))
+    if FLOATING:        # the base: a small offset and a tilt well inside the middle hinge's +-pi/2, linear and angular rates
+        q0 = np.column_stack([rng.uniform(-0.2, 0.2, (B, 3)), rng.uniform(-0.5, 0.5, (B, 3)), q0]); qd0 = np.column_stack([rng.uniform(-1.0, 1.0, (B, 3)), rng.uniform(-2.0, 2.0, (B, 3)), qd0])
+        n += 6
     ns = int(rng.integers(1, A.MH_ARTIC_MAX_SPHERES + 1))
-    sph = [(int(rng.integers(0, n)), rng.uniform(-0.2, 0.2, 3), float(rng.uniform(0.03, 0.15))) for _ in range(ns)]
+    sph = [(int(rng.integers(5 if FLOATING else 0, n)), rng.uniform(-0.2, 0.2, 3), float(rng.uniform(0.03, 0.15))) for _ in range(ns)]
     return m, links, sph, q0, qd0, rng
 
 
@@ -63,6 +75,7 @@ if __name__ == "__main__":
     o = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
     seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 900
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    FLOATING = len(sys.argv) > 3 and sys.argv[3] == "floating"
     SKIP_AFTER = 5.0
     bad = solves = minis = multi = flagged = skipped = 0
     for case in range(cases):
@@ -93,6 +106,6 @@ if __name__ == "__main__":
                 [f for f in FIELDS if not np.array_equal(aux_g[f], aux_o[f])]), flush=True)
         else:                                  # (every case: a run that stops writing for minutes is taken to be hung on the GPU box)
             print("case %d ok (nj %d, %d spheres, %d LCP solves so far)" % (case, m.nj, m.nspheres, solves), flush=True)
-    print("fuzz_artic: %d cases from seed %d (%d skipped as too slow for the oracle), %d mismatches; %d LCP solves (%d world-runs with multi-row LCPs), %d extra mini-steps, %d flagged world-runs"
-          % (cases, seed0, skipped, bad, solves, multi, minis, flagged))
+    print("fuzz_artic%s: %d cases from seed %d (%d skipped as too slow for the oracle), %d mismatches; %d LCP solves (%d world-runs with multi-row LCPs), %d extra mini-steps, %d flagged world-runs"
+          % (" (floating bases)" if FLOATING else "", cases, seed0, skipped, bad, solves, multi, minis, flagged))
     sys.exit(1 if bad else 0)
