@@ -92,3 +92,21 @@ def test_generalized_inertia_of_a_floating_body_against_numpy(oracle):
         H, _ = numpy_H_and_energy(m, q, qd)
         assert r["ok"] and np.allclose(r["H"], H, rtol=1e-12, atol=1e-13)
         assert np.allclose(np.diag(r["H"])[:3], 2.5, rtol=1e-13) and np.allclose(r["H"][:3, :3], 2.5 * np.eye(3), atol=1e-13)
+
+
+def test_python_builder_makes_the_readers_floating_layout(oracle):
+    """moby_amd.artic.model_from_links(floating_base=...) -- the programmatic way to a floating body -- against the model mh_io_load_xml_artic builds from
+    tests/scenes/floating_hinged_pair.xml: same virtual joints, same numbers, same accelerations"""
+    mx, _, _, q0, qd0, _ = A.load_xml(PAIR)
+    I_t = 2.0 / 5.0 * 2.0 * 0.2 ** 2; I_f = 2.0 / 5.0 * 0.5 * 0.1 ** 2
+    foot = dict(parent=-1, type=A.MH_JOINT_REVOLUTE, R0=np.eye(3), x0=(0.2, 0.30, 0.0), axis=(0.0, 0.0, 1.0), com=(0.25, -0.05, 0.0), inertia=np.eye(3) * I_f, mass=0.5, lo=-0.6, hi=0.4)
+    mp = A.model_from_links([foot], gravity=(0.0, -9.81, 0.0), floating_base=dict(R0=np.eye(3), x0=(0.0, 0.30, 0.0), mass=2.0, inertia=np.eye(3) * I_t))
+    assert mp.nj == mx.nj == 7 and mp.floating_base == 1
+    for f in ("parent", "jtype", "mass", "lolimit", "hilimit"):
+        assert list(getattr(mp, f))[:7] == list(getattr(mx, f))[:7], f
+    for i in range(7):
+        assert np.allclose(mp.Rrel[i], mx.Rrel[i], atol=1e-15) and np.allclose(mp.trel[i], mx.trel[i], atol=1e-15) and list(mp.axis[i]) == list(mx.axis[i])
+        assert np.allclose(mp.com[i], mx.com[i], atol=1e-15) and np.allclose(mp.inertia[i], mx.inertia[i], rtol=1e-14, atol=1e-18)
+    q = np.array([0.1, -0.2, 0.05, 0.3, -0.4, 0.2, 0.1]); qd = np.array([0.3, -0.5, 0.1, 0.2, 0.4, -1.5, 1.0])
+    a, b = oracle.artic_fwd_dyn(mp, q, qd), oracle.artic_fwd_dyn(mx, q, qd)
+    assert a["ok"] and b["ok"] and np.allclose(a["qdd"], b["qdd"], rtol=1e-11, atol=1e-12)
