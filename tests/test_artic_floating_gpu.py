@@ -10,6 +10,7 @@ import pytest
 from moby_amd import artic as A
 from moby_amd import scene as S
 from tests.test_artic_contacts_gpu import run
+from tests.test_artic_gpu import assert_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -101,3 +102,20 @@ def test_create_refuses_a_floating_layout_it_does_not_know():
     assert create(m) != 0 and b"carries no mass" in lib.mh_last_error()
     m = A.load_xml(PAIR)[0]; m.mass[5] = -1.0
     assert create(m) != 0
+
+
+@pytest.mark.parametrize("iters", [0, 10])
+def test_floating_body_without_geometry_keeps_its_hinge_limits(oracle, iters):
+    """the torso + foot in free fall, no collision geometry: the kernels of config 5 (one mini-step per step; the stabilising one for iters > 0) with six virtual columns
+    in H, the hinge driven into both limits (and started beyond them) -> limit rows through the no-slip path with NC = 0.  The stabiliser itself never acts here, on either
+    side: evaluate_unilateral_constraints reads the slacks of joint [body index] = joint 0 (CStab:117, kept), which for a floating body is a virtual slider without limits."""
+    m, _, _, q0, qd0, dt = A.load_xml(PAIR)
+    m.nspheres = 0; m.cstab_max_iterations = iters
+    B = 6
+    rng = np.random.default_rng(5)
+    q = np.tile(q0, (B, 1)); qd = np.tile(qd0, (B, 1))
+    q[:, 6] = [0.0, 0.45, -0.7, 0.39, -0.59, 0.2]; qd[:, 6] = [1.0, 2.0, -2.0, 3.0, -3.0, 0.0]; qd[1:, :6] += rng.uniform(-1, 1, (B - 1, 6))
+    ab = A.ArticBatch(m, q, qd)
+    aux = assert_parity(ab, oracle, m, q, qd, dt, 75, 4)
+    ab.close()
+    assert (aux["lcp_solves"][1:5] > 0).all() and (aux["status"] == 0).all() and (aux["stab_iters"] == 0).all()
