@@ -76,7 +76,9 @@ int mh_io_load_urdf(const char* path, const double gravity[3], mh_io_artic* out)
  * (mh_artic_model.floating_base, include/moby_hip_artic.h: sliders along the global x, y, z and hinges about the base link's own x, y, z through its COM; link 5 is the base
  * link, "<body id>.base-tx" ... "-rz" the joint ids), q0[0..5] = 0 is the pose the file states, qd0[0..2] the base link's linear-velocity and qd0[3..5] its angular-velocity in
  * its own axes, translate="x y z" moves the whole body (:176-199; taken with a floating base only), the model frame is the global frame and the base link's collision geometry
- * moves like any link's --
+ * moves like any link's.  <FixedJoint> (either kind of base): the batch knows 1-DOF joints only, so the outboard link is WELDED onto the link that carries it, as
+ * mh_io_load_urdf does for a URDF "fixed" joint -- masses add up, the COM and the (then full) tensor about it follow the parallel-axis theorem, the welded link's
+ * collision geometry and the joints hanging from it ride on the carrier; its id stays known to <DisabledPair> / <ContactParameters> --
  * (the files of example/joint-limits, example/reduced-coords: RigidBody links
  * with InertiaFromPrimitive | mass / inertia, <RevoluteJoint> / <PrismaticJoint> with location / axis in the global frame, lower-limits,
  * upper-limits, restitution-coeff, q, qd -- RCArticulatedBody.cpp:162-260, Joint.cpp:184-345, RevoluteJoint.cpp:39-55,

@@ -687,7 +687,13 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
       if (prim_common(a, p, 0.0, "Plane")) return 1;
       prims[a.str("id")] = p; } }
   // ---- links and joints of the body ----
-  struct XLink { std::string id; double x[3]; double R[9]; double mass; double J[3]; std::string geom; bool has_cg; double v[3], w[3]; };
+  struct XWeldGeom { std::string id, prim; double x[3]; double R[9]; };      // the collision geometry of a link a FixedJoint welded onto this one: its link's pose at q = 0
+  struct XLink { std::string id; double x[3]; double R[9]; double mass; double J[3]; std::string geom; bool has_cg; double v[3], w[3];
+                 double cx[3];                                               // the COM: x, unless links were welded on (x stays where the link's own frame and geometry are)
+                 bool composite; double Jf[9];                               // links were welded on: cx is the common COM, Jf the full tensor about it in this link's axes
+                 std::vector<XWeldGeom> wg; };
+  struct XFixed { std::string id, in, out; };
+  std::vector<XFixed> fixeds;
   struct XJoint { std::string id, in, out; int type; double loc[3], axis[3], lo, hi, q, qd, resti; };
   std::vector<XLink> links; std::vector<XJoint> joints;
   for (xmlNode* c = from_urdf ? nullptr : ab->children; c; c = c->next) {
@@ -699,7 +705,8 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
       for (int i = 0; i < 3; i++) L.x[i] = L.v[i] = L.w[i] = 0.0;
       for (int i = 0; i < 9; i++) L.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
       if (a.has("position")) { const std::vector<double> p = numbers(a.str("position")); if (p.size() != 3) return fail("link %s: bad position", L.id.c_str()); for (int i = 0; i < 3; i++) L.x[i] = p[i]; }
-      for (int i = 0; i < 3; i++) L.x[i] += shift[i];
+      for (int i = 0; i < 3; i++) { L.x[i] += shift[i]; L.cx[i] = L.x[i]; }
+      L.composite = false;
       if (a.has("linear-velocity")) { const std::vector<double> p = numbers(a.str("linear-velocity")); if (p.size() != 3) return fail("link %s: bad linear-velocity", L.id.c_str()); for (int i = 0; i < 3; i++) L.v[i] = p[i]; }
       if (a.has("angular-velocity")) { const std::vector<double> p = numbers(a.str("angular-velocity")); if (p.size() != 3) return fail("link %s: bad angular-velocity", L.id.c_str()); for (int i = 0; i < 3; i++) L.w[i] = p[i]; }
       if (a.has("rpy")) { const std::vector<double> r = numbers(a.str("rpy")); if (r.size() != 3) return fail("link %s: bad rpy", L.id.c_str()); rpy_to_R(r[0], r[1], r[2], L.R); }
@@ -736,12 +743,60 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
       if ((a.has("coulomb-friction-coeff") && std::atof(a.str("coulomb-friction-coeff").c_str()) != 0.0) ||
           (a.has("viscous-friction-coeff") && std::atof(a.str("viscous-friction-coeff").c_str()) != 0.0)) return fail("joint %s: joint friction is not supported", J.id.c_str());
       joints.push_back(J);
-    } else if (nm.size() > 5 && nm.compare(nm.size() - 5, 5, "Joint") == 0) return fail("%s %s: only revolute and prismatic joints are supported", nm.c_str(), a.str("id").c_str());
+    } else if (nm == "FixedJoint") {                                       // zero DOF: the outboard link rides on the inboard one (welded below)
+      XFixed F; F.id = a.str("id"); F.in = a.str("inboard-link-id"); F.out = a.str("outboard-link-id");
+      fixeds.push_back(F);
+    } else if (nm.size() > 5 && nm.compare(nm.size() - 5, 5, "Joint") == 0) return fail("%s %s: only revolute, prismatic and fixed joints are supported", nm.c_str(), a.str("id").c_str());
+  }
+  // ---- FixedJoints: the batch knows 1-DOF joints only, and in reduced coordinates a zero-DOF joint makes ONE rigid body of its two links (as mh_io_load_urdf does for a URDF
+  // "fixed" joint): masses add up, the COM and the tensor about it follow the parallel-axis theorem, the welded link's collision geometry and the joints hanging from it
+  // ride on the carrier.  Everything in the file is global at q = 0, so the merge is done in global coordinates.
+  std::map<std::string, std::string> welded_to;                             // welded link -> the link that ends up carrying it
+  if (!fixeds.empty()) {
+    std::map<std::string, std::string> onto;
+    std::map<std::string, int> li; for (size_t i = 0; i < links.size(); i++) li[links[i].id] = (int)i;
+    for (const XFixed& F : fixeds) {
+      if (!li.count(F.in) || !li.count(F.out)) return fail("FixedJoint %s: unknown link", F.id.c_str());
+      if (onto.count(F.out)) return fail("link %s is the outboard link of two joints (closed chains are not supported)", F.out.c_str());
+      for (const XJoint& J : joints) if (J.out == F.out) return fail("link %s is the outboard link of two joints (closed chains are not supported)", F.out.c_str());
+      onto[F.out] = F.in;
+    }
+    for (const auto& kv : onto) {
+      std::string t = kv.second; size_t guard = 0;
+      while (onto.count(t)) { t = onto[t]; if (++guard > links.size()) return fail("FixedJoint %s: a loop of fixed joints", kv.first.c_str()); }
+      welded_to[kv.first] = t;
+    }
+    auto global_tensor = [](const XLink& L, double* Jw) {                   // R diag(J) R' (or R Jf R' for a composite)
+      double D[9] = { L.J[0], 0, 0, 0, L.J[1], 0, 0, 0, L.J[2] }, T[9];
+      mat3mul(L.R, L.composite ? L.Jf : D, T);
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Jw[3*i+j] = (T[3*i] * L.R[3*j] + T[3*i+1] * L.R[3*j+1]) + T[3*i+2] * L.R[3*j+2];
+    };
+    for (XLink& T : links) {
+      if (welded_to.count(T.id)) continue;
+      std::vector<const XLink*> parts;
+      for (const XLink& W : links) if (welded_to.count(W.id) && welded_to[W.id] == T.id) parts.push_back(&W);
+      if (parts.empty()) continue;
+      double M = T.mass, c[3] = { T.mass * T.x[0], T.mass * T.x[1], T.mass * T.x[2] };
+      for (const XLink* W : parts) { M += W->mass; for (int k = 0; k < 3; k++) c[k] += W->mass * W->x[k]; }
+      if (M > 0.0) for (int k = 0; k < 3; k++) c[k] /= M; else for (int k = 0; k < 3; k++) c[k] = T.x[k];
+      double Jw[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+      auto add = [&](const XLink& L) { double Jl[9]; global_tensor(L, Jl); const double d[3] = { L.x[0] - c[0], L.x[1] - c[1], L.x[2] - c[2] }; const double dd = (d[0]*d[0] + d[1]*d[1]) + d[2]*d[2];
+        for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) Jw[3*r+q] += Jl[3*r+q] + L.mass * (((r == q) ? dd : 0.0) - d[r] * d[q]); };
+      add(T); for (const XLink* W : parts) add(*W);
+      for (const XLink* W : parts) if (W->has_cg) { XWeldGeom g; g.id = W->id; g.prim = W->geom; for (int k = 0; k < 3; k++) g.x[k] = W->x[k]; for (int k = 0; k < 9; k++) g.R[k] = W->R[k]; T.wg.push_back(g); }
+      double A[9]; mat3Tmul(T.R, Jw, A); mat3mul(A, T.R, T.Jf);
+      T.Jf[1] = T.Jf[3]; T.Jf[2] = T.Jf[6]; T.Jf[5] = T.Jf[7];              // exactly symmetric
+      T.composite = true; T.mass = M; for (int k = 0; k < 3; k++) T.cx[k] = c[k];
+    }
+    for (XJoint& J : joints) { if (welded_to.count(J.in)) J.in = welded_to[J.in]; }
+    std::vector<XLink> kept; for (const XLink& L : links) if (!welded_to.count(L.id)) kept.push_back(L);
+    links.swap(kept);
   }
   if (!from_urdf && joints.empty() && !floating) return fail("%s: an articulated body without joints", path);
   const int nv = floating ? 6 : 0;                                           // virtual joints in front of the file's
   if ((int)joints.size() + nv > MH_ARTIC_MAX_JOINTS) return fail("%zu joints%s > %d", joints.size(), floating ? " + 6 of the floating base" : "", MH_ARTIC_MAX_JOINTS);
   std::map<std::string, int> link_of; for (size_t i = 0; i < links.size(); i++) link_of[links[i].id] = (int)i;
+  for (const auto& kv : welded_to) link_of[kv.first] = link_of[kv.second];
   if (from_urdf) for (size_t i = 0; i < rob.link_names.size(); i++) link_of[rob.link_names[i]] = (int)i;   // (ids only: ContactParameters / DisabledPair may name a link)
   std::map<std::string, int> carried;                                      // outboard link -> joint
   for (size_t j = 0; j < joints.size(); j++) {
@@ -815,7 +870,7 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
   { std::string alg = aa.has("fdyn-algorithm") ? aa.str("fdyn-algorithm") : "crb"; for (char& ch : alg) ch = (char)tolower(ch);
     alg.erase(0, alg.find_first_not_of(" \t\n\r")); alg.erase(alg.find_last_not_of(" \t\n\r") + 1);
     if (alg == "fsab") m.algorithm = MH_ARTIC_FSAB; else if (alg == "crb") m.algorithm = MH_ARTIC_CRB; else return fail("fdyn-algorithm '%s': crb or fsab", alg.c_str()); }
-  XLink urdf_base; urdf_base.id = base; urdf_base.mass = 0.0; urdf_base.has_cg = false;      // a URDF robot's base link frame is the model frame
+  XLink urdf_base; urdf_base.id = base; urdf_base.mass = 0.0; urdf_base.has_cg = false; urdf_base.composite = false; urdf_base.cx[0] = urdf_base.cx[1] = urdf_base.cx[2] = 0.0;      // a URDF robot's base link frame is the model frame
   for (int k = 0; k < 3; k++) { urdf_base.x[k] = 0.0; urdf_base.J[k] = 0.0; }
   for (int k = 0; k < 9; k++) urdf_base.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
   const XLink& B0 = from_urdf ? urdf_base : links[link_of[base]];
@@ -827,13 +882,13 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
   }
   if (floating) {
     m.floating_base = 1;
-    if (!(B0.mass > 0.0) || !(B0.J[0] > 0.0) || !(B0.J[1] > 0.0) || !(B0.J[2] > 0.0)) return fail("link %s: a floating base link needs mass and inertia", B0.id.c_str());
+    if (!(B0.mass > 0.0) || !((B0.composite ? B0.Jf[0] : B0.J[0]) > 0.0) || !((B0.composite ? B0.Jf[4] : B0.J[1]) > 0.0) || !((B0.composite ? B0.Jf[8] : B0.J[2]) > 0.0)) return fail("link %s: a floating base link needs mass and inertia", B0.id.c_str());
     static const char* const vname[6] = { "tx", "ty", "tz", "rx", "ry", "rz" };
     for (int v = 0; v < 6; v++) {
       m.parent[v] = v - 1;
       m.jtype[v] = (v < 3) ? MH_JOINT_PRISMATIC : MH_JOINT_REVOLUTE;
       for (int k = 0; k < 9; k++) m.Rrel[v][k] = (v == 3) ? B0.R[k] : ((k % 4 == 0) ? 1.0 : 0.0);
-      for (int k = 0; k < 3; k++) { m.trel[v][k] = (v == 0) ? B0.x[k] : 0.0; m.axis[v][k] = (k == v % 3) ? 1.0 : 0.0; m.com[v][k] = 0.0; }
+      for (int k = 0; k < 3; k++) { m.trel[v][k] = (v == 0) ? B0.cx[k] : 0.0; m.axis[v][k] = (k == v % 3) ? 1.0 : 0.0; m.com[v][k] = 0.0; }
       for (int k = 0; k < 9; k++) m.inertia[v][k] = 0.0;
       m.mass[v] = 0.0;
       m.lolimit[v] = -1.7976931348623157e308; m.hilimit[v] = 1.7976931348623157e308; m.limit_restitution[v] = 0.0;
@@ -842,6 +897,7 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
       snprintf(out->joint_id[v], MH_IO_ID_LEN, "%.40s.base-%s", abid.c_str(), vname[v]);
     }
     m.mass[5] = B0.mass; m.inertia[5][0] = B0.J[0]; m.inertia[5][4] = B0.J[1]; m.inertia[5][8] = B0.J[2];
+    if (B0.composite) for (int k = 0; k < 9; k++) m.inertia[5][k] = B0.Jf[k];
     if (qd0) { double wl[3]; mat3Tvec(B0.R, B0.w, wl); for (int k = 0; k < 3; k++) { qd0[k] = B0.v[k]; qd0[3 + k] = wl[k]; } }
   }
   for (int i0 = 0; i0 < (from_urdf ? 0 : m.nj - nv); i0++) {
@@ -852,7 +908,7 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
     // the model's link frame i: origin at the joint location, axes of the link; the base link's frame is the model frame
     const double* Rp = from_base ? B0.R : links[link_of[J.in]].R;
     double xp[3];                                                            // origin of the parent frame: its own joint's location (base: the base link's position)
-    if (from_base) for (int k = 0; k < 3; k++) xp[k] = B0.x[k]; else for (int k = 0; k < 3; k++) xp[k] = joints[order[pos_of[J.in]]].loc[k];
+    if (from_base) for (int k = 0; k < 3; k++) xp[k] = floating ? B0.cx[k] : B0.x[k]; else for (int k = 0; k < 3; k++) xp[k] = joints[order[pos_of[J.in]]].loc[k];
     m.parent[i] = from_base ? nv - 1 : pos_of[J.in] + nv;                     // (a floating base link is link 5)
     m.jtype[i] = J.type;
     mat3Tmul(Rp, L.R, m.Rrel[i]);
@@ -862,12 +918,13 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
     const double nrm = std::sqrt(al[0]*al[0] + al[1]*al[1] + al[2]*al[2]);
     if (!(nrm > 0.0)) return fail("joint %s: zero axis", J.id.c_str());
     for (int k = 0; k < 3; k++) m.axis[i][k] = al[k] / nrm;
-    const double dc[3] = { L.x[0] - J.loc[0], L.x[1] - J.loc[1], L.x[2] - J.loc[2] };   // the RigidBody position is its COM
+    const double dc[3] = { L.cx[0] - J.loc[0], L.cx[1] - J.loc[1], L.cx[2] - J.loc[2] };   // the RigidBody position is its COM (a composite's: the common one)
     mat3Tvec(L.R, dc, m.com[i]);
     if (!(L.mass > 0.0)) return fail("link %s: no mass (InertiaFromPrimitive or mass / inertia)", L.id.c_str());
     m.mass[i] = L.mass;
     for (int k = 0; k < 9; k++) m.inertia[i][k] = 0.0;
     m.inertia[i][0] = L.J[0]; m.inertia[i][4] = L.J[1]; m.inertia[i][8] = L.J[2];
+    if (L.composite) for (int k = 0; k < 9; k++) m.inertia[i][k] = L.Jf[k];
     m.lolimit[i] = J.lo; m.hilimit[i] = J.hi; m.limit_restitution[i] = J.resti;
     if (q0) q0[i] = J.q;
     if (qd0) qd0[i] = J.qd;
@@ -893,17 +950,36 @@ int mh_io_load_xml_artic(const char* path, mh_io_artic* out, double* q0, double*
   if (from_urdf) geoms = rob.geoms;
   else {
     if (B0.has_cg && !floating) { UrdfGeom g; g.link = -1; g.id = base; g.sphere = false; g.radius = 0.0; g.center[0] = g.center[1] = g.center[2] = 0.0; geoms.push_back(g); }
+    // geometry that a FixedJoint welded onto model link `link` (frame: origin `org`, axes RT): the welded link's pose at q = 0 seen from there
+    auto add_welded = [&](const XLink& T, int link, const double* org) {
+      for (const XWeldGeom& w : T.wg) {
+        UrdfGeom g; g.link = link; g.id = w.id; g.sphere = prims.count(w.prim) && prims[w.prim].type == MH_GEOM_SPHERE; g.radius = g.sphere ? prims[w.prim].dim[0] : 0.0;
+        const double d[3] = { w.x[0] - org[0], w.x[1] - org[1], w.x[2] - org[2] };
+        double a[3], Rr[9], b[3] = { 0.0, 0.0, 0.0 };
+        mat3Tvec(T.R, d, a); mat3Tmul(T.R, w.R, Rr); if (g.sphere) mat3vec(Rr, prims[w.prim].o, b);
+        for (int k = 0; k < 3; k++) g.center[k] = a[k] + b[k];
+        geoms.push_back(g);
+      }
+    };
     if (B0.has_cg && floating) {                                             // the floating base link moves: link 5, its frame's origin is its COM
       UrdfGeom g; g.link = 5; g.id = base; g.sphere = prims.count(B0.geom) && prims[B0.geom].type == MH_GEOM_SPHERE; g.radius = g.sphere ? prims[B0.geom].dim[0] : 0.0;
       for (int k = 0; k < 3; k++) g.center[k] = g.sphere ? prims[B0.geom].o[k] : 0.0;
+      if (B0.composite) { const double d[3] = { B0.x[0] - B0.cx[0], B0.x[1] - B0.cx[1], B0.x[2] - B0.cx[2] }; double a[3]; mat3Tvec(B0.R, d, a); for (int k = 0; k < 3; k++) g.center[k] += a[k]; }
       geoms.push_back(g);
     }
+    if (floating) add_welded(B0, 5, B0.cx);
+    else for (const XWeldGeom& w : B0.wg) { UrdfGeom g; g.link = -1; g.id = w.id; g.sphere = false; g.radius = 0.0; g.center[0] = g.center[1] = g.center[2] = 0.0; geoms.push_back(g); }   // rides on the fixed base: static
     for (int i = nv; i < m.nj; i++) {
       const XLink& L = links[link_of[joints[order[i - nv]].out]];
+      add_welded(L, i, joints[order[i - nv]].loc);
       if (!L.has_cg) continue;
       UrdfGeom g; g.link = i; g.id = L.id; g.sphere = prims.count(L.geom) && prims[L.geom].type == MH_GEOM_SPHERE; g.radius = g.sphere ? prims[L.geom].dim[0] : 0.0;
       // centre in the model link frame (origin at the joint): COM offset + the primitive's own offset in the link's axes
       for (int k = 0; k < 3; k++) g.center[k] = m.com[i][k] + (g.sphere ? prims[L.geom].o[k] : 0.0);
+      if (L.composite) {                                                     // (the COM has moved away from the link's own position, where its geometry is)
+        const double* jl = joints[order[i - nv]].loc; const double d[3] = { L.x[0] - jl[0], L.x[1] - jl[1], L.x[2] - jl[2] }; double a[3]; mat3Tvec(L.R, d, a);
+        for (int k = 0; k < 3; k++) g.center[k] = a[k] + (g.sphere ? prims[L.geom].o[k] : 0.0);
+      }
       geoms.push_back(g);
     }
   }

@@ -110,3 +110,54 @@ def test_python_builder_makes_the_readers_floating_layout(oracle):
     q = np.array([0.1, -0.2, 0.05, 0.3, -0.4, 0.2, 0.1]); qd = np.array([0.3, -0.5, 0.1, 0.2, 0.4, -1.5, 1.0])
     a, b = oracle.artic_fwd_dyn(mp, q, qd), oracle.artic_fwd_dyn(mx, q, qd)
     assert a["ok"] and b["ok"] and np.allclose(a["qdd"], b["qdd"], rtol=1e-11, atol=1e-12)
+
+
+def test_fixed_joints_weld_links_into_one_rigid_body(oracle, tmp_path):
+    """tests/scenes/floating_welded_pair.xml: FixedJoints (a turned hat with an uneven tensor on the torso, a toe on the foot, a tail hinged to the HAT).  A zero-DOF
+    joint is a 1-DOF joint that never moves, so the welded model must be the UNWELDED one (the same file with the FixedJoints turned into hinges) with those hinges'
+    rows and columns struck out at angle 0: generalized inertia, bias forces, link poses and the spheres' positions -- which checks masses, the common COM, the turned
+    tensor, the parallel-axis terms, the re-hung joint and the welded geometry in one go, against numbers the welding code never touched."""
+    W = os.path.join(HERE, "scenes", "floating_welded_pair.xml")
+    src = open(W).read()
+    p = tmp_path / "unwelded.xml"
+    p.write_text(src.replace('<FixedJoint id="glue" location="0 0.2 0.05"', '<RevoluteJoint id="glue" axis="0 1 0" location="0 0.2 0.05"')
+                    .replace('<FixedJoint id="glue2" location="0.5 0 0"', '<RevoluteJoint id="glue2" axis="1 0 0" location="0.5 0 0"')
+                    .replace('<DisabledPair object1-id="hopper" object2-id="hopper"/>', '<DisabledPair object1-id="hopper" object2-id="hopper"/><DisabledPair object1-id="hopper" object2-id="ground"/>'))
+    mw, lw, jw, q0, qd0, _ = A.load_xml(W)
+    mu, lu, ju, _, _, _ = A.load_xml(str(p))
+    assert mw.nj == 8 and mu.nj == 10 and jw[6:] == ["hip", "wag"] and lw[5:] == ["torso", "foot", "tail"] and list(mw.parent[:8]) == [-1, 0, 1, 2, 3, 4, 5, 5]
+    assert mw.mass[5] == pytest.approx(2.3) and mw.mass[6] == pytest.approx(0.6) and mw.nspheres == 4 and sorted(mw.sphere_link[:4]) == [5, 5, 6, 6]
+    keep = [ju.index(n) for n in jw]                                   # the welded model's joints inside the unwelded one (virtual ones included)
+    # the unwelded base link's frame sits at the torso's own COM, the welded one's at the common COM: the same body, a different reference point
+    c = np.array(mw.trel[0]) - np.array(mu.trel[0])
+    rng = np.random.default_rng(11)
+    for _ in range(5):
+        qw = rng.uniform(-0.5, 0.5, 8); qdw = rng.uniform(-1, 1, 8); qw[:6] = 0.0; qdw[3:6] = 0.0          # (base at the file's pose and not turning: the two frames' sliders then carry the same numbers)
+        qu = np.zeros(10); qdu = np.zeros(10); qu[keep] = qw; qdu[keep] = qdw
+        a, b = oracle.artic_fwd_dyn(mw, qw, qdw), oracle.artic_fwd_dyn(mu, qu, qdu)
+        Hs = b["H"][np.ix_(keep, keep)]
+        # rows / columns of the real joints and of the sliders do not depend on the base link's reference point
+        idx = [0, 1, 2, 6, 7]
+        assert np.allclose(a["H"][np.ix_(idx, idx)], Hs[np.ix_(idx, idx)], rtol=1e-12, atol=1e-14)
+        assert np.allclose(a["C"][idx], b["C"][keep][idx], rtol=1e-11, atol=1e-12)
+        for lw_i, name in ((6, "foot"), (7, "tail")):
+            assert np.allclose(a["poses"][lw_i], b["poses"][lu.index(name)], atol=1e-14)
+    # the base's rotational block: the two models measure the same motion from two reference points (torso's COM / common COM of torso + hat), so the KINETIC ENERGY of
+    # one motion -- base turning at w while its reference point moves at v, joints moving -- must agree: the turned hat's tensor and every parallel-axis term are in there
+    for _ in range(5):
+        qw = np.zeros(8); qw[6:] = rng.uniform(-0.5, 0.5, 2); qu = np.zeros(10); qu[keep] = qw
+        w = rng.uniform(-1, 1, 3); v = rng.uniform(-1, 1, 3); jr = rng.uniform(-1, 1, 2)
+        qdu = np.zeros(10); qdu[:3] = v; qdu[3:6] = w; qdu[[keep[6], keep[7]]] = jr
+        qdw = np.zeros(8); qdw[:3] = v + np.cross(w, c); qdw[3:6] = w; qdw[6:] = jr
+        Hw = oracle.artic_fwd_dyn(mw, qw, qdw)["H"]; Hu = oracle.artic_fwd_dyn(mu, qu, qdu)["H"]
+        assert qdw @ Hw @ qdw == pytest.approx(qdu @ Hu @ qdu, rel=1e-12)
+    # spheres against the file: torso, hat (its primitive sits 0.02 along the hat's own y), foot, toe -- at q = 0
+    a = oracle.artic_fwd_dyn(mw, np.zeros(8), np.zeros(8))
+    P = a["poses"]
+    got = {round(float(mw.sphere_radius[s]), 3): P[mw.sphere_link[s], 9:12] + P[mw.sphere_link[s], :9].reshape(3, 3) @ np.array(mw.sphere_center[s]) for s in range(4)}
+    assert np.allclose(got[0.2], [0.0, 0.30, 0.0], atol=1e-14) and np.allclose(got[0.1], [0.45, 0.25, 0.0], atol=1e-14) and np.allclose(got[0.04], [0.58, 0.23, 0.01], atol=1e-14)
+    hat = np.array([0.0, 0.55, 0.1]); assert abs(np.linalg.norm(got[0.05] - hat) - 0.02) < 1e-14
+    # the base link's frame moved from the torso's COM to the common COM of torso + hat
+    assert np.allclose(c, [0.0, 0.3326086956521739 - 0.30, 0.013043478260869566], atol=1e-15)
+    # total mass on the sliders
+    assert np.allclose(a["H"][:3, :3], (2.3 + 0.6 + 0.2) * np.eye(3), atol=1e-13)

@@ -51,7 +51,7 @@ def test_reference_example_files_load():
     assert m5.nj == 5 and list(m5.parent[:5]) == [-1, 0, 1, 2, 3]
     m1 = A.load_xml(os.path.join(REF, "reduced-coords", "pendulum.xml"))[0]
     assert m1.nj == 1 and m1.algorithm == A.MH_ARTIC_FSAB
-    for bad, why in (("reduced-coords/pendulum-gears-impact.xml", "q-tare"), ("fixed-joint/fixed-articulated-table.xml", "FixedJoint"), ("tare/pendulum.xml", "q-tare"), ("reduced-coords/chain.xml", "Plane")):
+    for bad, why in (("reduced-coords/pendulum-gears-impact.xml", "q-tare"), ("fixed-joint/fixed-articulated-table.xml", "only Sphere collision geometry"), ("tare/pendulum.xml", "q-tare"), ("reduced-coords/chain.xml", "Plane")):
         with pytest.raises(mio.SceneError, match=why):
             A.load_xml(os.path.join(REF, bad))
 
@@ -61,7 +61,7 @@ def test_unsupported_files_are_rejected(tmp_path):
     cases = {"floating": src.replace('floating-base="false"', 'floating-base="true"'),
              "link-link": src.replace('<DisabledPair object1-id="arm" object2-id="arm" />', ""),
              "only Sphere": src.replace('<DisabledPair object1-id="l1" object2-id="ground" />', ""),
-             "revolute and prismatic": src.replace("<PrismaticJoint", "<SphericalJoint"),
+             "revolute, prismatic and fixed": src.replace("<PrismaticJoint", "<SphericalJoint"),
              "1-DOF": src.replace('lower-limits="-2"', 'lower-limits="-2 0"')}
     for why, text in cases.items():
         p = tmp_path / "x.xml"; p.write_text(text)
@@ -76,3 +76,23 @@ def test_loaded_arm_steps_in_the_oracle(oracle):
     oracle.artic_step(m, q, qd, aux, dt, 1500)
     assert aux["status"][0] & ~S.MH_WORLD_IMPACT_TOL == 0 and aux["lcp_solves"][0] > 0 and aux["mini_steps"][0] > 1500
     assert -0.5 - 1e-2 < q[0, 1] < 1.5 + 1e-2 and -0.05 - 1e-2 < q[0, 2] < 0.1 + 1e-2
+
+
+def test_fixed_joint_on_a_fixed_base_arm_welds_the_tip(oracle, tmp_path):
+    """arm_on_table.xml with its slider turned into a FixedJoint: l3 (and its tip sphere) ride on l2 -- the two-joint model's generalized inertia and bias are the
+    three-joint model's with the slider's row and column struck out at q = 0, the tip sphere sits where it sat"""
+    src = open(ARM).read()
+    p = tmp_path / "welded.xml"
+    p.write_text(src.replace('<PrismaticJoint id="slider" q="0" qd="0"', '<FixedJoint id="slider"'))
+    m3 = A.load_xml(ARM)[0]
+    m2, links, joints, q0, qd0, _ = A.load_xml(str(p))
+    assert m2.nj == 2 and links == ["l1", "l2"] and joints == ["shoulder", "elbow"] and m2.mass[1] == pytest.approx(m3.mass[1] + m3.mass[2])
+    assert m2.nspheres == 2 and list(m2.sphere_link[:2]) == [1, 1]
+    rng = np.random.default_rng(2)
+    for _ in range(4):
+        q = rng.uniform(-1, 1, 2); qd = rng.uniform(-2, 2, 2)
+        a = oracle.artic_fwd_dyn(m2, q, qd); b = oracle.artic_fwd_dyn(m3, np.append(q, 0.0), np.append(qd, 0.0))
+        assert np.allclose(a["H"], b["H"][:2, :2], rtol=1e-12, atol=1e-15) and np.allclose(a["C"], b["C"][:2], rtol=1e-11, atol=1e-13)
+        def centres(m, P):
+            return sorted(tuple(np.round(P[m.sphere_link[s], 9:12] + P[m.sphere_link[s], :9].reshape(3, 3) @ np.array(m.sphere_center[s]), 12)) for s in range(m.nspheres))
+        assert centres(m2, a["poses"]) == centres(m3, b["poses"])
