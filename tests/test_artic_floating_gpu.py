@@ -119,3 +119,17 @@ def test_floating_body_without_geometry_keeps_its_hinge_limits(oracle, iters):
     aux = assert_parity(ab, oracle, m, q, qd, dt, 75, 4)
     ab.close()
     assert (aux["lcp_solves"][1:5] > 0).all() and (aux["status"] == 0).all() and (aux["stab_iters"] == 0).all()
+
+
+def test_floating_body_with_welded_links_lands_like_the_oracle(oracle):
+    """tests/scenes/floating_welded_pair.xml (FixedJoints welded by the reader: full tensors on the base link and the foot, two spheres on each, a tail hinged to the
+    welded hat): perturbed copies thrown onto the floor, no-slip model, four contact rows at most + two hinges' limits"""
+    m, _, _, q0, qd0, dt = A.load_xml(os.path.join(HERE, "scenes", "floating_welded_pair.xml"))
+    B = 4
+    rng = np.random.default_rng(44)
+    q = np.tile(q0, (B, 1)); qd = np.tile(qd0, (B, 1))
+    q[1:, :3] += rng.uniform(-0.05, 0.05, (B - 1, 3)); q[1:, 3:6] += rng.uniform(-0.3, 0.3, (B - 1, 3)); q[1:, 6:] = rng.uniform(-0.5, 0.3, (B - 1, 2))
+    qd[1:] += rng.uniform(-0.5, 0.5, (B - 1, 8))
+    aux = run(oracle, m, q, qd, nsteps=60, chunks=4, dt=dt)
+    assert (aux["lcp_solves"] > 0).all() and (aux["mini_steps"] > aux["steps"]).all() and ((aux["status"] & ~S.MH_WORLD_IMPACT_TOL) == 0).all()
+    assert (aux["lcp_rows"] > aux["lcp_solves"]).any()
