@@ -18,6 +18,9 @@
  *   ::update_from_stacked, update_constraint_velocities_from_impulses, apply_restitution   src/ImpactConstraintHandler.cpp:298-525
  * One wavefront per world; H, its Cholesky factor, H^-1 and the limit LCP live in LDS.
  *
+ * MH_WORLD_LCP_FAILED is the end of a world's run here as everywhere (moby_hip.h): the exception it stands for -- LCPSolverException, a generalized inertia that is not
+ * positive definite, a failed compute_X -- is caught nowhere in the reference; the state stays where the throw left it and later steps pass the world over.
+ *
  * Scope: config 5 is the robot alone (self-collision disabled as in ur10.xml:12: no contact rows, one mini-step per step);
  * optionally sphere primitives on links against a static plane (mh_artic_model.nspheres, no-slip contacts), no actuator torques (controller plugins stay on the host side of the seam: add them
  * through qdd = H^-1 (tau - C) by passing tau).  Constraint stabilisation with joint-limit rows and, for bodies with link spheres, contact

@@ -637,25 +637,33 @@ MH_DEV void artic_step_body(const Model* __restrict__ Mg, int B, double dt, int 
   if (lane == 0) g_lcp_prof_on = 0;
   int status = uni(aux->status);
   unsigned long long solves = 0, rows = 0, pivs = 0, bytes = 0, stab_iters = 0, stab_rows = 0;
+  // An exception of calc_fwd_dyn, the impact handler or compute_X ends the run (oracle Artic::step): the state stays where the throw left it (positions
+  // integrated, velocities without the impulses), time and counters without that step, and a world that carries MH_WORLD_LCP_FAILED is not stepped again.
+  int minis = 0, steps = 0;                                          // mini-steps whose time was added / steps that ran to their end
   wave_sync();
   for (int s = 0; s < nsteps; s++) {
+    if (status & MH_WORLD_LCP_FAILED) break;
     // positions with the OLD velocity (TSS:156-164)
     if (lane < nj) { double qn = g[Y.qd + lane] * dt; qn = qn + g[Y.q + lane]; g[Y.q + lane] = qn; }
     wave_sync();
     const bool ok = (M.m.algorithm == MH_ARTIC_FSAB) ? dynamics_aba(M, Y, g, nullptr) : dynamics(M, Y, g, nullptr);
-    if (!ok) status |= MH_WORLD_LCP_FAILED;
-    if (lane < nj) { const double qdd = ok ? g[Y.qdd + lane] : 0.0; g[Y.qd + lane] = g[Y.qd + lane] + qdd * dt; }   // TSS:182-192
+    if (!ok) { status |= MH_WORLD_LCP_FAILED; break; }
+    if (lane < nj) g[Y.qd + lane] = g[Y.qd + lane] + g[Y.qdd + lane] * dt;   // TSS:182-192
     wave_sync();
-    if (ok) handle_limits(M, Y, g, aux, rng, status, solves, rows, pivs, bytes);
+    handle_limits(M, Y, g, aux, rng, status, solves, rows, pivs, bytes);
     wave_sync();
-    if (STAB) stabilize_limits(M, Y, g, rng, status, solves, rows, pivs, bytes, stab_iters, stab_rows);    // TSS:97
+    if (status & MH_WORLD_LCP_FAILED) break;
+    minis++;
+    if (STAB) { stabilize_limits(M, Y, g, rng, status, solves, rows, pivs, bytes, stab_iters, stab_rows); if (status & MH_WORLD_LCP_FAILED) break; }   // TSS:97
+    steps++;
   }
+  wave_sync();
   if (lane < nj) { qg[(size_t)b * nj + lane] = g[Y.q + lane]; qdg[(size_t)b * nj + lane] = g[Y.qd + lane]; }
   rng.store(aux->rng);
   if (lane == 0) {
-    double tm = aux->time; for (int s = 0; s < nsteps; s++) tm += dt;
+    double tm = aux->time; for (int s = 0; s < minis; s++) tm += dt;
     aux->time = tm; aux->status = status;
-    aux->steps += (unsigned long long)nsteps; aux->mini_steps += (unsigned long long)nsteps;
+    aux->steps += (unsigned long long)steps; aux->mini_steps += (unsigned long long)minis;
     aux->lcp_solves += solves; aux->lcp_rows += rows; aux->lcp_pivots += pivs; aux->lcp_alg_bytes += bytes;
     aux->stab_iters += stab_iters; aux->stab_rows += stab_rows;
   }
@@ -705,20 +713,26 @@ void k_artic_step_p2(const Model* __restrict__ Mg, int B, double dt, int nsteps,
   if (lane == 0) g_lcp_prof_on = 0;
   int status0 = uni(auxg[b0].status), status1 = two ? uni(auxg[b0 + 1].status) : 0;
   unsigned long long solves0 = 0, rows0 = 0, pivs0 = 0, bytes0 = 0, solves1 = 0, rows1 = 0, pivs1 = 0, bytes1 = 0;
+  int n0 = 0, n1 = 0;                                                // steps each world ran to their end (an exception ends a world's run: artic_step_body)
   wave_sync();
   for (int s = 0; s < nsteps; s++) {
-    if (hl < nj) { double qn = gw[Y.qd + hl] * dt; qn = qn + gw[Y.q + hl]; gw[Y.q + hl] = qn; }      // positions with the OLD velocity (TSS:156-164)
+    const bool a0 = !(status0 & MH_WORLD_LCP_FAILED), a1 = two && !(status1 & MH_WORLD_LCP_FAILED);    // still running (uniform)
+    if (!a0 && !a1) break;
+    const bool alive = (wl == 0) ? a0 : a1;                           // this lane's world: a dead world's image is computed on and never written back
+    if (hl < nj && alive) { double qn = gw[Y.qd + hl] * dt; qn = qn + gw[Y.q + hl]; gw[Y.q + hl] = qn; }      // positions with the OLD velocity (TSS:156-164)
     wave_sync();
     const bool okl = dynamics<2>(M, Y, gw, nullptr);
     const bool ok0 = (ballot(okl) & 1ull) != 0ull, ok1 = ((ballot(okl) >> 32) & 1ull) != 0ull;
-    if (!ok0) status0 |= MH_WORLD_LCP_FAILED;
-    if (two && !ok1) status1 |= MH_WORLD_LCP_FAILED;
-    if (hl < nj) { const double qdd = okl ? gw[Y.qdd + hl] : 0.0; gw[Y.qd + hl] = gw[Y.qd + hl] + qdd * dt; }   // TSS:182-192
+    if (a0 && !ok0) status0 |= MH_WORLD_LCP_FAILED;
+    if (a1 && !ok1) status1 |= MH_WORLD_LCP_FAILED;
+    if (hl < nj && alive && okl) gw[Y.qd + hl] = gw[Y.qd + hl] + gw[Y.qdd + hl] * dt;   // TSS:182-192
     wave_sync();
-    if (ok0) handle_limits(M, Y, g, auxg + b0, rng0, status0, solves0, rows0, pivs0, bytes0);
+    if (a0 && ok0) handle_limits(M, Y, g, auxg + b0, rng0, status0, solves0, rows0, pivs0, bytes0);
     wave_sync();
-    if (two && ok1) handle_limits(M, Y, g + Y.total, auxg + b0 + 1, rng1, status1, solves1, rows1, pivs1, bytes1);
+    if (a1 && ok1) handle_limits(M, Y, g + Y.total, auxg + b0 + 1, rng1, status1, solves1, rows1, pivs1, bytes1);
     wave_sync();
+    if (a0 && !(status0 & MH_WORLD_LCP_FAILED)) n0++;
+    if (a1 && !(status1 & MH_WORLD_LCP_FAILED)) n1++;
   }
   if (mine) { qg[(size_t)b * nj + hl] = gw[Y.q + hl]; qdg[(size_t)b * nj + hl] = gw[Y.qd + hl]; }
   rng0.store(auxg[b0].rng);
@@ -726,9 +740,10 @@ void k_artic_step_p2(const Model* __restrict__ Mg, int B, double dt, int nsteps,
   if (lane == 0) {
     for (int w = 0; w < (two ? 2 : 1); w++) {
       mh_world_aux* aux = auxg + b0 + w;
-      double tm = aux->time; for (int s = 0; s < nsteps; s++) tm += dt;
+      const int nw = w ? n1 : n0;
+      double tm = aux->time; for (int s = 0; s < nw; s++) tm += dt;
       aux->time = tm; aux->status = w ? status1 : status0;
-      aux->steps += (unsigned long long)nsteps; aux->mini_steps += (unsigned long long)nsteps;
+      aux->steps += (unsigned long long)nw; aux->mini_steps += (unsigned long long)nw;
       aux->lcp_solves += w ? solves1 : solves0; aux->lcp_rows += w ? rows1 : rows0; aux->lcp_pivots += w ? pivs1 : pivs0; aux->lcp_alg_bytes += w ? bytes1 : bytes0;
     }
   }

@@ -693,7 +693,8 @@ class Artic {
       h += tc;
     }
     double qdd[NJ];
-    if (!((m->algorithm == MH_ARTIC_FSAB) ? fwd_dyn_aba(nullptr, qdd) : fwd_dyn(nullptr, qdd))) { aux->status |= MH_WORLD_LCP_FAILED; for (int i = 0; i < nj; i++) qdd[i] = 0.0; }
+    // (an exception -- here: a generalized inertia that is not positive definite -- ends the run: nothing below happens)
+    if (!((m->algorithm == MH_ARTIC_FSAB) ? fwd_dyn_aba(nullptr, qdd) : fwd_dyn(nullptr, qdd))) { aux->status |= MH_WORLD_LCP_FAILED; return h; }
     for (int i = 0; i < nj; i++) qd[i] = qd[i] + qdd[i] * h;                                       // TSS:182-192
     std::vector<AContact> cs;                                        // find_unilateral_constraints (CSim:488-537)
     for (int s = 0; s < m->nspheres; s++) {
@@ -703,6 +704,7 @@ class Artic {
       if (dist < m->contact_dist_thresh && find_contact(s, m->contact_dist_thresh, c)) cs.push_back(c);
     }
     handle_impacts(cs);
+    if (aux->status & MH_WORLD_LCP_FAILED) return h;                 // thrown out of the impact handler: current_time += h (TSS:215) is not reached
     aux->time += h; aux->mini_steps++;
     return h;
   }
@@ -895,7 +897,11 @@ class Artic {
   }
 
   // TimeSteppingSimulator::step (TSS:52-111).  Without collision geometry: one mini-step of dt.
+  // An exception of the impact handler, of calc_fwd_dyn or of compute_X (LCPSolverException, "Unable to solve constraint LCP!", a factorisation that fails) is caught
+  // nowhere up to main(): the run of this simulator is over (as in world.hpp).  The state stays where the throw left it -- positions integrated, velocities
+  // without the impulses, time and counters without this mini-step / step -- and every later step() returns at once.
   void step(double dt) {
+    if (aux->status & MH_WORLD_LCP_FAILED) return;
     if (m->nspheres > 0 || force_general) {
       // a world whose contacts need a model this build does not have (the reference would throw out of step()), or whose step ran
       // into the mini-step cap (the reference would never return from step()), is frozen; without this it would burn the cap on
@@ -905,20 +911,24 @@ class Artic {
       double h = 0.0; unsigned guard = 0;
       while (h < dt) {
         h += do_mini_step(dt - h);
+        if (aux->status & MH_WORLD_LCP_FAILED) return;
         if (m->nspheres > 0 && (aux->status & FROZEN)) break;
         if (++guard > 100000u) { aux->status |= MH_WORLD_STALLED; break; }
       }
       stabilize();                                                   // TSS:97
+      if (aux->status & MH_WORLD_LCP_FAILED) return;
       aux->steps++;
       return;
     }
     for (int i = 0; i < nj; i++) { double qn = qd[i] * dt; qn = qn + q[i]; q[i] = qn; }        // positions with the OLD velocity (TSS:156-164)
     double qdd[NJ];
-    if (!((m->algorithm == MH_ARTIC_FSAB) ? fwd_dyn_aba(nullptr, qdd) : fwd_dyn(nullptr, qdd))) { aux->status |= MH_WORLD_LCP_FAILED; for (int i = 0; i < nj; i++) qdd[i] = 0.0; }
+    if (!((m->algorithm == MH_ARTIC_FSAB) ? fwd_dyn_aba(nullptr, qdd) : fwd_dyn(nullptr, qdd))) { aux->status |= MH_WORLD_LCP_FAILED; return; }
     for (int i = 0; i < nj; i++) qd[i] = qd[i] + qdd[i] * dt;                                      // TSS:182-192
     handle_limits();
+    if (aux->status & MH_WORLD_LCP_FAILED) return;
     aux->time += dt; aux->mini_steps++;
     stabilize();                                                   // TSS:97
+    if (aux->status & MH_WORLD_LCP_FAILED) return;
     aux->steps++;
   }
   bool force_general = false;     // tests: run a body without spheres through do_mini_step / handle_impacts (must agree with the path above)

@@ -133,3 +133,34 @@ def test_floating_body_with_welded_links_lands_like_the_oracle(oracle):
     aux = run(oracle, m, q, qd, nsteps=60, chunks=4, dt=dt)
     assert (aux["lcp_solves"] > 0).all() and (aux["mini_steps"] > aux["steps"]).all() and ((aux["status"] & ~S.MH_WORLD_IMPACT_TOL) == 0).all()
     assert (aux["lcp_rows"] > aux["lcp_solves"]).any()
+
+
+@pytest.mark.parametrize("variant", ["config5", "pack", "contacts", "contacts+stab", "stab"])
+def test_an_exception_ends_an_articulated_worlds_run(oracle, variant):
+    """MH_WORLD_LCP_FAILED on an articulated world is the end of its run, as on every other stepper: in a batch of four, worlds 1 and 3 carry the flag at upload
+    -- what an LCPSolverException, a generalized inertia that is not positive definite or a failed compute_X leave behind -- and the launch must not touch them (state,
+    time, counters, rand() stream), while worlds 0 and 2 step like the oracle's; through every step kernel (config 5's, two worlds per wavefront, contacts, both stabilising ones)."""
+    from moby_amd import _lib
+    m, _, _, q0, qd0, dt = A.load_xml(PAIR)
+    if variant in ("config5", "pack", "stab"): m.nspheres = 0
+    m.cstab_max_iterations = 10 if variant in ("stab", "contacts+stab") else 0
+    B = 4
+    rng = np.random.default_rng(8)
+    q = np.tile(q0, (B, 1)); qd = np.tile(qd0, (B, 1)); q[:, 6] = [0.0, 0.2, 0.39, -0.5]; qd[1:] += rng.uniform(-0.5, 0.5, (B - 1, 7)); q[:, 1] -= 0.08
+    aux0 = S.new_aux(B); aux0["status"][[1, 3]] = S.MH_WORLD_LCP_FAILED; aux0["time"][:] = [0.0, 0.5, 0.0, 0.25]; aux0["steps"][:] = [0, 7, 0, 3]
+    lib = _lib.load()
+    try:
+        _lib.check(lib.mh_debug_set(9, 1 if variant == "pack" else 0))
+        ab = A.ArticBatch(m, q, qd, aux0)
+        ab.step(dt, 25); ab.step(dt, 25)
+        q_g, qd_g, aux_g = ab.download(); ab.close()
+    finally:
+        _lib.check(lib.mh_debug_set(9, 0))
+    q_o, qd_o, aux_o = q.copy(), qd.copy(), aux0.copy()
+    oracle.artic_step(m, q_o, qd_o, aux_o, dt, 50)
+    assert np.array_equal(q_g, q_o) and np.array_equal(qd_g, qd_o)
+    for f in ("rng", "time", "status", "steps", "mini_steps", "lcp_solves", "lcp_rows", "lcp_pivots", "stab_iters"):
+        assert np.array_equal(aux_g[f], aux_o[f]), f
+    for w in (1, 3):
+        assert np.array_equal(q_g[w], q[w]) and np.array_equal(qd_g[w], qd[w]) and aux_g["time"][w] == aux0["time"][w] and aux_g["steps"][w] == aux0["steps"][w] and aux_g["mini_steps"][w] == 0
+    assert (aux_g["steps"][[0, 2]] == 50).all() and (aux_g["status"][[0, 2]] & S.MH_WORLD_LCP_FAILED == 0).all()
