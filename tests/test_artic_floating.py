@@ -161,3 +161,26 @@ def test_fixed_joints_weld_links_into_one_rigid_body(oracle, tmp_path):
     assert np.allclose(c, [0.0, 0.3326086956521739 - 0.30, 0.013043478260869566], atol=1e-15)
     # total mass on the sliders
     assert np.allclose(a["H"][:3, :3], (2.3 + 0.6 + 0.2) * np.eye(3), atol=1e-13)
+
+
+def test_an_exception_ends_an_articulated_worlds_run_in_the_oracle(oracle):
+    """tests/scenes/floating_welded_pair.xml, four perturbed bodies thrown onto the floor: the fourth one's impact LCP fails in its 170th step (LCPSolverException in the
+    reference: caught nowhere, the run is over).  The oracle leaves that world where the throw left it -- 169 counted steps, the clock at 0.169, no mini-step cap reached --
+    and passes it over afterwards, while the others go on (rounds 1-4 let such a world spin through 100 000 zero-length mini-steps and end MH_WORLD_STALLED).
+    The device side of the same rule: tests/test_artic_floating_gpu.py::test_an_exception_ends_an_articulated_worlds_run."""
+    m, _, _, q0, qd0, dt = A.load_xml(os.path.join(HERE, "scenes", "floating_welded_pair.xml"))
+    B = 4
+    rng = np.random.default_rng(42)
+    q = np.tile(q0, (B, 1)); qd = np.tile(qd0, (B, 1))
+    q[1:, :3] += rng.uniform(-0.05, 0.05, (B - 1, 3)); q[1:, 3:6] += rng.uniform(-0.3, 0.3, (B - 1, 3)); q[1:, 6:] = rng.uniform(-0.5, 0.3, (B - 1, 2))
+    qd[1:] += rng.uniform(-0.5, 0.5, (B - 1, 8))
+    aux = S.new_aux(B)
+    oracle.artic_step(m, q, qd, aux, dt, 240)
+    assert aux["status"][3] & S.MH_WORLD_LCP_FAILED and not (aux["status"][3] & S.MH_WORLD_STALLED) and not (aux["status"][:3] & S.MH_WORLD_LCP_FAILED).any()
+    assert aux["steps"][3] == 169 and aux["time"][3] == pytest.approx(0.169, abs=1e-12) and aux["mini_steps"][3] < 300 and (aux["steps"][:3] == 240).all()
+    q1, qd1, a1 = q.copy(), qd.copy(), aux.copy()
+    oracle.artic_step(m, q, qd, aux, dt, 50)
+    assert np.array_equal(q[3], q1[3]) and np.array_equal(qd[3], qd1[3])
+    for f in ("time", "steps", "mini_steps", "lcp_solves", "status", "rng"):
+        assert np.array_equal(aux[f][3], a1[f][3]), f
+    assert (aux["steps"][:3] == 290).all()
